@@ -1,0 +1,205 @@
+#!/usr/bin/env python3
+"""bench.py -- images/sec of one MTLoRA train step (BASELINE.json metric) on N MI355X.
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over one synthetic batch: bf16-autocast forward of the Swin-T/448
+MTLoRA backbone (r_shared 64, r_task 4, 4 tasks) + HRNet heads + weighted multi-task loss, backward,
+[RCCL all-reduce of the trainable gradients], clip_grad_norm_(5.0), AdamW, zero_grad -- dropout 0.05 and
+DropPath 0.2 active (train mode).  Per-GPU batch is fixed (weak scaling); inputs are resident in HBM
+before the timed region.  Rank 0 prints ONE JSON line.
+
+Extra objects in the line (this tier's contract):
+  roofline      the dominant HIP kernel (k_nt, the fused MTLoRALinear GEMM): algorithmic bytes of its
+                launches (SURVEY 8d formulas) / their HIP-event durations, measured over an extra K profiled
+                steps right after the timed region (events on the launch stream; see mtlora_prof_begin).
+  cpu_baseline  the oracle (a plain-PyTorch port of the reference) run on this box's host cores on a
+                bounded sample (B=2, fp32, 1 warm-up + 2 steps) -- kind "port".
+The eager PyTorch-ROCm comparator of the north star's ">= 4x" target is timed by tests/perf_eager_gpu.py
+(it runs the oracle's ATen dataflow on the GPU, and only tests/ may import the oracle for that).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+TASKS = ("semseg", "normals", "sal", "human_parts")
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s achievable)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32, help="per-GPU batch (BASELINE configs[1]: 32)")
+    ap.add_argument("--img", type=int, default=448)
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def init_dist(args):
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(backend="nccl", init_method="env://", device_id=torch.device("cuda", local))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    return rank, world, local
+
+
+def barrier(world):
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+    torch.cuda.synchronize()
+
+
+def time_steps(step_fn, steps, warmup, world):
+    for _ in range(warmup):
+        step_fn()
+    barrier(world)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step_fn()
+    barrier(world)
+    dt = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    return dt
+
+
+def roofline(step_fn, steps):
+    """HIP-event timing of every library launch over `steps` extra steps (same stream as the launches)."""
+    import ctypes
+    from mtlora_amd import _lib as L
+    lib = L.lib()
+    torch.cuda.synchronize()
+    L.check(lib.mtlora_prof_begin(200000), "prof_begin")
+    for _ in range(steps):
+        step_fn()
+    torch.cuda.synchronize()
+    s = L.ProfSummary()
+    L.check(lib.mtlora_prof_end(ctypes.byref(s)), "prof_end")
+    kinds = {}
+    for k in range(L.PROF_KINDS):
+        if s.count[k]:
+            kinds[lib.mtlora_prof_kind_name(k).decode()] = {
+                "launches_per_step": s.count[k] / steps, "ms_per_step": s.ms[k] / steps,
+                "avg_us": 1e3 * s.ms[k] / s.count[k], "alg_GB_per_step": s.alg_bytes[k] / steps / 1e9,
+                "GBps": (s.alg_bytes[k] / 1e9) / (s.ms[k] / 1e3) if s.ms[k] > 0 else None}
+    nt = [k for k in range(4) if s.count[k]]
+    n = sum(s.count[k] for k in nt)
+    ms = sum(s.ms[k] for k in nt)
+    by = sum(s.alg_bytes[k] for k in nt)
+    achieved = (by / 1e9) / (ms / 1e3) if ms > 0 else 0.0
+    return {"bound": "hbm", "kernel": "k_nt<bf16> (fused MTLoRALinear GEMM: fwd outputs, low-rank P/Q, bwd dX)",
+            "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+            "traffic": None, "launches_per_step": n / steps, "avg_launch_us": round(1e3 * ms / max(n, 1), 2),
+            "alg_bytes_per_launch": by / max(n, 1), "kernel_ms_per_step": round(ms / steps, 3),
+            "all_kernels": kinds}
+
+
+def cpu_baseline():
+    """oracle (port of the reference) on the host cores: C2 shapes, B=2, fp32, train mode, 1 warm-up + 2 steps."""
+    from oracle import mtlora_oracle as O
+    n = os.cpu_count() or 1
+    torch.set_num_threads(n)
+    cfg = O.swin_t_cfg(448, TASKS, 64, 4, drop_path_rate=0.2)
+    shapes = {("backbone." + k): v for k, v in O.backbone_param_shapes(cfg).items()}
+    shapes.update(O.head_param_shapes(cfg, O.NUM_OUTPUT))
+    P = O.make_params(shapes)
+    train = [v.requires_grad_(True) for k, v in P.items()
+             if O.trainable_filter(k) and not k.endswith(("running_mean", "running_var"))]
+    opt = torch.optim.AdamW(train, lr=5e-4, weight_decay=0.05)
+    B = 2
+    img, tg = O.synthetic_batch(B, 448, TASKS, seed=1234)
+    rng = torch.Generator().manual_seed(0)
+
+    def step():
+        out = O.full_model(P, img, cfg, train=True, rng=rng)
+        loss, _ = O.multi_task_loss(out, tg, TASKS)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_([p for p in train if p.grad is not None], 5.0)
+        opt.step()
+        opt.zero_grad(set_to_none=True)
+
+    step()
+    t0 = time.perf_counter()
+    for _ in range(2):
+        step()
+    dt = (time.perf_counter() - t0) / 2
+    return {"value": round(B / dt, 4), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"Swin-T/448 4-task r64/4 train step, B={B}, fp32, 1 warm-up + 2 timed steps ({dt:.2f} s/step)"}
+
+
+def main():
+    args = parse()
+    rank, world, local = init_dist(args)
+    dev = torch.device("cuda", local)
+    from mtlora_amd import _lib as L
+    from mtlora_amd import mtl_harness as H
+    from mtlora_amd.ddp import GradReducer
+    L.lib()  # fail loudly if the HIP extension is missing
+
+    result = {}
+    if True:
+        model = H.build_model(img_size=args.img, tasks=TASKS, r_shared=64, r_task=4, drop_path_rate=0.2, seed=0).to(dev)
+        model.train()
+        crit = H.MultiTaskLoss(TASKS)
+        opt = H.build_optimizer(model, lr=5e-4 * args.batch * world / 512.0)  # main.py:578-583 linear LR scaling
+        reducer = GradReducer(model.parameters(), bucket_mb=16.0) if world > 1 else None
+        img, tg = H.synthetic_batch(args.batch, args.img, TASKS, seed=1234 + rank, device=dev)
+        torch.manual_seed(1234 + rank)
+
+        def step():
+            H.train_step(model, crit, opt, img, tg, clip_grad=5.0, reducer=reducer, amp_dtype=torch.bfloat16)
+
+        dt = time_steps(step, args.steps, args.warmup, world)
+        ips = args.batch * world * args.steps / dt
+        n_train = sum(p.numel() for p in model.parameters() if p.requires_grad)
+        result = {
+            "metric": "images/sec (train step) Swin-T/448 r=64 4-task", "value": round(ips, 2), "unit": "images/sec",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: Swin-T 448, 4 tasks (semseg,normals,sal,human_parts), "
+                                   "r_shared=64 r_task=4 scale4, train step (fwd+loss+bwd+clip+AdamW), dropout .05, "
+                                   "drop_path .2", "per_gpu_batch": args.batch, "global_batch": args.batch * world,
+                       "img_size": args.img, "parallelism": f"dp{world}", "trainable_params": n_train,
+                       "allreduce_bytes": reducer.nbytes if reducer else 0},
+        }
+        if rank == 0 and not args.no_roofline:
+            result["roofline"] = roofline(step, max(2, min(args.steps, 5)))
+        elif not args.no_roofline and world > 1:
+            for _ in range(max(2, min(args.steps, 5))):  # keep ranks in lock-step with rank 0's profiled steps
+                step()
+        del model, opt
+        torch.cuda.empty_cache()
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline()
+    if world > 1:
+        barrier(world)
+        import torch.distributed as dist
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,181 @@
+/*
+ * mtlora_hip.h -- C ABI of libmtlora_hip.so, the MI355X (gfx950) implementation of the
+ * MTLoRA data-parallel hot path.
+ *
+ * Boundary contract:
+ *   - plain C, raw DEVICE pointers + sizes + a dtype enum + a hipStream_t passed as void*;
+ *     no torch / ATen / pybind types anywhere;
+ *   - the CALLER owns every buffer (inputs, outputs, ctx, scratch); the library never
+ *     allocates, frees, retains a pointer or synchronises; every launch goes on `stream`;
+ *   - re-entrant, no global mutable state (safe from the autograd thread and across DDP ranks);
+ *   - every function returns MTLORA_OK (0) or a negative mtlora_status; the Python shim
+ *     (mtlora_amd/_lib.py) turns a non-zero status into RuntimeError -- the same observable
+ *     behaviour as the reference's AT_ASSERTM -> RuntimeError (swin_window_process.cpp:64-66).
+ *
+ * Each entry point cites the reference interface it replaces.
+ */
+#ifndef MTLORA_HIP_H
+#define MTLORA_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MTLORA_ABI_VERSION 1
+#define MTLORA_MAX_TASKS 8
+
+typedef enum mtlora_dtype {
+    MTLORA_F32 = 0,  /* exact-f32 MFMA path (v_mfma_f32_32x32x2_f32) */
+    MTLORA_BF16 = 1, /* bf16 in/out, fp32 accumulate (v_mfma_f32_32x32x16_bf16) */
+    MTLORA_F16 = 2   /* window_process copies only */
+} mtlora_dtype;
+
+typedef enum mtlora_status {
+    MTLORA_OK = 0,
+    MTLORA_ERR_DTYPE = -1,
+    MTLORA_ERR_SHAPE = -2,
+    MTLORA_ERR_ALIGN = -3,
+    MTLORA_ERR_NULL = -4,
+    MTLORA_ERR_WORKSPACE = -5,
+    MTLORA_ERR_HIP = -6,
+    MTLORA_ERR_UNSUPPORTED = -7
+} mtlora_status;
+
+/* ABI version of the loaded library (== MTLORA_ABI_VERSION of the header it was built from). */
+int mtlora_version(void);
+const char* mtlora_error_string(int status);
+
+/* ------------------------------------------------------------------------------------------
+ * Window process -- replaces the pybind module `swin_window_process`
+ * (kernels/window_process/swin_window_process.cpp:127-132) and its four CUDA kernels
+ * (swin_window_process_kernel.cu:42,69,96,124).  Same argument meaning and SIGN CONVENTION:
+ *   WindowProcess.apply(x,B,H,W,C,-shift,ws)         -> *_partition_forward (shift_size = -shift)
+ *   WindowProcessReverse.apply(w,B,H,W,C,+shift,ws)  -> *_merge_and_roll_forward (shift_size = +shift)
+ * Differences: output is caller-allocated; bf16 supported (reference: fp16/fp32 only,
+ * .cu:170-175); correct for H != W (reference .cu:113-115 is only exact for square maps);
+ * launches on `stream` (reference: default stream, .cu:178).
+ * `image` is (B,H,W,C) contiguous, `windows` is (B*(H/ws)*(W/ws), ws, ws, C) contiguous.
+ * ------------------------------------------------------------------------------------------ */
+int mtlora_roll_and_window_partition_forward(const void* image, void* windows, int64_t B, int64_t H, int64_t W,
+                                             int64_t C, int shift_size, int window_size, int dtype, void* stream);
+int mtlora_roll_and_window_partition_backward(const void* grad_windows, void* grad_image, int64_t B, int64_t H,
+                                              int64_t W, int64_t C, int shift_size, int window_size, int dtype,
+                                              void* stream);
+int mtlora_window_merge_and_roll_forward(const void* windows, void* image, int64_t B, int64_t H, int64_t W,
+                                         int64_t C, int shift_size, int window_size, int dtype, void* stream);
+int mtlora_window_merge_and_roll_backward(const void* grad_image, void* grad_windows, int64_t B, int64_t H,
+                                          int64_t W, int64_t C, int shift_size, int window_size, int dtype,
+                                          void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * MTLoRALinear -- replaces the ATen op sequence of models/lora.py:253-284 (forward) and its
+ * autograd backward:
+ *   Y_s = X W^T + b + s_s (D(X) A_s^T) B_s^T
+ *   Y_t = X W^T + b [+ s_s(...) if mode==matrixv2] + s_t (X_t A_t^T) B_t^T,   X_t = x_tasks[t] or D(X)
+ * D = dropout(p) (train only; counter-based generator `mtl_dropout_keep`, restated in
+ * oracle/mtlora_oracle.py:dropout_keep_mask).  'addition' mode = r_s 0 + T>0 here; its
+ * LayerNorm(sum_t) tail is applied by the host module.
+ *
+ * Layouts: X, X_t, Y_*: (M,K)/(M,N) row-major in `dtype`.  W (N,K), bias (N): `dtype` / fp32.
+ * LoRA masters A_* (r,K), B_* (N,r): fp32 (the nn.Parameters themselves).  Parameter
+ * gradients are fp32.  Wt is W transposed, (K,N) row-major in `dtype` (W is frozen; the host
+ * caches it).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct mtlora_linear_desc {
+    int64_t M, K, N;
+    int32_t dtype;      /* MTLORA_F32 | MTLORA_BF16 */
+    int32_t mode;       /* 0 = 'matrix', 1 = 'matrixv2' (lora.py:259-274) */
+    int32_t T;          /* number of task outputs, 0..MTLORA_MAX_TASKS (0 <=> tasks is None) */
+    int32_t r_s;        /* shared rank, 0 = no shared update */
+    int32_t r_t[MTLORA_MAX_TASKS];
+    float scale_s;
+    float scale_t[MTLORA_MAX_TASKS];
+    int32_t has_x_tasks; /* 1: task t reads x_t[t] undropped; 0: task t reads D(X) (lora.py:262-263) */
+    float dropout_p;     /* 0 in eval */
+    uint64_t seed;       /* dropout seed of this call (same value for fwd and bwd) */
+} mtlora_linear_desc;
+
+/* bytes of the context buffer written by fwd and read by bwd (packed low-rank factors + P). */
+int64_t mtlora_linear_ctx_bytes(const mtlora_linear_desc* d);
+/* bytes of the backward scratch buffer. */
+int64_t mtlora_linear_bwd_scratch_bytes(const mtlora_linear_desc* d);
+
+int mtlora_linear_fwd(const mtlora_linear_desc* d, const void* x, const void* const* x_t, const void* W,
+                      const float* bias, const float* A_s, const float* B_s, const float* const* A_t,
+                      const float* const* B_t, void* y_s, void* const* y_t, void* ctx, int64_t ctx_bytes,
+                      void* stream);
+
+/* dy_s / dy_t[t] may be NULL (that output received no gradient).  dx_t is only written when
+ * has_x_tasks; dA_x / dB_x may be NULL to skip a factor whose output got no gradient. */
+int mtlora_linear_bwd(const mtlora_linear_desc* d, const void* x, const void* const* x_t, const void* Wt,
+                      const void* dy_s, const void* const* dy_t, const void* ctx, int64_t ctx_bytes, void* dx,
+                      void* const* dx_t, float* dA_s, float* dB_s, float* const* dA_t, float* const* dB_t,
+                      void* scratch, int64_t scratch_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Window attention core -- replaces swin_transformer_mtlora.py:194-220 (q*scale, q@k^T, + relative
+ * position bias, + shift mask, softmax, @v, head merge) and, with image_layout = 1, also the
+ * cyclic shift + window partition before it and the window merge + reverse shift after it
+ * (:336-350, :365-377), by folding them into the kernel's load/store addressing.
+ *
+ * qkv: `dtype`, last dim laid out [3][num_heads][head_dim] (the reshape at :194-197).
+ *   image_layout = 0: qkv is (n_windows, N, 3C) window-major exactly as the reference module sees it;
+ *   image_layout = 1: qkv is (B, H, W, 3C) in natural token order; window w of image b covers
+ *                     rows/cols ((wy*ws+ty+shift) mod H, (wx*ws+tx+shift) mod W).
+ * out has the same token order as qkv, (.., C).  bias: dense (num_heads, N, N) fp32
+ * (table[index] gathered by the host, :202-206).  mask: (nW_per_image, N, N) fp32 or NULL (:209-213).
+ * N = ws*ws <= 64, head_dim == 32 (every Swin variant).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct mtlora_attn_desc {
+    int64_t B;            /* images */
+    int32_t H, W;         /* token map */
+    int32_t window_size;
+    int32_t shift;        /* >= 0; only used for addressing when image_layout = 1 */
+    int32_t num_heads;
+    int32_t head_dim;
+    int32_t image_layout;
+    int32_t dtype;
+    float scale;
+} mtlora_attn_desc;
+
+int64_t mtlora_window_attn_bwd_scratch_bytes(const mtlora_attn_desc* d);
+
+/* bias / mask are passed in the two orientations the kernels read coalesced (both tiny, built once by
+ * the host from table[index] / attn_mask):   bias[h][i][j]   and   bias_t[h][j][i] = bias[h][i][j]
+ * (i = query, j = key), same for mask / mask_t (both NULL when there is no mask). */
+int mtlora_window_attn_fwd(const mtlora_attn_desc* d, const void* qkv, const float* bias_t, const float* mask_t,
+                           void* out, void* stream);
+/* dbias: (num_heads, N, N) fp32 [h][i][j], overwritten.  dqkv: same shape/dtype as qkv, fully written. */
+int mtlora_window_attn_bwd(const mtlora_attn_desc* d, const void* qkv, const float* bias, const float* bias_t,
+                           const float* mask, const float* mask_t, const void* dout, void* dqkv, float* dbias,
+                           void* scratch, int64_t scratch_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Hardware self-test: writes the lane->element maps of the MFMA / LDS-transpose primitives the
+ * kernels rely on into `out` (int32[4096]) so a GPU test can assert them (tests/test_gpu_layouts.py).
+ * ------------------------------------------------------------------------------------------ */
+int mtlora_selftest_layouts(int32_t* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Opt-in per-launch timing for the roofline report (bench.py): between begin and end every kernel
+ * launch of this library is bracketed by two HIP events recorded on ITS launch stream and tagged with
+ * a kind and the algorithmic bytes of that launch.  `end` must be called after the streams
+ * were synchronised.  A process-wide diagnostic switch -- the only global state in the library; the
+ * compute entry points stay re-entrant.
+ * ------------------------------------------------------------------------------------------ */
+#define MTLORA_PROF_KINDS 16
+typedef struct mtlora_prof_summary {
+    int64_t count[MTLORA_PROF_KINDS];
+    double ms[MTLORA_PROF_KINDS];        /* sum of launch durations */
+    double alg_bytes[MTLORA_PROF_KINDS]; /* sum of algorithmic bytes */
+} mtlora_prof_summary;
+int mtlora_prof_begin(int max_records);
+int mtlora_prof_end(mtlora_prof_summary* out);
+const char* mtlora_prof_kind_name(int kind);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MTLORA_HIP_H */

@@ -1,0 +1,126 @@
+"""ctypes binding of libmtlora_hip.so (include/mtlora_hip.h).
+
+The library is the ONLY compute path: if it cannot be loaded, or a tensor is not on a GPU, the
+callers raise -- there is no eager / CPU fallback (the oracle under oracle/ is test-only).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_uint64, c_void_p
+
+import torch
+
+MAX_TASKS = 8
+ABI_VERSION = 1
+F32, BF16, F16 = 0, 1, 2
+_DT = {torch.float32: F32, torch.bfloat16: BF16, torch.float16: F16}
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libmtlora_hip.so")
+
+
+class LinearDesc(Structure):
+    _fields_ = [("M", c_int64), ("K", c_int64), ("N", c_int64), ("dtype", c_int32), ("mode", c_int32),
+                ("T", c_int32), ("r_s", c_int32), ("r_t", c_int32 * MAX_TASKS), ("scale_s", c_float),
+                ("scale_t", c_float * MAX_TASKS), ("has_x_tasks", c_int32), ("dropout_p", c_float),
+                ("seed", c_uint64)]
+
+
+class AttnDesc(Structure):
+    _fields_ = [("B", c_int64), ("H", c_int32), ("W", c_int32), ("window_size", c_int32), ("shift", c_int32),
+                ("num_heads", c_int32), ("head_dim", c_int32), ("image_layout", c_int32), ("dtype", c_int32),
+                ("scale", c_float)]
+
+
+PROF_KINDS = 16
+
+
+class ProfSummary(Structure):
+    _fields_ = [("count", c_int64 * PROF_KINDS), ("ms", ctypes.c_double * PROF_KINDS),
+                ("alg_bytes", ctypes.c_double * PROF_KINDS)]
+
+
+PtrArr = c_void_p * MAX_TASKS
+
+_SIGS = {
+    "mtlora_version": (c_int, []),
+    "mtlora_error_string": (c_char_p, [c_int]),
+    "mtlora_roll_and_window_partition_forward": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int, c_int, c_int, c_void_p]),
+    "mtlora_roll_and_window_partition_backward": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int, c_int, c_int, c_void_p]),
+    "mtlora_window_merge_and_roll_forward": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int, c_int, c_int, c_void_p]),
+    "mtlora_window_merge_and_roll_backward": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int, c_int, c_int, c_void_p]),
+    "mtlora_linear_ctx_bytes": (c_int64, [POINTER(LinearDesc)]),
+    "mtlora_linear_bwd_scratch_bytes": (c_int64, [POINTER(LinearDesc)]),
+    "mtlora_linear_fwd": (c_int, [POINTER(LinearDesc), c_void_p, POINTER(c_void_p), c_void_p, c_void_p, c_void_p, c_void_p,
+                                  POINTER(c_void_p), POINTER(c_void_p), c_void_p, POINTER(c_void_p), c_void_p, c_int64,
+                                  c_void_p]),
+    "mtlora_linear_bwd": (c_int, [POINTER(LinearDesc), c_void_p, POINTER(c_void_p), c_void_p, c_void_p, POINTER(c_void_p),
+                                  c_void_p, c_int64, c_void_p, POINTER(c_void_p), c_void_p, c_void_p, POINTER(c_void_p),
+                                  POINTER(c_void_p), c_void_p, c_int64, c_void_p]),
+    "mtlora_window_attn_bwd_scratch_bytes": (c_int64, [POINTER(AttnDesc)]),
+    "mtlora_window_attn_fwd": (c_int, [POINTER(AttnDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mtlora_window_attn_bwd": (c_int, [POINTER(AttnDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                       c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "mtlora_selftest_layouts": (c_int, [c_void_p, c_void_p]),
+    "mtlora_prof_begin": (c_int, [c_int]),
+    "mtlora_prof_end": (c_int, [POINTER(ProfSummary)]),
+    "mtlora_prof_kind_name": (c_char_p, [c_int]),
+}
+EXPORTS = tuple(_SIGS)
+
+_lib = None
+
+
+def lib() -> ctypes.CDLL:
+    """Load (once) and return the HIP library; raise loudly if it is missing or stale."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"mtlora_amd: {LIB_PATH} not found. Build it with `python -m mtlora_amd.csrc.build` "
+                "(or __graft_entry__.build()). There is no eager/CPU fallback for the MTLoRA hot path.")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(L, name)  # AttributeError if the .so does not export a declared symbol
+            fn.restype, fn.argtypes = res, args
+        v = L.mtlora_version()
+        if v != ABI_VERSION:
+            raise RuntimeError(f"mtlora_amd: libmtlora_hip.so ABI {v} != binding ABI {ABI_VERSION}; rebuild")
+        _lib = L
+    return _lib
+
+
+def check(status: int, what: str) -> None:
+    if status != 0:
+        msg = lib().mtlora_error_string(status).decode()
+        raise RuntimeError(f"mtlora_amd: {what} failed: {msg} (status {status})")
+
+
+def dtype_code(t: torch.Tensor, allow_f16: bool = False) -> int:
+    code = _DT.get(t.dtype)
+    if code is None or (code == F16 and not allow_f16):
+        raise RuntimeError(f"mtlora_amd: unsupported dtype {t.dtype} (fp32 and bf16 are supported"
+                           + (", fp16 for window_process" if allow_f16 else "") + ")")
+    return code
+
+
+def require_gpu(*tensors: torch.Tensor) -> None:
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("mtlora_amd: tensors must live on a ROCm GPU (MI355X); the HIP path has no CPU fallback")
+
+
+def ptr(t) -> c_void_p:
+    return c_void_p(0 if t is None else t.data_ptr())
+
+
+def ptr_array(ts) -> "PtrArr":
+    a = PtrArr()
+    for i in range(MAX_TASKS):
+        a[i] = 0 if (ts is None or i >= len(ts) or ts[i] is None) else ts[i].data_ptr()
+    return a
+
+
+def stream_ptr() -> c_void_p:
+    return c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,575 @@
+// attention.hip -- (shifted-)window attention core, forward and backward, on CDNA4 (gfx950).
+// Replaces swin_transformer_mtlora.py:194-220 and, with image_layout = 1, also the roll/partition
+// (:336-350) before it and the merge/roll (:365-377) after it (folded into the addressing).
+//
+// One wave (one 64-thread workgroup) processes one (window, head) pair at a time:
+//   N = ws*ws <= 64 tokens padded to 64, head_dim = 32  ->  every product is a handful of
+//   32x32 MFMA tiles; nothing but Q/K/V(/dO) rows ever leaves registers/LDS (no (B_,nH,N,N)
+//   score tensor in HBM -- the reference materialises it 3+ times).
+//
+// forward:   S^T[j][i] = K Q^T (lane owns query column i, registers span keys j)
+//            softmax over keys = in-lane reduction + one exchange with lane^32
+//            O^T[d][i]  = V^T P^T : V^T operand via ds_read_b64_tr_b16 on the row-major LDS image,
+//                                   P^T operand straight from the accumulator registers.
+// backward:  pass 1 (query-owned):  P^T, dP^T = V dO^T, D_i, dS^T -> dbias (LDS accumulate), dQ^T = K^T dS^T
+//            pass 2 (key-owned):    S, P, dP recomputed in the other orientation from the row stats of
+//                                   pass 1 -> dK^T = Q^T dS, dV^T = dO^T P
+// The k-slot <-> key assignment of every register-fed operand follows the accumulator layout
+// (row = (r&3) + 8(r>>2) + 4(lane>>5)); the LDS-fed partner operand is gathered in the same order.
+#include "common.h"
+
+namespace {
+
+constexpr int AN = 64;  // padded tokens per window
+constexpr int HD = 32;  // head_dim
+
+template <typename T>
+struct AC;
+template <>
+struct AC<bf16> {
+    static constexpr int KT_D = 1;  // k-tiles across head_dim (32 bf16 = 64 B)
+    static constexpr int KT_N = 2;  // k-tiles across the 64 padded tokens
+    static constexpr int RS = 80;   // LDS row stride in bytes (64 + 16)
+    static constexpr int VPR = 4;   // 16-byte vectors per row
+};
+template <>
+struct AC<float> {
+    static constexpr int KT_D = 2;
+    static constexpr int KT_N = 4;
+    static constexpr int RS = 144;  // 128 + 16
+    static constexpr int VPR = 8;
+};
+
+struct AttnParams {
+    const void* qkv;
+    const float* bias;    // (nH, N, N) [h][i][j]
+    const float* bias_t;  // (nH, N, N) [h][j][i]
+    const float* mask;    // (nWimg, N, N) [w][i][j] or null
+    const float* mask_t;  // (nWimg, N, N) [w][j][i] or null
+    void* out;
+    const void* dout;
+    void* dqkv;
+    float* dbias_part;  // [G][nH][N(j)][N(i)]
+    int64_t n_windows;
+    int H, W, ws, shift, nH, N, C, nWx, nWy, image_layout;
+    int G;
+    float scale;
+};
+
+__device__ __forceinline__ int64_t token_index(const AttnParams& p, int64_t w, int t) {
+    if (!p.image_layout) return w * p.N + t;
+    const int wx = (int)(w % p.nWx);
+    const int64_t r = w / p.nWx;
+    const int wy = (int)(r % p.nWy);
+    const int64_t b = r / p.nWy;
+    const int ty = t / p.ws, tx = t - ty * p.ws;
+    const int y = (wy * p.ws + ty + p.shift) % p.H;
+    const int x = (wx * p.ws + tx + p.shift) % p.W;
+    return (b * p.H + y) * p.W + x;
+}
+
+// copy N rows of 32 elements (row r at base + tok[r]*stride) into a [64][RS] LDS image, zero padded
+template <typename T>
+__device__ __forceinline__ void stage_rows(unsigned char* s, const T* base, int64_t stride, const int* tok, int n,
+                                           int lane) {
+    constexpr int VPR = AC<T>::VPR, VEC = ET<T>::VEC, RS = AC<T>::RS;
+#pragma unroll
+    for (int it = 0; it < VPR; ++it) {
+        const int idx = it * 64 + lane;
+        const int row = idx / VPR, vec = idx % VPR;
+        u32x4 v = u32x4{0u, 0u, 0u, 0u};
+        if (row < n) v = *reinterpret_cast<const u32x4*>(base + (int64_t)tok[row] * stride + vec * VEC);
+        *reinterpret_cast<u32x4*>(s + row * RS + vec * 16) = v;
+    }
+}
+
+// operand whose MFMA rows are the LDS image rows sub*32 + (lane&31), k = columns of k-tile kt
+template <typename T>
+__device__ __forceinline__ Frag<T> rowfrag(const unsigned char* s, int sub, int kt, int lane) {
+    const int h = lane >> 5;
+    const unsigned char* p = s + (sub * 32 + (lane & 31)) * AC<T>::RS + kt * 64;
+    Frag<T> f;
+    f.v[0] = *reinterpret_cast<const u32x4*>(p + h * 16);
+    f.v[1] = *reinterpret_cast<const u32x4*>(p + (2 + h) * 16);
+    return f;
+}
+
+// operand whose MFMA rows are the 32 COLUMNS (d) of the image, k = image rows of k-tile kt, slot order =
+// accumulator order: slot (h, r) <-> row kt*KE + (r&3) + 8(r>>2) + 4h
+__device__ __forceinline__ Frag<bf16> colfrag(const unsigned char* s, int kt, int lane, bf16*) {
+    const int g = lane >> 4, i = lane & 15, h = g >> 1;
+    const int col = 16 * (g & 1) + 4 * (i & 3);
+    uint32_t w[8];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int row = kt * 32 + 8 * q + 4 * h + (i >> 2);
+        const unsigned char* p = s + row * AC<bf16>::RS + col * 2;
+        s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
+        u32x2 u = __builtin_bit_cast(u32x2, v);
+        w[2 * q] = u[0];
+        w[2 * q + 1] = u[1];
+    }
+    Frag<bf16> f;
+    f.v[0] = u32x4{w[0], w[1], w[2], w[3]};
+    f.v[1] = u32x4{w[4], w[5], w[6], w[7]};
+    return f;
+}
+__device__ __forceinline__ Frag<float> colfrag(const unsigned char* s, int kt, int lane, float*) {
+    const int h = lane >> 5, d = lane & 31;
+    uint32_t w[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int row = kt * 16 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        w[e] = *reinterpret_cast<const uint32_t*>(s + row * AC<float>::RS + d * 4);
+    }
+    Frag<float> f;
+    f.v[0] = u32x4{w[0], w[1], w[2], w[3]};
+    f.v[1] = u32x4{w[4], w[5], w[6], w[7]};
+    return f;
+}
+
+// operand fed from accumulator registers: acc[0..1] are the two 32-row subtiles along the k axis
+__device__ __forceinline__ uint32_t pack_bf16(float a, float b) {
+    bf16 x = (bf16)a, y = (bf16)b;
+    return (uint32_t)__builtin_bit_cast(uint16_t, x) | ((uint32_t)__builtin_bit_cast(uint16_t, y) << 16);
+}
+__device__ __forceinline__ Frag<bf16> regfrag(const f32x16 (&acc)[2], int kt, bf16*) {
+    Frag<bf16> f;
+    const f32x16& a = acc[kt];
+    f.v[0] = u32x4{pack_bf16(a[0], a[1]), pack_bf16(a[2], a[3]), pack_bf16(a[4], a[5]), pack_bf16(a[6], a[7])};
+    f.v[1] = u32x4{pack_bf16(a[8], a[9]), pack_bf16(a[10], a[11]), pack_bf16(a[12], a[13]), pack_bf16(a[14], a[15])};
+    return f;
+}
+__device__ __forceinline__ Frag<float> regfrag(const f32x16 (&acc)[2], int kt, float*) {
+    Frag<float> f;
+    const f32x16& a = acc[kt >> 1];
+    const int o = (kt & 1) * 8;
+    f.v[0] = __builtin_bit_cast(u32x4, f32x4{a[o + 0], a[o + 1], a[o + 2], a[o + 3]});
+    f.v[1] = __builtin_bit_cast(u32x4, f32x4{a[o + 4], a[o + 5], a[o + 6], a[o + 7]});
+    return f;
+}
+
+__device__ __forceinline__ void zero(f32x16& a) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) a[r] = 0.f;
+}
+
+// store a [d][token] accumulator subtile: lane owns token row `tok_off` (element offset of that token's
+// 32-wide head slice), registers 4q..4q+3 are d = 8q + 4h + 0..3
+template <typename T>
+__device__ __forceinline__ void store_dt(T* base, int64_t tok_off, const f32x16& a, float mul, int lane) {
+    const int h = lane >> 5;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        T* dst = base + tok_off + 8 * q + 4 * h;
+        if constexpr (sizeof(T) == 4) {
+            *reinterpret_cast<f32x4*>(dst) = f32x4{a[4 * q] * mul, a[4 * q + 1] * mul, a[4 * q + 2] * mul, a[4 * q + 3] * mul};
+        } else {
+            bf16x4 pk = {(bf16)(a[4 * q] * mul), (bf16)(a[4 * q + 1] * mul), (bf16)(a[4 * q + 2] * mul),
+                         (bf16)(a[4 * q + 3] * mul)};
+            *reinterpret_cast<bf16x4*>(dst) = pk;
+        }
+    }
+}
+
+constexpr float NEG_BIG = -1.0e30f;
+
+// scores for query half `si` in the query-owned orientation: st[sj][r] = S^T[key][query]
+template <typename T>
+__device__ __forceinline__ void scores_t(f32x16 (&st)[2], const unsigned char* sK, const unsigned char* sQ, int si,
+                                         const AttnParams& p, int head, int wm, int lane) {
+    zero(st[0]);
+    zero(st[1]);
+#pragma unroll
+    for (int kt = 0; kt < AC<T>::KT_D; ++kt) {
+        Frag<T> fq = rowfrag<T>(sQ, si, kt, lane);
+#pragma unroll
+        for (int sj = 0; sj < 2; ++sj) {
+            Frag<T> fk = rowfrag<T>(sK, sj, kt, lane);
+            mtl_mma(fk, fq, st[sj]);
+        }
+    }
+    const int i = si * 32 + (lane & 31);
+    const bool iv = i < p.N;
+    const float* bt = p.bias_t + (int64_t)head * p.N * p.N;
+    const float* mt = p.mask_t ? p.mask_t + (int64_t)wm * p.N * p.N : nullptr;
+#pragma unroll
+    for (int sj = 0; sj < 2; ++sj)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int j = sj * 32 + mtl_d_row(lane, r);
+            float v = st[sj][r] * p.scale;
+            if (j < p.N) {
+                if (iv) {
+                    v += bt[j * p.N + i];
+                    if (mt) v += mt[j * p.N + i];
+                }
+            } else {
+                v = NEG_BIG;
+            }
+            st[sj][r] = v;
+        }
+}
+
+// in-place softmax over the 64 keys of a query column (32 in this lane, 32 in lane^32)
+__device__ __forceinline__ void softmax_t(f32x16 (&st)[2], float& m_out, float& inv_l_out) {
+    float m = NEG_BIG;
+#pragma unroll
+    for (int sj = 0; sj < 2; ++sj)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) m = fmaxf(m, st[sj][r]);
+    m = fmaxf(m, __shfl_xor(m, 32));
+    float l = 0.f;
+#pragma unroll
+    for (int sj = 0; sj < 2; ++sj)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float e = __expf(st[sj][r] - m);
+            st[sj][r] = e;
+            l += e;
+        }
+    l += __shfl_xor(l, 32);
+    const float inv = 1.f / l;
+#pragma unroll
+    for (int sj = 0; sj < 2; ++sj)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st[sj][r] *= inv;
+    m_out = m;
+    inv_l_out = inv;
+}
+
+__device__ __forceinline__ int64_t xcd_remap(int64_t b, int64_t n) {
+    const int64_t q = n / 8, r = n % 8, x = b % 8;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + b / 8;
+}
+
+template <typename T>
+__global__ __launch_bounds__(64) void k_attn_fwd(const AttnParams p) {
+    constexpr int RS = AC<T>::RS;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[3 * AN * RS + AN * 4];
+    unsigned char* sQ = smem;
+    unsigned char* sK = smem + AN * RS;
+    unsigned char* sV = smem + 2 * AN * RS;
+    int* tok = reinterpret_cast<int*>(smem + 3 * AN * RS);
+    const int lane = threadIdx.x;
+    const int64_t total = p.n_windows * p.nH;
+    const int64_t first = xcd_remap(blockIdx.x, gridDim.x);
+    const int nWimg = p.nWx * p.nWy;
+    const T* qkv = reinterpret_cast<const T*>(p.qkv);
+    T* out = reinterpret_cast<T*>(p.out);
+    const int64_t C3 = 3 * (int64_t)p.C;
+
+    for (int64_t item = first; item < total; item += gridDim.x) {
+        const int head = (int)(item % p.nH);
+        const int64_t w = item / p.nH;
+        const int wm = (int)(w % nWimg);
+        __syncthreads();  // previous item's LDS reads are done
+        tok[lane] = lane < p.N ? (int)token_index(p, w, lane) : 0;
+        __syncthreads();
+        stage_rows<T>(sQ, qkv + head * HD, C3, tok, p.N, lane);
+        stage_rows<T>(sK, qkv + p.C + head * HD, C3, tok, p.N, lane);
+        stage_rows<T>(sV, qkv + 2 * p.C + head * HD, C3, tok, p.N, lane);
+        __syncthreads();
+#pragma unroll 1
+        for (int si = 0; si < 2; ++si) {
+            if (si * 32 >= p.N) break;
+            f32x16 st[2];
+            scores_t<T>(st, sK, sQ, si, p, head, wm, lane);
+            float m, inv_l;
+            softmax_t(st, m, inv_l);
+            f32x16 o;
+            zero(o);
+#pragma unroll
+            for (int kt = 0; kt < AC<T>::KT_N; ++kt) {
+                Frag<T> fv = colfrag(sV, kt, lane, (T*)nullptr);
+                Frag<T> fp = regfrag(st, kt, (T*)nullptr);
+                mtl_mma(fv, fp, o);
+            }
+            const int i = si * 32 + (lane & 31);
+            if (i < p.N) store_dt<T>(out, (int64_t)tok[i] * p.C + head * HD, o, 1.f, lane);
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(64) void k_attn_bwd(const AttnParams p) {
+    constexpr int RS = AC<T>::RS;
+    // Q, K, V, dO images + token table + row stats (m, 1/l, D) + dbias accumulator [N][64]
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* sQ = smem;
+    unsigned char* sK = smem + AN * RS;
+    unsigned char* sV = smem + 2 * AN * RS;
+    unsigned char* sO = smem + 3 * AN * RS;
+    int* tok = reinterpret_cast<int*>(smem + 4 * AN * RS);
+    float* st_m = reinterpret_cast<float*>(smem + 4 * AN * RS + AN * 4);
+    float* st_il = st_m + AN;
+    float* st_D = st_il + AN;
+    float* sDB = st_D + AN;  // [N][64]
+    const int lane = threadIdx.x;
+    const int64_t L = xcd_remap(blockIdx.x, gridDim.x);
+    const int head = (int)(L % p.nH);
+    const int g = (int)(L / p.nH);
+    const int nWimg = p.nWx * p.nWy;
+    const T* qkv = reinterpret_cast<const T*>(p.qkv);
+    const T* dout = reinterpret_cast<const T*>(p.dout);
+    T* dqkv = reinterpret_cast<T*>(p.dqkv);
+    const int64_t C3 = 3 * (int64_t)p.C;
+    const float* bn = p.bias + (int64_t)head * p.N * p.N;
+
+    for (int idx = lane; idx < p.N * 64; idx += 64) sDB[idx] = 0.f;
+
+    for (int64_t w = g; w < p.n_windows; w += p.G) {
+        const int wm = (int)(w % nWimg);
+        __syncthreads();
+        tok[lane] = lane < p.N ? (int)token_index(p, w, lane) : 0;
+        __syncthreads();
+        stage_rows<T>(sQ, qkv + head * HD, C3, tok, p.N, lane);
+        stage_rows<T>(sK, qkv + p.C + head * HD, C3, tok, p.N, lane);
+        stage_rows<T>(sV, qkv + 2 * p.C + head * HD, C3, tok, p.N, lane);
+        stage_rows<T>(sO, dout + head * HD, (int64_t)p.C, tok, p.N, lane);
+        __syncthreads();
+
+        // ---- pass 1: query-owned ------------------------------------------------------------
+#pragma unroll 1
+        for (int si = 0; si < 2; ++si) {
+            if (si * 32 >= p.N) break;
+            f32x16 pt[2];
+            scores_t<T>(pt, sK, sQ, si, p, head, wm, lane);
+            float m, inv_l;
+            softmax_t(pt, m, inv_l);
+            // dP^T[j][i] = sum_d V[j][d] dO[i][d]
+            f32x16 dp[2];
+            zero(dp[0]);
+            zero(dp[1]);
+#pragma unroll
+            for (int kt = 0; kt < AC<T>::KT_D; ++kt) {
+                Frag<T> fo = rowfrag<T>(sO, si, kt, lane);
+#pragma unroll
+                for (int sj = 0; sj < 2; ++sj) {
+                    Frag<T> fv = rowfrag<T>(sV, sj, kt, lane);
+                    mtl_mma(fv, fo, dp[sj]);
+                }
+            }
+            float D = 0.f;
+#pragma unroll
+            for (int sj = 0; sj < 2; ++sj)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) D += pt[sj][r] * dp[sj][r];
+            D += __shfl_xor(D, 32);
+            const int i = si * 32 + (lane & 31);
+            if (lane < 32) {
+                st_m[i] = m;
+                st_il[i] = inv_l;
+                st_D[i] = D;
+            }
+            // dS^T in place of dp; accumulate dbias
+#pragma unroll
+            for (int sj = 0; sj < 2; ++sj)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float ds = pt[sj][r] * (dp[sj][r] - D);
+                    dp[sj][r] = ds;
+                    const int j = sj * 32 + mtl_d_row(lane, r);
+                    if (j < p.N && i < p.N) sDB[j * 64 + i] += ds;
+                }
+            // dQ^T[d][i] = scale * sum_j K[j][d] dS^T[j][i]
+            f32x16 dq;
+            zero(dq);
+#pragma unroll
+            for (int kt = 0; kt < AC<T>::KT_N; ++kt) {
+                Frag<T> fk = colfrag(sK, kt, lane, (T*)nullptr);
+                Frag<T> fs = regfrag(dp, kt, (T*)nullptr);
+                mtl_mma(fk, fs, dq);
+            }
+            if (i < p.N) store_dt<T>(dqkv, (int64_t)tok[i] * C3 + head * HD, dq, p.scale, lane);
+        }
+        __syncthreads();
+
+        // ---- pass 2: key-owned ----------------------------------------------------------------
+#pragma unroll 1
+        for (int sj = 0; sj < 2; ++sj) {
+            if (sj * 32 >= p.N) break;
+            const int j = sj * 32 + (lane & 31);
+            const bool jv = j < p.N;
+            f32x16 pp[2], dp[2];  // [si]: P[i][j], dP[i][j]
+            zero(pp[0]);
+            zero(pp[1]);
+            zero(dp[0]);
+            zero(dp[1]);
+#pragma unroll
+            for (int kt = 0; kt < AC<T>::KT_D; ++kt) {
+                Frag<T> fk = rowfrag<T>(sK, sj, kt, lane);
+                Frag<T> fv = rowfrag<T>(sV, sj, kt, lane);
+#pragma unroll
+                for (int si = 0; si < 2; ++si) {
+                    Frag<T> fq = rowfrag<T>(sQ, si, kt, lane);
+                    Frag<T> fo = rowfrag<T>(sO, si, kt, lane);
+                    mtl_mma(fq, fk, pp[si]);
+                    mtl_mma(fo, fv, dp[si]);
+                }
+            }
+            const float* mn = p.mask ? p.mask + (int64_t)wm * p.N * p.N : nullptr;
+#pragma unroll
+            for (int si = 0; si < 2; ++si)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int i = si * 32 + mtl_d_row(lane, r);
+                    float pv = 0.f, ds = 0.f;
+                    if (i < p.N && jv) {
+                        float s = pp[si][r] * p.scale + bn[i * p.N + j];
+                        if (mn) s += mn[i * p.N + j];
+                        pv = __expf(s - st_m[i]) * st_il[i];
+                        ds = pv * (dp[si][r] - st_D[i]);
+                    }
+                    pp[si][r] = pv;
+                    dp[si][r] = ds;
+                }
+            f32x16 dk, dv;
+            zero(dk);
+            zero(dv);
+#pragma unroll
+            for (int kt = 0; kt < AC<T>::KT_N; ++kt) {
+                Frag<T> fq = colfrag(sQ, kt, lane, (T*)nullptr);
+                Frag<T> fo = colfrag(sO, kt, lane, (T*)nullptr);
+                Frag<T> fds = regfrag(dp, kt, (T*)nullptr);
+                Frag<T> fp = regfrag(pp, kt, (T*)nullptr);
+                mtl_mma(fq, fds, dk);
+                mtl_mma(fo, fp, dv);
+            }
+            if (jv) {
+                store_dt<T>(dqkv, (int64_t)tok[j] * C3 + p.C + head * HD, dk, p.scale, lane);
+                store_dt<T>(dqkv, (int64_t)tok[j] * C3 + 2 * p.C + head * HD, dv, 1.f, lane);
+            }
+        }
+    }
+    __syncthreads();
+    float* dst = p.dbias_part + ((int64_t)g * p.nH + head) * p.N * p.N;
+    for (int idx = lane; idx < p.N * p.N; idx += 64) {
+        const int j = idx / p.N, i = idx % p.N;
+        dst[idx] = sDB[j * 64 + i];
+    }
+}
+
+// dbias[h][i][j] = sum_g part[g][h][j][i]
+__global__ __launch_bounds__(256) void k_dbias_reduce(const float* part, float* dbias, int G, int nH, int N) {
+    const int total = nH * N * N;
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += gridDim.x * 256) {
+        const int h = idx / (N * N), rem = idx % (N * N);
+        const int i = rem / N, j = rem % N;
+        float s = 0.f;
+        for (int g = 0; g < G; ++g) s += part[((int64_t)g * nH + h) * N * N + j * N + i];
+        dbias[idx] = s;
+    }
+}
+
+int check(const mtlora_attn_desc* d) {
+    if (!d) return MTLORA_ERR_NULL;
+    if (d->dtype != MTLORA_F32 && d->dtype != MTLORA_BF16) return MTLORA_ERR_DTYPE;
+    if (d->head_dim != HD) return MTLORA_ERR_UNSUPPORTED;
+    if (d->window_size <= 0 || d->window_size * d->window_size > AN) return MTLORA_ERR_UNSUPPORTED;
+    if (d->B < 0 || d->H <= 0 || d->W <= 0 || d->num_heads <= 0) return MTLORA_ERR_SHAPE;
+    if (d->H % d->window_size || d->W % d->window_size) return MTLORA_ERR_SHAPE;
+    if (d->shift < 0 || d->shift >= d->window_size) return MTLORA_ERR_SHAPE;
+    if (d->B * d->H * d->W >= ((int64_t)1 << 31)) return MTLORA_ERR_SHAPE;
+    return MTLORA_OK;
+}
+
+int bwd_groups(const mtlora_attn_desc* d) {
+    const int64_t nwin = d->B * (d->H / d->window_size) * (d->W / d->window_size);
+    int64_t G = (256 * 4 + d->num_heads - 1) / d->num_heads;
+    if (G > nwin) G = nwin;
+    if (G < 1) G = 1;
+    // keep nH * G a multiple of 8 when possible is not required (bijective remap)
+    return (int)G;
+}
+
+AttnParams make_params(const mtlora_attn_desc* d) {
+    AttnParams p = {};
+    p.H = d->H;
+    p.W = d->W;
+    p.ws = d->window_size;
+    p.shift = d->shift;
+    p.nH = d->num_heads;
+    p.N = d->window_size * d->window_size;
+    p.C = d->num_heads * d->head_dim;
+    p.nWx = d->W / d->window_size;
+    p.nWy = d->H / d->window_size;
+    p.n_windows = d->B * p.nWx * p.nWy;
+    p.image_layout = d->image_layout;
+    p.scale = d->scale;
+    return p;
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t mtlora_window_attn_bwd_scratch_bytes(const mtlora_attn_desc* d) {
+    if (check(d) != MTLORA_OK) return -1;
+    const int N = d->window_size * d->window_size;
+    return (int64_t)bwd_groups(d) * d->num_heads * N * N * 4 + 256;
+}
+
+int mtlora_window_attn_fwd(const mtlora_attn_desc* d, const void* qkv, const float* bias_t, const float* mask_t,
+                           void* out, void* stream) {
+    int st = check(d);
+    if (st != MTLORA_OK) return st;
+    if (!qkv || !bias_t || !out) return MTLORA_ERR_NULL;
+    if (((uintptr_t)qkv | (uintptr_t)out) & 15u) return MTLORA_ERR_ALIGN;
+    AttnParams p = make_params(d);
+    if (p.n_windows == 0) return MTLORA_OK;
+    p.qkv = qkv;
+    p.bias_t = bias_t;
+    p.mask_t = mask_t;
+    p.out = out;
+    const int64_t total = p.n_windows * p.nH;
+    int64_t grid = total < 256 * 12 ? total : 256 * 12;
+    hipStream_t s = (hipStream_t)stream;
+    MtlProfScope prof(PK_ATTN_FWD, 4.0 * mtl_elem_size(d->dtype) * (double)p.n_windows * p.N * p.C, s);
+    if (d->dtype == MTLORA_F32)
+        hipLaunchKernelGGL(k_attn_fwd<float>, dim3((unsigned)grid), dim3(64), 0, s, p);
+    else
+        hipLaunchKernelGGL(k_attn_fwd<bf16>, dim3((unsigned)grid), dim3(64), 0, s, p);
+    MTL_CHECK_LAUNCH();
+    return MTLORA_OK;
+}
+
+int mtlora_window_attn_bwd(const mtlora_attn_desc* d, const void* qkv, const float* bias, const float* bias_t,
+                           const float* mask, const float* mask_t, const void* dout, void* dqkv, float* dbias,
+                           void* scratch, int64_t scratch_bytes, void* stream) {
+    int st = check(d);
+    if (st != MTLORA_OK) return st;
+    if (!qkv || !bias || !bias_t || !dout || !dqkv || !dbias || !scratch) return MTLORA_ERR_NULL;
+    if ((mask == nullptr) != (mask_t == nullptr)) return MTLORA_ERR_NULL;
+    if (((uintptr_t)qkv | (uintptr_t)dout | (uintptr_t)dqkv | (uintptr_t)scratch) & 15u) return MTLORA_ERR_ALIGN;
+    if (scratch_bytes < mtlora_window_attn_bwd_scratch_bytes(d) - 256) return MTLORA_ERR_WORKSPACE;
+    AttnParams p = make_params(d);
+    hipStream_t s = (hipStream_t)stream;
+    if (p.n_windows == 0) {
+        hipMemsetAsync(dbias, 0, (size_t)p.nH * p.N * p.N * 4, s);
+        return MTLORA_OK;
+    }
+    p.qkv = qkv;
+    p.bias = bias;
+    p.bias_t = bias_t;
+    p.mask = mask;
+    p.mask_t = mask_t;
+    p.dout = dout;
+    p.dqkv = dqkv;
+    p.dbias_part = reinterpret_cast<float*>(scratch);
+    p.G = bwd_groups(d);
+    const unsigned grid = (unsigned)(p.G * p.nH);
+    const int rs = d->dtype == MTLORA_F32 ? AC<float>::RS : AC<bf16>::RS;
+    const size_t lds = (size_t)4 * AN * rs + AN * 4 * 4 + (size_t)p.N * 64 * 4;
+    {
+        MtlProfScope prof(PK_ATTN_BWD, 7.0 * mtl_elem_size(d->dtype) * (double)p.n_windows * p.N * p.C, s);
+        if (d->dtype == MTLORA_F32)
+            hipLaunchKernelGGL(k_attn_bwd<float>, dim3(grid), dim3(64), lds, s, p);
+        else
+            hipLaunchKernelGGL(k_attn_bwd<bf16>, dim3(grid), dim3(64), lds, s, p);
+    }
+    hipLaunchKernelGGL(k_dbias_reduce, dim3(32), dim3(256), 0, s, (const float*)p.dbias_part, dbias, p.G, p.nH, p.N);
+    MTL_CHECK_LAUNCH();
+    return MTLORA_OK;
+}
+}

@@ -1,0 +1,175 @@
+// common.h -- shared device/host helpers for libmtlora_hip (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/mtlora_hip.h"
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+#define MTL_WAVE 64
+
+#define MTL_CHECK_LAUNCH()                                   \
+    do {                                                     \
+        hipError_t e__ = hipGetLastError();                  \
+        if (e__ != hipSuccess) return MTLORA_ERR_HIP;        \
+    } while (0)
+
+static inline int64_t mtl_ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+static inline int64_t mtl_round_up(int64_t a, int64_t b) { return mtl_ceil_div(a, b) * b; }
+static inline int mtl_elem_size(int dtype) { return dtype == MTLORA_F32 ? 4 : 2; }
+
+// ---------------------------------------------------------------------------------------------
+// counter-based dropout (restated in oracle/mtlora_oracle.py:dropout_keep_mask)
+//   row hash   rh = mix32(m * 0x9E3779B1 + seed_lo + stream * 0x85EBCA77)
+//   pair hash  h  = mix32(rh ^ ((k >> 1) + seed_hi * 0x27D4EB2F))
+//   16 bits per element: keep <=> ((k & 1) ? h >> 16 : h & 0xFFFF) >= floor(p * 65536)
+// ---------------------------------------------------------------------------------------------
+__host__ __device__ __forceinline__ uint32_t mtl_mix32(uint32_t x) {
+    x ^= x >> 16;
+    x *= 0x7FEB352Du;
+    x ^= x >> 15;
+    x *= 0x846CA68Bu;
+    x ^= x >> 16;
+    return x;
+}
+
+struct DropoutCfg {
+    uint32_t seed_lo, seed_hi, thr16;  // thr16 == 0 -> disabled
+    __host__ __device__ bool enabled() const { return thr16 != 0; }
+};
+
+static inline DropoutCfg mtl_make_dropout(float p, uint64_t seed) {
+    DropoutCfg c;
+    c.seed_lo = (uint32_t)(seed & 0xFFFFFFFFu);
+    c.seed_hi = (uint32_t)(seed >> 32);
+    double t = (double)p * 65536.0;
+    c.thr16 = p > 0.f ? (uint32_t)(t > 65535.0 ? 65535.0 : t) : 0u;
+    return c;
+}
+
+__device__ __forceinline__ uint32_t mtl_dropout_rowhash(const DropoutCfg& c, uint32_t stream, uint32_t m) {
+    return mtl_mix32(m * 0x9E3779B1u + c.seed_lo + stream * 0x85EBCA77u);
+}
+// 32 bits covering elements (k & ~1, k | 1) of row m
+__device__ __forceinline__ uint32_t mtl_dropout_pairbits(const DropoutCfg& c, uint32_t rowhash, uint32_t k) {
+    return mtl_mix32(rowhash ^ ((k >> 1) + c.seed_hi * 0x27D4EB2Fu));
+}
+__device__ __forceinline__ bool mtl_dropout_keep(const DropoutCfg& c, uint32_t rowhash, uint32_t k) {
+    uint32_t h = mtl_dropout_pairbits(c, rowhash, k);
+    uint32_t bits = (k & 1u) ? (h >> 16) : (h & 0xFFFFu);
+    return bits >= c.thr16;
+}
+
+// ---------------------------------------------------------------------------------------------
+// element traits: one 16-byte vector = VEC elements
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+struct ET;
+template <>
+struct ET<float> {
+    static constexpr int VEC = 4;
+    static constexpr int DT = MTLORA_F32;
+};
+template <>
+struct ET<bf16> {
+    static constexpr int VEC = 8;
+    static constexpr int DT = MTLORA_BF16;
+};
+
+__device__ __forceinline__ float mtl_to_f32(float v) { return v; }
+__device__ __forceinline__ float mtl_to_f32(bf16 v) { return (float)v; }
+template <typename T>
+__device__ __forceinline__ T mtl_from_f32(float v);
+template <>
+__device__ __forceinline__ float mtl_from_f32<float>(float v) { return v; }
+template <>
+__device__ __forceinline__ bf16 mtl_from_f32<bf16>(float v) { return (bf16)v; }
+
+// 16-byte vector view of VEC elements of T
+template <typename T>
+union Vec16 {
+    u32x4 raw;
+    T e[ET<T>::VEC];
+};
+
+template <typename T>
+__device__ __forceinline__ Vec16<T> mtl_ld16(const T* p) {
+    Vec16<T> v;
+    v.raw = *reinterpret_cast<const u32x4*>(p);
+    return v;
+}
+template <typename T>
+__device__ __forceinline__ Vec16<T> mtl_zero16() {
+    Vec16<T> v;
+    v.raw = u32x4{0u, 0u, 0u, 0u};
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// MFMA wrappers.  A "fragment" is the 2x16 bytes a lane holds for one 64-byte-wide k-tile:
+// the SAME (lane, slot) -> k assignment is used for both operands, so the k order inside the
+// instruction is irrelevant (dot products are permutation invariant); only the row/col <-> lane
+// map (l & 31) and the C/D map matter:
+//     D[i][j], lane l, reg r:  j = l & 31,  i = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5).
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+struct Frag {
+    u32x4 v[2];
+};
+
+__device__ __forceinline__ void mtl_mma(const Frag<bf16>& a, const Frag<bf16>& b, f32x16& c) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a.v[0]), __builtin_bit_cast(bf16x8, b.v[0]),
+                                                c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a.v[1]), __builtin_bit_cast(bf16x8, b.v[1]),
+                                                c, 0, 0, 0);
+}
+__device__ __forceinline__ void mtl_mma(const Frag<float>& a, const Frag<float>& b, f32x16& c) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        f32x4 av = __builtin_bit_cast(f32x4, a.v[h]);
+        f32x4 bv = __builtin_bit_cast(f32x4, b.v[h]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) c = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], bv[e], c, 0, 0, 0);
+    }
+}
+
+// D-layout helpers for a 32x32 tile
+__device__ __forceinline__ int mtl_d_row(int lane, int reg) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
+__device__ __forceinline__ int mtl_d_col(int lane) { return lane & 31; }
+
+// ---------------------------------------------------------------------------------------------
+// opt-in per-launch timing (mtlora_prof_begin / mtlora_prof_end): HIP events recorded on the launch
+// stream around each kernel, tagged with a kind and the ALGORITHMIC bytes of that launch
+// (SURVEY 8d formulas).  Inactive (one relaxed atomic load) unless enabled.
+// ---------------------------------------------------------------------------------------------
+enum MtlProfKind {
+    PK_NT_FWD_MAIN = 0,  // k_nt: all 1+T outputs         reads X, writes Y_*        es*(MK + (1+T)MN)
+    PK_NT_FWD_P = 1,     // k_nt: P = a D(X) A^T          reads x_t                  es*(T*x_t*MK)
+    PK_NT_BWD_Q = 2,     // k_nt: Q = a dY B              (re-read of dY)            0
+    PK_NT_BWD_DX = 3,    // k_nt: dX [+dX_t]              reads dY_*, writes dX_*    es*(n_dy*MN + (1+T*x_t)MK)
+    PK_TN = 4,           // k_tn: dA / dB                 reads X, x_t               es*((1+T*x_t)MK)
+    PK_ATTN_FWD = 5,     // k_attn_fwd                    qkv in, out                es*4*M*C
+    PK_ATTN_BWD = 6,     // k_attn_bwd                    qkv, dout in, dqkv out     es*7*M*C
+    PK_PACK = 7,
+    PK_REDUCE = 8,
+    PK_WINDOW = 9,
+    PK_COUNT = 16
+};
+int mtl_prof_start(int kind, double alg_bytes, hipStream_t s);
+void mtl_prof_stop(int idx, hipStream_t s);
+struct MtlProfScope {
+    int idx;
+    hipStream_t s;
+    MtlProfScope(int kind, double bytes, hipStream_t st) : idx(mtl_prof_start(kind, bytes, st)), s(st) {}
+    ~MtlProfScope() {
+        if (idx >= 0) mtl_prof_stop(idx, s);
+    }
+};

@@ -1,0 +1,1042 @@
+// linear.hip -- MTLoRALinear forward / backward on CDNA4 (gfx950).
+// Replaces the ATen sequence of models/lora.py:253-284 and its autograd backward.
+//
+// Kernel families (all hand-written MFMA, 64-wide waves, 256-thread workgroups):
+//
+//   k_pack   fp32 LoRA masters -> compute-dtype packed factors, every rank padded to 16:
+//              A_cat (R x K), B_cat (N x R), At_cat (K x R), Bt_cat (R x N), alpha (R)   R = sum_o rp(o)
+//   k_nt     "NT" tile GEMM  D[n][m] = sum_k Wgt[n][k] * Act[m][k]  with
+//              - multi-source activation (sum of up to 1+T tensors formed while staging: G = dY_s + sum dY_t)
+//              - optional dropout mask applied to the staged activation (P = alpha * D(X) A^T)
+//              - bias / per-row alpha epilogue
+//              - multi-output low-rank epilogue: for each output o, extra k-steps over the o-th rank
+//                segment of L (M x R) and R (N x R) chained onto the shared base accumulator
+//                (Y_o = base + L_o R_o^T), optionally masked (dX = G W + keep .* (Q A)).
+//            The MFMA "A" operand is the weight tile and "B" the activation tile, so a lane's four
+//            consecutive accumulator registers are four consecutive output COLUMNS -> 8/16-byte stores.
+//   k_tn     "TN" split-M reduction  Out[a][b] = sum_m SrcA[m][a] * SrcB[m][b]  (dA = Q^T D(X), dB = dY^T P):
+//            both operands are read with the LDS transpose load (ds_read_b64_tr_b16) for bf16;
+//            per-split partials (deterministic) + k_reduce.
+//
+// Forward  = k_pack, k_nt (P = alpha D(X) A^T, per source), k_nt (all 1+T outputs, base shared).
+// Backward = k_nt (Q = alpha dY_o B_o per output), k_nt (dX [+ dX_t]), k_tn (+ k_reduce) for dA/dB.
+#include "common.h"
+
+namespace {
+
+constexpr int TILE = 128;    // rows per CTA tile, both operands
+constexpr int ROWB = 64;     // payload bytes per row per k-tile (32 bf16 / 16 f32)
+constexpr int LDSB = 80;     // padded LDS row stride (conflict-free ds_read_b128, 16-B aligned)
+constexpr int MAXO = MTLORA_MAX_TASKS + 1;
+
+// ------------------------------------------------------------------------------------------------
+// segment table: output o (0 = shared, 1..T = tasks) owns columns [off, off + rp) of the rank axis
+// ------------------------------------------------------------------------------------------------
+struct Segs {
+    int n;  // 1 + T
+    int r[MAXO], rp[MAXO], off[MAXO];
+    int R;  // total padded rank
+};
+
+static Segs make_segs(const mtlora_linear_desc* d) {
+    Segs s;
+    s.n = 1 + d->T;
+    int off = 0;
+    for (int o = 0; o < s.n; ++o) {
+        int r = (o == 0) ? d->r_s : d->r_t[o - 1];
+        s.r[o] = r;
+        s.rp[o] = (int)mtl_round_up(r, 16);
+        s.off[o] = off;
+        off += s.rp[o];
+    }
+    for (int o = s.n; o < MAXO; ++o) s.r[o] = s.rp[o] = s.off[o] = 0;
+    s.R = off;
+    return s;
+}
+
+struct CtxLayout {
+    int64_t a_cat, b_cat, at_cat, bt_cat, alpha, p, total;
+};
+static CtxLayout ctx_layout(const mtlora_linear_desc* d, const Segs& s) {
+    const int es = mtl_elem_size(d->dtype);
+    CtxLayout L;
+    int64_t o = 0;
+    auto take = [&](int64_t bytes) {
+        int64_t at = o;
+        o += mtl_round_up(bytes, 256);
+        return at;
+    };
+    L.a_cat = take((int64_t)s.R * d->K * es);
+    L.b_cat = take((int64_t)d->N * s.R * es);
+    L.at_cat = take((int64_t)d->K * s.R * es);
+    L.bt_cat = take((int64_t)s.R * d->N * es);
+    L.alpha = take((int64_t)s.R * 4);
+    L.p = take(d->M * s.R * es);
+    L.total = o;
+    return L;
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_pack
+// ------------------------------------------------------------------------------------------------
+struct PackParams {
+    const float* A[MAXO];
+    const float* B[MAXO];
+    float alpha[MAXO];
+    Segs s;
+    int K, N;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_pack(PackParams p, T* a_cat, T* b_cat, T* at_cat, T* bt_cat, float* alpha) {
+    const int R = p.s.R;
+    const int64_t na = (int64_t)R * p.K, nb = (int64_t)R * p.N;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < na + nb + R; i += (int64_t)gridDim.x * 256) {
+        int64_t j = i < na ? i : (i < na + nb ? i - na : i - na - nb);
+        const int dim = i < na ? p.K : p.N;
+        int rr = (i < na + nb) ? (int)(j / dim) : (int)j;
+        int c = (i < na + nb) ? (int)(j % dim) : 0;
+        int o = 0;
+#pragma unroll
+        for (int q = 1; q < MAXO; ++q)
+            if (q < p.s.n && rr >= p.s.off[q]) o = q;
+        const int lr = rr - p.s.off[o];
+        const bool valid = lr < p.s.r[o];
+        if (i < na) {  // A_o[lr][c]  (r x K)
+            float v = (valid && p.A[o]) ? p.A[o][(int64_t)lr * p.K + c] : 0.f;
+            a_cat[(int64_t)rr * p.K + c] = mtl_from_f32<T>(v);
+            at_cat[(int64_t)c * R + rr] = mtl_from_f32<T>(v);
+        } else if (i < na + nb) {  // B_o[c][lr]  (N x r)
+            float v = (valid && p.B[o]) ? p.B[o][(int64_t)c * p.s.r[o] + lr] : 0.f;
+            b_cat[(int64_t)c * R + rr] = mtl_from_f32<T>(v);
+            bt_cat[(int64_t)rr * p.N + c] = mtl_from_f32<T>(v);
+        } else {
+            alpha[rr] = p.alpha[o];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_nt
+// ------------------------------------------------------------------------------------------------
+struct NtOut {
+    void* ptr;       // (M x ld_out) output, element type T
+    int seg_lo, seg_hi;  // rank-column range of L/R chained onto this output ([lo,hi) empty -> none)
+    int use_base;    // add the shared base accumulator
+    int mask_lr;     // multiply the low-rank part by the dropout keep mask of (m, n)
+    int fold;        // after storing: base += low-rank part ('matrixv2': tasks see the shared update)
+};
+
+struct NtParams {
+    // base GEMM
+    const void* act[MAXO];  // (M x K) sources, summed while staging
+    int n_act;
+    int act_mask;           // dropout keep-mask applied to the staged activation
+    int64_t ld_act;
+    const void* wgt;        // (n_rows x K)
+    int64_t ld_wgt;
+    int64_t M;
+    int n_rows;             // rows of wgt == output columns
+    int K;                  // reduction length of the base GEMM (0 -> no base GEMM)
+    const float* bias;      // per output column, nullable
+    const float* alpha;     // per output column multiplier on the base GEMM, nullable
+    // low-rank epilogue
+    const void* L;          // (M x ldL)
+    const void* Rm;         // (n_rows x ldR)
+    int64_t ldL, ldR;
+    int n_out;
+    NtOut out[MAXO];
+    int64_t ld_out;
+    // batched form (gridDim.z = nz > 0): z selects activation / weight row slab / output column slab
+    int nz;
+    const void* zact[MAXO];
+    int zrow0[MAXO], zrows[MAXO], zmask[MAXO];
+    DropoutCfg drop;
+};
+
+template <typename T>
+struct TileRegs {
+    u32x4 w[2], a[2];
+};
+
+// stage one 128-row x 64-byte k-tile of the weight-like and activation-like operands into registers
+template <typename T>
+__device__ __forceinline__ void nt_load(TileRegs<T>& rg, int tid, const T* wgt, int64_t ld_w, int w_row0, int w_rows,
+                                        const void* act0, const NtParams& P, int n_act, int64_t ld_a, int64_t a_row0,
+                                        int64_t a_rows, int k0, int k_hi, bool mask, const DropoutCfg& dc) {
+    constexpr int VEC = ET<T>::VEC;
+    const int v = tid & 3;
+    const int k = k0 + v * VEC;
+    const bool kin = k < k_hi;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = (tid >> 2) + i * 64;
+        // weights
+        const int wr = w_row0 + r;
+        rg.w[i] = (kin && wr < w_rows) ? *reinterpret_cast<const u32x4*>(wgt + (int64_t)wr * ld_w + k)
+                                       : u32x4{0u, 0u, 0u, 0u};
+        // activations
+        const int64_t ar = a_row0 + r;
+        if (kin && ar < a_rows) {
+            Vec16<T> x = mtl_ld16<T>(reinterpret_cast<const T*>(act0) + ar * ld_a + k);
+            if (n_act > 1) {
+                float f[VEC];
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) f[e] = mtl_to_f32(x.e[e]);
+#pragma unroll
+                for (int s = 1; s < MAXO; ++s) {
+                    if (s < n_act) {
+                        Vec16<T> y = mtl_ld16<T>(reinterpret_cast<const T*>(P.act[s]) + ar * ld_a + k);
+#pragma unroll
+                        for (int e = 0; e < VEC; ++e) f[e] += mtl_to_f32(y.e[e]);
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) x.e[e] = mtl_from_f32<T>(f[e]);
+            }
+            if (mask) {
+                const uint32_t rh = mtl_dropout_rowhash(dc, 0u, (uint32_t)ar);
+#pragma unroll
+                for (int e = 0; e < VEC; e += 2) {
+                    const uint32_t h = mtl_dropout_pairbits(dc, rh, (uint32_t)(k + e));
+                    if ((h & 0xFFFFu) < dc.thr16) x.e[e] = mtl_from_f32<T>(0.f);
+                    if ((h >> 16) < dc.thr16) x.e[e + 1] = mtl_from_f32<T>(0.f);
+                }
+            }
+            rg.a[i] = x.raw;
+        } else {
+            rg.a[i] = u32x4{0u, 0u, 0u, 0u};
+        }
+    }
+}
+
+template <typename T>
+__device__ __forceinline__ void nt_store_lds(const TileRegs<T>& rg, int tid, unsigned char* sW, unsigned char* sA) {
+    const int v = tid & 3;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = (tid >> 2) + i * 64;
+        *reinterpret_cast<u32x4*>(sW + r * LDSB + v * 16) = rg.w[i];
+        *reinterpret_cast<u32x4*>(sA + r * LDSB + v * 16) = rg.a[i];
+    }
+}
+
+template <typename T>
+__device__ __forceinline__ void nt_compute(f32x16 (&acc)[2][2], const unsigned char* sW, const unsigned char* sA,
+                                           int lane, int wn, int wm) {
+    const int h = lane >> 5, rl = lane & 31;
+    Frag<T> fw[2], fa[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const unsigned char* pw = sW + (wn * 64 + s * 32 + rl) * LDSB;
+        const unsigned char* pa = sA + (wm * 64 + s * 32 + rl) * LDSB;
+        fw[s].v[0] = *reinterpret_cast<const u32x4*>(pw + h * 16);
+        fw[s].v[1] = *reinterpret_cast<const u32x4*>(pw + (2 + h) * 16);
+        fa[s].v[0] = *reinterpret_cast<const u32x4*>(pa + h * 16);
+        fa[s].v[1] = *reinterpret_cast<const u32x4*>(pa + (2 + h) * 16);
+    }
+#pragma unroll
+    for (int sn = 0; sn < 2; ++sn)
+#pragma unroll
+        for (int sm = 0; sm < 2; ++sm) mtl_mma(fw[sn], fa[sm], acc[sn][sm]);
+}
+
+// acc += Wgt[n0.., k_lo..k_hi) * Act[m0.., k_lo..k_hi)^T   (register-prefetched, 2 barriers per k-tile)
+template <typename T>
+__device__ __forceinline__ void nt_loop(f32x16 (&acc)[2][2], unsigned char* smem, int tid, const T* wgt, int64_t ld_w,
+                                        int w_row0, int w_rows, const void* act0, const NtParams& P, int n_act,
+                                        int64_t ld_a, int64_t a_row0, int64_t a_rows, int k_lo, int k_hi, bool mask,
+                                        const DropoutCfg& dc) {
+    constexpr int KE = ROWB / (int)sizeof(T);
+    unsigned char* sW = smem;
+    unsigned char* sA = smem + TILE * LDSB;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wn = wave >> 1, wm = wave & 1;
+    if (k_hi <= k_lo) return;
+    TileRegs<T> rg;
+    nt_load<T>(rg, tid, wgt, ld_w, w_row0, w_rows, act0, P, n_act, ld_a, a_row0, a_rows, k_lo, k_hi, mask, dc);
+    for (int k0 = k_lo; k0 < k_hi; k0 += KE) {
+        nt_store_lds<T>(rg, tid, sW, sA);
+        __syncthreads();
+        if (k0 + KE < k_hi)
+            nt_load<T>(rg, tid, wgt, ld_w, w_row0, w_rows, act0, P, n_act, ld_a, a_row0, a_rows, k0 + KE, k_hi, mask,
+                       dc);
+        nt_compute<T>(acc, sW, sA, lane, wn, wm);
+        __syncthreads();
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256, 2) void k_nt(const NtParams P) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * TILE * LDSB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wn = wave >> 1, wm = wave & 1;
+
+    // batched form
+    const void* act0 = P.act[0];
+    int row_off = 0, n_rows = P.n_rows;
+    bool act_mask = P.act_mask != 0;
+    if (P.nz > 0) {
+        const int z = blockIdx.z;  // static-index select chain: a dynamic index would copy P to scratch
+#pragma unroll
+        for (int q = 0; q < MAXO; ++q)
+            if (q == z) {
+                act0 = P.zact[q];
+                row_off = P.zrow0[q];
+                n_rows = P.zrows[q];
+                act_mask = P.zmask[q] != 0;
+            }
+    }
+    if (n_rows <= 0) return;
+    act_mask = act_mask && P.drop.enabled();
+
+    // XCD-aware tile order: hardware places block b on XCD b % 8; give every XCD a contiguous run of
+    // logical tiles so that the n-tiles sharing one activation row-block hit the same L2 (T1, bijective).
+    const int n_tiles = (n_rows + TILE - 1) / TILE;
+    const int64_t m_tiles = (P.M + TILE - 1) / TILE;
+    const int64_t nwg = m_tiles * n_tiles;
+    int64_t b = blockIdx.x;
+    if (b >= nwg) return;
+    {
+        const int64_t q = nwg / 8, r = nwg % 8, xcd = b % 8;
+        b = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + b / 8;
+    }
+    const int64_t bm = b / n_tiles;
+    const int bn = (int)(b % n_tiles);
+    const int64_t m0 = bm * TILE;
+    const int n0 = bn * TILE;
+
+    const T* wgt = reinterpret_cast<const T*>(P.wgt) + (int64_t)row_off * P.ld_wgt;
+
+    f32x16 base[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) base[i][j][r] = 0.f;
+
+    if (P.K > 0)
+        nt_loop<T>(base, smem, tid, wgt, P.ld_wgt, n0, n_rows, act0, P, P.n_act, P.ld_act, m0, P.M, 0, P.K, act_mask,
+                   P.drop);
+
+    // per-column alpha / bias on the base
+    if (P.alpha || P.bias) {
+#pragma unroll
+        for (int sn = 0; sn < 2; ++sn)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n = n0 + wn * 64 + sn * 32 + 8 * q + 4 * (lane >> 5);
+                if (n < n_rows) {
+                    f32x4 al = {1.f, 1.f, 1.f, 1.f}, bi = {0.f, 0.f, 0.f, 0.f};
+                    if (P.alpha) al = *reinterpret_cast<const f32x4*>(P.alpha + row_off + n);
+                    if (P.bias) bi = *reinterpret_cast<const f32x4*>(P.bias + row_off + n);
+#pragma unroll
+                    for (int sm = 0; sm < 2; ++sm)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) base[sn][sm][q * 4 + e] = base[sn][sm][q * 4 + e] * al[e] + bi[e];
+                }
+            }
+    }
+
+    for (int o = 0; o < P.n_out; ++o) {
+        NtOut O = P.out[0];
+#pragma unroll
+        for (int q = 1; q < MAXO; ++q)
+            if (q == o) O = P.out[q];
+        f32x16 lr[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) lr[i][j][r] = 0.f;
+        const bool has_lr = O.seg_hi > O.seg_lo;
+        if (has_lr)
+            nt_loop<T>(lr, smem, tid, reinterpret_cast<const T*>(P.Rm), P.ldR, n0, n_rows, P.L, P, 1, P.ldL, m0, P.M,
+                       O.seg_lo, O.seg_hi, false, P.drop);
+        const bool mask_lr = O.mask_lr && P.drop.enabled() && has_lr;
+        T* outp = reinterpret_cast<T*>(O.ptr);
+#pragma unroll
+        for (int sm = 0; sm < 2; ++sm) {
+            const int64_t m = m0 + wm * 64 + sm * 32 + (lane & 31);
+            const uint32_t rh = mask_lr ? mtl_dropout_rowhash(P.drop, 0u, (uint32_t)m) : 0u;
+#pragma unroll
+            for (int sn = 0; sn < 2; ++sn)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int n = n0 + wn * 64 + sn * 32 + 8 * q + 4 * (lane >> 5);
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = lr[sn][sm][q * 4 + e];
+                    if (mask_lr) {
+                        const uint32_t h0 = mtl_dropout_pairbits(P.drop, rh, (uint32_t)n);
+                        const uint32_t h1 = mtl_dropout_pairbits(P.drop, rh, (uint32_t)(n + 2));
+                        if ((h0 & 0xFFFFu) < P.drop.thr16) v[0] = 0.f;
+                        if ((h0 >> 16) < P.drop.thr16) v[1] = 0.f;
+                        if ((h1 & 0xFFFFu) < P.drop.thr16) v[2] = 0.f;
+                        if ((h1 >> 16) < P.drop.thr16) v[3] = 0.f;
+                    }
+                    if (O.use_base) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += base[sn][sm][q * 4 + e];
+                    }
+                    if (O.fold) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) base[sn][sm][q * 4 + e] = v[e];
+                    }
+                    if (m < P.M && n < n_rows && outp) {
+                        T* dst = outp + m * P.ld_out + row_off + n;
+                        if constexpr (sizeof(T) == 4) {
+                            *reinterpret_cast<f32x4*>(dst) = f32x4{v[0], v[1], v[2], v[3]};
+                        } else {
+                            bf16x4 pk = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+                            *reinterpret_cast<bf16x4*>(dst) = pk;
+                        }
+                    }
+                }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_tn : Out[a][b] = sum_m SrcA[m][a0 + a] * SrcB[m][b0 + b]   (64 x 64 tiles, split over m)
+// ------------------------------------------------------------------------------------------------
+constexpr int TN_T = 64;
+struct TnProblem {
+    const void* A;
+    const void* B;
+    int64_t lda, ldb;
+    int a0, Na, b0, Nb;  // column windows
+    int b_mask;          // dropout keep-mask on SrcB (keyed by (m, b0 + b))
+    int tiles_a, tiles_b;
+    float* part;         // [nsplit][tiles_a*tiles_b][64*64]
+    float* out;          // (Na_valid x Nb_valid) fp32, ld = ldo
+    int out_rows, out_cols, ldo;
+};
+struct TnParams {
+    TnProblem p[2 * MAXO];
+    int n_prob;
+    int64_t M;
+    int nsplit;
+    int64_t rows_per_split;
+    DropoutCfg drop;
+};
+
+template <typename T>
+struct TnCfg;
+template <>
+struct TnCfg<bf16> {
+    static constexpr int KE = 32;      // rows (m) per chunk
+    static constexpr int LDS_ROW = 144;  // bytes: 64 cols * 2 + 16 pad
+};
+template <>
+struct TnCfg<float> {
+    static constexpr int KE = 16;
+    static constexpr int LDS_ROW = 272;  // 64 * 4 + 16
+};
+
+// transposed fragment: lane (i = l & 31, h = l >> 5) gets Src[m = slot(h, e)][col0 + i]
+__device__ __forceinline__ Frag<bf16> tn_frag(const unsigned char* s, int col0, int lane, bf16*) {
+    // ds_read_b64_tr_b16: within each 16-lane group, lane i supplies the 8-byte address of row (i>>2),
+    // columns 4*(i&3)..+3 of a [4][16] block and receives column i of that block (4 rows).
+    const int g = lane >> 4, i = lane & 15, h = g >> 1;
+    const int col = col0 + 16 * (g & 1) + 4 * (i & 3);
+    Frag<bf16> f;
+    uint32_t w[8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {  // rows: {8h+0..3}, {8h+4..7}, {16+8h+0..3}, {16+8h+4..7}
+        const int row = ((j >> 1) * 16) + 8 * h + 4 * (j & 1) + (i >> 2);
+        const unsigned char* p = s + row * TnCfg<bf16>::LDS_ROW + col * 2;
+        s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) s16x4*)(p));
+        u32x2 u = __builtin_bit_cast(u32x2, v);
+        w[2 * j] = u[0];
+        w[2 * j + 1] = u[1];
+    }
+    f.v[0] = u32x4{w[0], w[1], w[2], w[3]};
+    f.v[1] = u32x4{w[4], w[5], w[6], w[7]};
+    return f;
+}
+__device__ __forceinline__ Frag<float> tn_frag(const unsigned char* s, int col0, int lane, float*) {
+    const int h = lane >> 5, i = lane & 31;
+    Frag<float> f;
+    uint32_t w[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {  // rows {4h..4h+3} U {8+4h..8+4h+3}
+        const int row = (e >> 2) * 8 + 4 * h + (e & 3);
+        w[e] = *reinterpret_cast<const uint32_t*>(s + row * TnCfg<float>::LDS_ROW + (col0 + i) * 4);
+    }
+    f.v[0] = u32x4{w[0], w[1], w[2], w[3]};
+    f.v[1] = u32x4{w[4], w[5], w[6], w[7]};
+    return f;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_tn(const TnParams P) {
+    constexpr int KE = TnCfg<T>::KE;
+    constexpr int LR = TnCfg<T>::LDS_ROW;
+    constexpr int VEC = ET<T>::VEC;
+    constexpr int VPR = TN_T / VEC;  // 16-byte vectors per tile row
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * KE * LR];
+    unsigned char* sA = smem;
+    unsigned char* sB = smem + KE * LR;
+    const TnProblem& pr = P.p[blockIdx.z];
+    const int tile = blockIdx.y;
+    if (tile >= pr.tiles_a * pr.tiles_b) return;
+    const int ta = tile / pr.tiles_b, tb = tile % pr.tiles_b;
+    const int split = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int sa = wave >> 1, sb = wave & 1;
+
+    const int64_t m_lo = (int64_t)split * P.rows_per_split;
+    int64_t m_hi = m_lo + P.rows_per_split;
+    if (m_hi > P.M) m_hi = P.M;
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+    // loader coordinates: one 16-byte vector per operand per thread (f32: KE*VPR = 256 too)
+    const int lrow = tid / VPR, lvec = tid % VPR;
+    const int ca = ta * TN_T + lvec * VEC;  // column inside the A window
+    const int cb = tb * TN_T + lvec * VEC;
+    const bool a_in = ca < pr.Na, b_in = cb < pr.Nb;
+    const T* Ap = reinterpret_cast<const T*>(pr.A) + pr.a0 + ca;
+    const T* Bp = reinterpret_cast<const T*>(pr.B) + pr.b0 + cb;
+    const bool bmask = pr.b_mask && P.drop.enabled();
+
+    auto load = [&](int64_t mrow, u32x4& ra, u32x4& rb) {
+        const int64_t m = mrow + lrow;
+        ra = (a_in && m < m_hi) ? *reinterpret_cast<const u32x4*>(Ap + m * pr.lda) : u32x4{0u, 0u, 0u, 0u};
+        if (b_in && m < m_hi) {
+            Vec16<T> x = mtl_ld16<T>(Bp + m * pr.ldb);
+            if (bmask) {
+                const uint32_t rh = mtl_dropout_rowhash(P.drop, 0u, (uint32_t)m);
+#pragma unroll
+                for (int e = 0; e < VEC; e += 2) {
+                    const uint32_t h = mtl_dropout_pairbits(P.drop, rh, (uint32_t)(pr.b0 + cb + e));
+                    if ((h & 0xFFFFu) < P.drop.thr16) x.e[e] = mtl_from_f32<T>(0.f);
+                    if ((h >> 16) < P.drop.thr16) x.e[e + 1] = mtl_from_f32<T>(0.f);
+                }
+            }
+            rb = x.raw;
+        } else {
+            rb = u32x4{0u, 0u, 0u, 0u};
+        }
+    };
+
+    u32x4 ra, rb;
+    if (m_lo < m_hi) load(m_lo, ra, rb);
+    for (int64_t mrow = m_lo; mrow < m_hi; mrow += KE) {
+        *reinterpret_cast<u32x4*>(sA + lrow * LR + lvec * 16) = ra;
+        *reinterpret_cast<u32x4*>(sB + lrow * LR + lvec * 16) = rb;
+        __syncthreads();
+        if (mrow + KE < m_hi) load(mrow + KE, ra, rb);
+        Frag<T> fa = tn_frag(sA, sa * 32, lane, (T*)nullptr);
+        Frag<T> fb = tn_frag(sB, sb * 32, lane, (T*)nullptr);
+        mtl_mma(fa, fb, acc);
+        __syncthreads();
+    }
+
+    float* dst = pr.part + ((int64_t)split * (pr.tiles_a * pr.tiles_b) + tile) * (TN_T * TN_T);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int i = sa * 32 + mtl_d_row(lane, r), j = sb * 32 + mtl_d_col(lane);
+        dst[i * TN_T + j] = acc[r];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_tn_reduce(const TnParams P) {
+    const TnProblem& pr = P.p[blockIdx.y];
+    const int64_t total = (int64_t)pr.out_rows * pr.out_cols;
+    const int ntile = pr.tiles_a * pr.tiles_b;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int a = (int)(i / pr.out_cols), b = (int)(i % pr.out_cols);
+        const int tile = (a / TN_T) * pr.tiles_b + b / TN_T;
+        const float* src = pr.part + (int64_t)tile * (TN_T * TN_T) + (a % TN_T) * TN_T + (b % TN_T);
+        float s = 0.f;
+        for (int sp = 0; sp < P.nsplit; ++sp) s += src[(int64_t)sp * ntile * (TN_T * TN_T)];
+        pr.out[(int64_t)a * pr.ldo + b] = s;
+    }
+}
+
+// elementwise sum of up to MAXO tensors (matrixv2 backward: G for the shared factors)
+struct SumParams {
+    const void* src[MAXO];
+    int n;
+    int64_t nvec;
+};
+template <typename T>
+__global__ __launch_bounds__(256) void k_sum(SumParams P, T* out) {
+    constexpr int VEC = ET<T>::VEC;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < P.nvec; i += (int64_t)gridDim.x * 256) {
+        float f[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) f[e] = 0.f;
+        for (int s = 0; s < P.n; ++s) {
+            Vec16<T> y = mtl_ld16<T>(reinterpret_cast<const T*>(P.src[s]) + i * VEC);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) f[e] += mtl_to_f32(y.e[e]);
+        }
+        Vec16<T> o;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) o.e[e] = mtl_from_f32<T>(f[e]);
+        *reinterpret_cast<u32x4*>(out + i * VEC) = o.raw;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+static int check_desc(const mtlora_linear_desc* d) {
+    if (!d) return MTLORA_ERR_NULL;
+    if (d->dtype != MTLORA_F32 && d->dtype != MTLORA_BF16) return MTLORA_ERR_DTYPE;
+    if (d->M < 0 || d->K <= 0 || d->N <= 0 || d->T < 0 || d->T > MTLORA_MAX_TASKS || d->r_s < 0)
+        return MTLORA_ERR_SHAPE;
+    if (d->M >= ((int64_t)1 << 31)) return MTLORA_ERR_SHAPE;
+    const int vec = d->dtype == MTLORA_F32 ? 4 : 8;
+    if (d->K % vec || d->N % vec) return MTLORA_ERR_ALIGN;
+    for (int t = 0; t < d->T; ++t)
+        if (d->r_t[t] <= 0) return MTLORA_ERR_SHAPE;
+    if (d->mode != 0 && d->mode != 1) return MTLORA_ERR_UNSUPPORTED;
+    if (d->dropout_p < 0.f || d->dropout_p >= 1.f) return MTLORA_ERR_SHAPE;
+    return MTLORA_OK;
+}
+
+static bool misaligned(const void* p) { return ((uintptr_t)p & 15u) != 0; }
+
+template <typename T>
+static void launch_nt(const NtParams& P, hipStream_t s, int kind, double alg_bytes) {
+    MtlProfScope prof(kind, alg_bytes, s);
+    int max_rows = P.n_rows;
+    if (P.nz > 0) {
+        max_rows = 0;
+        for (int z = 0; z < P.nz; ++z) max_rows = P.zrows[z] > max_rows ? P.zrows[z] : max_rows;
+    }
+    const int64_t m_tiles = mtl_ceil_div(P.M, TILE);
+    const int64_t n_tiles = mtl_ceil_div(max_rows, TILE);
+    if (m_tiles * n_tiles == 0) return;
+    dim3 g((unsigned)(m_tiles * n_tiles), 1, (unsigned)(P.nz > 0 ? P.nz : 1));
+    hipLaunchKernelGGL(k_nt<T>, g, dim3(256), 0, s, P);
+}
+
+template <typename T>
+static int fwd_impl(const mtlora_linear_desc* d, const void* x, const void* const* x_t, const void* W,
+                    const float* bias, const float* A_s, const float* B_s, const float* const* A_t,
+                    const float* const* B_t, void* y_s, void* const* y_t, void* ctx, hipStream_t s) {
+    const Segs sg = make_segs(d);
+    const CtxLayout L = ctx_layout(d, sg);
+    unsigned char* c = reinterpret_cast<unsigned char*>(ctx);
+    T* a_cat = reinterpret_cast<T*>(c + L.a_cat);
+    T* b_cat = reinterpret_cast<T*>(c + L.b_cat);
+    T* at_cat = reinterpret_cast<T*>(c + L.at_cat);
+    T* bt_cat = reinterpret_cast<T*>(c + L.bt_cat);
+    float* alpha = reinterpret_cast<float*>(c + L.alpha);
+    T* Pm = reinterpret_cast<T*>(c + L.p);
+    const DropoutCfg dc = mtl_make_dropout(d->dropout_p, d->seed);
+    const float keep_scale = dc.enabled() ? 1.f / (1.f - d->dropout_p) : 1.f;
+
+    if (sg.R > 0) {
+        PackParams pp;
+        pp.s = sg;
+        pp.K = (int)d->K;
+        pp.N = (int)d->N;
+        for (int o = 0; o < MAXO; ++o) {
+            pp.A[o] = nullptr;
+            pp.B[o] = nullptr;
+            pp.alpha[o] = 0.f;
+        }
+        pp.A[0] = A_s;
+        pp.B[0] = B_s;
+        pp.alpha[0] = d->scale_s * keep_scale;
+        for (int t = 0; t < d->T; ++t) {
+            pp.A[t + 1] = A_t[t];
+            pp.B[t + 1] = B_t[t];
+            pp.alpha[t + 1] = d->scale_t[t] * (d->has_x_tasks ? 1.f : keep_scale);
+        }
+        const int64_t work = (int64_t)sg.R * (d->K + d->N + 1);
+        int64_t blocks = mtl_ceil_div(work, 256);
+        if (blocks > 2048) blocks = 2048;
+        {
+            MtlProfScope prof(PK_PACK, 0.0, s);
+            hipLaunchKernelGGL(k_pack<T>, dim3((unsigned)blocks), dim3(256), 0, s, pp, a_cat, b_cat, at_cat, bt_cat,
+                               alpha);
+        }
+
+        // P = alpha * D(X) A^T  (per source)
+        NtParams q = {};
+        q.n_act = 1;
+        q.ld_act = d->K;
+        q.wgt = a_cat;
+        q.ld_wgt = d->K;
+        q.M = d->M;
+        q.K = (int)d->K;
+        q.alpha = alpha;
+        q.n_out = 1;
+        q.out[0].ptr = Pm;
+        q.out[0].use_base = 1;
+        q.ld_out = sg.R;
+        q.drop = dc;
+        if (d->T > 0 && d->has_x_tasks) {
+            q.nz = 0;
+            for (int o = 0; o < sg.n; ++o) {
+                if (sg.rp[o] == 0) continue;
+                q.zact[q.nz] = (o == 0) ? x : x_t[o - 1];
+                q.zrow0[q.nz] = sg.off[o];
+                q.zrows[q.nz] = sg.rp[o];
+                q.zmask[q.nz] = (o == 0) ? 1 : 0;
+                ++q.nz;
+            }
+            q.n_rows = 0;
+        } else {
+            q.act[0] = x;
+            q.act_mask = 1;
+            q.n_rows = sg.R;
+            q.nz = 0;
+        }
+        launch_nt<T>(q, s, PK_NT_FWD_P, (double)sizeof(T) * (d->has_x_tasks ? d->T : 0) * d->M * d->K);
+    }
+
+    // all outputs
+    NtParams m = {};
+    m.act[0] = x;
+    m.n_act = 1;
+    m.ld_act = d->K;
+    m.wgt = W;
+    m.ld_wgt = d->K;
+    m.M = d->M;
+    m.n_rows = (int)d->N;
+    m.K = (int)d->K;
+    m.bias = bias;
+    m.L = Pm;
+    m.ldL = sg.R;
+    m.Rm = b_cat;
+    m.ldR = sg.R;
+    m.ld_out = d->N;
+    m.drop = dc;
+    m.n_out = 1 + d->T;
+    for (int o = 0; o < sg.n; ++o) {
+        NtOut& O = m.out[o];
+        O.ptr = (o == 0) ? y_s : y_t[o - 1];
+        O.seg_lo = sg.off[o];
+        O.seg_hi = sg.off[o] + sg.rp[o];
+        O.use_base = 1;
+        O.mask_lr = 0;
+        O.fold = (o == 0 && d->mode == 1 && d->T > 0) ? 1 : 0;
+    }
+    launch_nt<T>(m, s, PK_NT_FWD_MAIN, (double)sizeof(T) * d->M * (d->K + (double)(1 + d->T) * d->N));
+    return MTLORA_OK;
+}
+
+struct BwdScratch {
+    int64_t q, g, part, total;
+    int nsplit;
+    int64_t rows_per_split;
+};
+static BwdScratch bwd_scratch(const mtlora_linear_desc* d, const Segs& sg) {
+    const int es = mtl_elem_size(d->dtype);
+    BwdScratch S;
+    int64_t o = 0;
+    auto take = [&](int64_t bytes) {
+        int64_t at = o;
+        o += mtl_round_up(bytes, 256);
+        return at;
+    };
+    S.q = take(d->M * sg.R * es);
+    S.g = take((d->mode == 1 && d->T > 0) ? d->M * d->N * es : 0);
+    // TN tiles
+    int64_t tiles = 0;
+    for (int oo = 0; oo < sg.n; ++oo) {
+        if (sg.rp[oo] == 0) continue;
+        tiles += mtl_ceil_div(d->N, TN_T) * mtl_ceil_div(sg.rp[oo], TN_T);  // dB
+        tiles += mtl_ceil_div(sg.rp[oo], TN_T) * mtl_ceil_div(d->K, TN_T);  // dA
+    }
+    int nsplit = 1;
+    if (tiles > 0) {
+        nsplit = (int)(2048 / tiles);
+        const int64_t max_by_rows = mtl_ceil_div(d->M, 256);  // at least 256 rows per split
+        if (nsplit > max_by_rows) nsplit = (int)max_by_rows;
+        if (nsplit > 128) nsplit = 128;
+        if (nsplit < 1) nsplit = 1;
+    }
+    S.nsplit = nsplit;
+    int64_t rps = mtl_ceil_div(d->M > 0 ? d->M : 1, nsplit);
+    rps = mtl_round_up(rps, 32);
+    S.rows_per_split = rps;
+    S.part = take(tiles * nsplit * (int64_t)(TN_T * TN_T) * 4);
+    S.total = o;
+    return S;
+}
+
+template <typename T>
+static int bwd_impl(const mtlora_linear_desc* d, const void* x, const void* const* x_t, const void* Wt,
+                    const void* dy_s, const void* const* dy_t, const void* ctx, void* dx, void* const* dx_t,
+                    float* dA_s, float* dB_s, float* const* dA_t, float* const* dB_t, void* scratch, hipStream_t s) {
+    const Segs sg = make_segs(d);
+    const CtxLayout L = ctx_layout(d, sg);
+    const BwdScratch S = bwd_scratch(d, sg);
+    const unsigned char* c = reinterpret_cast<const unsigned char*>(ctx);
+    const T* at_cat = reinterpret_cast<const T*>(c + L.at_cat);
+    const T* bt_cat = reinterpret_cast<const T*>(c + L.bt_cat);
+    const float* alpha = reinterpret_cast<const float*>(c + L.alpha);
+    const T* Pm = reinterpret_cast<const T*>(c + L.p);
+    unsigned char* sc = reinterpret_cast<unsigned char*>(scratch);
+    T* Qm = reinterpret_cast<T*>(sc + S.q);
+    T* Gm = reinterpret_cast<T*>(sc + S.g);
+    float* part = reinterpret_cast<float*>(sc + S.part);
+    const DropoutCfg dc = mtl_make_dropout(d->dropout_p, d->seed);
+    const bool v2 = d->mode == 1 && d->T > 0;
+
+    // gradient sources per output
+    const void* dy[MAXO];
+    dy[0] = dy_s;
+    for (int t = 0; t < d->T; ++t) dy[t + 1] = dy_t ? dy_t[t] : nullptr;
+    int n_dy = 0;
+    const void* dy_all[MAXO];
+    for (int o = 0; o < sg.n; ++o)
+        if (dy[o]) dy_all[n_dy++] = dy[o];
+
+    // matrixv2: the shared factors see G = sum of every output gradient
+    const void* dy_shared = dy[0];
+    if (v2 && n_dy > 0) {
+        if (n_dy == 1) {
+            dy_shared = dy_all[0];
+        } else {
+            SumParams sp;
+            sp.n = n_dy;
+            for (int i = 0; i < n_dy; ++i) sp.src[i] = dy_all[i];
+            sp.nvec = d->M * d->N / ET<T>::VEC;
+            int64_t blocks = mtl_ceil_div(sp.nvec, 256);
+            if (blocks > 4096) blocks = 4096;
+            hipLaunchKernelGGL(k_sum<T>, dim3((unsigned)blocks), dim3(256), 0, s, sp, Gm);
+            dy_shared = Gm;
+        }
+    }
+    const void* dyo[MAXO];  // gradient feeding factor o
+    for (int o = 0; o < sg.n; ++o) dyo[o] = (o == 0) ? dy_shared : dy[o];
+
+    // Q[:, seg_o] = alpha_o * dY_o B_o   (zero where the output got no gradient)
+    if (sg.R > 0) {
+        bool any_missing = false;
+        for (int o = 0; o < sg.n; ++o)
+            if (sg.rp[o] > 0 && !dyo[o]) any_missing = true;
+        if (any_missing) hipMemsetAsync(Qm, 0, (size_t)(d->M * sg.R * sizeof(T)), s);
+        NtParams q = {};
+        q.n_act = 1;
+        q.ld_act = d->N;
+        q.wgt = bt_cat;
+        q.ld_wgt = d->N;
+        q.M = d->M;
+        q.K = (int)d->N;
+        q.alpha = alpha;
+        q.n_out = 1;
+        q.out[0].ptr = Qm;
+        q.out[0].use_base = 1;
+        q.ld_out = sg.R;
+        q.drop = dc;
+        q.nz = 0;
+        for (int o = 0; o < sg.n; ++o) {
+            if (sg.rp[o] == 0 || !dyo[o]) continue;
+            q.zact[q.nz] = dyo[o];
+            q.zrow0[q.nz] = sg.off[o];
+            q.zrows[q.nz] = sg.rp[o];
+            q.zmask[q.nz] = 0;
+            ++q.nz;
+        }
+        if (q.nz > 0) launch_nt<T>(q, s, PK_NT_BWD_Q, 0.0);
+    }
+
+    // dX = G W + keep .* (Q_s A_s [+ sum_t Q_t A_t]),  dX_t = Q_t A_t
+    {
+        NtParams m = {};
+        m.n_act = n_dy;
+        for (int i = 0; i < n_dy; ++i) m.act[i] = dy_all[i];
+        m.ld_act = d->N;
+        m.wgt = Wt;
+        m.ld_wgt = d->N;
+        m.M = d->M;
+        m.n_rows = (int)d->K;
+        m.K = n_dy > 0 ? (int)d->N : 0;
+        m.L = Qm;
+        m.ldL = sg.R;
+        m.Rm = at_cat;
+        m.ldR = sg.R;
+        m.ld_out = d->K;
+        m.drop = dc;
+        m.n_out = 1;
+        NtOut& O = m.out[0];
+        O.ptr = dx;
+        O.use_base = 1;
+        O.mask_lr = 1;
+        if (d->T > 0 && d->has_x_tasks) {
+            O.seg_lo = sg.off[0];
+            O.seg_hi = sg.off[0] + sg.rp[0];
+            for (int t = 0; t < d->T; ++t) {
+                if (!dx_t || !dx_t[t]) continue;
+                NtOut& Ot = m.out[m.n_out++];
+                Ot.ptr = dx_t[t];
+                Ot.seg_lo = sg.off[t + 1];
+                Ot.seg_hi = sg.off[t + 1] + sg.rp[t + 1];
+                Ot.use_base = 0;
+                Ot.mask_lr = 0;
+                Ot.fold = 0;
+            }
+        } else {
+            O.seg_lo = 0;
+            O.seg_hi = sg.R;
+        }
+        if (dx)
+            launch_nt<T>(m, s, PK_NT_BWD_DX,
+                         (double)sizeof(T) * d->M * ((double)n_dy * d->N + (double)(1 + (d->has_x_tasks ? d->T : 0)) * d->K));
+    }
+
+    // dA_o = Q_o^T D(X_o),  dB_o = dY_o^T P_o
+    if (sg.R > 0) {
+        TnParams tp = {};
+        tp.M = d->M;
+        tp.nsplit = S.nsplit;
+        tp.rows_per_split = S.rows_per_split;
+        tp.drop = dc;
+        float* pp = part;
+        int max_tiles = 0;
+        for (int o = 0; o < sg.n; ++o) {
+            if (sg.rp[o] == 0 || !dyo[o]) continue;
+            float* dAo = (o == 0) ? dA_s : (dA_t ? dA_t[o - 1] : nullptr);
+            float* dBo = (o == 0) ? dB_s : (dB_t ? dB_t[o - 1] : nullptr);
+            if (dBo) {  // (N x r_o) = dY_o^T (M x N)  .  P[:, seg_o]
+                TnProblem& p = tp.p[tp.n_prob++];
+                p.A = dyo[o];
+                p.lda = d->N;
+                p.a0 = 0;
+                p.Na = (int)d->N;
+                p.B = Pm;
+                p.ldb = sg.R;
+                p.b0 = sg.off[o];
+                p.Nb = sg.rp[o];
+                p.b_mask = 0;
+                p.tiles_a = (int)mtl_ceil_div(p.Na, TN_T);
+                p.tiles_b = (int)mtl_ceil_div(p.Nb, TN_T);
+                p.part = pp;
+                pp += (int64_t)p.tiles_a * p.tiles_b * S.nsplit * (TN_T * TN_T);
+                p.out = dBo;
+                p.out_rows = (int)d->N;
+                p.out_cols = sg.r[o];
+                p.ldo = sg.r[o];
+                if (p.tiles_a * p.tiles_b > max_tiles) max_tiles = p.tiles_a * p.tiles_b;
+            }
+            if (dAo) {  // (r_o x K) = Q[:, seg_o]^T . D(X_o)
+                TnProblem& p = tp.p[tp.n_prob++];
+                p.A = Qm;
+                p.lda = sg.R;
+                p.a0 = sg.off[o];
+                p.Na = sg.rp[o];
+                const bool own_x = (o > 0 && d->has_x_tasks);
+                p.B = own_x ? x_t[o - 1] : x;
+                p.ldb = d->K;
+                p.b0 = 0;
+                p.Nb = (int)d->K;
+                p.b_mask = own_x ? 0 : 1;
+                p.tiles_a = (int)mtl_ceil_div(p.Na, TN_T);
+                p.tiles_b = (int)mtl_ceil_div(p.Nb, TN_T);
+                p.part = pp;
+                pp += (int64_t)p.tiles_a * p.tiles_b * S.nsplit * (TN_T * TN_T);
+                p.out = dAo;
+                p.out_rows = sg.r[o];
+                p.out_cols = (int)d->K;
+                p.ldo = (int)d->K;
+                if (p.tiles_a * p.tiles_b > max_tiles) max_tiles = p.tiles_a * p.tiles_b;
+            }
+        }
+        if (tp.n_prob > 0 && d->M > 0) {
+            {
+                MtlProfScope prof(PK_TN, (double)sizeof(T) * d->M * (double)(1 + (d->has_x_tasks ? d->T : 0)) * d->K, s);
+                hipLaunchKernelGGL(k_tn<T>, dim3((unsigned)S.nsplit, (unsigned)max_tiles, (unsigned)tp.n_prob),
+                                   dim3(256), 0, s, tp);
+            }
+            MtlProfScope prof(PK_REDUCE, 0.0, s);
+            hipLaunchKernelGGL(k_tn_reduce, dim3(64, (unsigned)tp.n_prob), dim3(256), 0, s, tp);
+        }
+    }
+    return MTLORA_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t mtlora_linear_ctx_bytes(const mtlora_linear_desc* d) {
+    if (check_desc(d) != MTLORA_OK) return -1;
+    const Segs sg = make_segs(d);
+    return ctx_layout(d, sg).total + 256;
+}
+
+int64_t mtlora_linear_bwd_scratch_bytes(const mtlora_linear_desc* d) {
+    if (check_desc(d) != MTLORA_OK) return -1;
+    const Segs sg = make_segs(d);
+    return bwd_scratch(d, sg).total + 256;
+}
+
+int mtlora_linear_fwd(const mtlora_linear_desc* d, const void* x, const void* const* x_t, const void* W,
+                      const float* bias, const float* A_s, const float* B_s, const float* const* A_t,
+                      const float* const* B_t, void* y_s, void* const* y_t, void* ctx, int64_t ctx_bytes,
+                      void* stream) {
+    int st = check_desc(d);
+    if (st != MTLORA_OK) return st;
+    if (!x || !W || !y_s) return MTLORA_ERR_NULL;
+    if (d->r_s > 0 && (!A_s || !B_s)) return MTLORA_ERR_NULL;
+    if (misaligned(x) || misaligned(W) || misaligned(y_s) || misaligned(bias)) return MTLORA_ERR_ALIGN;
+    for (int t = 0; t < d->T; ++t) {
+        if (!A_t || !B_t || !y_t || !A_t[t] || !B_t[t] || !y_t[t]) return MTLORA_ERR_NULL;
+        if (misaligned(y_t[t])) return MTLORA_ERR_ALIGN;
+        if (d->has_x_tasks && (!x_t || !x_t[t])) return MTLORA_ERR_NULL;
+        if (d->has_x_tasks && misaligned(x_t[t])) return MTLORA_ERR_ALIGN;
+    }
+    const Segs sg = make_segs(d);
+    if (sg.R > 0) {
+        if (!ctx) return MTLORA_ERR_NULL;
+        if (misaligned(ctx)) return MTLORA_ERR_ALIGN;
+        if (ctx_bytes < ctx_layout(d, sg).total) return MTLORA_ERR_WORKSPACE;
+    }
+    if (d->M == 0) return MTLORA_OK;
+    hipStream_t s = (hipStream_t)stream;
+    if (d->dtype == MTLORA_F32)
+        st = fwd_impl<float>(d, x, x_t, W, bias, A_s, B_s, A_t, B_t, y_s, y_t, ctx, s);
+    else
+        st = fwd_impl<bf16>(d, x, x_t, W, bias, A_s, B_s, A_t, B_t, y_s, y_t, ctx, s);
+    if (st != MTLORA_OK) return st;
+    MTL_CHECK_LAUNCH();
+    return MTLORA_OK;
+}
+
+int mtlora_linear_bwd(const mtlora_linear_desc* d, const void* x, const void* const* x_t, const void* Wt,
+                      const void* dy_s, const void* const* dy_t, const void* ctx, int64_t ctx_bytes, void* dx,
+                      void* const* dx_t, float* dA_s, float* dB_s, float* const* dA_t, float* const* dB_t,
+                      void* scratch, int64_t scratch_bytes, void* stream) {
+    int st = check_desc(d);
+    if (st != MTLORA_OK) return st;
+    if (!x || !Wt) return MTLORA_ERR_NULL;
+    if (misaligned(x) || misaligned(Wt) || misaligned(dx) || misaligned(dy_s)) return MTLORA_ERR_ALIGN;
+    const Segs sg = make_segs(d);
+    if (sg.R > 0) {
+        if (!ctx || !scratch) return MTLORA_ERR_NULL;
+        if (misaligned(ctx) || misaligned(scratch)) return MTLORA_ERR_ALIGN;
+        if (ctx_bytes < ctx_layout(d, sg).total) return MTLORA_ERR_WORKSPACE;
+        if (scratch_bytes < bwd_scratch(d, sg).total) return MTLORA_ERR_WORKSPACE;
+    }
+    for (int t = 0; t < d->T; ++t) {
+        if (d->has_x_tasks && (!x_t || !x_t[t])) return MTLORA_ERR_NULL;
+        if (dy_t && misaligned(dy_t[t])) return MTLORA_ERR_ALIGN;
+        if (dx_t && misaligned(dx_t[t])) return MTLORA_ERR_ALIGN;
+    }
+    if (d->M == 0) return MTLORA_OK;
+    hipStream_t s = (hipStream_t)stream;
+    if (d->dtype == MTLORA_F32)
+        st = bwd_impl<float>(d, x, x_t, Wt, dy_s, dy_t, ctx, dx, dx_t, dA_s, dB_s, dA_t, dB_t, scratch, s);
+    else
+        st = bwd_impl<bf16>(d, x, x_t, Wt, dy_s, dy_t, ctx, dx, dx_t, dA_s, dB_s, dA_t, dB_t, scratch, s);
+    if (st != MTLORA_OK) return st;
+    MTL_CHECK_LAUNCH();
+    return MTLORA_OK;
+}
+}

@@ -1,0 +1,130 @@
+"""Data-parallel gradient exchange for the MTLoRA train step: one process per GPU, RCCL over xGMI.
+
+The reference has NO gradient synchronisation at all (it initialises NCCL and calls one barrier,
+main.py:566-568; the model is never wrapped, main.py:167) -- SURVEY 2.3.  This is therefore new
+behaviour, specified in SURVEY 8e: replicas each take their own synthetic shard and the gradients of the
+TRAINABLE parameters only (LoRA factors, norms, relative-position tables, patch embed, downsample
+reductions, decoder heads: 8.34 M fp32 = 33.4 MB at C2; the 26 M frozen W never move) are averaged with an
+all-reduce once per step.
+
+Design for 8 fully-connected MI355X (7 xGMI links x ~153 GB/s per GPU): 33 MB is far too small to be
+bandwidth-bound (~0.1-0.4 ms), so the cost is launch latency and exposure.  Gradients are packed into a few
+large flat fp32 buckets in REVERSE parameter order (the order backward produces them: heads first, stage-0
+LoRA last); a bucket's all-reduce is launched asynchronously from the autograd hook of its last-arriving
+gradient, so everything but the final bucket overlaps the remaining backward kernels.  Parameters that get
+no gradient in a step (the final stage's shared fc2 factors are never used) simply contribute
+zeros and keep ``.grad is None`` -- no ``find_unused_parameters`` graph walk.
+"""
+from __future__ import annotations
+
+from typing import Iterable, List, Optional
+
+import torch
+import torch.distributed as dist
+
+
+class _Bucket:
+    __slots__ = ("params", "offsets", "flat", "pending", "handle", "seen")
+
+    def __init__(self, params: List[torch.nn.Parameter]):
+        self.params = params
+        self.offsets = []
+        n = 0
+        for p in params:
+            self.offsets.append(n)
+            n += p.numel()
+        self.flat = torch.zeros(n, dtype=torch.float32, device=params[0].device)
+        self.pending = len(params)
+        self.handle = None
+        self.seen = [False] * len(params)
+
+
+class GradReducer:
+    """Bucketed, backward-overlapped all-reduce (mean) of the trainable gradients.
+
+        reducer = GradReducer(model.parameters(), bucket_mb=16)
+        reducer.prepare(); loss.backward(); reducer.finish()   # .grad now holds the cross-rank mean
+    """
+
+    def __init__(self, params: Iterable[torch.nn.Parameter], bucket_mb: float = 16.0,
+                 process_group: Optional[dist.ProcessGroup] = None):
+        self.group = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        plist = [p for p in params if p.requires_grad]
+        plist.reverse()  # approximate backward completion order
+        cap = int(bucket_mb * 1024 * 1024 / 4)
+        self.buckets: List[_Bucket] = []
+        cur, cur_n = [], 0
+        for p in plist:
+            if cur and cur_n + p.numel() > cap:
+                self.buckets.append(_Bucket(cur))
+                cur, cur_n = [], 0
+            cur.append(p)
+            cur_n += p.numel()
+        if cur:
+            self.buckets.append(_Bucket(cur))
+        self._where = {}
+        self._hooks = []
+        for bi, b in enumerate(self.buckets):
+            for pi, p in enumerate(b.params):
+                self._where[p] = (bi, pi)
+                self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
+        self._armed = False
+
+    @property
+    def nbytes(self) -> int:
+        return sum(b.flat.numel() * 4 for b in self.buckets)
+
+    def prepare(self) -> None:
+        """call before backward."""
+        for b in self.buckets:
+            b.pending = len(b.params)
+            b.handle = None
+            b.seen = [False] * len(b.params)
+        self._armed = True
+
+    def _launch(self, b: _Bucket) -> None:
+        if self.world > 1:
+            b.handle = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def _on_grad(self, p: torch.nn.Parameter) -> None:
+        if not self._armed:
+            return
+        bi, pi = self._where[p]
+        b = self.buckets[bi]
+        if b.seen[pi]:
+            return  # gradient accumulation touching the same parameter twice in one backward
+        n = p.numel()
+        b.flat[b.offsets[pi]:b.offsets[pi] + n].copy_(p.grad.reshape(-1))
+        b.seen[pi] = True
+        b.pending -= 1
+        if b.pending == 0:
+            self._launch(b)
+
+    def finish(self) -> None:
+        """call after backward: flush incomplete buckets, wait, write the mean back into ``.grad``."""
+        self._armed = False
+        for b in self.buckets:
+            if b.pending > 0:  # some parameters produced no gradient on this rank this step: they count as zero
+                for pi, p in enumerate(b.params):
+                    if not b.seen[pi]:
+                        b.flat[b.offsets[pi]:b.offsets[pi] + p.numel()].zero_()
+                self._launch(b)
+        inv = 1.0 / self.world
+        for b in self.buckets:
+            if b.handle is not None:
+                b.handle.wait()
+            if self.world > 1:
+                b.flat.mul_(inv)
+            dst, src = [], []
+            for pi, p in enumerate(b.params):
+                if b.seen[pi]:  # parameters without a local gradient keep grad None (all ranks agree on the set)
+                    dst.append(p.grad)
+                    src.append(b.flat[b.offsets[pi]:b.offsets[pi] + p.numel()].view_as(p.grad))
+            if dst and self.world > 1:
+                torch._foreach_copy_(dst, src)
+
+    def remove(self) -> None:
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []

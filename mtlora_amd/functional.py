@@ -1,0 +1,286 @@
+"""torch.autograd.Function wrappers over the C ABI (include/mtlora_hip.h).
+
+Host-side plumbing only: allocate outputs / ctx / scratch with torch, pass raw pointers and the
+current stream to the library.  Every op raises if the library or a GPU tensor is missing.
+"""
+from __future__ import annotations
+
+import ctypes
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib as L
+
+# ----------------------------------------------------------------------------------------------
+# dropout seeds: one fresh 64-bit seed per MTLoRALinear call in training mode, derived from
+# torch.initial_seed() and a call counter (deterministic under torch.manual_seed + fixed call order)
+# ----------------------------------------------------------------------------------------------
+_seed_counter = 0
+
+
+def next_seed() -> int:
+    global _seed_counter
+    _seed_counter += 1
+    x = (torch.initial_seed() * 0x9E3779B97F4A7C15 + _seed_counter * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
+    x ^= x >> 31
+    return x & 0xFFFFFFFFFFFFFFFF
+
+
+def compute_dtype(x: torch.Tensor) -> torch.dtype:
+    """dtype the hot path runs in: the autocast dtype when autocast is on (like F.linear), else x's."""
+    if torch.is_autocast_enabled():
+        dt = torch.get_autocast_dtype("cuda")
+        if dt == torch.float16:
+            raise RuntimeError("mtlora_amd: fp16 autocast is not supported on the MI355X path; use "
+                               "torch.autocast('cuda', dtype=torch.bfloat16)")
+        return dt
+    if x.dtype not in (torch.float32, torch.bfloat16):
+        raise RuntimeError(f"mtlora_amd: unsupported activation dtype {x.dtype}")
+    return x.dtype
+
+
+# ----------------------------------------------------------------------------------------------
+# MTLoRALinear
+# ----------------------------------------------------------------------------------------------
+@dataclass
+class LinearMeta:
+    """static description of one MTLoRALinear call (lora.py:253-284)."""
+    K: int
+    N: int
+    r_s: int
+    r_t: Tuple[int, ...]
+    scale_s: float
+    scale_t: Tuple[float, ...]
+    mode: int                 # 0 matrix, 1 matrixv2
+    has_x_tasks: bool
+    dropout_p: float          # 0 in eval
+    seed: int
+    dtype: torch.dtype
+    weight_requires_grad: bool = False
+    n_scale_t: int = 0        # >0: per-task scales are trainable Parameters passed after B_t
+
+    @property
+    def T(self) -> int:
+        return len(self.r_t)
+
+    def desc(self, M: int) -> L.LinearDesc:
+        d = L.LinearDesc()
+        d.M, d.K, d.N = M, self.K, self.N
+        d.dtype = L.BF16 if self.dtype == torch.bfloat16 else L.F32
+        d.mode, d.T, d.r_s = self.mode, self.T, self.r_s
+        for i, r in enumerate(self.r_t):
+            d.r_t[i] = r
+            d.scale_t[i] = self.scale_t[i]
+        d.scale_s = self.scale_s
+        d.has_x_tasks = 1 if self.has_x_tasks else 0
+        d.dropout_p = self.dropout_p
+        d.seed = self.seed
+        return d
+
+
+class MTLoRALinearFn(torch.autograd.Function):
+    """(y_s, y_t[0..T-1]) = f(x, x_t[0..T-1], A_s, B_s, A_t[..], B_t[..]); W (and bias) frozen by default.
+
+    args: meta, x, W_c, Wt_c, bias_f32, W_master, bias_master, A_s, B_s, scale_s_param,
+          *x_t(T or 0), *A_t(T), *B_t(T), *scale_t_params(T or 0)
+    W_c / Wt_c are the compute-dtype copies the module caches; W_master / bias_master are only used to
+    route gradients when the pretrained weight is left trainable (MTLORA.FREEZE_PRETRAINED False);
+    scale_*_param are the 1-element Parameters of TRAINABLE_SCALE_* (None otherwise): the kernels take the
+    scales as scalars and d(loss)/d(scale) = <dB, B> / scale is formed from the factor gradient."""
+
+    @staticmethod
+    def forward(ctx, meta: LinearMeta, x, W_c, Wt_c, bias_f32, W_master, bias_master, A_s, B_s, scale_s_param, *rest):
+        ctx.set_materialize_grads(False)  # an unused output must reach backward as None, not as zeros
+        T = meta.T
+        nx = T if meta.has_x_tasks else 0
+        x_t, A_t, B_t = list(rest[:nx]), list(rest[nx:nx + T]), list(rest[nx + T:nx + 2 * T])
+        L.require_gpu(x, W_c, *x_t)
+        lead = x.shape[:-1]
+        x2 = x.reshape(-1, meta.K).to(meta.dtype).contiguous()
+        xt2 = [t.reshape(-1, meta.K).to(meta.dtype).contiguous() for t in x_t]
+        M = x2.shape[0]
+        d = meta.desc(M)
+        lib = L.lib()
+        ctx_bytes = lib.mtlora_linear_ctx_bytes(ctypes.byref(d))
+        if ctx_bytes < 0:
+            raise RuntimeError(f"mtlora_amd: invalid MTLoRALinear shape M={M} K={meta.K} N={meta.N} (K, N must be "
+                               "multiples of 8)")
+        ctxbuf = torch.empty(ctx_bytes, dtype=torch.uint8, device=x.device)
+        ys = torch.empty((M, meta.N), dtype=meta.dtype, device=x.device)
+        yt = [torch.empty((M, meta.N), dtype=meta.dtype, device=x.device) for _ in range(T)]
+        fl = lambda p: None if p is None else p.detach().float().contiguous()
+        A_s_c, B_s_c = fl(A_s), fl(B_s)
+        A_t_c, B_t_c = [fl(a) for a in A_t], [fl(b) for b in B_t]
+        st = lib.mtlora_linear_fwd(ctypes.byref(d), L.ptr(x2), L.ptr_array(xt2), L.ptr(W_c), L.ptr(bias_f32),
+                                   L.ptr(A_s_c), L.ptr(B_s_c), L.ptr_array(A_t_c), L.ptr_array(B_t_c), L.ptr(ys),
+                                   L.ptr_array(yt), L.ptr(ctxbuf), ctx_bytes, L.stream_ptr())
+        L.check(st, "mtlora_linear_fwd")
+        ctx.meta, ctx.lead, ctx.nx = meta, lead, nx
+        ctx.in_dtypes = [x.dtype] + [t.dtype for t in x_t]
+        ctx.save_for_backward(x2, Wt_c, ctxbuf, *xt2)
+        ctx.keep = (A_s_c, B_s_c, A_t_c, B_t_c)  # fp32 factor views (also used for the trainable-scale gradients)
+        ctx.has_scale_s = scale_s_param is not None
+        outs = [ys.reshape(*lead, meta.N)] + [y.reshape(*lead, meta.N) for y in yt]
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        meta: LinearMeta = ctx.meta
+        T, nx = meta.T, ctx.nx
+        if all(g is None for g in grads):
+            return (None,) * (10 + nx + 2 * T + meta.n_scale_t)
+        x2, Wt_c, ctxbuf, *xt2 = ctx.saved_tensors
+        M = x2.shape[0]
+        dev = x2.device
+        g2 = [None if g is None else g.reshape(-1, meta.N).to(meta.dtype).contiguous() for g in grads]
+        dy_s, dy_t = g2[0], g2[1:1 + T]
+        d = meta.desc(M)
+        lib = L.lib()
+        scratch_bytes = lib.mtlora_linear_bwd_scratch_bytes(ctypes.byref(d))
+        scratch = torch.empty(scratch_bytes, dtype=torch.uint8, device=dev)
+        need = ctx.needs_input_grad  # (meta, x, W_c, Wt_c, bias_f32, W_master, bias_master, A_s, B_s, scale_s, *rest)
+        dx = torch.empty((M, meta.K), dtype=meta.dtype, device=dev)
+        dxt = [torch.empty((M, meta.K), dtype=meta.dtype, device=dev) for _ in range(nx)]
+        has_s = meta.r_s > 0 and (dy_s is not None or (meta.mode == 1 and any(g is not None for g in dy_t)))
+        dA_s = torch.empty((meta.r_s, meta.K), dtype=torch.float32, device=dev) if has_s else None
+        dB_s = torch.empty((meta.N, meta.r_s), dtype=torch.float32, device=dev) if has_s else None
+        dA_t = [torch.empty((meta.r_t[t], meta.K), dtype=torch.float32, device=dev) if dy_t[t] is not None else None
+                for t in range(T)]
+        dB_t = [torch.empty((meta.N, meta.r_t[t]), dtype=torch.float32, device=dev) if dy_t[t] is not None else None
+                for t in range(T)]
+        if nx:  # a task input whose output got no gradient still needs a defined (zero) gradient
+            for t in range(T):
+                if dy_t[t] is None:
+                    dxt[t].zero_()
+        st = lib.mtlora_linear_bwd(ctypes.byref(d), L.ptr(x2), L.ptr_array(xt2), L.ptr(Wt_c), L.ptr(dy_s),
+                                   L.ptr_array(dy_t), L.ptr(ctxbuf), ctxbuf.numel(), L.ptr(dx), L.ptr_array(dxt),
+                                   L.ptr(dA_s), L.ptr(dB_s), L.ptr_array(dA_t), L.ptr_array(dB_t), L.ptr(scratch),
+                                   scratch_bytes, L.stream_ptr())
+        L.check(st, "mtlora_linear_bwd")
+        dW = dbias = None
+        if meta.weight_requires_grad:  # pretrained weight left trainable: dense dW outside the frozen-W hot path
+            G = None
+            for g in g2:
+                if g is not None:
+                    G = g.float() if G is None else G + g.float()
+            if G is not None:
+                if need[5]:
+                    dW = G.t() @ x2.float()
+                if need[6]:
+                    dbias = G.sum(0)
+        dxo = dx.reshape(*ctx.lead, meta.K).to(ctx.in_dtypes[0])
+        dxto = [dxt[t].reshape(*ctx.lead, meta.K).to(ctx.in_dtypes[1 + t]) for t in range(nx)]
+        _, B_s_c, _, B_t_c = ctx.keep
+        d_ss = None
+        if ctx.has_scale_s and dB_s is not None and meta.scale_s != 0.0:
+            d_ss = ((dB_s * B_s_c).sum() / meta.scale_s).reshape(1)
+        d_st = []
+        for t in range(meta.n_scale_t):
+            ok = dB_t[t] is not None and meta.scale_t[t] != 0.0
+            d_st.append(((dB_t[t] * B_t_c[t]).sum() / meta.scale_t[t]).reshape(1) if ok else None)
+        return (None, dxo, None, None, None, dW, dbias, dA_s, dB_s, d_ss, *dxto, *dA_t, *dB_t, *d_st)
+
+
+# ----------------------------------------------------------------------------------------------
+# window attention core
+# ----------------------------------------------------------------------------------------------
+@dataclass
+class AttnMeta:
+    B: int
+    H: int
+    W: int
+    window_size: int
+    shift: int
+    num_heads: int
+    head_dim: int
+    image_layout: bool
+    scale: float
+
+    def desc(self, dtype: torch.dtype) -> L.AttnDesc:
+        d = L.AttnDesc()
+        d.B, d.H, d.W = self.B, self.H, self.W
+        d.window_size, d.shift = self.window_size, self.shift
+        d.num_heads, d.head_dim = self.num_heads, self.head_dim
+        d.image_layout = 1 if self.image_layout else 0
+        d.dtype = L.BF16 if dtype == torch.bfloat16 else L.F32
+        d.scale = self.scale
+        return d
+
+
+class WindowAttentionFn(torch.autograd.Function):
+    """out = softmax(scale * q k^T + bias[h] + mask[w]) v per (window, head)  (swin_transformer_mtlora.py:194-220).
+    qkv: (..., 3C) [3][nH][hd]; bias: (nH, N, N) fp32 dense; mask/mask_t: (nW, N, N) fp32 or None."""
+
+    @staticmethod
+    def forward(ctx, meta: AttnMeta, qkv, bias, mask, mask_t):
+        L.require_gpu(qkv, bias, mask)
+        dt = qkv.dtype
+        if dt not in (torch.float32, torch.bfloat16):
+            raise RuntimeError(f"mtlora_amd: window attention supports fp32/bf16, got {dt}")
+        qkv_c = qkv.contiguous()
+        bias_c = bias.detach().float().contiguous()
+        bias_t = bias_c.transpose(1, 2).contiguous()
+        C = meta.num_heads * meta.head_dim
+        out = torch.empty(qkv_c.shape[:-1] + (C,), dtype=dt, device=qkv.device)
+        d = meta.desc(dt)
+        st = L.lib().mtlora_window_attn_fwd(ctypes.byref(d), L.ptr(qkv_c), L.ptr(bias_t), L.ptr(mask_t), L.ptr(out),
+                                            L.stream_ptr())
+        L.check(st, "mtlora_window_attn_fwd")
+        ctx.meta = meta
+        ctx.save_for_backward(qkv_c, bias_c, bias_t, mask, mask_t)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        meta: AttnMeta = ctx.meta
+        qkv, bias, bias_t, mask, mask_t = ctx.saved_tensors
+        dout = dout.to(qkv.dtype).contiguous()
+        d = meta.desc(qkv.dtype)
+        lib = L.lib()
+        sb = lib.mtlora_window_attn_bwd_scratch_bytes(ctypes.byref(d))
+        scratch = torch.empty(sb, dtype=torch.uint8, device=qkv.device)
+        dqkv = torch.empty_like(qkv)
+        dbias = torch.empty_like(bias)
+        st = lib.mtlora_window_attn_bwd(ctypes.byref(d), L.ptr(qkv), L.ptr(bias), L.ptr(bias_t), L.ptr(mask),
+                                        L.ptr(mask_t), L.ptr(dout), L.ptr(dqkv), L.ptr(dbias), L.ptr(scratch), sb,
+                                        L.stream_ptr())
+        L.check(st, "mtlora_window_attn_bwd")
+        return None, dqkv, dbias, None, None
+
+
+# ----------------------------------------------------------------------------------------------
+# window process (kernels/window_process/window_process.py)
+# ----------------------------------------------------------------------------------------------
+def _wp(fn_name: str, src: torch.Tensor, out_shape, B, H, W, C, shift_size, window_size) -> torch.Tensor:
+    L.require_gpu(src)
+    if not src.is_contiguous():
+        raise RuntimeError("input must be contiguous")  # CHECK_CONTIGUOUS, swin_window_process.cpp:65
+    if src.numel() != B * H * W * C:
+        raise RuntimeError(f"mtlora_amd: {fn_name}: tensor has {src.numel()} elements, expected B*H*W*C={B * H * W * C}")
+    out = torch.empty(out_shape, dtype=src.dtype, device=src.device)
+    st = getattr(L.lib(), fn_name)(L.ptr(src), L.ptr(out), B, H, W, C, shift_size, window_size,
+                                   L.dtype_code(src, allow_f16=True), L.stream_ptr())
+    L.check(st, fn_name)
+    return out
+
+
+def roll_and_window_partition_forward(input, B, H, W, C, shift_size, window_size):
+    n = B * (H // window_size) * (W // window_size)
+    return _wp("mtlora_roll_and_window_partition_forward", input, (n, window_size, window_size, C), B, H, W, C,
+               shift_size, window_size)
+
+
+def roll_and_window_partition_backward(grad_in, B, H, W, C, shift_size, window_size):
+    return _wp("mtlora_roll_and_window_partition_backward", grad_in, (B, H, W, C), B, H, W, C, shift_size, window_size)
+
+
+def window_merge_and_roll_forward(input, B, H, W, C, shift_size, window_size):
+    return _wp("mtlora_window_merge_and_roll_forward", input, (B, H, W, C), B, H, W, C, shift_size, window_size)
+
+
+def window_merge_and_roll_backward(grad_in, B, H, W, C, shift_size, window_size):
+    n = B * (H // window_size) * (W // window_size)
+    return _wp("mtlora_window_merge_and_roll_backward", grad_in, (n, window_size, window_size, C), B, H, W, C,
+               shift_size, window_size)

@@ -1,0 +1,212 @@
+"""MI355X drop-in for ``models.lora`` (reference models/lora.py): ``LoRALayer``, ``MTLoRALinear``,
+``mark_only_lora_as_trainable`` and ``map_old_state_dict_weights`` with the same constructor
+arguments, attribute / parameter names and tuple-returning ``forward`` -- but forward and backward
+run as fused gfx950 kernels (csrc/linear.hip) through the C ABI instead of 6+4T ATen launches.
+
+Only the classes the reference actually instantiates are provided (``LoRALinear``, ``MTLoRAQKV`` and
+``LoRAQKVLinear`` are dead code there).
+"""
+from __future__ import annotations
+
+import math
+from typing import Any, Dict, Mapping, Optional, Tuple, Union
+
+import torch
+import torch.nn as nn
+
+from . import functional as Fn
+
+_MODES = ("matrix", "matrixv2", "add", "addition", "lora_only")
+
+
+class LoRALayer(nn.Module):
+    """r, lora_alpha, dropout-or-identity, merged flag (reference lora.py:62-84)."""
+
+    def __init__(self, r: int, lora_alpha: float, lora_dropout: float):
+        super().__init__()
+        assert r >= 0
+        self.r = r
+        self.lora_alpha = lora_alpha
+        # kept for API parity; the HIP kernels apply the dropout themselves, reading `.p`
+        self.lora_dropout = nn.Dropout(p=lora_dropout) if lora_dropout > 0.0 else (lambda x: x)
+        self.merged = False
+
+    @property
+    def dropout_p(self) -> float:
+        d = self.lora_dropout
+        return float(d.p) if isinstance(d, nn.Dropout) else 0.0
+
+
+class MTLoRALinear(LoRALayer):
+    """Frozen ``linear`` + one shared and T per-task low-rank updates -> (y_shared, {task: y_task} | None).
+
+    Same signature as reference lora.py:161-176; ``forward`` semantics of lora.py:253-284 (formulas in
+    include/mtlora_hip.h)."""
+
+    def __init__(self, in_features: int, out_features: int, r: Union[int, Mapping[str, int]] = 0,
+                 lora_shared_scale: float = 1.0, lora_task_scale: Union[float, Mapping[str, float]] = 1.0,
+                 lora_dropout: float = 0.0, tasks=None, trainable_scale_shared=False,
+                 trainable_scale_per_task=False, shared_mode: str = "matrix", **kwargs):
+        assert shared_mode in _MODES
+        if shared_mode == "add":
+            shared_mode = "addition"
+        if shared_mode == "lora_only":
+            tasks = None
+        has_tasks = tasks is not None
+        if not has_tasks and shared_mode != "matrix":
+            shared_mode = "matrix"
+        if isinstance(r, int):
+            r = {"shared": r}
+        super().__init__(r=r["shared"], lora_alpha=lora_shared_scale, lora_dropout=lora_dropout)
+        self.linear = nn.Linear(in_features, out_features, **kwargs)
+        self.tasks = tasks
+        self.shared_mode = shared_mode
+        self._ranks = dict(r)
+        if r["shared"] > 0:
+            w = self.linear.weight
+            if has_tasks:
+                self.lora_tasks_A = nn.ParameterDict({t: nn.Parameter(w.new_zeros((r[t], in_features))) for t in tasks})
+                self.lora_tasks_B = nn.ParameterDict({t: nn.Parameter(w.new_zeros((out_features, r[t]))) for t in tasks})
+                per_task = (lambda t: lora_task_scale[t]) if isinstance(lora_task_scale, Mapping) else (lambda t: lora_task_scale)
+                if trainable_scale_per_task:
+                    self.lora_task_scale = nn.ParameterDict(
+                        {t: nn.Parameter(torch.FloatTensor([float(per_task(t))])) for t in tasks})
+                else:
+                    self.lora_task_scale = {t: lora_task_scale[t] for t in tasks}
+            if shared_mode == "addition":
+                assert has_tasks
+                self.lora_norm = nn.LayerNorm(out_features)
+            else:
+                self.lora_shared_A = nn.Parameter(w.new_zeros((r["shared"], in_features)))
+                self.lora_shared_B = nn.Parameter(w.new_zeros((out_features, r["shared"])))
+            if trainable_scale_shared:
+                self.lora_shared_scale = nn.Parameter(torch.FloatTensor([lora_shared_scale]))
+            else:
+                self.lora_shared_scale = lora_shared_scale
+            self.reset_parameters()
+        self._wcache: Dict[Any, Any] = {}
+
+    def reset_parameters(self):
+        """A ~ kaiming_uniform(a=sqrt 5), B = 0 (reference lora.py:236-247)."""
+        if hasattr(self, "lora_shared_A"):
+            nn.init.kaiming_uniform_(self.lora_shared_A, a=math.sqrt(5))
+            nn.init.zeros_(self.lora_shared_B)
+        if hasattr(self, "lora_tasks_A"):
+            for t in self.tasks:
+                nn.init.kaiming_uniform_(self.lora_tasks_A[t], a=math.sqrt(5))
+                nn.init.zeros_(self.lora_tasks_B[t])
+
+    def merge(self):
+        raise NotImplementedError  # as the reference (lora.py:249-251)
+
+    # -- frozen-weight copies in the compute dtype (W, W^T) and an fp32 bias, refreshed when W changes
+    def _weights(self, dtype: torch.dtype):
+        w, b = self.linear.weight, self.linear.bias
+        key = (dtype, w.device)
+        ver = (w._version, w.data_ptr(), None if b is None else (b._version, b.data_ptr()))
+        hit = self._wcache.get(key)
+        if hit is None or hit[0] != ver:
+            with torch.no_grad():
+                wc = w.detach().to(dtype).contiguous()
+                wt = w.detach().t().to(dtype).contiguous()
+                bf = None if b is None else b.detach().float().contiguous()
+            hit = (ver, wc, wt, bf)
+            self._wcache = {key: hit}
+        return hit[1], hit[2], hit[3]
+
+    def _apply(self, fn, *a, **k):  # .to() / .cuda() invalidates the cached copies
+        self._wcache = {}
+        return super()._apply(fn, *a, **k)
+
+    def forward(self, x: torch.Tensor, x_tasks: Optional[Dict[str, torch.Tensor]] = None
+                ) -> Tuple[torch.Tensor, Optional[Dict[str, torch.Tensor]]]:
+        Fn.L.require_gpu(x)
+        dtype = Fn.compute_dtype(x)
+        wc, wt, bf = self._weights(dtype)
+        has_lora = self.r > 0
+        tasks = list(self.tasks) if (has_lora and self.tasks is not None) else []
+        shared = has_lora and self.shared_mode in ("matrix", "matrixv2")
+        p = self.dropout_p if (self.training and has_lora) else 0.0
+        val = lambda s: float(s.detach().item()) if isinstance(s, torch.Tensor) else float(s)
+        par = lambda s: s if isinstance(s, nn.Parameter) else None
+        ss = self.lora_shared_scale if shared else 0.0
+        st = [self.lora_task_scale[t] for t in tasks]
+        meta = Fn.LinearMeta(
+            K=self.linear.in_features, N=self.linear.out_features,
+            r_s=self.r if shared else 0, r_t=tuple(self._ranks[t] for t in tasks),
+            scale_s=val(ss), scale_t=tuple(val(s) for s in st),
+            mode=1 if (self.shared_mode == "matrixv2" and tasks) else 0,
+            has_x_tasks=bool(tasks) and x_tasks is not None, dropout_p=p, seed=Fn.next_seed() if p > 0 else 0,
+            dtype=dtype, weight_requires_grad=self.linear.weight.requires_grad,
+            n_scale_t=len(tasks) if (tasks and isinstance(st[0], nn.Parameter)) else 0)
+        args = [meta, x, wc, wt, bf, self.linear.weight, self.linear.bias,
+                self.lora_shared_A if shared else None, self.lora_shared_B if shared else None, par(ss)]
+        if meta.has_x_tasks:
+            args += [x_tasks[t] for t in tasks]
+        args += [self.lora_tasks_A[t] for t in tasks] + [self.lora_tasks_B[t] for t in tasks]
+        if meta.n_scale_t:
+            args += st
+        outs = Fn.MTLoRALinearFn.apply(*args)
+        y = outs[0]
+        if not has_lora:
+            return y, None
+        y_tasks = {t: outs[1 + i] for i, t in enumerate(tasks)} if tasks else None
+        if self.shared_mode == "addition":  # lora.py:275-282: LayerNorm(sum_t y_t) added to the pretrained output
+            tot = torch.stack(list(y_tasks.values()), 0).sum(0).float()
+            y = y + nn.functional.layer_norm(tot, (tot.shape[-1],), self.lora_norm.weight.float(),
+                                             self.lora_norm.bias.float(), self.lora_norm.eps).to(y.dtype)
+        return y, y_tasks
+
+
+def mark_only_lora_as_trainable(model: nn.Module, bias: str = "none", freeze_patch_embed: bool = False,
+                                freeze_norm: bool = False, free_relative_bias: bool = False,
+                                freeze_downsample_reduction=False) -> None:
+    """Same filters, flags (incl. the inverted-sounding ``free_relative_bias``) and bias modes as reference
+    lora.py:580-630: a parameter stays trainable iff its name contains ``lora_`` or one of the un-frozen
+    families (patch_embed / norm / downsample.reduction / relative_position_bias_table)."""
+    keep = [("lora_", True), ("patch_embed", not freeze_patch_embed), ("norm", not freeze_norm),
+            ("downsample.reduction", not freeze_downsample_reduction),
+            ("relative_position_bias_table", not free_relative_bias)]
+    for name, p in model.named_parameters():
+        if not any(on and key in name for key, on in keep):
+            p.requires_grad = False
+    if bias == "none":
+        return
+    if bias == "all":
+        for name, p in model.named_parameters():
+            if "bias" in name:
+                p.requires_grad = True
+    elif bias == "lora_only":
+        for m in model.modules():
+            if isinstance(m, LoRALayer) and getattr(m, "bias", None) is not None:
+                m.bias.requires_grad = True
+    else:
+        raise NotImplementedError
+
+
+def lora_filter(key: str, value: Any) -> bool:
+    return "lora_" in key
+
+
+def map_old_state_dict_weights(state_dict: Dict, mapping: Mapping, prefix: str, split_qkv: bool = False) -> Dict:
+    """Rename vanilla-Swin checkpoint keys to the MTLoRA layout (``attn.qkv.weight`` -> ``attn.qkv.linear.weight``),
+    optionally splitting fused qkv rows into q/k/v (reference lora.py:644-668)."""
+    missing = []
+    for old, new in mapping.items():
+        src = prefix + old
+        if src not in state_dict:
+            missing.append(old)
+            continue
+        w = state_dict.pop(src)
+        dst = prefix + new
+        tail = ".".join(dst.split(".")[-4:])
+        if split_qkv and tail in ("attn.qkv.linear.weight", "attn.qkv.linear.bias"):
+            kind = tail.split(".")[-1]
+            stem = ".".join(dst.split(".")[:-2])
+            for nm, part in zip("qkv", torch.chunk(w, chunks=3)):
+                state_dict[f"{stem}.{nm}.linear.{kind}"] = part
+        else:
+            state_dict[dst] = w
+    if missing:
+        print(f"WARNING: The following keys from the checkpoint were not mapped: {missing}")
+    return state_dict

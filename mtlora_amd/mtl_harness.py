@@ -1,0 +1,239 @@
+"""Callers of the hot path: the multi-task wrapper, the decoder heads, the losses and the
+train step, restated in plain PyTorch so that ``bench.py`` / ``smoke()`` can run the reference's train step
+on a GPU box that has no copy of the reference.
+
+Nothing here is accelerated: the north star says the Swin-MTL wrapper and the semseg / normals / sal /
+human_parts heads "drop in unchanged", i.e. a user keeps using the reference's ``models/swin_mtl.py``
+and ``mtl_loss_schemes.py`` on top of ``mtlora_amd.swin_transformer_mtlora``.  The module / parameter
+names below equal the reference's (``downsampler.{task}.downsample_{i}``, ``decoders.decoders.{task}.
+last_layer.{0,1,3}``) so one state dict serves both.
+
+Reference: models/swin_mtl.py:60-246, models/seg_hrnet.py:498-526, mtl_loss_schemes.py:22-263,
+main.py:192-204 (loss weights), main.py:329-354 + utils.py:348-375 (train step).
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Mapping, Optional, Sequence
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .lora import mark_only_lora_as_trainable
+from .swin_transformer_mtlora import SwinTransformerMTLoRA
+
+NUM_OUTPUT = {"semseg": 21, "normals": 3, "sal": 1, "human_parts": 7, "depth": 1, "edge": 1}  # data/mtl_ds.py:749-780
+LOSS_WEIGHTS = {"depth": 1.0, "semseg": 1.0, "human_parts": 2.0, "sal": 5.0, "edge": 50.0, "normals": 10.0}
+
+
+class AttrDict(dict):
+    """stand-in for the yacs CfgNode the reference constructors read attributes from."""
+    __getattr__ = dict.__getitem__
+    __setattr__ = dict.__setitem__
+
+
+def mtlora_namespace(tasks: Sequence[str], r_shared=64, r_task=4, scale=4.0, dropout=0.05, shared_mode="matrix",
+                     n_stages=4, **over) -> AttrDict:
+    """the ``config.MODEL.MTLORA`` namespace after config.py:477-557 normalisation (``*_pertask`` yamls)."""
+    ns = AttrDict(ENABLED=True, QKV_ENABLED=True, PROJ_ENABLED=True, FC1_ENABLED=True, FC2_ENABLED=True,
+                  DOWNSAMPLER_ENABLED=False, INTERMEDIATE_SPECIALIZATION=False, TRAINABLE_SCALE_SHARED=False,
+                  TRAINABLE_SCALE_PER_TASK=False, SHARED_MODE=shared_mode, DROPOUT=[dropout] * n_stages,
+                  SHARED_SCALE=[scale] * n_stages,
+                  R_PER_TASK_LIST=[{"shared": r_shared, **{t: r_task for t in tasks}} for _ in range(n_stages)],
+                  SCALE_PER_TASK_LIST=[{t: scale for t in tasks} for _ in range(n_stages)])
+    ns.update(over)
+    return ns
+
+
+# --------------------------------------------------------------------------------------------------
+class Downsampler(nn.Module):
+    """tokens (B, L_i, C_i) of the four stages -> NCHW maps through four bias-free 1x1 convs."""
+
+    def __init__(self, dims, channels, input_res, bias=False, enabled=True):
+        super().__init__()
+        self.dims, self.input_res, self.enabled = dims, input_res, enabled
+        if enabled:
+            for i, (d, c) in enumerate(zip(dims, channels)):
+                setattr(self, f"downsample_{i}", nn.Conv2d(d, c, 1, bias=bias))
+
+    def forward(self, feats):
+        maps = [f.view(-1, r, r, d).permute(0, 3, 1, 2) for f, r, d in zip(feats, self.input_res, self.dims)]
+        if not self.enabled:
+            return maps
+        return [getattr(self, f"downsample_{i}")(m) for i, m in enumerate(maps)]
+
+
+class HighResolutionHead(nn.Module):
+    """upsample the 3 coarse maps to the finest, concat, 1x1 conv -> BN -> ReLU -> 1x1 conv (seg_hrnet.py:498-526)."""
+
+    def __init__(self, backbone_channels, num_outputs):
+        super().__init__()
+        c = sum(backbone_channels)
+        self.last_layer = nn.Sequential(nn.Conv2d(c, 4 * c, 1), nn.BatchNorm2d(4 * c, momentum=0.1),
+                                        nn.ReLU(inplace=False), nn.Conv2d(4 * c, num_outputs, 1))
+
+    def forward(self, x):
+        size = x[0].shape[2:]
+        cat = torch.cat([x[0]] + [F.interpolate(m, size, mode="bilinear") for m in x[1:]], 1)
+        return self.last_layer(cat)
+
+
+class DecoderGroup(nn.Module):
+    def __init__(self, tasks, num_outputs, channels, out_size):
+        super().__init__()
+        self.tasks, self.out_size = tasks, out_size
+        self.decoders = nn.ModuleDict({t: HighResolutionHead(channels, num_outputs[t]) for t in tasks})
+
+    def forward(self, x):
+        return {t: F.interpolate(self.decoders[t](x[t]), self.out_size, mode="bilinear") for t in self.tasks}
+
+
+class MultiTaskSwin(nn.Module):
+    """backbone + per-task Downsampler + DecoderGroup (swin_mtl.py:138-246, MTLoRA-enabled, per-task downsampler,
+    ``DECODER_HEAD: hrnet`` path -- the one every shipped config uses)."""
+
+    def __init__(self, backbone: SwinTransformerMTLoRA, tasks: Sequence[str], num_outputs: Mapping[str, int] = NUM_OUTPUT,
+                 decoder_channels=(18, 36, 72, 144)):
+        super().__init__()
+        self.backbone = backbone
+        self.tasks = list(tasks)
+        res = backbone.patch_embed.patches_resolution
+        n = backbone.num_layers
+        self.dims = [int(backbone.embed_dim * 2 ** ((i + 1) if i < n - 1 else i)) for i in range(n)]
+        self.input_res = [res[0] // (2 ** ((i + 1) if i < n - 1 else i)) for i in range(n)]
+        self.img_size = backbone.patch_embed.img_size
+        self.downsampler = nn.ModuleDict({t: Downsampler(self.dims, decoder_channels, self.input_res) for t in self.tasks})
+        self.decoders = DecoderGroup(self.tasks, num_outputs, decoder_channels, self.img_size)
+
+    def forward(self, x):
+        stages = self.backbone(x, return_stages=True)
+        feats = {t: self.downsampler[t]([tl[t] for _, tl in stages]) for t in self.tasks}
+        return self.decoders(feats)
+
+
+# --------------------------------------------------------------------------------------------------
+# losses (mtl_loss_schemes.py), sync-free restatements: same value, no .item() / masked_select host round trip
+# --------------------------------------------------------------------------------------------------
+def task_loss(task: str, out: torch.Tensor, label: torch.Tensor) -> torch.Tensor:
+    out = out.float()
+    if task in ("semseg", "human_parts"):          # SoftMaxwithLoss (:22-39)
+        return F.nll_loss(F.log_softmax(out, 1), label[:, 0].long(), ignore_index=255)
+    if task == "normals":                           # NormalsLoss(normalize=True, L1, size_average) (:162-220)
+        mask = (label != 255).to(out.dtype)
+        on = out / (torch.norm(out, p=2, dim=1, keepdim=True) + 1e-12)
+        return ((on - label).abs() * mask).sum() / mask.sum().clamp_min(1e-6)
+    if task == "sal":                               # BalancedCrossEntropyLoss(size_average) (:42-89)
+        labels = (label >= 0.5).to(out.dtype)
+        w = (1.0 - labels).sum() / labels.numel()
+        gz = (out >= 0).to(out.dtype)
+        lv = out * (labels - gz) - torch.log(1 + torch.exp(out - 2 * out * gz))
+        return (w * (-(labels * lv)).sum() + (1 - w) * (-((1.0 - labels) * lv)).sum()) / labels.numel()
+    if task == "depth":                             # DepthLoss l1 (:132-148)
+        mask = (label != 255).to(out.dtype)
+        return ((out - label).abs() * mask).sum() / mask.sum().clamp_min(1.0)
+    raise NotImplementedError(task)
+
+
+class MultiTaskLoss(nn.Module):
+    """sum_t w_t * loss_t with the fixed weights of main.py:192-199 (mtl_loss_schemes.py:223-238)."""
+
+    def __init__(self, tasks: Sequence[str], loss_weights: Optional[Mapping[str, float]] = None):
+        super().__init__()
+        self.tasks = list(tasks)
+        self.loss_weights = dict(loss_weights or {t: LOSS_WEIGHTS[t] for t in tasks})
+
+    def forward(self, pred, gt):
+        per = {t: task_loss(t, pred[t], gt[t]) for t in self.tasks}
+        total = torch.stack([self.loss_weights[t] * per[t] for t in self.tasks]).sum()
+        per["total"] = total
+        return total, per
+
+
+# --------------------------------------------------------------------------------------------------
+def build_model(img_size=448, tasks=("semseg", "normals", "sal", "human_parts"), embed_dim=96, depths=(2, 2, 6, 2),
+                num_heads=(3, 6, 12, 24), r_shared=64, r_task=4, drop_path_rate=0.2, lora_b_std=0.02, seed=0,
+                freeze=True, **mt_over) -> MultiTaskSwin:
+    """random-init model of the BASELINE configs: trunc_normal(.02) weights (reference :717-724),
+    lora_*_B ~ N(0, lora_b_std) so that the LoRA paths are numerically live, and the reference's
+    trainable set (mark_only_lora_as_trainable with every freeze flag False, main.py:257-262)."""
+    torch.manual_seed(seed)
+    mt = mtlora_namespace(tasks, r_shared, r_task, n_stages=len(depths), **mt_over)
+    bb = SwinTransformerMTLoRA(img_size=img_size, patch_size=4, in_chans=3, num_classes=0, embed_dim=embed_dim,
+                               depths=list(depths), num_heads=list(num_heads), window_size=7, mlp_ratio=4.0,
+                               qkv_bias=True, drop_rate=0.0, drop_path_rate=drop_path_rate, ape=False, patch_norm=True,
+                               tasks=list(tasks), mtlora=mt)
+    model = MultiTaskSwin(bb, tasks, {t: NUM_OUTPUT[t] for t in tasks})
+    if lora_b_std > 0:
+        with torch.no_grad():
+            for n, p in model.named_parameters():
+                if "lora_" in n and "_B" in n:
+                    p.normal_(0.0, lora_b_std)
+    if freeze:
+        mark_only_lora_as_trainable(model.backbone, bias="none")
+    return model
+
+
+def build_optimizer(model: nn.Module, lr=5e-4, weight_decay=0.05, fused: Optional[bool] = None) -> torch.optim.Optimizer:
+    """AdamW(betas .9/.999, eps 1e-8, wd .05) with the no-decay set of optimizer.py:71-85 (1-D tensors, biases,
+    relative_position_bias_table); only trainable tensors are handed over (frozen ones never get a grad in the
+    reference either)."""
+    decay, no_decay = [], []
+    for n, p in model.named_parameters():
+        if not p.requires_grad:
+            continue
+        if p.ndim == 1 or n.endswith(".bias") or "relative_position_bias_table" in n or "absolute_pos_embed" in n:
+            no_decay.append(p)
+        else:
+            decay.append(p)
+    groups = [{"params": decay}, {"params": no_decay, "weight_decay": 0.0}]
+    if fused is None:
+        fused = all(p.is_cuda for p in decay + no_decay)
+    return torch.optim.AdamW(groups, lr=lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=weight_decay, fused=fused)
+
+
+def synthetic_batch(B: int, S: int, tasks: Sequence[str], seed: int, device="cpu"):
+    """SURVEY 8d synthetic inputs: image ~ N(0,1); semseg/human_parts class ids with 5 % 255; sal Bernoulli(.3);
+    normals unit vectors with 5 % pixels 255."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    img = torch.randn(B, 3, S, S, generator=g)
+    tg = {}
+    for t in tasks:
+        if t in ("semseg", "human_parts"):
+            lab = torch.randint(0, NUM_OUTPUT[t], (B, 1, S, S), generator=g).float()
+            lab[torch.rand(B, 1, S, S, generator=g) < 0.05] = 255.0
+        elif t == "sal":
+            lab = (torch.rand(B, 1, S, S, generator=g) < 0.3).float()
+        elif t == "normals":
+            lab = F.normalize(torch.randn(B, 3, S, S, generator=g), dim=1)
+            ign = (torch.rand(B, 1, S, S, generator=g) < 0.05).expand(B, 3, S, S)
+            lab = torch.where(ign, torch.full_like(lab, 255.0), lab)
+        elif t == "depth":
+            lab = torch.rand(B, 1, S, S, generator=g) * 10
+        else:
+            raise NotImplementedError(t)
+        tg[t] = lab.to(device)
+    return img.to(device), tg
+
+
+def train_step(model, criterion, optimizer, images, targets, clip_grad: float = 5.0, reducer=None,
+               amp_dtype: Optional[torch.dtype] = torch.bfloat16):
+    """one reference train step (main.py:329-354): autocast fwd + weighted multi-task loss, backward,
+    [gradient all-reduce], clip_grad_norm_(5.0), AdamW, zero_grad.  bf16 autocast needs no GradScaler
+    (the reference's scaler exists for its fp16 default)."""
+    if amp_dtype is not None:
+        with torch.autocast("cuda", dtype=amp_dtype):
+            out = model(images)
+            loss, per = criterion(out, targets)
+    else:
+        out = model(images)
+        loss, per = criterion(out, targets)
+    if reducer is not None:
+        reducer.prepare()
+    loss.backward()
+    if reducer is not None:
+        reducer.finish()
+    params = [p for g in optimizer.param_groups for p in g["params"] if p.grad is not None]
+    norm = torch.nn.utils.clip_grad_norm_(params, clip_grad, foreach=True) if clip_grad else None
+    optimizer.step()
+    optimizer.zero_grad(set_to_none=True)
+    return loss.detach(), norm

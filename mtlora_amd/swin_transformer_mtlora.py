@@ -1,0 +1,466 @@
+"""MI355X drop-in for ``models.swin_transformer_mtlora`` (reference models/swin_transformer_mtlora.py).
+
+Same public classes, constructor arguments, parameter / buffer names (so reference checkpoints and
+``mark_only_lora_as_trainable`` name filters keep working) and the same tuple-returning calling
+convention ``(shared, {task: tensor} | None)``; ``MultiTaskSwin`` (models/swin_mtl.py) and the decoder
+heads run on top of it unchanged.
+
+What is different is the dataflow of a block.  The reference rolls + partitions the normalised map,
+runs qkv on window-ordered tokens, materialises (B_, nH, N, N) scores, and un-partitions + un-rolls
+the result (and every per-task result) again (reference :326-408).  Here
+
+  * qkv / proj / fc1 / fc2 are the fused MTLoRALinear kernels (csrc/linear.hip) and run on tokens in
+    their NATURAL (B, H*W) order -- they are per-token maps, so the order is irrelevant to them;
+  * the cyclic shift, window partition, bias + mask softmax attention, window merge and reverse shift
+    are ONE kernel (csrc/attention.hip) that gathers the tokens of each shifted window by address
+    and scatters the result back, so no permutation pass touches HBM and the per-task outputs of
+    ``proj`` come out already in image order (the reference re-permutes each of them, :378-386).
+
+``attention_layout = "windows"`` on a block restores the reference's window-ordered dataflow using
+the stand-alone window-process kernels (csrc/window_process.hip) -- kept for parity tests and for
+users of ``WindowAttention.forward(x_windows, mask)``.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import torch
+import torch.nn as nn
+from torch import Tensor
+
+from . import functional as Fn
+from .lora import MTLoRALinear
+from .window_process import WindowProcess, WindowProcessReverse
+
+
+# -- small stand-ins for the three timm helpers the reference imports (timm is not a dependency) ----
+def to_2tuple(v):
+    return tuple(v) if isinstance(v, (tuple, list)) else (v, v)
+
+
+trunc_normal_ = nn.init.trunc_normal_
+
+
+class DropPath(nn.Module):
+    """per-sample stochastic depth (timm DropPath semantics: scale kept samples by 1/keep)."""
+
+    def __init__(self, drop_prob: float = 0.0, scale_by_keep: bool = True):
+        super().__init__()
+        self.drop_prob, self.scale_by_keep = drop_prob, scale_by_keep
+
+    def forward(self, x):
+        if self.drop_prob == 0.0 or not self.training:
+            return x
+        keep = 1.0 - self.drop_prob
+        m = x.new_empty((x.shape[0],) + (1,) * (x.ndim - 1)).bernoulli_(keep)
+        if keep > 0.0 and self.scale_by_keep:
+            m.div_(keep)
+        return x * m
+
+    def extra_repr(self):
+        return f"drop_prob={self.drop_prob:.3f}"
+
+
+class CompatLinear(nn.Linear):
+    """plain linear with the tuple calling convention (reference :36-41); stays on rocBLAS/hipBLASLt."""
+
+    def forward(self, input: Tensor, x_tasks: dict = None):
+        return super().forward(input), None
+
+
+def _mtlora_linear(mtlora, layer_idx, fin, fout, tasks, **kw):
+    return MTLoRALinear(fin, fout, r=mtlora.R_PER_TASK_LIST[layer_idx], lora_shared_scale=mtlora.SHARED_SCALE[layer_idx],
+                        lora_task_scale=mtlora.SCALE_PER_TASK_LIST[layer_idx], lora_dropout=mtlora.DROPOUT[layer_idx],
+                        tasks=tasks, trainable_scale_shared=mtlora.TRAINABLE_SCALE_SHARED,
+                        trainable_scale_per_task=mtlora.TRAINABLE_SCALE_PER_TASK, shared_mode=mtlora.SHARED_MODE, **kw)
+
+
+class Mlp(nn.Module):
+    def __init__(self, in_features, hidden_features=None, out_features=None, act_layer=nn.GELU, drop=0.0, lora=False,
+                 tasks=None, mtlora=None, layer_idx=0):
+        super().__init__()
+        out_features = out_features or in_features
+        hidden_features = hidden_features or in_features
+        t = tasks if (lora or mtlora.INTERMEDIATE_SPECIALIZATION) else None
+        self.fc1 = (_mtlora_linear(mtlora, layer_idx, in_features, hidden_features, t) if mtlora.FC1_ENABLED
+                    else CompatLinear(in_features, hidden_features))
+        self.act = act_layer()
+        self.fc2 = (_mtlora_linear(mtlora, layer_idx, hidden_features, out_features, t) if mtlora.FC2_ENABLED
+                    else CompatLinear(hidden_features, out_features))
+        self.tasks = tasks
+        self.drop = nn.Dropout(drop)
+
+    def forward(self, x, x_tasks=None):
+        h, h_t = self.fc1(x, x_tasks)
+        h = self.drop(self.act(h))
+        if h_t is not None:
+            h_t = {t: self.drop(self.act(h_t[t])) for t in self.tasks}
+        y, y_t = self.fc2(h, h_t)
+        y = self.drop(y)
+        if y_t is not None:
+            y_t = {t: self.drop(y_t[t]) for t in self.tasks}
+        return y, y_t
+
+
+def window_partition(x, window_size):
+    """(B,H,W,C) -> (nW*B, ws, ws, C) (pure-torch helper kept for API parity; reference :84-98)."""
+    B, H, W, C = x.shape
+    x = x.view(B, H // window_size, window_size, W // window_size, window_size, C)
+    return x.permute(0, 1, 3, 2, 4, 5).contiguous().view(-1, window_size, window_size, C)
+
+
+def window_reverse(windows, window_size, H, W):
+    """inverse of window_partition (reference :101-116)."""
+    B = int(windows.shape[0] / (H * W / window_size / window_size))
+    x = windows.view(B, H // window_size, W // window_size, window_size, window_size, -1)
+    return x.permute(0, 1, 3, 2, 4, 5).contiguous().view(B, H, W, -1)
+
+
+def _relative_position_index(wh: int, ww: int) -> Tensor:
+    ys, xs = torch.meshgrid(torch.arange(wh), torch.arange(ww), indexing="ij")
+    pos = torch.stack([ys.reshape(-1), xs.reshape(-1)])            # 2, N
+    rel = pos[:, :, None] - pos[:, None, :]                        # 2, N, N
+    return (rel[0] + wh - 1) * (2 * ww - 1) + (rel[1] + ww - 1)
+
+
+class WindowAttention(nn.Module):
+    """W-MSA / SW-MSA with relative position bias; qkv and proj are MTLoRALinear (reference :119-243)."""
+
+    def __init__(self, dim, window_size, num_heads, qkv_bias=True, qk_scale=None, attn_drop=0.0, proj_drop=0.0,
+                 lora=False, tasks=None, mtlora=None, layer_idx=0):
+        super().__init__()
+        self.dim = dim
+        self.window_size = window_size  # (Wh, Ww)
+        self.num_heads = num_heads
+        head_dim = dim // num_heads
+        self.scale = qk_scale or head_dim ** -0.5
+        self.relative_position_bias_table = nn.Parameter(
+            torch.zeros((2 * window_size[0] - 1) * (2 * window_size[1] - 1), num_heads))
+        self.register_buffer("relative_position_index", _relative_position_index(*window_size))
+        self.qkv = (_mtlora_linear(mtlora, layer_idx, dim, dim * 3, None, bias=qkv_bias) if mtlora.QKV_ENABLED
+                    else CompatLinear(dim, dim * 3, bias=qkv_bias))
+        self.attn_drop = nn.Dropout(attn_drop)
+        self.proj = (_mtlora_linear(mtlora, layer_idx, dim, dim,
+                                    tasks if (lora or mtlora.INTERMEDIATE_SPECIALIZATION) else None)
+                     if mtlora.PROJ_ENABLED else CompatLinear(dim, dim))
+        self.tasks = tasks
+        self.proj_drop = nn.Dropout(proj_drop)
+        trunc_normal_(self.relative_position_bias_table, std=0.02)
+        self.softmax = nn.Softmax(dim=-1)
+
+    def dense_bias(self) -> Tensor:
+        """(nH, N, N) = table[index] (reference :202-206); autograd routes the kernel's dbias into the table."""
+        n = self.window_size[0] * self.window_size[1]
+        b = self.relative_position_bias_table[self.relative_position_index.view(-1)]
+        return b.view(n, n, -1).permute(2, 0, 1).float()
+
+    def _core(self, qkv: Tensor, meta: Fn.AttnMeta, mask: Optional[Tensor], mask_t: Optional[Tensor]) -> Tensor:
+        if self.training and self.attn_drop.p > 0:
+            raise NotImplementedError("mtlora_amd: attn_drop > 0 is not supported by the fused attention kernel "
+                                      "(every MTLoRA config uses 0)")
+        if mask is not None:
+            mask = mask.float().contiguous()
+            if mask_t is None:
+                mask_t = mask.transpose(1, 2).contiguous()
+        return Fn.WindowAttentionFn.apply(meta, qkv, self.dense_bias(), mask, mask_t)
+
+    def _project(self, a: Tensor):
+        y, y_t = self.proj(a)
+        y = self.proj_drop(y)
+        if y_t is not None:
+            y_t = {t: self.proj_drop(y_t[t]) for t in self.tasks}
+        return y, y_t
+
+    def forward(self, x, mask=None):
+        """x: (num_windows*B, N, C) window-ordered tokens, mask: (nW, N, N) or None -- the reference API (:186-227)."""
+        B_, N, C = x.shape
+        qkv, _ = self.qkv(x)
+        nW = 1 if mask is None else mask.shape[0]
+        ws = self.window_size[0]
+        meta = Fn.AttnMeta(B=B_ // nW, H=ws, W=ws * nW, window_size=ws, shift=0, num_heads=self.num_heads,
+                           head_dim=C // self.num_heads, image_layout=False, scale=self.scale)
+        return self._project(self._core(qkv, meta, mask, None))
+
+    def forward_image(self, x, H: int, W: int, shift: int, mask=None, mask_t=None):
+        """x: (B, H*W, C) tokens in image order.  Equivalent to roll(-shift) -> partition -> forward ->
+        merge -> roll(+shift), with the permutations folded into the attention kernel's addressing."""
+        B, L, C = x.shape
+        qkv, _ = self.qkv(x)
+        meta = Fn.AttnMeta(B=B, H=H, W=W, window_size=self.window_size[0], shift=shift, num_heads=self.num_heads,
+                           head_dim=C // self.num_heads, image_layout=True, scale=self.scale)
+        return self._project(self._core(qkv, meta, mask, mask_t))
+
+    def extra_repr(self) -> str:
+        return f"dim={self.dim}, window_size={self.window_size}, num_heads={self.num_heads}"
+
+    def flops(self, N):
+        return 4 * N * self.dim * self.dim + 2 * self.num_heads * N * N * (self.dim // self.num_heads)
+
+
+def _shift_mask(H: int, W: int, ws: int, shift: int) -> Tensor:
+    """(nW, N, N) 0 / -100 mask of SW-MSA (reference :297-323): tokens of different cyclic regions do not attend."""
+    ids = torch.zeros(H, W)
+    edges_h = (0, H - ws, H - shift, H)
+    edges_w = (0, W - ws, W - shift, W)
+    for a in range(3):
+        for b in range(3):
+            ids[edges_h[a]:edges_h[a + 1], edges_w[b]:edges_w[b + 1]] = 3 * a + b
+    win = ids.view(H // ws, ws, W // ws, ws).permute(0, 2, 1, 3).reshape(-1, ws * ws)
+    diff = win[:, None, :] - win[:, :, None]
+    return torch.where(diff != 0, torch.full_like(diff, -100.0), torch.zeros_like(diff))
+
+
+class SwinTransformerBlock(nn.Module):
+    def __init__(self, dim, input_resolution, num_heads, window_size=7, shift_size=0, mlp_ratio=4.0, qkv_bias=True,
+                 qk_scale=None, drop=0.0, attn_drop=0.0, drop_path=0.0, act_layer=nn.GELU, norm_layer=nn.LayerNorm,
+                 fused_window_process=False, lora=False, tasks=None, mtlora=None, layer_idx=0):
+        super().__init__()
+        self.dim = dim
+        self.input_resolution = input_resolution
+        self.num_heads = num_heads
+        self.window_size = window_size
+        self.shift_size = shift_size
+        self.mlp_ratio = mlp_ratio
+        self.tasks = tasks
+        self.lora = lora
+        if min(self.input_resolution) <= self.window_size:  # one window covers the map: no shift (reference :271-274)
+            self.shift_size = 0
+            self.window_size = min(self.input_resolution)
+        assert 0 <= self.shift_size < self.window_size, "shift_size must in 0-window_size"
+        self.norm1 = norm_layer(dim)
+        self.attn = WindowAttention(dim, window_size=to_2tuple(self.window_size), num_heads=num_heads,
+                                    qkv_bias=qkv_bias, qk_scale=qk_scale, attn_drop=attn_drop, proj_drop=drop, lora=lora,
+                                    tasks=tasks, mtlora=mtlora, layer_idx=layer_idx)
+        self.drop_path = DropPath(drop_path) if drop_path > 0.0 else nn.Identity()
+        self.norm2 = norm_layer(dim)
+        self.mlp = Mlp(in_features=dim, hidden_features=int(dim * mlp_ratio), act_layer=act_layer, drop=drop, lora=lora,
+                       tasks=tasks, mtlora=mtlora, layer_idx=layer_idx)
+        H, W = self.input_resolution
+        mask = _shift_mask(H, W, self.window_size, self.shift_size) if self.shift_size > 0 else None
+        self.register_buffer("attn_mask", mask)
+        self.register_buffer("_attn_mask_t", None if mask is None else mask.transpose(1, 2).contiguous(),
+                             persistent=False)
+        self.fused_window_process = fused_window_process
+        self.attention_layout = "image"  # "windows": reference dataflow through the window-process kernels
+
+    # -- attention half ------------------------------------------------------------------------------
+    def _attend_windows(self, xn: Tensor, B: int, H: int, W: int, C: int):
+        ws, s = self.window_size, self.shift_size
+        xw = WindowProcess.apply(xn.view(B, H, W, C).contiguous(), B, H, W, C, -s, ws).view(-1, ws * ws, C)
+        a, a_t = self.attn(xw, mask=self.attn_mask)
+        merge = lambda v: WindowProcessReverse.apply(v.reshape(-1, ws, ws, C).contiguous(), B, H, W, C, s, ws).view(B, H * W, C)
+        return merge(a), None if a_t is None else {t: merge(a_t[t]) for t in self.tasks}
+
+    def forward(self, x):
+        H, W = self.input_resolution
+        B, L, C = x.shape
+        assert L == H * W, "input feature has wrong size"
+        shortcut = x
+        xn = self.norm1(x)
+        if self.attention_layout == "windows":
+            a, a_t = self._attend_windows(xn, B, H, W, C)
+        else:
+            a, a_t = self.attn.forward_image(xn, H, W, self.shift_size, self.attn_mask, self._attn_mask_t)
+        # residuals: an independent DropPath draw per call, like the reference (:389-392)
+        x_t = None
+        if a_t is not None:
+            x_t = {t: shortcut + self.drop_path(a_t[t]) for t in self.tasks}
+        x = shortcut + self.drop_path(a)
+        # MLP half
+        m, m_t = self.mlp(self.norm2(x), None if x_t is None else {t: self.norm2(x_t[t]) for t in self.tasks})
+        out = x + self.drop_path(m)
+        if m_t is None:
+            return out, None
+        if x_t is None:  # INTERMEDIATE_SPECIALIZATION-style: mlp specialises but attention did not (:401-403)
+            return out, {t: self.drop_path(m_t[t]) for t in self.tasks}
+        return out, {t: x_t[t] + self.drop_path(m_t[t]) for t in self.tasks}
+
+    def extra_repr(self) -> str:
+        return (f"dim={self.dim}, input_resolution={self.input_resolution}, num_heads={self.num_heads}, "
+                f"window_size={self.window_size}, shift_size={self.shift_size}, mlp_ratio={self.mlp_ratio}")
+
+    def flops(self):
+        H, W = self.input_resolution
+        nW = H * W / self.window_size / self.window_size
+        return (2 * self.dim * H * W + nW * self.attn.flops(self.window_size * self.window_size)
+                + 2 * H * W * self.dim * self.dim * self.mlp_ratio)
+
+
+class PatchMerging(nn.Module):
+    """2x2 neighbourhood concat -> LayerNorm(4C) -> reduction 4C->2C (reference :429-481)."""
+
+    def __init__(self, input_resolution, dim, norm_layer=nn.LayerNorm, layer_idx=0, mtlora=None):
+        super().__init__()
+        self.input_resolution = input_resolution
+        self.dim = dim
+        self.reduction = (_mtlora_linear(mtlora, layer_idx, 4 * dim, 2 * dim, None, bias=False)
+                          if mtlora.DOWNSAMPLER_ENABLED else CompatLinear(4 * dim, 2 * dim, bias=False))
+        self.norm = norm_layer(4 * dim)
+
+    def forward(self, x):
+        H, W = self.input_resolution
+        B, L, C = x.shape
+        assert L == H * W, "input feature has wrong size"
+        assert H % 2 == 0 and W % 2 == 0, f"x size ({H}*{W}) are not even."
+        # (B, H/2, 2, W/2, 2, C) -> channel order [x(0,0), x(1,0), x(0,1), x(1,1)] as the reference's cat
+        g = x.view(B, H // 2, 2, W // 2, 2, C).permute(0, 1, 3, 4, 2, 5).reshape(B, (H // 2) * (W // 2), 4 * C)
+        y, _ = self.reduction(self.norm(g))
+        return y
+
+    def extra_repr(self) -> str:
+        return f"input_resolution={self.input_resolution}, dim={self.dim}"
+
+    def flops(self):
+        H, W = self.input_resolution
+        return H * W * self.dim + (H // 2) * (W // 2) * 4 * self.dim * 2 * self.dim
+
+
+class BasicLayer(nn.Module):
+    """one stage: `depth` blocks (odd ones shifted; only the last is task-specialised) + PatchMerging that is
+    applied to the shared tensor and to every task tensor (reference :484-562)."""
+
+    def __init__(self, dim, input_resolution, depth, num_heads, window_size, mlp_ratio=4.0, qkv_bias=True, qk_scale=None,
+                 drop=0.0, attn_drop=0.0, drop_path=0.0, norm_layer=nn.LayerNorm, downsample=None, use_checkpoint=False,
+                 fused_window_process=False, tasks=None, mtlora=None, layer_idx=0):
+        super().__init__()
+        self.dim = dim
+        self.input_resolution = input_resolution
+        self.depth = depth
+        self.use_checkpoint = use_checkpoint
+        self.tasks = tasks
+        self.blocks = nn.ModuleList([
+            SwinTransformerBlock(dim=dim, input_resolution=input_resolution, num_heads=num_heads, window_size=window_size,
+                                 shift_size=0 if i % 2 == 0 else window_size // 2, mlp_ratio=mlp_ratio,
+                                 qkv_bias=qkv_bias, qk_scale=qk_scale, drop=drop, attn_drop=attn_drop,
+                                 drop_path=drop_path[i] if isinstance(drop_path, list) else drop_path,
+                                 norm_layer=norm_layer, fused_window_process=fused_window_process,
+                                 lora=(i == depth - 1), tasks=tasks, mtlora=mtlora, layer_idx=layer_idx)
+            for i in range(depth)])
+        self.downsample = (downsample(input_resolution, dim=dim, norm_layer=norm_layer, layer_idx=layer_idx, mtlora=mtlora)
+                           if downsample is not None else None)
+
+    def forward(self, x):
+        tasks_lora = None
+        for blk in self.blocks:
+            x, tasks_lora = blk(x)
+        if self.downsample is not None:
+            x = self.downsample(x)
+            if tasks_lora is not None:
+                tasks_lora = {t: self.downsample(tasks_lora[t]) for t in self.tasks}
+        return x, tasks_lora
+
+    def extra_repr(self) -> str:
+        return f"dim={self.dim}, input_resolution={self.input_resolution}, depth={self.depth}"
+
+    def flops(self):
+        return sum(b.flops() for b in self.blocks) + (self.downsample.flops() if self.downsample is not None else 0)
+
+
+class PatchEmbed(nn.Module):
+    def __init__(self, img_size=224, patch_size=4, in_chans=3, embed_dim=96, norm_layer=None):
+        super().__init__()
+        img_size, patch_size = to_2tuple(img_size), to_2tuple(patch_size)
+        self.img_size = img_size
+        self.patch_size = patch_size
+        self.patches_resolution = [img_size[0] // patch_size[0], img_size[1] // patch_size[1]]
+        self.num_patches = self.patches_resolution[0] * self.patches_resolution[1]
+        self.in_chans = in_chans
+        self.embed_dim = embed_dim
+        self.proj = nn.Conv2d(in_chans, embed_dim, kernel_size=patch_size, stride=patch_size)
+        self.norm = norm_layer(embed_dim) if norm_layer is not None else None
+
+    def forward(self, x):
+        B, C, H, W = x.shape
+        assert H == self.img_size[0] and W == self.img_size[1], \
+            f"Input image size ({H}*{W}) doesn't match model ({self.img_size[0]}*{self.img_size[1]})."
+        x = self.proj(x).flatten(2).transpose(1, 2)
+        return x if self.norm is None else self.norm(x)
+
+    def flops(self):
+        Ho, Wo = self.patches_resolution
+        f = Ho * Wo * self.embed_dim * self.in_chans * (self.patch_size[0] * self.patch_size[1])
+        return f + (Ho * Wo * self.embed_dim if self.norm is not None else 0)
+
+
+class SwinTransformerMTLoRA(nn.Module):
+    """Swin backbone whose last block per stage emits one feature map per task (reference :616-772)."""
+
+    def __init__(self, img_size=224, patch_size=4, in_chans=3, num_classes=1000, embed_dim=96, depths=[2, 2, 6, 2],
+                 num_heads=[3, 6, 12, 24], window_size=7, mlp_ratio=4.0, qkv_bias=True, qk_scale=None, drop_rate=0.0,
+                 attn_drop_rate=0.0, drop_path_rate=0.1, norm_layer=nn.LayerNorm, ape=False, patch_norm=True,
+                 use_checkpoint=False, fused_window_process=False, basic_layer=BasicLayer, tasks=None, mtlora=None,
+                 **kwargs):
+        super().__init__()
+        self.num_classes = num_classes
+        self.num_layers = len(depths)
+        self.embed_dim = embed_dim
+        self.ape = ape
+        self.patch_norm = patch_norm
+        self.num_features = int(embed_dim * 2 ** (self.num_layers - 1))
+        self.mlp_ratio = mlp_ratio
+        self.tasks = tasks
+        self.mtlora = mtlora
+        self.patch_embed = PatchEmbed(img_size=img_size, patch_size=patch_size, in_chans=in_chans, embed_dim=embed_dim,
+                                      norm_layer=norm_layer if patch_norm else None)
+        res = self.patch_embed.patches_resolution
+        self.patches_resolution = res
+        if ape:
+            self.absolute_pos_embed = nn.Parameter(torch.zeros(1, self.patch_embed.num_patches, embed_dim))
+            trunc_normal_(self.absolute_pos_embed, std=0.02)
+        self.pos_drop = nn.Dropout(p=drop_rate)
+        dpr = [v.item() for v in torch.linspace(0, drop_path_rate, sum(depths))]  # stochastic depth decay rule
+        self.layers = nn.ModuleList()
+        for i in range(self.num_layers):
+            self.layers.append(basic_layer(
+                dim=int(embed_dim * 2 ** i), input_resolution=(res[0] // 2 ** i, res[1] // 2 ** i), depth=depths[i],
+                num_heads=num_heads[i], window_size=window_size, mlp_ratio=mlp_ratio, qkv_bias=qkv_bias,
+                qk_scale=qk_scale, drop=drop_rate, attn_drop=attn_drop_rate,
+                drop_path=dpr[sum(depths[:i]):sum(depths[:i + 1])], norm_layer=norm_layer,
+                downsample=PatchMerging if i < self.num_layers - 1 else None, use_checkpoint=use_checkpoint,
+                fused_window_process=fused_window_process, tasks=tasks, mtlora=mtlora, layer_idx=i))
+        self.avgpool = nn.AdaptiveAvgPool1d(1)
+        self.head = nn.Linear(self.num_features, num_classes) if num_classes > 0 else nn.Identity()
+        self.apply(self._init_weights)
+
+    @staticmethod
+    def _init_weights(m):
+        if isinstance(m, nn.Linear):
+            trunc_normal_(m.weight, std=0.02)
+            if m.bias is not None:
+                nn.init.constant_(m.bias, 0)
+        elif isinstance(m, nn.LayerNorm):
+            nn.init.constant_(m.bias, 0)
+            nn.init.constant_(m.weight, 1.0)
+
+    @torch.jit.ignore
+    def no_weight_decay(self):
+        return {"absolute_pos_embed"}
+
+    @torch.jit.ignore
+    def no_weight_decay_keywords(self):
+        return {"relative_position_bias_table"}
+
+    def forward_features(self, x, return_stages=False, flatten_ft=False):
+        x = self.patch_embed(x)
+        if self.ape:
+            x = x + self.absolute_pos_embed
+        x = self.pos_drop(x)
+        stages = []
+        for layer in self.layers:
+            x, tasks_lora = layer(x)
+            if tasks_lora is None:
+                tasks_lora = {t: x for t in self.tasks}
+            stages.append((x, tasks_lora))
+        if return_stages:
+            return stages
+        if flatten_ft:
+            x = torch.flatten(self.avgpool(x.transpose(1, 2)), 1)
+        return x
+
+    def forward(self, x, return_stages=False, flatten_ft=False):
+        return self.head(self.forward_features(x, return_stages, flatten_ft))
+
+    def flops(self, images=None, logger=None, detailed=False):
+        f = self.patch_embed.flops() + sum(l.flops() for l in self.layers)
+        f += self.num_features * self.patches_resolution[0] * self.patches_resolution[1] // (2 ** self.num_layers)
+        return f + self.num_features * self.num_classes

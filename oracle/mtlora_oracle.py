@@ -58,8 +58,10 @@ def _mix32(x: np.ndarray) -> np.ndarray:
 def dropout_keep_mask(seed: int, stream: int, rows: int, cols: int, p: float) -> Tensor:
     """keep[m, k] for element (m, k) of an (rows, cols) activation.
 
-    hash = mix32(mix32(m * 0x9E3779B1 + seed_lo + stream * 0x85EBCA77) ^ (k + seed_hi * 0x27D4EB2F));
-    keep  <=>  hash >= floor(p * 2**32).
+        rh   = mix32(m * 0x9E3779B1 + seed_lo + stream * 0x85EBCA77)          (row hash)
+        h    = mix32(rh ^ ((k >> 1) + seed_hi * 0x27D4EB2F))                    (32 bits per element PAIR)
+        bits = h >> 16 if k odd else h & 0xFFFF
+        keep <=> bits >= floor(p * 65536)
     Mirrors ``mtl_dropout_keep`` in mtlora_amd/csrc/common.h.
     """
     if p <= 0.0:
@@ -68,12 +70,11 @@ def dropout_keep_mask(seed: int, stream: int, rows: int, cols: int, p: float) ->
     seed_hi = np.uint64((seed >> 32) & 0xFFFFFFFF)
     m = np.arange(rows, dtype=np.uint64)[:, None]
     k = np.arange(cols, dtype=np.uint64)[None, :]
-    h = (m * np.uint64(0x9E3779B1) + seed_lo + np.uint64(stream) * np.uint64(0x85EBCA77)) & _M32
-    h = _mix32(h)
-    h = (h ^ ((k + seed_hi * np.uint64(0x27D4EB2F)) & _M32)) & _M32
-    h = _mix32(h)
-    thr = np.uint64(min(int(p * 4294967296.0), 0xFFFFFFFF))
-    return torch.from_numpy((h >= thr))
+    rh = _mix32((m * np.uint64(0x9E3779B1) + seed_lo + np.uint64(stream) * np.uint64(0x85EBCA77)) & _M32)
+    h = _mix32((rh ^ (((k >> np.uint64(1)) + seed_hi * np.uint64(0x27D4EB2F)) & _M32)) & _M32)
+    bits = np.where((k & np.uint64(1)) == 1, h >> np.uint64(16), h & np.uint64(0xFFFF))
+    thr = np.uint64(min(int(p * 65536.0), 65535))
+    return torch.from_numpy(bits >= thr)
 
 
 # --------------------------------------------------------------------------

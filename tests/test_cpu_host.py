@@ -1,0 +1,181 @@
+"""CPU-side tests: the C-ABI library loads and exports every symbol the header declares, host logic of the
+drop-in modules (construction, names, trainable set, failure modes), and the 2-rank gradient reducer on gloo."""
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def built_lib():
+    from mtlora_amd.csrc.build import build
+    return build(verbose=False)
+
+
+def test_header_symbols_exported(built_lib):
+    hdr = open(os.path.join(ROOT, "include", "mtlora_hip.h")).read()
+    declared = set(re.findall(r"\b(mtlora_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"mtlora_linear_desc", "mtlora_attn_desc", "mtlora_prof_summary"}
+    from mtlora_amd import _lib
+    assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
+    L = _lib.lib()  # loads, binds every symbol (AttributeError if one is missing), checks the ABI version
+    assert L.mtlora_version() == _lib.ABI_VERSION
+    assert L.mtlora_error_string(-5).decode().startswith("ctx/scratch")
+    nm = subprocess.run(["nm", "-D", built_lib], capture_output=True, text=True).stdout
+    for s in declared:
+        assert f" T {s}" in nm, s
+
+
+def test_size_queries_and_validation(built_lib):
+    """pure host calls (no GPU): shape validation and workspace sizing of the C ABI."""
+    import ctypes
+    from mtlora_amd import _lib
+    L = _lib.lib()
+    d = _lib.LinearDesc()
+    d.M, d.K, d.N, d.dtype, d.T, d.r_s = 1000, 96, 384, _lib.BF16, 4, 64
+    for i in range(4):
+        d.r_t[i] = 4
+    n = L.mtlora_linear_ctx_bytes(ctypes.byref(d))
+    assert n >= 1000 * 128 * 2  # P: M x (64 + 4*16) bf16
+    assert L.mtlora_linear_bwd_scratch_bytes(ctypes.byref(d)) > 0
+    d.K = 100  # not a multiple of 8
+    assert L.mtlora_linear_ctx_bytes(ctypes.byref(d)) < 0
+    assert L.mtlora_linear_fwd(ctypes.byref(d), None, None, None, None, None, None, None, None, None, None, None, 0, None) == -3
+    a = _lib.AttnDesc()
+    a.B, a.H, a.W, a.window_size, a.shift, a.num_heads, a.head_dim, a.dtype = 2, 14, 14, 7, 3, 3, 32, _lib.BF16
+    assert L.mtlora_window_attn_bwd_scratch_bytes(ctypes.byref(a)) > 0
+    a.head_dim = 64
+    assert L.mtlora_window_attn_bwd_scratch_bytes(ctypes.byref(a)) < 0  # unsupported head_dim
+    # null pointers / bad shapes are rejected before any launch
+    assert L.mtlora_roll_and_window_partition_forward(None, None, 1, 14, 14, 8, -3, 7, 0, None) == -4
+    assert L.mtlora_roll_and_window_partition_forward(ctypes.c_void_p(16), ctypes.c_void_p(32), 1, 14, 14, 8, -3, 5, 0, None) == -2
+
+
+def test_no_cpu_fallback():
+    from mtlora_amd.lora import MTLoRALinear
+    from mtlora_amd import window_process as WP
+    m = MTLoRALinear(96, 96, r=4)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(torch.randn(2, 96))
+    with pytest.raises(RuntimeError):
+        WP.WindowProcess.apply(torch.randn(1, 7, 7, 8), 1, 7, 7, 8, 0, 7)
+
+
+def test_module_api_parity(golden):
+    """constructor semantics of reference lora.py:161-247 and the state dict / trainable set of the C2 model."""
+    from mtlora_amd.lora import LoRALayer, MTLoRALinear, mark_only_lora_as_trainable
+    from mtlora_amd import mtl_harness as H
+    m = MTLoRALinear(96, 288, r=8, lora_shared_scale=4.0, lora_dropout=0.05, bias=False)
+    assert isinstance(m, LoRALayer) and m.r == 8 and m.tasks is None and m.shared_mode == "matrix" and not m.merged
+    assert m.linear.bias is None and isinstance(m.lora_dropout, torch.nn.Dropout)
+    assert m.lora_shared_B.abs().sum() == 0 and m.lora_shared_A.abs().sum() > 0   # B = 0, A ~ kaiming
+    m = MTLoRALinear(96, 96, r={"shared": 8, "a": 4}, lora_task_scale={"a": 2.0}, tasks=["a"], shared_mode="add")
+    assert m.shared_mode == "addition" and hasattr(m, "lora_norm") and not hasattr(m, "lora_shared_A")
+    m = MTLoRALinear(96, 96, r={"shared": 8, "a": 4}, lora_task_scale={"a": 2.0}, tasks=["a"], shared_mode="lora_only")
+    assert m.tasks is None and m.shared_mode == "matrix"
+    m = MTLoRALinear(96, 96, r=0)
+    assert not hasattr(m, "lora_shared_A")
+    with pytest.raises(NotImplementedError):
+        m.merge()
+    c = golden("c2_structure.pt")
+    model = H.build_model(img_size=448, freeze=True)
+    mine = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    assert mine == c["state"]
+    assert sorted(n for n, p in model.named_parameters() if p.requires_grad) == sorted(c["trainable"])
+    assert sum(p.numel() for p in model.parameters()) == c["n_params"] == 34262906
+    assert sum(p.numel() for p in model.parameters() if p.requires_grad) == c["n_trainable"] == 8344634
+    # mark_only_lora_as_trainable flags (reference lora.py:580-630)
+    model = H.build_model(img_size=224, tasks=("semseg",), freeze=False)
+    mark_only_lora_as_trainable(model.backbone, bias="none", freeze_patch_embed=True, freeze_norm=True,
+                                free_relative_bias=True, freeze_downsample_reduction=True)
+    assert all("lora_" in n for n, p in model.backbone.named_parameters() if p.requires_grad)
+    mark_only_lora_as_trainable(model.backbone, bias="all")
+    assert any(n.endswith("linear.bias") and p.requires_grad for n, p in model.backbone.named_parameters())
+
+
+def test_checkpoint_key_mapping():
+    """vanilla-Swin keys -> MTLoRA keys (reference lora.py:644-668, utils.py:125-149)."""
+    from mtlora_amd.lora import map_old_state_dict_weights
+    sd = {"layers.0.blocks.0.attn.qkv.weight": torch.arange(12.).reshape(6, 2), "layers.0.blocks.0.attn.qkv.bias": torch.arange(6.)}
+    mapping = {"attn.qkv.weight": "attn.qkv.linear.weight", "attn.qkv.bias": "attn.qkv.linear.bias", "x.y": "x.z"}
+    out = map_old_state_dict_weights(dict(sd), mapping, "layers.0.blocks.0.")
+    assert set(out) == {"layers.0.blocks.0.attn.qkv.linear.weight", "layers.0.blocks.0.attn.qkv.linear.bias"}
+    out = map_old_state_dict_weights(dict(sd), mapping, "layers.0.blocks.0.", split_qkv=True)
+    assert torch.equal(out["layers.0.blocks.0.attn.qkv.k.linear.weight"], torch.arange(12.).reshape(6, 2)[2:4])
+
+
+def test_harness_losses_match_golden(golden):
+    from mtlora_amd import mtl_harness as H
+    for t, d in golden("losses.pt").items():
+        pred = d["pred"].clone().requires_grad_(True)
+        l = H.task_loss(t, pred, d["label"])
+        assert abs(l.item() - d["loss"]) < 1e-5 * max(1.0, abs(d["loss"])), t
+        l.backward()
+        assert torch.allclose(pred.grad, d["dpred"], rtol=1e-4, atol=1e-7), t
+
+
+def test_dropout_mask_statistics():
+    from oracle import mtlora_oracle as O
+    for p in (0.05, 0.25, 0.5):
+        k = O.dropout_keep_mask(0xABCDEF0123456789, 0, 2000, 96, p)
+        assert abs(k.float().mean().item() - (1 - p)) < 0.01
+        assert abs(k.float().mean(0).std().item()) < 0.03  # no column bias
+    a = O.dropout_keep_mask(1, 0, 64, 64, 0.5)
+    b = O.dropout_keep_mask(2, 0, 64, 64, 0.5)
+    assert (a != b).float().mean() > 0.3
+
+
+_DDP_WORKER = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from mtlora_amd.ddp import GradReducer
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", init_method="env://")
+torch.manual_seed(0)
+net = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.ReLU(), torch.nn.Linear(16, 4), torch.nn.Linear(4, 4))
+net[0].weight.requires_grad_(False)            # frozen parameters never enter a bucket
+unused = torch.nn.Parameter(torch.zeros(3))     # trainable but never used -> grad stays None
+params = list(net.parameters()) + [unused]
+red = GradReducer(params, bucket_mb=0.0002)     # several buckets
+assert red.nbytes == 4 * sum(p.numel() for p in params if p.requires_grad)
+g = torch.Generator().manual_seed(100)
+xs = torch.randn(world, 5, 8, generator=g)
+red.prepare(); net(xs[rank]).pow(2).sum().backward(); red.finish()
+# single-process reference on the concatenated batch: mean over ranks of per-rank grads
+ref = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.ReLU(), torch.nn.Linear(16, 4), torch.nn.Linear(4, 4))
+ref.load_state_dict(net.state_dict())
+sum(ref(xs[r]).pow(2).sum() for r in range(world)).backward()
+for (n, p), q in zip(net.named_parameters(), ref.parameters()):
+    if p.requires_grad:
+        assert torch.allclose(p.grad, q.grad / world, rtol=1e-5, atol=1e-6), n
+    else:
+        assert p.grad is None
+assert unused.grad is None
+# second step reuses the buckets
+net.zero_grad(); red.prepare(); net(xs[rank] * 2).pow(2).sum().backward(); red.finish()
+t = torch.stack([p.grad.sum() for p in net.parameters() if p.requires_grad]).sum().reshape(1)
+gathered = [torch.zeros(1) for _ in range(world)]
+dist.all_gather(gathered, t)
+assert all(torch.allclose(gathered[0], v) for v in gathered)   # every rank holds the same averaged gradients
+dist.destroy_process_group()
+print("OK", rank)
+'''
+
+
+def test_grad_reducer_two_ranks_gloo(tmp_path):
+    script = tmp_path / "w.py"
+    script.write_text(_DDP_WORKER)
+    port = 29500 + (os.getpid() % 500)
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script), ROOT], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=240)[0] for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0 and "OK" in o, o

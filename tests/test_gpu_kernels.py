@@ -1,0 +1,434 @@
+"""GPU parity tests: the HIP path (through the C ABI / autograd Functions / modules) against the oracle and
+the golden vectors captured from the reference.  Tolerances (BASELINE.json north_star): 1e-3 for fp32,
+1e-2 for bf16, both relative to the output scale (max |ref|), since the reference's own bf16-vs-fp32
+difference is 5e-3 relative."""
+import ctypes
+
+import pytest
+import torch
+
+from oracle import mtlora_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+TOL = {torch.float32: 1e-3, torch.bfloat16: 1e-2}
+
+
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a ROCm device"
+    return torch.device("cuda:0")
+
+
+def rel_err(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-12)).item()
+
+
+def assert_close(a, b, dtype, what="", mult=1.0):
+    e = rel_err(a, b)
+    assert e <= TOL[dtype] * mult, f"{what}: rel err {e:.3e} > {TOL[dtype] * mult:.1e}"
+
+
+# ------------------------------------------------------------------------------------------------
+def test_library_loaded_and_layouts():
+    """MFMA C/D layout and ds_read_b64_tr_b16 gather the kernels assume."""
+    from mtlora_amd import _lib as L
+    out = torch.zeros(4096, dtype=torch.int32, device=dev())
+    L.check(L.lib().mtlora_selftest_layouts(L.ptr(out), L.stream_ptr()), "selftest")
+    torch.cuda.synchronize()
+    o = out.cpu()
+    for base in (0, 1024):
+        for lane in range(64):
+            for r in range(16):
+                row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+                col = lane & 31
+                assert o[base + lane * 16 + r].item() == (row + 1) * (col + 1), (base, lane, r)
+    for lane in range(64):
+        for e in range(4):
+            assert o[2048 + lane * 4 + e].item() == (lane & 15) + 16 * e + 64 * (lane >> 4), ("tr linear", lane, e)
+    for lane in range(64):
+        g, ig = lane >> 4, lane & 15
+        for e in range(4):  # block base row 2g, cols 16(g&1)..+15 ; lane gets column ig, rows 0..3
+            exp = (2 * g + e) * 72 + 16 * (g & 1) + ig
+            assert o[2304 + lane * 4 + e].item() == exp, ("tr block", lane, e, o[2304 + lane * 4 + e].item(), exp)
+
+
+# ------------------------------------------------------------------------------------------------
+# window process
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("case", ["sq", "rect", "noshift", "unit"])
+def test_window_process_golden(golden, case):
+    from mtlora_amd import window_process as WP
+    c = golden("window_ops.pt")[case]
+    B, H, W, C, ws, shift = c["dims"]
+    x = c["x"].to(dev())
+    got = WP.WindowProcess.apply(x, B, H, W, C, -shift, ws)
+    assert torch.equal(got.cpu(), c["partitioned"])
+    w = c["w"].to(dev())
+    got = WP.WindowProcessReverse.apply(w, B, H, W, C, shift, ws)
+    assert torch.equal(got.cpu(), c["merged"])
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16])
+def test_window_process_reference_unit_test_shape(dtype):
+    """kernels/window_process/unit_test.py:123-195 (B=192, H=W=56, C=96, shift=2, ws=7), bit-exact,
+    plus a REAL backward check (the reference's 'backward' tests compare forward outputs)."""
+    from mtlora_amd import window_process as WP
+    B, H, W, C, s, ws = 192, 56, 56, 96, 2, 7
+    torch.manual_seed(0)
+    x = torch.randn(B, H, W, C, device=dev()).to(dtype).requires_grad_(True)
+    y = WP.WindowProcess.apply(x, B, H, W, C, -s, ws)
+    exp = O.roll_and_window_partition(x.detach(), s, ws)
+    assert torch.equal(y, exp)
+    g = torch.randn_like(y)
+    y.backward(g)
+    assert torch.equal(x.grad, O.window_merge_and_roll(g, s, ws, H, W))
+    w = torch.randn(B * (H // ws) * (W // ws), ws, ws, C, device=dev()).to(dtype).requires_grad_(True)
+    z = WP.WindowProcessReverse.apply(w, B, H, W, C, s, ws)
+    assert torch.equal(z, O.window_merge_and_roll(w.detach(), s, ws, H, W))
+    g = torch.randn_like(z)
+    z.backward(g)
+    assert torch.equal(w.grad, O.roll_and_window_partition(g, s, ws))
+
+
+def test_window_process_errors():
+    from mtlora_amd import window_process as WP
+    x = torch.randn(2, 14, 14, 8, device=dev())
+    with pytest.raises(RuntimeError):
+        WP.WindowProcess.apply(x.permute(0, 2, 1, 3), 2, 14, 14, 8, -3, 7)  # non-contiguous (CHECK_CONTIGUOUS)
+    with pytest.raises(RuntimeError):
+        WP.WindowProcess.apply(x.cpu(), 2, 14, 14, 8, -3, 7)  # CPU tensor (CHECK_CUDA)
+    with pytest.raises(RuntimeError):
+        WP.WindowProcess.apply(x, 2, 14, 14, 8, -3, 5)  # H % ws != 0
+
+
+# ------------------------------------------------------------------------------------------------
+# MTLoRALinear
+# ------------------------------------------------------------------------------------------------
+LINEAR_CASES = ["matrix_notasks", "matrix_tasks", "matrix_xtasks", "matrix_xtasks_nobias_r", "matrixv2_xtasks",
+                "matrixv2_tasks", "addition_xtasks", "r0"]
+
+
+def build_linear(c, dtype):
+    from mtlora_amd.lora import MTLoRALinear
+    K = c["params"]["linear.weight"].shape[1]
+    N = c["params"]["linear.weight"].shape[0]
+    m = MTLoRALinear(K, N, r=c["r"], lora_shared_scale=c["scale_s"], lora_task_scale=c["scale_t"], lora_dropout=0.0,
+                     tasks=c["tasks"], shared_mode=c["mode"], bias=c["bias"])
+    m.load_state_dict({k: v.float() for k, v in c["params"].items()})
+    m.linear.weight.requires_grad_(False)
+    if m.linear.bias is not None:
+        m.linear.bias.requires_grad_(False)
+    return m.to(dev())
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", LINEAR_CASES)
+def test_linear_golden(golden, case, dtype):
+    c = golden("linear.pt")[case]
+    m = build_linear(c, dtype)
+    x = c["x"].to(dev()).to(dtype).requires_grad_(True)
+    xt = {t: v.to(dev()).to(dtype).requires_grad_(True) for t, v in c["x_tasks"].items()} if c["x_tasks"] else None
+    y, yt = m(x, xt)
+    assert y.dtype == dtype
+    assert_close(y, c["y"], dtype, "y")
+    loss = (y.float() * c["gy"].to(dev()).float()).sum()
+    if c["y_tasks"] is not None:
+        for t in c["tasks"]:
+            assert_close(yt[t], c["y_tasks"][t], dtype, f"y[{t}]")
+            loss = loss + (yt[t].float() * c["gy_tasks"][t].to(dev()).float()).sum()
+    else:
+        assert yt is None
+    loss.backward()
+    assert_close(x.grad, c["dx"], dtype, "dx", mult=2)
+    if xt is not None:
+        for t in c["tasks"]:
+            assert_close(xt[t].grad, c["dx_tasks"][t], dtype, f"dx[{t}]", mult=2)
+    named = dict(m.named_parameters())
+    for n, g in c["grads"].items():
+        if n.startswith("linear."):
+            assert named[n].grad is None  # frozen
+            continue
+        assert_close(named[n].grad, g, dtype, f"grad {n}", mult=2)
+
+
+def _oracle_linear(m, x, xt, keep=None, p=0.0):
+    tasks = list(m.tasks) if (m.tasks is not None and m.r > 0) else None
+    P = {k: v.detach().double().cpu().requires_grad_(v.requires_grad) for k, v in m.named_parameters()}
+    xs = x.detach().double().cpu().requires_grad_(True)
+    xts = {t: v.detach().double().cpu().requires_grad_(True) for t, v in xt.items()} if xt else None
+    y, yt = O.mtlora_linear(
+        xs, P["linear.weight"], P.get("linear.bias"), P.get("lora_shared_A"), P.get("lora_shared_B"),
+        m.lora_shared_scale if m.r > 0 else 0.0, tasks=tasks,
+        A_t={t: P["lora_tasks_A." + t] for t in tasks} if tasks else None,
+        B_t={t: P["lora_tasks_B." + t] for t in tasks} if tasks else None,
+        scale_t=m.lora_task_scale if tasks else None, x_tasks=xts, shared_mode=m.shared_mode, keep_mask=keep, p=p)
+    return P, xs, xts, y, yt
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [
+    # (M, K, N, r_s, r_t, T, x_tasks)   Swin-T stage shapes at reduced M, incl. ragged M and K % 32 != 0
+    (1000, 96, 288, 64, 4, 0, False),     # qkv stage 0
+    (777, 96, 384, 64, 4, 4, True),       # fc1 last block stage 0
+    (520, 384, 96, 64, 4, 4, True),       # fc2 last block stage 0
+    (300, 192, 192, 64, 4, 4, False),     # proj last block stage 1 (tasks read D(x))
+    (260, 768, 3072, 64, 4, 0, False),    # fc1 stage 3
+    (130, 3072, 768, 128, 128, 2, True),  # C4-like ranks
+    (1, 96, 96, 16, 4, 1, True),          # single row
+])
+def test_linear_random_vs_oracle(shape, dtype):
+    from mtlora_amd.lora import MTLoRALinear
+    M, K, N, rs, rt, T, use_xt = shape
+    tasks = [f"t{i}" for i in range(T)] or None
+    torch.manual_seed(M + K)
+    r = {"shared": rs, **{t: rt for t in (tasks or [])}}
+    m = MTLoRALinear(K, N, r=r, lora_shared_scale=4.0, lora_task_scale={t: 4.0 for t in (tasks or [])} if tasks else 1.0,
+                     lora_dropout=0.0, tasks=tasks).to(dev())
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            p.copy_(torch.randn_like(p) * (0.05 if "lora" in n else 0.02))
+            if dtype == torch.bfloat16:
+                p.copy_(p.to(dtype).float())  # parameters exactly representable -> only accumulation order differs
+    m.linear.weight.requires_grad_(False)
+    m.linear.bias.requires_grad_(False)
+    x = torch.randn(M, K, device=dev()).to(dtype).requires_grad_(True)
+    xt = {t: torch.randn(M, K, device=dev()).to(dtype).requires_grad_(True) for t in tasks} if (tasks and use_xt) else None
+    y, yt = m(x, xt)
+    P, xs, xts, yo, yto = _oracle_linear(m, x, xt)
+    gy = torch.randn(M, N, device=dev()).to(dtype)
+    assert_close(y, yo, dtype, "y")
+    loss, loss_o = (y.float() * gy.float()).sum(), (yo * gy.double().cpu()).sum()
+    gyt = {}
+    for t in tasks or []:
+        assert_close(yt[t], yto[t], dtype, f"y[{t}]")
+        gyt[t] = torch.randn(M, N, device=dev()).to(dtype)
+        loss = loss + (yt[t].float() * gyt[t].float()).sum()
+        loss_o = loss_o + (yto[t] * gyt[t].double().cpu()).sum()
+    loss.backward()
+    loss_o.backward()
+    assert_close(x.grad, xs.grad, dtype, "dx", mult=2)
+    for t in (tasks or []) if use_xt else []:
+        assert_close(xt[t].grad, xts[t].grad, dtype, f"dx[{t}]", mult=2)
+    for n, p in m.named_parameters():
+        if p.requires_grad:
+            assert_close(p.grad, P[n].grad, dtype, f"grad {n}", mult=3)
+
+
+@pytest.mark.parametrize("use_xt", [False, True])
+def test_linear_dropout_matches_specified_generator(use_xt):
+    """train mode: the kernel's counter-based mask == oracle.dropout_keep_mask, forward and backward."""
+    from mtlora_amd.lora import MTLoRALinear
+    from mtlora_amd import functional as Fn
+    M, K, N = 333, 96, 160
+    tasks = ["a", "b"]
+    torch.manual_seed(3)
+    m = MTLoRALinear(K, N, r={"shared": 16, "a": 4, "b": 8}, lora_shared_scale=2.0, lora_task_scale={"a": 3.0, "b": 1.5},
+                     lora_dropout=0.25, tasks=tasks).to(dev())
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            p.copy_(torch.randn_like(p) * 0.05)
+    m.linear.weight.requires_grad_(False)
+    m.linear.bias.requires_grad_(False)
+    m.train()
+    x = torch.randn(M, K, device=dev(), requires_grad=True)
+    xt = {t: torch.randn(M, K, device=dev(), requires_grad=True) for t in tasks} if use_xt else None
+    seed_before = Fn._seed_counter
+    y, yt = m(x, xt)
+    # recover the seed the module drew
+    Fn._seed_counter = seed_before
+    seed = Fn.next_seed()
+    keep = O.dropout_keep_mask(seed, 0, M, K, 0.25)
+    frac = keep.float().mean().item()
+    assert abs(frac - 0.75) < 0.01, frac
+    P, xs, xts, yo, yto = _oracle_linear(m, x, xt, keep=keep, p=0.25)
+    assert_close(y, yo, torch.float32, "y")
+    loss, loss_o = y.sum() * 0.5, yo.sum() * 0.5
+    for i, t in enumerate(tasks):
+        assert_close(yt[t], yto[t], torch.float32, f"y[{t}]")
+        loss, loss_o = loss + yt[t].sum() * (i + 1), loss_o + yto[t].sum() * (i + 1)
+    loss.backward()
+    loss_o.backward()
+    assert_close(x.grad, xs.grad, torch.float32, "dx", mult=2)
+    for n, p in m.named_parameters():
+        if p.requires_grad:
+            assert_close(p.grad, P[n].grad, torch.float32, f"grad {n}", mult=3)
+    m.eval()
+    y2, _ = m(x, xt)
+    P, xs, xts, yo2, _ = _oracle_linear(m, x, xt)
+    assert_close(y2, yo2, torch.float32, "eval y")
+
+
+def test_linear_unused_output_gets_none_grad():
+    """final stage: the shared output is never consumed -> lora_shared_{A,B} must get NO gradient."""
+    from mtlora_amd.lora import MTLoRALinear
+    m = MTLoRALinear(96, 96, r={"shared": 8, "a": 4}, lora_shared_scale=1.0, lora_task_scale={"a": 1.0}, tasks=["a"]).to(dev())
+    with torch.no_grad():
+        m.lora_shared_B.normal_()
+        m.lora_tasks_B["a"].normal_()
+    x = torch.randn(50, 96, device=dev(), requires_grad=True)
+    y, yt = m(x)
+    yt["a"].sum().backward()
+    assert m.lora_shared_A.grad is None and m.lora_shared_B.grad is None
+    assert m.lora_tasks_A["a"].grad is not None and x.grad is not None
+
+
+def test_linear_errors():
+    from mtlora_amd.lora import MTLoRALinear
+    m = MTLoRALinear(96, 96, r=4)
+    with pytest.raises(RuntimeError):
+        m(torch.randn(4, 96))  # CPU tensor: no fallback
+    m = MTLoRALinear(96, 98, r=4).to(dev())  # N % 4 != 0
+    with pytest.raises(RuntimeError):
+        m(torch.randn(4, 96, device=dev()))
+    with pytest.raises(NotImplementedError):
+        m.merge()
+
+
+# ------------------------------------------------------------------------------------------------
+# window attention
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("cfg", [
+    # (B, H, W, heads, ws, shift)
+    (2, 14, 14, 3, 7, 3), (2, 14, 14, 3, 7, 0), (1, 14, 21, 2, 7, 2), (3, 7, 7, 6, 7, 0), (2, 8, 8, 1, 4, 2),
+    (1, 16, 16, 2, 8, 3),
+])
+def test_attention_core_vs_oracle(cfg, dtype):
+    """both layouts: image (shift folded into addressing) and windows (reference module API)."""
+    from mtlora_amd import functional as Fn
+    B, H, W, nH, ws, shift = cfg
+    C, N = nH * 32, ws * ws
+    torch.manual_seed(H * W + nH)
+    qkv_img = (torch.randn(B, H, W, 3 * C, device=dev()) * 0.7).to(dtype).requires_grad_(True)
+    bias = (torch.randn(nH, N, N, device=dev()) * 0.5).requires_grad_(True)
+    mask = O.shifted_window_mask(H, W, ws, shift)
+    mask_d = None if mask is None else mask.to(dev())
+    scale = 32 ** -0.5
+    meta = Fn.AttnMeta(B=B, H=H, W=W, window_size=ws, shift=shift, num_heads=nH, head_dim=32, image_layout=True, scale=scale)
+    out = Fn.WindowAttentionFn.apply(meta, qkv_img, bias, mask_d, None if mask is None else mask_d.transpose(1, 2).contiguous())
+    # oracle: roll + partition -> core -> merge + roll
+    q64 = qkv_img.detach().double().cpu().requires_grad_(True)
+    b64 = bias.detach().double().cpu().requires_grad_(True)
+    win = O.roll_and_window_partition(q64, shift, ws).reshape(-1, N, 3 * C)
+    core = O.window_attention_core(win, b64, None if mask is None else mask.double(), nH, scale)
+    ref = O.window_merge_and_roll(core.reshape(-1, ws, ws, C), shift, ws, H, W)
+    assert_close(out, ref, dtype, "attn out")
+    g = torch.randn_like(out)
+    out.backward(g)
+    ref.backward(g.double().cpu())
+    assert_close(qkv_img.grad, q64.grad, dtype, "dqkv", mult=2)
+    assert_close(bias.grad, b64.grad, dtype, "dbias", mult=3)
+    # window-major layout
+    qkv_win = win.detach().to(dev()).to(dtype).contiguous().requires_grad_(True)
+    nW = 1 if mask is None else mask.shape[0]
+    meta_w = Fn.AttnMeta(B=qkv_win.shape[0] // nW, H=ws, W=ws * nW, window_size=ws, shift=0, num_heads=nH, head_dim=32,
+                         image_layout=False, scale=scale)
+    out_w = Fn.WindowAttentionFn.apply(meta_w, qkv_win, bias.detach(), mask_d,
+                                       None if mask is None else mask_d.transpose(1, 2).contiguous())
+    assert_close(out_w, core, dtype, "attn out (windows)")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", ["nomask", "mask"])
+def test_window_attention_module_golden(golden, case, dtype):
+    from mtlora_amd.swin_transformer_mtlora import WindowAttention
+    c = golden("window_attention.pt")[case]
+    mt = O.mtlora_config(c["tasks"], r_shared=8, r_task=4, dropout=0.0)
+    att = WindowAttention(64, (7, 7), c["heads"], lora=c["lora"], tasks=c["tasks"], mtlora=mt, layer_idx=0)
+    att.load_state_dict({**{k: v.float() for k, v in c["params"].items()}, "relative_position_index": c["rel_index"]})
+    att = att.to(dev()).eval()
+    x = c["x"].to(dev()).to(dtype).requires_grad_(True)
+    mask = None if c["mask"] is None else c["mask"].float().to(dev())
+    ctx = torch.autocast("cuda", dtype=torch.bfloat16) if dtype == torch.bfloat16 else torch.autocast("cuda", enabled=False)
+    with ctx:
+        y, yt = att(x, mask)
+    assert_close(y, c["y"], dtype, "y")
+    loss = (y.float() * O.det_tensor(f"att.{case}.gy", y.shape, 1.0).to(dev())).sum()
+    if c["y_tasks"]:
+        for t in c["tasks"]:
+            assert_close(yt[t], c["y_tasks"][t], dtype, f"y[{t}]")
+            loss = loss + (yt[t].float() * O.det_tensor(f"att.{case}.gy.{t}", y.shape, 1.0).to(dev())).sum()
+    loss.backward()
+    assert_close(x.grad, c["dx"], dtype, "dx", mult=3)
+    named = dict(att.named_parameters())
+    for n, g in c["grads"].items():
+        assert_close(named[n].grad, g, dtype, f"grad {n}", mult=3)
+
+
+# ------------------------------------------------------------------------------------------------
+# block / backbone
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("layout", ["image", "windows"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", ["shift_lora", "noshift_plain"])
+def test_swin_block_golden(golden, case, dtype, layout):
+    from mtlora_amd.swin_transformer_mtlora import SwinTransformerBlock
+    c = golden("swin_block.pt")[case]
+    tasks = c["tasks"]
+    mt = O.mtlora_config(tasks, r_shared=8, r_task=4, dropout=0.0)
+    blk = SwinTransformerBlock(64, (14, 14), 2, window_size=7, shift_size=c["shift"], lora=c["lora"], tasks=tasks,
+                               mtlora=mt, layer_idx=0, drop_path=0.1)
+    O.det_fill_(blk.named_parameters())
+    blk = blk.to(dev()).eval()
+    blk.attention_layout = layout
+    x = c["x"].to(dev()).float().requires_grad_(True)
+    ctx = torch.autocast("cuda", dtype=torch.bfloat16) if dtype == torch.bfloat16 else torch.autocast("cuda", enabled=False)
+    with ctx:
+        y, yt = blk(x)
+    assert_close(y, c["y"], dtype, "y")
+    loss = (y.float() * O.det_tensor(f"blk.{case}.gy", y.shape, 1.0).to(dev())).sum()
+    if c["y_tasks"]:
+        for t in tasks:
+            assert_close(yt[t], c["y_tasks"][t], dtype, f"y[{t}]")
+            loss = loss + (yt[t].float() * O.det_tensor(f"blk.{case}.gy.{t}", y.shape, 1.0).to(dev())).sum()
+    else:
+        assert yt is None
+    loss.backward()
+    assert_close(x.grad, c["dx"], dtype, "dx", mult=3)
+    named = dict(blk.named_parameters())
+    for n, g in c["grads"].items():
+        if isinstance(g, dict):
+            s = named[n].grad.double().flatten().cpu()
+            ref = g["samples"]
+            assert ((s[g["idx"]] - ref).abs().max() / ref.abs().max().clamp_min(1e-12)).item() <= TOL[dtype] * 5, n
+        else:
+            assert_close(named[n].grad, g, dtype, f"grad {n}", mult=5)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_backbone_small_golden(golden, dtype):
+    from mtlora_amd.swin_transformer_mtlora import SwinTransformerMTLoRA
+    c = golden("backbone_small.pt")
+    tasks = c["tasks"]
+    cfg = O.swin_t_cfg(img_size=56, tasks=tasks, r_shared=8, r_task=4, depths=(2, 2), num_heads=(3, 6),
+                       drop_path_rate=0.1, dropout=0.05)
+    bb = SwinTransformerMTLoRA(img_size=56, patch_size=4, in_chans=3, num_classes=0, embed_dim=96, depths=[2, 2],
+                               num_heads=[3, 6], window_size=7, drop_path_rate=0.1, tasks=tasks, mtlora=cfg["mtlora"])
+    assert list(bb.state_dict().keys()) == c["names"]
+    O.det_fill_(bb.named_parameters())
+    bb = bb.to(dev()).eval()
+    x = O.det_tensor("bbs.x", (1, 3, 56, 56), 1.0).to(dev())
+    ctx = torch.autocast("cuda", dtype=torch.bfloat16) if dtype == torch.bfloat16 else torch.autocast("cuda", enabled=False)
+    with ctx:
+        stages = bb(x, return_stages=True)
+    loss = 0
+    for i, (s, tl) in enumerate(stages):
+        assert_close(s, c["stages"][i][0], dtype, f"stage {i}", mult=2)
+        loss = loss + (s.float() * O.det_tensor(f"bbs.g.{i}", s.shape, 1.0).to(dev())).sum()
+        for t in tasks:
+            assert_close(tl[t], c["stages"][i][1][t], dtype, f"stage {i} {t}", mult=2)
+            loss = loss + (tl[t].float() * O.det_tensor(f"bbs.g.{i}.{t}", s.shape, 1.0).to(dev())).sum()
+    loss.backward()
+    named = dict(bb.named_parameters())
+    for n, g in c["grads"].items():
+        if g is None:
+            assert named[n].grad is None, n
+        elif isinstance(g, dict):
+            s = named[n].grad.double().flatten().cpu()
+            ref = g["samples"]
+            assert ((s[g["idx"]] - ref).abs().max() / ref.abs().max().clamp_min(1e-12)).item() <= TOL[dtype] * 10, n
+        else:
+            assert_close(named[n].grad, g, dtype, f"grad {n}", mult=10)
+    assert sorted(n for n, p in bb.named_parameters() if p.grad is None) == c["grad_is_none"]

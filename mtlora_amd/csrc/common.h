@@ -161,6 +161,8 @@ enum MtlProfKind {
     PK_PACK = 7,
     PK_REDUCE = 8,
     PK_WINDOW = 9,
+    PK_LN_FWD = 10,      // k_ln_fwd                      x in, y out
+    PK_LN_BWD = 11,      // k_ln_bwd                      x, dy in, dx out
     PK_COUNT = 16
 };
 int mtl_prof_start(int kind, double alg_bytes, hipStream_t s);

@@ -152,6 +152,8 @@ extern "C" const char* mtlora_prof_kind_name(int kind) {
         case PK_PACK: return "k_pack";
         case PK_REDUCE: return "k_tn_reduce";
         case PK_WINDOW: return "k_window_process";
+        case PK_LN_FWD: return "k_ln_fwd";
+        case PK_LN_BWD: return "k_ln_bwd";
         default: return "";
     }
 }

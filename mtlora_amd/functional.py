@@ -284,3 +284,56 @@ def window_merge_and_roll_backward(grad_in, B, H, W, C, shift_size, window_size)
     n = B * (H // window_size) * (W // window_size)
     return _wp("mtlora_window_merge_and_roll_backward", grad_in, (n, window_size, window_size, C), B, H, W, C,
                shift_size, window_size)
+
+
+# ----------------------------------------------------------------------------------------------
+# LayerNorm (block glue): reads x once, writes y directly in the dtype the next linear consumes
+# ----------------------------------------------------------------------------------------------
+class LayerNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps: float, out_dtype: torch.dtype):
+        L.require_gpu(x, weight, bias)
+        C = x.shape[-1]
+        x2 = x.reshape(-1, C).contiguous()
+        M = x2.shape[0]
+        w, b = weight.detach().float().contiguous(), bias.detach().float().contiguous()
+        y = torch.empty((M, C), dtype=out_dtype, device=x.device)
+        mean = torch.empty(M, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(M, dtype=torch.float32, device=x.device)
+        st = L.lib().mtlora_layernorm_fwd(L.ptr(x2), L.ptr(w), L.ptr(b), L.ptr(y), L.ptr(mean), L.ptr(rstd), M, C,
+                                          float(eps), L.dtype_code(x2), L.dtype_code(y), L.stream_ptr())
+        L.check(st, "mtlora_layernorm_fwd")
+        ctx.save_for_backward(x2, w, mean, rstd)
+        ctx.shape = x.shape
+        return y.reshape(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w, mean, rstd = ctx.saved_tensors
+        M, C = x2.shape
+        dy2 = dy.reshape(M, C).contiguous()
+        if dy2.dtype not in (torch.float32, torch.bfloat16):
+            dy2 = dy2.float()
+        lib = L.lib()
+        sb = lib.mtlora_layernorm_bwd_scratch_bytes(M, C, L.dtype_code(x2))
+        scratch = torch.empty(sb, dtype=torch.uint8, device=x2.device)
+        dx = torch.empty_like(x2)
+        dg = torch.empty(C, dtype=torch.float32, device=x2.device)
+        db = torch.empty(C, dtype=torch.float32, device=x2.device)
+        st = lib.mtlora_layernorm_bwd(L.ptr(dy2), L.ptr(x2), L.ptr(w), L.ptr(mean), L.ptr(rstd), L.ptr(dx), L.ptr(dg),
+                                      L.ptr(db), M, C, L.dtype_code(x2), L.dtype_code(dy2), L.ptr(scratch), sb,
+                                      L.stream_ptr())
+        L.check(st, "mtlora_layernorm_bwd")
+        return dx.reshape(ctx.shape), dg, db, None, None
+
+
+def layer_norm(mod: torch.nn.Module, x: torch.Tensor) -> torch.Tensor:
+    """``mod(x)`` for an ``nn.LayerNorm`` over the last dim, through the HIP kernel: output in the hot path's compute
+    dtype (bf16 under autocast -- no fp32 intermediate + cast pass), otherwise the input dtype.  Anything else
+    (custom norm layers, no affine, exotic dtypes) goes to the module itself."""
+    ok = (type(mod) is torch.nn.LayerNorm and mod.elementwise_affine and mod.bias is not None
+          and len(mod.normalized_shape) == 1 and x.is_cuda and x.dtype in (torch.float32, torch.bfloat16)
+          and x.shape[-1] % 8 == 0 and x.shape[-1] <= 4096)
+    if not ok:
+        return mod(x)
+    return LayerNormFn.apply(x, mod.weight, mod.bias, mod.eps, compute_dtype(x))

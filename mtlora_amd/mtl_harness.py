@@ -47,7 +47,10 @@ def mtlora_namespace(tasks: Sequence[str], r_shared=64, r_task=4, scale=4.0, dro
 
 # --------------------------------------------------------------------------------------------------
 class Downsampler(nn.Module):
-    """tokens (B, L_i, C_i) of the four stages -> NCHW maps through four bias-free 1x1 convs."""
+    """tokens (B, L_i, C_i) of the four stages -> NCHW maps through four bias-free 1x1 convs (swin_mtl.py:88-135).
+    A 1x1 convolution on a token tensor is a per-token linear map, so it is evaluated as ``F.linear`` on the
+    (B, L, C) tokens (hipBLASLt GEMM) and the result is only VIEWED as NCHW (channels-last strides): same
+    parameters (``downsample_{i}.weight`` of shape (c, C, 1, 1)), same values, no MIOpen find / NCHW copy."""
 
     def __init__(self, dims, channels, input_res, bias=False, enabled=True):
         super().__init__()
@@ -57,14 +60,19 @@ class Downsampler(nn.Module):
                 setattr(self, f"downsample_{i}", nn.Conv2d(d, c, 1, bias=bias))
 
     def forward(self, feats):
-        maps = [f.view(-1, r, r, d).permute(0, 3, 1, 2) for f, r, d in zip(feats, self.input_res, self.dims)]
-        if not self.enabled:
-            return maps
-        return [getattr(self, f"downsample_{i}")(m) for i, m in enumerate(maps)]
+        maps = []
+        for i, (f, r, d) in enumerate(zip(feats, self.input_res, self.dims)):
+            if self.enabled:
+                conv = getattr(self, f"downsample_{i}")
+                f = F.linear(f, conv.weight.view(conv.out_channels, d), conv.bias)
+            maps.append(f.view(-1, r, r, f.shape[-1]).permute(0, 3, 1, 2))
+        return maps
 
 
 class HighResolutionHead(nn.Module):
-    """upsample the 3 coarse maps to the finest, concat, 1x1 conv -> BN -> ReLU -> 1x1 conv (seg_hrnet.py:498-526)."""
+    """upsample the 3 coarse maps to the finest, concat, 1x1 conv -> BN -> ReLU -> 1x1 conv (seg_hrnet.py:498-526).
+    Same parameters and values as the reference's ``last_layer`` Sequential; the two 1x1 convolutions and the
+    BatchNorm are evaluated on the (B*H*W, C) pixel matrix (channels-last), i.e. as GEMMs."""
 
     def __init__(self, backbone_channels, num_outputs):
         super().__init__()
@@ -73,9 +81,17 @@ class HighResolutionHead(nn.Module):
                                         nn.ReLU(inplace=False), nn.Conv2d(4 * c, num_outputs, 1))
 
     def forward(self, x):
-        size = x[0].shape[2:]
-        cat = torch.cat([x[0]] + [F.interpolate(m, size, mode="bilinear") for m in x[1:]], 1)
-        return self.last_layer(cat)
+        B, _, Hh, Ww = x[0].shape
+        cat = torch.cat([x[0]] + [F.interpolate(m, (Hh, Ww), mode="bilinear") for m in x[1:]], 1)
+        c0, bn, _, c3 = self.last_layer
+        t = cat.permute(0, 2, 3, 1).reshape(B * Hh * Ww, cat.shape[1])
+        h = F.linear(t, c0.weight.view(c0.out_channels, c0.in_channels), c0.bias)
+        if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
+            bn.num_batches_tracked.add_(1)
+        h = F.batch_norm(h, bn.running_mean, bn.running_var, bn.weight, bn.bias, bn.training or not bn.track_running_stats,
+                         bn.momentum, bn.eps)
+        o = F.linear(F.relu(h), c3.weight.view(c3.out_channels, c3.in_channels), c3.bias)
+        return o.view(B, Hh, Ww, c3.out_channels).permute(0, 3, 1, 2)
 
 
 class DecoderGroup(nn.Module):

@@ -256,7 +256,7 @@ class SwinTransformerBlock(nn.Module):
         B, L, C = x.shape
         assert L == H * W, "input feature has wrong size"
         shortcut = x
-        xn = self.norm1(x)
+        xn = Fn.layer_norm(self.norm1, x)
         if self.attention_layout == "windows":
             a, a_t = self._attend_windows(xn, B, H, W, C)
         else:
@@ -267,7 +267,8 @@ class SwinTransformerBlock(nn.Module):
             x_t = {t: shortcut + self.drop_path(a_t[t]) for t in self.tasks}
         x = shortcut + self.drop_path(a)
         # MLP half
-        m, m_t = self.mlp(self.norm2(x), None if x_t is None else {t: self.norm2(x_t[t]) for t in self.tasks})
+        m, m_t = self.mlp(Fn.layer_norm(self.norm2, x),
+                          None if x_t is None else {t: Fn.layer_norm(self.norm2, x_t[t]) for t in self.tasks})
         out = x + self.drop_path(m)
         if m_t is None:
             return out, None
@@ -304,7 +305,7 @@ class PatchMerging(nn.Module):
         assert H % 2 == 0 and W % 2 == 0, f"x size ({H}*{W}) are not even."
         # (B, H/2, 2, W/2, 2, C) -> channel order [x(0,0), x(1,0), x(0,1), x(1,1)] as the reference's cat
         g = x.view(B, H // 2, 2, W // 2, 2, C).permute(0, 1, 3, 4, 2, 5).reshape(B, (H // 2) * (W // 2), 4 * C)
-        y, _ = self.reduction(self.norm(g))
+        y, _ = self.reduction(Fn.layer_norm(self.norm, g))
         return y
 
     def extra_repr(self) -> str:
@@ -373,8 +374,12 @@ class PatchEmbed(nn.Module):
         B, C, H, W = x.shape
         assert H == self.img_size[0] and W == self.img_size[1], \
             f"Input image size ({H}*{W}) doesn't match model ({self.img_size[0]}*{self.img_size[1]})."
-        x = self.proj(x).flatten(2).transpose(1, 2)
-        return x if self.norm is None else self.norm(x)
+        # a kernel==stride convolution is a per-patch linear map: gather the (C, ph, pw) patches and run one GEMM
+        # (same `proj.weight` / `proj.bias` parameters and values as the reference's Conv2d, no MIOpen find)
+        ph, pw = self.patch_size
+        p = x.view(B, C, H // ph, ph, W // pw, pw).permute(0, 2, 4, 1, 3, 5).reshape(B, -1, C * ph * pw)
+        x = nn.functional.linear(p, self.proj.weight.view(self.embed_dim, -1), self.proj.bias)
+        return x if self.norm is None else Fn.layer_norm(self.norm, x)
 
     def flops(self):
         Ho, Wo = self.patches_resolution

@@ -290,7 +290,7 @@ def det_fill_(named_tensors, skip_int=True) -> None:
             last = n.split(".")[-1]
             if last == "running_var":
                 p.copy_(det_tensor(n, p.shape, 0.05, 1.0).abs())
-            elif (("norm" in n or ".last_layer.1." in n) and last == "weight"):
+            elif last == "weight" and (n.split(".")[-2].startswith("norm") or ".last_layer.1." in n):
                 p.copy_(det_tensor(n, p.shape, 0.05, 1.0))
             elif last in ("bias", "running_mean"):
                 p.copy_(det_tensor(n, p.shape, 0.02))

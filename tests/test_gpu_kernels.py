@@ -432,3 +432,29 @@ def test_backbone_small_golden(golden, dtype):
         else:
             assert_close(named[n].grad, g, dtype, f"grad {n}", mult=10)
     assert sorted(n for n, p in bb.named_parameters() if p.grad is None) == c["grad_is_none"]
+
+
+# ------------------------------------------------------------------------------------------------
+# LayerNorm glue kernel
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("xdt,ydt", [(torch.float32, torch.float32), (torch.float32, torch.bfloat16),
+                                     (torch.bfloat16, torch.bfloat16)])
+@pytest.mark.parametrize("M,C", [(1000, 96), (333, 192), (257, 384), (100, 768), (65, 1536), (3, 3072), (50, 40)])
+def test_layernorm_vs_torch(M, C, xdt, ydt):
+    from mtlora_amd import functional as Fn
+    torch.manual_seed(M + C)
+    x = (torch.randn(M, C, device=dev()) * 2 + 0.5).to(xdt).requires_grad_(True)
+    w = (torch.randn(C, device=dev()) * 0.2 + 1).requires_grad_(True)
+    b = (torch.randn(C, device=dev()) * 0.1).requires_grad_(True)
+    y = Fn.LayerNormFn.apply(x, w, b, 1e-5, ydt)
+    assert y.dtype == ydt
+    x64 = x.detach().double().cpu().requires_grad_(True)
+    w64, b64 = w.detach().double().cpu().requires_grad_(True), b.detach().double().cpu().requires_grad_(True)
+    ref = torch.nn.functional.layer_norm(x64, (C,), w64, b64, 1e-5)
+    assert_close(y, ref, ydt, "y")
+    g = torch.randn(M, C, device=dev()).to(ydt)
+    y.backward(g)
+    ref.backward(g.double().cpu())
+    assert_close(x.grad, x64.grad, xdt, "dx", mult=2)
+    assert_close(w.grad, w64.grad, torch.float32 if ydt == torch.float32 else torch.bfloat16, "dgamma", mult=2)
+    assert_close(b.grad, b64.grad, torch.float32 if ydt == torch.float32 else torch.bfloat16, "dbeta", mult=2)

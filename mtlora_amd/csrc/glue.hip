@@ -248,14 +248,31 @@ __global__ __launch_bounds__(256) void k_ln_bwd(const LnParams p) {
     }
 }
 
+// second stage: one workgroup per 64 columns; its 4 waves stride over the partial rows (coalesced 256-byte
+// reads), then a fixed-order LDS combine -> deterministic
 __global__ __launch_bounds__(256) void k_ln_reduce(const float* part, float* dgamma, float* dbeta, int nblk, int C) {
-    for (int c = blockIdx.x * 256 + threadIdx.x; c < 2 * C; c += gridDim.x * 256) {
-        float s = 0.f;
-        for (int b = 0; b < nblk; ++b) s += part[(int64_t)b * 2 * C + c];
+    __shared__ float sm[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;  // column in [0, 2C)
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (c < 2 * C) {
+        int b = wave;
+        for (; b + 12 < nblk; b += 16) {
+            a0 += part[(int64_t)b * 2 * C + c];
+            a1 += part[(int64_t)(b + 4) * 2 * C + c];
+            a2 += part[(int64_t)(b + 8) * 2 * C + c];
+            a3 += part[(int64_t)(b + 12) * 2 * C + c];
+        }
+        for (; b < nblk; b += 4) a0 += part[(int64_t)b * 2 * C + c];
+    }
+    sm[wave][lane] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (wave == 0 && c < 2 * C) {
+        const float t = (sm[0][lane] + sm[1][lane]) + (sm[2][lane] + sm[3][lane]);
         if (c < C)
-            dgamma[c] = s;
+            dgamma[c] = t;
         else
-            dbeta[c - C] = s;
+            dbeta[c - C] = t;
     }
 }
 
@@ -268,7 +285,7 @@ int pick_lpr(int nvec) {
 int ln_grid(int64_t M, int lpr) {
     const int64_t rows_per_blk = 4 * (64 / lpr);
     int64_t g = mtl_ceil_div(M, rows_per_blk);
-    if (g > 256 * 8) g = 256 * 8;
+    if (g > 256 * 2) g = 256 * 2;  // also the number of dgamma/dbeta partials the second stage sums
     return (int)(g < 1 ? 1 : g);
 }
 
@@ -374,7 +391,8 @@ int mtlora_layernorm_bwd(const void* dy, const void* x, const float* gamma, cons
             LN_DISPATCH_LPR(k_ln_bwd, bf16, bf16)
         }
     }
-    hipLaunchKernelGGL(k_ln_reduce, dim3(8), dim3(256), 0, s, (const float*)p.part, dgamma, dbeta, grid, (int)C);
+    hipLaunchKernelGGL(k_ln_reduce, dim3((unsigned)mtl_ceil_div(2 * C, 64)), dim3(256), 0, s, (const float*)p.part, dgamma,
+                       dbeta, grid, (int)C);
     MTL_CHECK_LAUNCH();
     return MTLORA_OK;
 }

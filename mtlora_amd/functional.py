@@ -327,13 +327,19 @@ class LayerNormFn(torch.autograd.Function):
         return dx.reshape(ctx.shape), dg, db, None, None
 
 
-def layer_norm(mod: torch.nn.Module, x: torch.Tensor) -> torch.Tensor:
-    """``mod(x)`` for an ``nn.LayerNorm`` over the last dim, through the HIP kernel: output in the hot path's compute
-    dtype (bf16 under autocast -- no fp32 intermediate + cast pass), otherwise the input dtype.  Anything else
-    (custom norm layers, no affine, exotic dtypes) goes to the module itself."""
+def layer_norm(mod: torch.nn.Module, x: torch.Tensor, feeds_linear: bool = True) -> torch.Tensor:
+    """``mod(x)`` for an ``nn.LayerNorm`` over the last dim, through the HIP kernel.  ``feeds_linear``: the output is
+    only consumed by an MTLoRALinear, so it is written directly in the hot path's compute dtype (bf16 under autocast
+    -- no fp32 intermediate + cast pass).  Otherwise (patch_embed.norm, whose output IS the residual stream) the
+    output dtype is what the reference produces: fp32 under autocast (autocast runs layer_norm in fp32), else the
+    input dtype.  Anything else (custom norm layers, no affine, exotic dtypes) goes to the module itself."""
     ok = (type(mod) is torch.nn.LayerNorm and mod.elementwise_affine and mod.bias is not None
           and len(mod.normalized_shape) == 1 and x.is_cuda and x.dtype in (torch.float32, torch.bfloat16)
-          and x.shape[-1] % 8 == 0 and x.shape[-1] <= 4096)
+          and x.shape[-1] % 8 == 0 and x.shape[-1] <= (2048 if x.dtype == torch.float32 else 4096))
     if not ok:
         return mod(x)
-    return LayerNormFn.apply(x, mod.weight, mod.bias, mod.eps, compute_dtype(x))
+    if feeds_linear:
+        out_dtype = compute_dtype(x)
+    else:
+        out_dtype = torch.float32 if torch.is_autocast_enabled() else x.dtype
+    return LayerNormFn.apply(x, mod.weight, mod.bias, mod.eps, out_dtype)

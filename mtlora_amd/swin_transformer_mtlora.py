@@ -379,7 +379,7 @@ class PatchEmbed(nn.Module):
         ph, pw = self.patch_size
         p = x.view(B, C, H // ph, ph, W // pw, pw).permute(0, 2, 4, 1, 3, 5).reshape(B, -1, C * ph * pw)
         x = nn.functional.linear(p, self.proj.weight.view(self.embed_dim, -1), self.proj.bias)
-        return x if self.norm is None else Fn.layer_norm(self.norm, x)
+        return x if self.norm is None else Fn.layer_norm(self.norm, x, feeds_linear=False)
 
     def flops(self):
         Ho, Wo = self.patches_resolution

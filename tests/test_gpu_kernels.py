@@ -439,7 +439,7 @@ def test_backbone_small_golden(golden, dtype):
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("xdt,ydt", [(torch.float32, torch.float32), (torch.float32, torch.bfloat16),
                                      (torch.bfloat16, torch.bfloat16)])
-@pytest.mark.parametrize("M,C", [(1000, 96), (333, 192), (257, 384), (100, 768), (65, 1536), (3, 3072), (50, 40)])
+@pytest.mark.parametrize("M,C", [(1000, 96), (333, 192), (257, 384), (100, 768), (65, 1536), (3, 2048), (50, 40)])
 def test_layernorm_vs_torch(M, C, xdt, ydt):
     from mtlora_amd import functional as Fn
     torch.manual_seed(M + C)

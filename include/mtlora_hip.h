@@ -138,19 +138,21 @@ typedef struct mtlora_attn_desc {
     int32_t image_layout;
     int32_t dtype;
     float scale;
+    float mask_value;     /* value added where mask_ids differ (Swin: -100) */
 } mtlora_attn_desc;
 
 int64_t mtlora_window_attn_bwd_scratch_bytes(const mtlora_attn_desc* d);
 
-/* bias / mask are passed in the two orientations the kernels read coalesced (both tiny, built once by
- * the host from table[index] / attn_mask):   bias[h][i][j]   and   bias_t[h][j][i] = bias[h][i][j]
- * (i = query, j = key), same for mask / mask_t (both NULL when there is no mask). */
-int mtlora_window_attn_fwd(const mtlora_attn_desc* d, const void* qkv, const float* bias_t, const float* mask_t,
-                           void* out, void* stream);
+/* bias: dense (num_heads, N, N) fp32, [h][i][j] added to score(query i, key j).  The shift mask can be given
+ * either as region ids -- mask_ids (nW_per_image, N) int32: mask(i,j) = ids differ ? d->mask_value : 0, which is how
+ * SW-MSA builds it (swin_transformer_mtlora.py:297-323); the fast path -- or as a general dense `mask`
+ * (nW_per_image, N, N) fp32; both NULL = no mask.  When mask_ids is given, `mask` is ignored. */
+int mtlora_window_attn_fwd(const mtlora_attn_desc* d, const void* qkv, const float* bias, const float* mask,
+                           const int32_t* mask_ids, void* out, void* stream);
 /* dbias: (num_heads, N, N) fp32 [h][i][j], overwritten.  dqkv: same shape/dtype as qkv, fully written. */
-int mtlora_window_attn_bwd(const mtlora_attn_desc* d, const void* qkv, const float* bias, const float* bias_t,
-                           const float* mask, const float* mask_t, const void* dout, void* dqkv, float* dbias,
-                           void* scratch, int64_t scratch_bytes, void* stream);
+int mtlora_window_attn_bwd(const mtlora_attn_desc* d, const void* qkv, const float* bias, const float* mask,
+                           const int32_t* mask_ids, const void* dout, void* dqkv, float* dbias, void* scratch,
+                           int64_t scratch_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * LayerNorm over the last dim (block glue around the path: norm1 / norm2 / PatchMerging.norm,

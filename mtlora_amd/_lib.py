@@ -30,7 +30,7 @@ class LinearDesc(Structure):
 class AttnDesc(Structure):
     _fields_ = [("B", c_int64), ("H", c_int32), ("W", c_int32), ("window_size", c_int32), ("shift", c_int32),
                 ("num_heads", c_int32), ("head_dim", c_int32), ("image_layout", c_int32), ("dtype", c_int32),
-                ("scale", c_float)]
+                ("scale", c_float), ("mask_value", c_float)]
 
 
 PROF_KINDS = 16
@@ -59,9 +59,9 @@ _SIGS = {
                                   c_void_p, c_int64, c_void_p, POINTER(c_void_p), c_void_p, c_void_p, POINTER(c_void_p),
                                   POINTER(c_void_p), c_void_p, c_int64, c_void_p]),
     "mtlora_window_attn_bwd_scratch_bytes": (c_int64, [POINTER(AttnDesc)]),
-    "mtlora_window_attn_fwd": (c_int, [POINTER(AttnDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mtlora_window_attn_fwd": (c_int, [POINTER(AttnDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mtlora_window_attn_bwd": (c_int, [POINTER(AttnDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                       c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+                                       c_void_p, c_void_p, c_int64, c_void_p]),
     "mtlora_layernorm_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_float,
                                      c_int, c_int, c_void_p]),
     "mtlora_layernorm_bwd_scratch_bytes": (c_int64, [c_int64, c_int64, c_int]),

@@ -42,10 +42,10 @@ struct AC<float> {
 
 struct AttnParams {
     const void* qkv;
-    const float* bias;    // (nH, N, N) [h][i][j]
-    const float* bias_t;  // (nH, N, N) [h][j][i]
-    const float* mask;    // (nWimg, N, N) [w][i][j] or null
-    const float* mask_t;  // (nWimg, N, N) [w][j][i] or null
+    const float* bias;     // (nH, N, N) [h][i][j]
+    const float* mask;     // (nWimg, N, N) [w][i][j] or null  (general additive mask, slow path)
+    const int* mask_ids;   // (nWimg, N) region id per token or null: mask[i][j] = ids differ ? mask_value : 0
+    float mask_value;
     void* out;
     const void* dout;
     void* dqkv;
@@ -68,26 +68,37 @@ __device__ __forceinline__ int64_t token_index(const AttnParams& p, int64_t w, i
     return (b * p.H + y) * p.W + x;
 }
 
-// copy N rows of 32 elements (row r at base + tok[r]*stride) into a [64][RS] LDS image, zero padded
+// The LDS image of a (window, head) operand holds its N token rows plus ONE shared zero row (index N): every
+// padded row 64 > r >= N of the 64-row MFMA tiles reads that row (clamped index), so an image costs
+// (N + 1) * RS bytes instead of 64 * RS.
+__device__ __forceinline__ int img_rows(int N) { return N < AN ? N + 1 : AN; }
+__host__ __device__ __forceinline__ int img_rows_h(int N) { return N < AN ? N + 1 : AN; }
+
+// copy N rows of 32 elements (row r at base + tok[r]*stride) into the image, row N zeroed
 template <typename T>
 __device__ __forceinline__ void stage_rows(unsigned char* s, const T* base, int64_t stride, const int* tok, int n,
                                            int lane) {
     constexpr int VPR = AC<T>::VPR, VEC = ET<T>::VEC, RS = AC<T>::RS;
+    const int rows = img_rows(n);
 #pragma unroll
     for (int it = 0; it < VPR; ++it) {
         const int idx = it * 64 + lane;
         const int row = idx / VPR, vec = idx % VPR;
-        u32x4 v = u32x4{0u, 0u, 0u, 0u};
-        if (row < n) v = *reinterpret_cast<const u32x4*>(base + (int64_t)tok[row] * stride + vec * VEC);
-        *reinterpret_cast<u32x4*>(s + row * RS + vec * 16) = v;
+        if (row < rows) {
+            u32x4 v = u32x4{0u, 0u, 0u, 0u};
+            if (row < n) v = *reinterpret_cast<const u32x4*>(base + (int64_t)tok[row] * stride + vec * VEC);
+            *reinterpret_cast<u32x4*>(s + row * RS + vec * 16) = v;
+        }
     }
 }
 
 // operand whose MFMA rows are the LDS image rows sub*32 + (lane&31), k = columns of k-tile kt
 template <typename T>
-__device__ __forceinline__ Frag<T> rowfrag(const unsigned char* s, int sub, int kt, int lane) {
+__device__ __forceinline__ Frag<T> rowfrag(const unsigned char* s, int sub, int kt, int lane, int n) {
     const int h = lane >> 5;
-    const unsigned char* p = s + (sub * 32 + (lane & 31)) * AC<T>::RS + kt * 64;
+    int row = sub * 32 + (lane & 31);
+    row = row < n ? row : n;  // padded rows -> the shared zero row
+    const unsigned char* p = s + row * AC<T>::RS + kt * 64;
     Frag<T> f;
     f.v[0] = *reinterpret_cast<const u32x4*>(p + h * 16);
     f.v[1] = *reinterpret_cast<const u32x4*>(p + (2 + h) * 16);
@@ -96,13 +107,14 @@ __device__ __forceinline__ Frag<T> rowfrag(const unsigned char* s, int sub, int 
 
 // operand whose MFMA rows are the 32 COLUMNS (d) of the image, k = image rows of k-tile kt, slot order =
 // accumulator order: slot (h, r) <-> row kt*KE + (r&3) + 8(r>>2) + 4h
-__device__ __forceinline__ Frag<bf16> colfrag(const unsigned char* s, int kt, int lane, bf16*) {
+__device__ __forceinline__ Frag<bf16> colfrag(const unsigned char* s, int kt, int lane, int n, bf16*) {
     const int g = lane >> 4, i = lane & 15, h = g >> 1;
     const int col = 16 * (g & 1) + 4 * (i & 3);
     uint32_t w[8];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        const int row = kt * 32 + 8 * q + 4 * h + (i >> 2);
+        int row = kt * 32 + 8 * q + 4 * h + (i >> 2);
+        row = row < n ? row : n;
         const unsigned char* p = s + row * AC<bf16>::RS + col * 2;
         s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
         u32x2 u = __builtin_bit_cast(u32x2, v);
@@ -114,12 +126,13 @@ __device__ __forceinline__ Frag<bf16> colfrag(const unsigned char* s, int kt, in
     f.v[1] = u32x4{w[4], w[5], w[6], w[7]};
     return f;
 }
-__device__ __forceinline__ Frag<float> colfrag(const unsigned char* s, int kt, int lane, float*) {
+__device__ __forceinline__ Frag<float> colfrag(const unsigned char* s, int kt, int lane, int n, float*) {
     const int h = lane >> 5, d = lane & 31;
     uint32_t w[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-        const int row = kt * 16 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        int row = kt * 16 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        row = row < n ? row : n;
         w[e] = *reinterpret_cast<const uint32_t*>(s + row * AC<float>::RS + d * 4);
     }
     Frag<float> f;
@@ -174,25 +187,36 @@ __device__ __forceinline__ void store_dt(T* base, int64_t tok_off, const f32x16&
 
 constexpr float NEG_BIG = -1.0e30f;
 
+__device__ __forceinline__ int bias_stride(int N) { return (N & 1) ? N : N + 1; }
+
+// stage bias[head] (N x N fp32) into LDS with an odd row stride: lane-over-i and lane-over-j reads are both
+// conflict-free, so ONE image serves the query-owned and the key-owned pass
+__device__ __forceinline__ void stage_bias(float* sBias, const float* bias, int head, int N, int lane) {
+    const float* src = bias + (int64_t)head * N * N;
+    const int bs = bias_stride(N);
+    for (int idx = lane; idx < N * N; idx += 64) sBias[(idx / N) * bs + (idx % N)] = src[idx];
+}
+
 // scores for query half `si` in the query-owned orientation: st[sj][r] = S^T[key][query]
 template <typename T>
 __device__ __forceinline__ void scores_t(f32x16 (&st)[2], const unsigned char* sK, const unsigned char* sQ, int si,
-                                         const AttnParams& p, int head, int wm, int lane) {
+                                         const AttnParams& p, const float* sBias, const int* srid, int wm, int lane) {
     zero(st[0]);
     zero(st[1]);
 #pragma unroll
     for (int kt = 0; kt < AC<T>::KT_D; ++kt) {
-        Frag<T> fq = rowfrag<T>(sQ, si, kt, lane);
+        Frag<T> fq = rowfrag<T>(sQ, si, kt, lane, p.N);
 #pragma unroll
         for (int sj = 0; sj < 2; ++sj) {
-            Frag<T> fk = rowfrag<T>(sK, sj, kt, lane);
+            Frag<T> fk = rowfrag<T>(sK, sj, kt, lane, p.N);
             mtl_mma(fk, fq, st[sj]);
         }
     }
     const int i = si * 32 + (lane & 31);
     const bool iv = i < p.N;
-    const float* bt = p.bias_t + (int64_t)head * p.N * p.N;
-    const float* mt = p.mask_t ? p.mask_t + (int64_t)wm * p.N * p.N : nullptr;
+    const int bs = bias_stride(p.N);
+    const int rid_i = (p.mask_ids && iv) ? srid[i] : 0;
+    const float* mg = (p.mask && !p.mask_ids) ? p.mask + (int64_t)wm * p.N * p.N : nullptr;
 #pragma unroll
     for (int sj = 0; sj < 2; ++sj)
 #pragma unroll
@@ -201,8 +225,12 @@ __device__ __forceinline__ void scores_t(f32x16 (&st)[2], const unsigned char* s
             float v = st[sj][r] * p.scale;
             if (j < p.N) {
                 if (iv) {
-                    v += bt[j * p.N + i];
-                    if (mt) v += mt[j * p.N + i];
+                    v += sBias[i * bs + j];
+                    if (p.mask_ids) {
+                        if (srid[j] != rid_i) v += p.mask_value;
+                    } else if (mg) {
+                        v += mg[i * p.N + j];
+                    }
                 }
             } else {
                 v = NEG_BIG;
@@ -246,25 +274,29 @@ __device__ __forceinline__ int64_t xcd_remap(int64_t b, int64_t n) {
 template <typename T>
 __global__ __launch_bounds__(64) void k_attn_fwd(const AttnParams p) {
     constexpr int RS = AC<T>::RS;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[3 * AN * RS + AN * 4];
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int IB = ((img_rows(p.N) * RS + 15) / 16) * 16;  // bytes per image
     unsigned char* sQ = smem;
-    unsigned char* sK = smem + AN * RS;
-    unsigned char* sV = smem + 2 * AN * RS;
-    int* tok = reinterpret_cast<int*>(smem + 3 * AN * RS);
+    unsigned char* sK = smem + IB;
+    unsigned char* sV = smem + 2 * IB;
+    int* tok = reinterpret_cast<int*>(smem + 3 * IB);
+    int* srid = tok + AN;
+    float* sBias = reinterpret_cast<float*>(srid + AN);
     const int lane = threadIdx.x;
-    const int64_t total = p.n_windows * p.nH;
-    const int64_t first = xcd_remap(blockIdx.x, gridDim.x);
+    const int64_t L = xcd_remap(blockIdx.x, gridDim.x);
+    const int head = (int)(L % p.nH);
+    const int g = (int)(L / p.nH);
     const int nWimg = p.nWx * p.nWy;
     const T* qkv = reinterpret_cast<const T*>(p.qkv);
     T* out = reinterpret_cast<T*>(p.out);
     const int64_t C3 = 3 * (int64_t)p.C;
+    stage_bias(sBias, p.bias, head, p.N, lane);
 
-    for (int64_t item = first; item < total; item += gridDim.x) {
-        const int head = (int)(item % p.nH);
-        const int64_t w = item / p.nH;
+    for (int64_t w = g; w < p.n_windows; w += p.G) {
         const int wm = (int)(w % nWimg);
         __syncthreads();  // previous item's LDS reads are done
         tok[lane] = lane < p.N ? (int)token_index(p, w, lane) : 0;
+        if (p.mask_ids) srid[lane] = lane < p.N ? p.mask_ids[wm * p.N + lane] : 0;
         __syncthreads();
         stage_rows<T>(sQ, qkv + head * HD, C3, tok, p.N, lane);
         stage_rows<T>(sK, qkv + p.C + head * HD, C3, tok, p.N, lane);
@@ -274,14 +306,14 @@ __global__ __launch_bounds__(64) void k_attn_fwd(const AttnParams p) {
         for (int si = 0; si < 2; ++si) {
             if (si * 32 >= p.N) break;
             f32x16 st[2];
-            scores_t<T>(st, sK, sQ, si, p, head, wm, lane);
+            scores_t<T>(st, sK, sQ, si, p, sBias, srid, wm, lane);
             float m, inv_l;
             softmax_t(st, m, inv_l);
             f32x16 o;
             zero(o);
 #pragma unroll
             for (int kt = 0; kt < AC<T>::KT_N; ++kt) {
-                Frag<T> fv = colfrag(sV, kt, lane, (T*)nullptr);
+                Frag<T> fv = colfrag(sV, kt, lane, p.N, (T*)nullptr);
                 Frag<T> fp = regfrag(st, kt, (T*)nullptr);
                 mtl_mma(fv, fp, o);
             }
@@ -296,15 +328,19 @@ __global__ __launch_bounds__(64) void k_attn_bwd(const AttnParams p) {
     constexpr int RS = AC<T>::RS;
     // Q, K, V, dO images + token table + row stats (m, 1/l, D) + dbias accumulator [N][64]
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int IB = ((img_rows(p.N) * RS + 15) / 16) * 16;  // bytes per image
+    const int DBS = p.N + 1;                                 // dbias accumulator row stride
     unsigned char* sQ = smem;
-    unsigned char* sK = smem + AN * RS;
-    unsigned char* sV = smem + 2 * AN * RS;
-    unsigned char* sO = smem + 3 * AN * RS;
-    int* tok = reinterpret_cast<int*>(smem + 4 * AN * RS);
-    float* st_m = reinterpret_cast<float*>(smem + 4 * AN * RS + AN * 4);
+    unsigned char* sK = smem + IB;
+    unsigned char* sV = smem + 2 * IB;
+    unsigned char* sO = smem + 3 * IB;
+    int* tok = reinterpret_cast<int*>(smem + 4 * IB);
+    int* srid = tok + AN;
+    float* st_m = reinterpret_cast<float*>(srid + AN);
     float* st_il = st_m + AN;
     float* st_D = st_il + AN;
-    float* sDB = st_D + AN;  // [N][64]
+    float* sDB = st_D + AN;             // [N][N + 1]
+    float* sBias = sDB + p.N * DBS;     // [N][bias_stride(N)]
     const int lane = threadIdx.x;
     const int64_t L = xcd_remap(blockIdx.x, gridDim.x);
     const int head = (int)(L % p.nH);
@@ -314,14 +350,15 @@ __global__ __launch_bounds__(64) void k_attn_bwd(const AttnParams p) {
     const T* dout = reinterpret_cast<const T*>(p.dout);
     T* dqkv = reinterpret_cast<T*>(p.dqkv);
     const int64_t C3 = 3 * (int64_t)p.C;
-    const float* bn = p.bias + (int64_t)head * p.N * p.N;
-
-    for (int idx = lane; idx < p.N * 64; idx += 64) sDB[idx] = 0.f;
+    const int bs = bias_stride(p.N);
+    stage_bias(sBias, p.bias, head, p.N, lane);
+    for (int idx = lane; idx < p.N * DBS; idx += 64) sDB[idx] = 0.f;
 
     for (int64_t w = g; w < p.n_windows; w += p.G) {
         const int wm = (int)(w % nWimg);
         __syncthreads();
         tok[lane] = lane < p.N ? (int)token_index(p, w, lane) : 0;
+        if (p.mask_ids) srid[lane] = lane < p.N ? p.mask_ids[wm * p.N + lane] : 0;
         __syncthreads();
         stage_rows<T>(sQ, qkv + head * HD, C3, tok, p.N, lane);
         stage_rows<T>(sK, qkv + p.C + head * HD, C3, tok, p.N, lane);
@@ -334,7 +371,7 @@ __global__ __launch_bounds__(64) void k_attn_bwd(const AttnParams p) {
         for (int si = 0; si < 2; ++si) {
             if (si * 32 >= p.N) break;
             f32x16 pt[2];
-            scores_t<T>(pt, sK, sQ, si, p, head, wm, lane);
+            scores_t<T>(pt, sK, sQ, si, p, sBias, srid, wm, lane);
             float m, inv_l;
             softmax_t(pt, m, inv_l);
             // dP^T[j][i] = sum_d V[j][d] dO[i][d]
@@ -343,10 +380,10 @@ __global__ __launch_bounds__(64) void k_attn_bwd(const AttnParams p) {
             zero(dp[1]);
 #pragma unroll
             for (int kt = 0; kt < AC<T>::KT_D; ++kt) {
-                Frag<T> fo = rowfrag<T>(sO, si, kt, lane);
+                Frag<T> fo = rowfrag<T>(sO, si, kt, lane, p.N);
 #pragma unroll
                 for (int sj = 0; sj < 2; ++sj) {
-                    Frag<T> fv = rowfrag<T>(sV, sj, kt, lane);
+                    Frag<T> fv = rowfrag<T>(sV, sj, kt, lane, p.N);
                     mtl_mma(fv, fo, dp[sj]);
                 }
             }
@@ -370,14 +407,14 @@ __global__ __launch_bounds__(64) void k_attn_bwd(const AttnParams p) {
                     const float ds = pt[sj][r] * (dp[sj][r] - D);
                     dp[sj][r] = ds;
                     const int j = sj * 32 + mtl_d_row(lane, r);
-                    if (j < p.N && i < p.N) sDB[j * 64 + i] += ds;
+                    if (j < p.N && i < p.N) sDB[j * DBS + i] += ds;
                 }
             // dQ^T[d][i] = scale * sum_j K[j][d] dS^T[j][i]
             f32x16 dq;
             zero(dq);
 #pragma unroll
             for (int kt = 0; kt < AC<T>::KT_N; ++kt) {
-                Frag<T> fk = colfrag(sK, kt, lane, (T*)nullptr);
+                Frag<T> fk = colfrag(sK, kt, lane, p.N, (T*)nullptr);
                 Frag<T> fs = regfrag(dp, kt, (T*)nullptr);
                 mtl_mma(fk, fs, dq);
             }
@@ -398,17 +435,18 @@ __global__ __launch_bounds__(64) void k_attn_bwd(const AttnParams p) {
             zero(dp[1]);
 #pragma unroll
             for (int kt = 0; kt < AC<T>::KT_D; ++kt) {
-                Frag<T> fk = rowfrag<T>(sK, sj, kt, lane);
-                Frag<T> fv = rowfrag<T>(sV, sj, kt, lane);
+                Frag<T> fk = rowfrag<T>(sK, sj, kt, lane, p.N);
+                Frag<T> fv = rowfrag<T>(sV, sj, kt, lane, p.N);
 #pragma unroll
                 for (int si = 0; si < 2; ++si) {
-                    Frag<T> fq = rowfrag<T>(sQ, si, kt, lane);
-                    Frag<T> fo = rowfrag<T>(sO, si, kt, lane);
+                    Frag<T> fq = rowfrag<T>(sQ, si, kt, lane, p.N);
+                    Frag<T> fo = rowfrag<T>(sO, si, kt, lane, p.N);
                     mtl_mma(fq, fk, pp[si]);
                     mtl_mma(fo, fv, dp[si]);
                 }
             }
-            const float* mn = p.mask ? p.mask + (int64_t)wm * p.N * p.N : nullptr;
+            const float* mn = (p.mask && !p.mask_ids) ? p.mask + (int64_t)wm * p.N * p.N : nullptr;
+            const int rid_j = (p.mask_ids && jv) ? srid[j] : 0;
 #pragma unroll
             for (int si = 0; si < 2; ++si)
 #pragma unroll
@@ -416,8 +454,12 @@ __global__ __launch_bounds__(64) void k_attn_bwd(const AttnParams p) {
                     const int i = si * 32 + mtl_d_row(lane, r);
                     float pv = 0.f, ds = 0.f;
                     if (i < p.N && jv) {
-                        float s = pp[si][r] * p.scale + bn[i * p.N + j];
-                        if (mn) s += mn[i * p.N + j];
+                        float s = pp[si][r] * p.scale + sBias[i * bs + j];
+                        if (p.mask_ids) {
+                            if (srid[i] != rid_j) s += p.mask_value;
+                        } else if (mn) {
+                            s += mn[i * p.N + j];
+                        }
                         pv = __expf(s - st_m[i]) * st_il[i];
                         ds = pv * (dp[si][r] - st_D[i]);
                     }
@@ -429,8 +471,8 @@ __global__ __launch_bounds__(64) void k_attn_bwd(const AttnParams p) {
             zero(dv);
 #pragma unroll
             for (int kt = 0; kt < AC<T>::KT_N; ++kt) {
-                Frag<T> fq = colfrag(sQ, kt, lane, (T*)nullptr);
-                Frag<T> fo = colfrag(sO, kt, lane, (T*)nullptr);
+                Frag<T> fq = colfrag(sQ, kt, lane, p.N, (T*)nullptr);
+                Frag<T> fo = colfrag(sO, kt, lane, p.N, (T*)nullptr);
                 Frag<T> fds = regfrag(dp, kt, (T*)nullptr);
                 Frag<T> fp = regfrag(pp, kt, (T*)nullptr);
                 mtl_mma(fq, fds, dk);
@@ -446,19 +488,31 @@ __global__ __launch_bounds__(64) void k_attn_bwd(const AttnParams p) {
     float* dst = p.dbias_part + ((int64_t)g * p.nH + head) * p.N * p.N;
     for (int idx = lane; idx < p.N * p.N; idx += 64) {
         const int j = idx / p.N, i = idx % p.N;
-        dst[idx] = sDB[j * 64 + i];
+        dst[idx] = sDB[j * DBS + i];
     }
 }
 
-// dbias[h][i][j] = sum_g part[g][h][j][i]
+// dbias[h][i][j] = sum_g part[g][h][j][i]: one workgroup per 64 outputs, 4 waves stride over g, fixed-order combine
 __global__ __launch_bounds__(256) void k_dbias_reduce(const float* part, float* dbias, int G, int nH, int N) {
+    __shared__ float sm[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int total = nH * N * N;
-    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += gridDim.x * 256) {
+    const int idx = blockIdx.x * 64 + lane;  // index in the [h][j][i] partial layout
+    float a0 = 0.f, a1 = 0.f;
+    if (idx < total) {
+        int g = wave;
+        for (; g + 4 < G; g += 8) {
+            a0 += part[(int64_t)g * total + idx];
+            a1 += part[(int64_t)(g + 4) * total + idx];
+        }
+        for (; g < G; g += 4) a0 += part[(int64_t)g * total + idx];
+    }
+    sm[wave][lane] = a0 + a1;
+    __syncthreads();
+    if (wave == 0 && idx < total) {
         const int h = idx / (N * N), rem = idx % (N * N);
-        const int i = rem / N, j = rem % N;
-        float s = 0.f;
-        for (int g = 0; g < G; ++g) s += part[((int64_t)g * nH + h) * N * N + j * N + i];
-        dbias[idx] = s;
+        const int j = rem / N, i = rem % N;
+        dbias[((int64_t)h * N + i) * N + j] = (sm[0][lane] + sm[1][lane]) + (sm[2][lane] + sm[3][lane]);
     }
 }
 
@@ -474,13 +528,30 @@ int check(const mtlora_attn_desc* d) {
     return MTLORA_OK;
 }
 
+static int bias_stride_host(int N) { return (N & 1) ? N : N + 1; }
+
+// persistent launch: G window-groups per head such that G * nH workgroups are all resident
+// (LDS-limited workgroups per CU, capped by `cap`), never more groups than windows
+static int groups_for(size_t lds_bytes, int cap, int nH, int64_t n_windows) {
+    int per_cu = (int)((160 * 1024) / (lds_bytes + 512));
+    if (per_cu > cap) per_cu = cap;
+    if (per_cu < 1) per_cu = 1;
+    int64_t G = ((int64_t)256 * per_cu) / nH;
+    if (G > n_windows) G = n_windows;
+    if (G < 1) G = 1;
+    return (int)G;
+}
+
+static size_t bwd_lds_bytes(const mtlora_attn_desc* d) {
+    const int N = d->window_size * d->window_size;
+    const int rs = d->dtype == MTLORA_F32 ? AC<float>::RS : AC<bf16>::RS;
+    const size_t ib = (size_t)((img_rows_h(N) * rs + 15) / 16) * 16;
+    return 4 * ib + 5 * AN * 4 + (size_t)N * (N + 1) * 4 + (size_t)N * bias_stride_host(N) * 4;
+}
+
 int bwd_groups(const mtlora_attn_desc* d) {
     const int64_t nwin = d->B * (d->H / d->window_size) * (d->W / d->window_size);
-    int64_t G = (256 * 4 + d->num_heads - 1) / d->num_heads;
-    if (G > nwin) G = nwin;
-    if (G < 1) G = 1;
-    // keep nH * G a multiple of 8 when possible is not required (bijective remap)
-    return (int)G;
+    return groups_for(bwd_lds_bytes(d), 8, d->num_heads, nwin);
 }
 
 AttnParams make_params(const mtlora_attn_desc* d) {
@@ -510,37 +581,41 @@ int64_t mtlora_window_attn_bwd_scratch_bytes(const mtlora_attn_desc* d) {
     return (int64_t)bwd_groups(d) * d->num_heads * N * N * 4 + 256;
 }
 
-int mtlora_window_attn_fwd(const mtlora_attn_desc* d, const void* qkv, const float* bias_t, const float* mask_t,
-                           void* out, void* stream) {
+int mtlora_window_attn_fwd(const mtlora_attn_desc* d, const void* qkv, const float* bias, const float* mask,
+                           const int32_t* mask_ids, void* out, void* stream) {
     int st = check(d);
     if (st != MTLORA_OK) return st;
-    if (!qkv || !bias_t || !out) return MTLORA_ERR_NULL;
+    if (!qkv || !bias || !out) return MTLORA_ERR_NULL;
     if (((uintptr_t)qkv | (uintptr_t)out) & 15u) return MTLORA_ERR_ALIGN;
     AttnParams p = make_params(d);
     if (p.n_windows == 0) return MTLORA_OK;
     p.qkv = qkv;
-    p.bias_t = bias_t;
-    p.mask_t = mask_t;
+    p.bias = bias;
+    p.mask = mask;
+    p.mask_ids = mask_ids;
+    p.mask_value = d->mask_value;
     p.out = out;
-    const int64_t total = p.n_windows * p.nH;
-    int64_t grid = total < 256 * 12 ? total : 256 * 12;
+    const int rs = d->dtype == MTLORA_F32 ? AC<float>::RS : AC<bf16>::RS;
+    const size_t ib = (size_t)((img_rows_h(p.N) * rs + 15) / 16) * 16;
+    const size_t lds = 3 * ib + 2 * AN * 4 + (size_t)p.N * bias_stride_host(p.N) * 4;
+    p.G = groups_for(lds, 8, p.nH, p.n_windows);  // persistent grid: exactly the resident workgroups
+    const unsigned grid = (unsigned)(p.G * p.nH);
     hipStream_t s = (hipStream_t)stream;
     MtlProfScope prof(PK_ATTN_FWD, 4.0 * mtl_elem_size(d->dtype) * (double)p.n_windows * p.N * p.C, s);
     if (d->dtype == MTLORA_F32)
-        hipLaunchKernelGGL(k_attn_fwd<float>, dim3((unsigned)grid), dim3(64), 0, s, p);
+        hipLaunchKernelGGL(k_attn_fwd<float>, dim3(grid), dim3(64), lds, s, p);
     else
-        hipLaunchKernelGGL(k_attn_fwd<bf16>, dim3((unsigned)grid), dim3(64), 0, s, p);
+        hipLaunchKernelGGL(k_attn_fwd<bf16>, dim3(grid), dim3(64), lds, s, p);
     MTL_CHECK_LAUNCH();
     return MTLORA_OK;
 }
 
-int mtlora_window_attn_bwd(const mtlora_attn_desc* d, const void* qkv, const float* bias, const float* bias_t,
-                           const float* mask, const float* mask_t, const void* dout, void* dqkv, float* dbias,
-                           void* scratch, int64_t scratch_bytes, void* stream) {
+int mtlora_window_attn_bwd(const mtlora_attn_desc* d, const void* qkv, const float* bias, const float* mask,
+                           const int32_t* mask_ids, const void* dout, void* dqkv, float* dbias, void* scratch,
+                           int64_t scratch_bytes, void* stream) {
     int st = check(d);
     if (st != MTLORA_OK) return st;
-    if (!qkv || !bias || !bias_t || !dout || !dqkv || !dbias || !scratch) return MTLORA_ERR_NULL;
-    if ((mask == nullptr) != (mask_t == nullptr)) return MTLORA_ERR_NULL;
+    if (!qkv || !bias || !dout || !dqkv || !dbias || !scratch) return MTLORA_ERR_NULL;
     if (((uintptr_t)qkv | (uintptr_t)dout | (uintptr_t)dqkv | (uintptr_t)scratch) & 15u) return MTLORA_ERR_ALIGN;
     if (scratch_bytes < mtlora_window_attn_bwd_scratch_bytes(d) - 256) return MTLORA_ERR_WORKSPACE;
     AttnParams p = make_params(d);
@@ -551,16 +626,15 @@ int mtlora_window_attn_bwd(const mtlora_attn_desc* d, const void* qkv, const flo
     }
     p.qkv = qkv;
     p.bias = bias;
-    p.bias_t = bias_t;
     p.mask = mask;
-    p.mask_t = mask_t;
+    p.mask_ids = mask_ids;
+    p.mask_value = d->mask_value;
     p.dout = dout;
     p.dqkv = dqkv;
     p.dbias_part = reinterpret_cast<float*>(scratch);
     p.G = bwd_groups(d);
     const unsigned grid = (unsigned)(p.G * p.nH);
-    const int rs = d->dtype == MTLORA_F32 ? AC<float>::RS : AC<bf16>::RS;
-    const size_t lds = (size_t)4 * AN * rs + AN * 4 * 4 + (size_t)p.N * 64 * 4;
+    const size_t lds = bwd_lds_bytes(d);
     {
         MtlProfScope prof(PK_ATTN_BWD, 7.0 * mtl_elem_size(d->dtype) * (double)p.n_windows * p.N * p.C, s);
         if (d->dtype == MTLORA_F32)
@@ -568,7 +642,9 @@ int mtlora_window_attn_bwd(const mtlora_attn_desc* d, const void* qkv, const flo
         else
             hipLaunchKernelGGL(k_attn_bwd<bf16>, dim3(grid), dim3(64), lds, s, p);
     }
-    hipLaunchKernelGGL(k_dbias_reduce, dim3(32), dim3(256), 0, s, (const float*)p.dbias_part, dbias, p.G, p.nH, p.N);
+    const int total = p.nH * p.N * p.N;
+    hipLaunchKernelGGL(k_dbias_reduce, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, s, (const float*)p.dbias_part,
+                       dbias, p.G, p.nH, p.N);
     MTL_CHECK_LAUNCH();
     return MTLORA_OK;
 }

@@ -113,6 +113,61 @@ __device__ __forceinline__ Vec16<T> mtl_zero16() {
     return v;
 }
 
+// register-only vector helpers (no unions: element access through a union can push the staging registers of a
+// big kernel into scratch)
+__device__ __forceinline__ uint32_t mtl_pack_bf16(float a, float b) {
+    bf16 x = (bf16)a, y = (bf16)b;
+    return (uint32_t)__builtin_bit_cast(uint16_t, x) | ((uint32_t)__builtin_bit_cast(uint16_t, y) << 16);
+}
+template <typename T>
+struct VOps;
+template <>
+struct VOps<bf16> {
+    static constexpr int N = 8;
+    static __device__ __forceinline__ void unpack(const u32x4& v, float (&f)[8]) {
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            f[2 * w] = __builtin_bit_cast(float, v[w] << 16);
+            f[2 * w + 1] = __builtin_bit_cast(float, v[w] & 0xFFFF0000u);
+        }
+    }
+    static __device__ __forceinline__ u32x4 pack(const float (&f)[8]) {
+        return u32x4{mtl_pack_bf16(f[0], f[1]), mtl_pack_bf16(f[2], f[3]), mtl_pack_bf16(f[4], f[5]),
+                     mtl_pack_bf16(f[6], f[7])};
+    }
+    // zero the dropped elements of the 8 consecutive elements starting at column k (k even)
+    static __device__ __forceinline__ void drop(u32x4& v, const DropoutCfg& c, uint32_t rowhash, uint32_t k) {
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const uint32_t h = mtl_dropout_pairbits(c, rowhash, k + 2 * w);
+            uint32_t keep = 0u;
+            if ((h & 0xFFFFu) >= c.thr16) keep |= 0x0000FFFFu;
+            if ((h >> 16) >= c.thr16) keep |= 0xFFFF0000u;
+            v[w] &= keep;
+        }
+    }
+};
+template <>
+struct VOps<float> {
+    static constexpr int N = 4;
+    static __device__ __forceinline__ void unpack(const u32x4& v, float (&f)[8]) {
+#pragma unroll
+        for (int w = 0; w < 4; ++w) f[w] = __builtin_bit_cast(float, v[w]);
+    }
+    static __device__ __forceinline__ u32x4 pack(const float (&f)[8]) {
+        return u32x4{__builtin_bit_cast(uint32_t, f[0]), __builtin_bit_cast(uint32_t, f[1]),
+                     __builtin_bit_cast(uint32_t, f[2]), __builtin_bit_cast(uint32_t, f[3])};
+    }
+    static __device__ __forceinline__ void drop(u32x4& v, const DropoutCfg& c, uint32_t rowhash, uint32_t k) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const uint32_t h = mtl_dropout_pairbits(c, rowhash, k + 2 * p);
+            if ((h & 0xFFFFu) < c.thr16) v[2 * p] = 0u;
+            if ((h >> 16) < c.thr16) v[2 * p + 1] = 0u;
+        }
+    }
+};
+
 // ---------------------------------------------------------------------------------------------
 // MFMA wrappers.  A "fragment" is the 2x16 bytes a lane holds for one 64-byte-wide k-tile:
 // the SAME (lane, slot) -> k assignment is used for both operands, so the k order inside the

@@ -25,9 +25,14 @@
 namespace {
 
 constexpr int TILE = 128;    // rows per CTA tile, both operands
-constexpr int ROWB = 64;     // payload bytes per row per k-tile (32 bf16 / 16 f32)
-constexpr int LDSB = 80;     // padded LDS row stride (conflict-free ds_read_b128, 16-B aligned)
+constexpr int SUBT = 3;             // 64-byte MFMA sub-tiles per staged k-tile: a tile covers K = 96 bf16 in ONE round trip
+constexpr int ROWB = 64 * SUBT;     // payload bytes per row per k-tile (96 bf16 / 48 f32)
+constexpr int LDSB = ROWB + 16;     // padded LDS row stride (conflict-free ds_read_b128, 16-B aligned)
+constexpr int VPT = SUBT;           // 16-byte vectors per thread per row-half per operand (4 * SUBT vectors / 4 lanes)
 constexpr int MAXO = MTLORA_MAX_TASKS + 1;
+#ifndef MTL_NT_LEAN_WAVES
+#define MTL_NT_LEAN_WAVES 2
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // segment table: output o (0 = shared, 1..T = tasks) owns columns [off, off + rp) of the rank axis
@@ -154,146 +159,221 @@ struct NtParams {
     DropoutCfg drop;
 };
 
+// kernel parameters are read straight from the kernarg segment (constant address space): dynamic indexing of a
+// by-value struct argument would make the compiler copy the whole struct to scratch
+typedef const __attribute__((address_space(4))) NtParams* NtPtr;
+
 template <typename T>
 struct TileRegs {
-    u32x4 w[2], a[2];
+    u32x4 w[2][VPT], a[2][VPT];
 };
 
 // stage one 128-row x 64-byte k-tile of the weight-like and activation-like operands into registers
-template <typename T>
+template <typename T, bool MS>
 __device__ __forceinline__ void nt_load(TileRegs<T>& rg, int tid, const T* wgt, int64_t ld_w, int w_row0, int w_rows,
-                                        const void* act0, const NtParams& P, int n_act, int64_t ld_a, int64_t a_row0,
+                                        const void* act0, NtPtr P, int n_act, int64_t ld_a, int64_t a_row0,
                                         int64_t a_rows, int k0, int k_hi, bool mask, const DropoutCfg& dc) {
     constexpr int VEC = ET<T>::VEC;
-    const int v = tid & 3;
-    const int k = k0 + v * VEC;
-    const bool kin = k < k_hi;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int r = (tid >> 2) + i * 64;
-        // weights
-        const int wr = w_row0 + r;
-        rg.w[i] = (kin && wr < w_rows) ? *reinterpret_cast<const u32x4*>(wgt + (int64_t)wr * ld_w + k)
-                                       : u32x4{0u, 0u, 0u, 0u};
-        // activations
-        const int64_t ar = a_row0 + r;
-        if (kin && ar < a_rows) {
-            Vec16<T> x = mtl_ld16<T>(reinterpret_cast<const T*>(act0) + ar * ld_a + k);
-            if (n_act > 1) {
-                float f[VEC];
+    for (int j = 0; j < VPT; ++j) {
+        const int v = (tid & 3) + 4 * j;
+        const int k = k0 + v * VEC;
+        const bool kin = k < k_hi;
 #pragma unroll
-                for (int e = 0; e < VEC; ++e) f[e] = mtl_to_f32(x.e[e]);
+        for (int i = 0; i < 2; ++i) {
+            const int r = (tid >> 2) + i * 64;
+            // weights
+            const int wr = w_row0 + r;
+            rg.w[i][j] = (kin && wr < w_rows) ? *reinterpret_cast<const u32x4*>(wgt + (int64_t)wr * ld_w + k)
+                                              : u32x4{0u, 0u, 0u, 0u};
+            // activations
+            const int64_t ar = a_row0 + r;
+            if (kin && ar < a_rows) {
+                u32x4 x = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(act0) + ar * ld_a + k);
+                if (MS && n_act > 1) {
+                    if constexpr (sizeof(T) == 4) {
+                        f32x4 fx = __builtin_bit_cast(f32x4, x);
 #pragma unroll
-                for (int s = 1; s < MAXO; ++s) {
-                    if (s < n_act) {
-                        Vec16<T> y = mtl_ld16<T>(reinterpret_cast<const T*>(P.act[s]) + ar * ld_a + k);
+                        for (int s = 1; s < MAXO; ++s) {
+                            if (s < n_act)
+                                fx += *reinterpret_cast<const f32x4*>(reinterpret_cast<const T*>(P->act[s]) + ar * ld_a + k);
+                        }
+                        x = __builtin_bit_cast(u32x4, fx);
+                    } else {
+                        float f[8];
+                        VOps<T>::unpack(x, f);
 #pragma unroll
-                        for (int e = 0; e < VEC; ++e) f[e] += mtl_to_f32(y.e[e]);
+                        for (int s = 1; s < MAXO; ++s) {
+                            if (s < n_act) {
+                                const u32x4 y =
+                                    *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(P->act[s]) + ar * ld_a + k);
+                                float g[8];
+                                VOps<T>::unpack(y, g);
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) f[e] += g[e];
+                            }
+                        }
+                        x = VOps<T>::pack(f);
                     }
                 }
-#pragma unroll
-                for (int e = 0; e < VEC; ++e) x.e[e] = mtl_from_f32<T>(f[e]);
+                if (mask) VOps<T>::drop(x, dc, mtl_dropout_rowhash(dc, 0u, (uint32_t)ar), (uint32_t)k);
+                rg.a[i][j] = x;
+            } else {
+                rg.a[i][j] = u32x4{0u, 0u, 0u, 0u};
             }
-            if (mask) {
-                const uint32_t rh = mtl_dropout_rowhash(dc, 0u, (uint32_t)ar);
-#pragma unroll
-                for (int e = 0; e < VEC; e += 2) {
-                    const uint32_t h = mtl_dropout_pairbits(dc, rh, (uint32_t)(k + e));
-                    if ((h & 0xFFFFu) < dc.thr16) x.e[e] = mtl_from_f32<T>(0.f);
-                    if ((h >> 16) < dc.thr16) x.e[e + 1] = mtl_from_f32<T>(0.f);
-                }
-            }
-            rg.a[i] = x.raw;
-        } else {
-            rg.a[i] = u32x4{0u, 0u, 0u, 0u};
         }
     }
 }
 
 template <typename T>
 __device__ __forceinline__ void nt_store_lds(const TileRegs<T>& rg, int tid, unsigned char* sW, unsigned char* sA) {
-    const int v = tid & 3;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int r = (tid >> 2) + i * 64;
-        *reinterpret_cast<u32x4*>(sW + r * LDSB + v * 16) = rg.w[i];
-        *reinterpret_cast<u32x4*>(sA + r * LDSB + v * 16) = rg.a[i];
+    for (int j = 0; j < VPT; ++j) {
+        const int v = (tid & 3) + 4 * j;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int r = (tid >> 2) + i * 64;
+            *reinterpret_cast<u32x4*>(sW + r * LDSB + v * 16) = rg.w[i][j];
+            *reinterpret_cast<u32x4*>(sA + r * LDSB + v * 16) = rg.a[i][j];
+        }
     }
 }
 
+// multiply the staged tile; k_left = elements of the part's k range still ahead (sub-tiles past it are all zero
+// and skipped -- wave-uniform)
 template <typename T>
 __device__ __forceinline__ void nt_compute(f32x16 (&acc)[2][2], const unsigned char* sW, const unsigned char* sA,
-                                           int lane, int wn, int wm) {
+                                           int lane, int wn, int wm, int k_left) {
+    constexpr int KS = 64 / (int)sizeof(T);  // elements per 64-byte sub-tile
     const int h = lane >> 5, rl = lane & 31;
-    Frag<T> fw[2], fa[2];
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-        const unsigned char* pw = sW + (wn * 64 + s * 32 + rl) * LDSB;
-        const unsigned char* pa = sA + (wm * 64 + s * 32 + rl) * LDSB;
-        fw[s].v[0] = *reinterpret_cast<const u32x4*>(pw + h * 16);
-        fw[s].v[1] = *reinterpret_cast<const u32x4*>(pw + (2 + h) * 16);
-        fa[s].v[0] = *reinterpret_cast<const u32x4*>(pa + h * 16);
-        fa[s].v[1] = *reinterpret_cast<const u32x4*>(pa + (2 + h) * 16);
+    for (int t = 0; t < SUBT; ++t) {
+        if (t * KS >= k_left) break;
+        Frag<T> fw[2], fa[2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const unsigned char* pw = sW + (wn * 64 + s * 32 + rl) * LDSB + t * 64;
+            const unsigned char* pa = sA + (wm * 64 + s * 32 + rl) * LDSB + t * 64;
+            fw[s].v[0] = *reinterpret_cast<const u32x4*>(pw + h * 16);
+            fw[s].v[1] = *reinterpret_cast<const u32x4*>(pw + (2 + h) * 16);
+            fa[s].v[0] = *reinterpret_cast<const u32x4*>(pa + h * 16);
+            fa[s].v[1] = *reinterpret_cast<const u32x4*>(pa + (2 + h) * 16);
+        }
+#pragma unroll
+        for (int sn = 0; sn < 2; ++sn)
+#pragma unroll
+            for (int sm = 0; sm < 2; ++sm) mtl_mma(fw[sn], fa[sm], acc[sn][sm]);
     }
-#pragma unroll
-    for (int sn = 0; sn < 2; ++sn)
-#pragma unroll
-        for (int sm = 0; sm < 2; ++sm) mtl_mma(fw[sn], fa[sm], acc[sn][sm]);
 }
 
-// acc += Wgt[n0.., k_lo..k_hi) * Act[m0.., k_lo..k_hi)^T   (register-prefetched, 2 barriers per k-tile)
-template <typename T>
-__device__ __forceinline__ void nt_loop(f32x16 (&acc)[2][2], unsigned char* smem, int tid, const T* wgt, int64_t ld_w,
-                                        int w_row0, int w_rows, const void* act0, const NtParams& P, int n_act,
-                                        int64_t ld_a, int64_t a_row0, int64_t a_rows, int k_lo, int k_hi, bool mask,
-                                        const DropoutCfg& dc) {
+// ------------------------------------------------------------------------------------------------
+// k_nt: one software-pipelined TILE STREAM per workgroup.
+// The k-tiles of the base GEMM and of every output's rank segment are consumed as ONE sequence: the register
+// prefetch of tile i+1 is issued before tile i is multiplied, ACROSS the boundaries between base / outputs, so a
+// workgroup pays the global->LDS latency once instead of once per output (with K = 96 a base GEMM is only
+// 3 k-tiles; cold starts per output were the dominant cost).
+//   MULTI  (forward with task outputs):  base | out0: base+lr0 | out1: base+lr1 ...   (base kept in registers)
+//   lean   (everything else):            per output: lr_o -> [mask] -> base -> store   (ONE accumulator set:
+//          the low-rank part is formed first so the dropout mask of dX = G W + keep.(Q A) applies to it alone)
+// ------------------------------------------------------------------------------------------------
+struct NtCursor {
+    int q;         // index in the part sequence
+    int k0;        // current k-tile origin
+    int k_hi;      // end of the part's k range
+    int lr;        // 1: rank-segment part (L x Rm), 0: base part (act x wgt)
+    int valid;
+};
+
+__device__ __forceinline__ NtOut nt_out(NtPtr P, int o) {
+    NtOut O;
+    O.ptr = P->out[o].ptr;
+    O.seg_lo = P->out[o].seg_lo;
+    O.seg_hi = P->out[o].seg_hi;
+    O.use_base = P->out[o].use_base;
+    O.mask_lr = P->out[o].mask_lr;
+    O.fold = P->out[o].fold;
+    return O;
+}
+
+// k range of part q.  MULTI: q = 0 base, q = 1 + o rank segment of output o.
+// lean: q = 2 o rank segment of output o, q = 2 o + 1 base (if that output uses it).
+template <bool MULTI>
+__device__ __forceinline__ void nt_part(NtPtr P, int q, int& lr, int& k_lo, int& k_hi) {
+    if (MULTI) {
+        if (q == 0) {
+            lr = 0;
+            k_lo = 0;
+            k_hi = P->K;
+        } else {
+            const NtOut O = nt_out(P, q - 1);
+            lr = 1;
+            k_lo = O.seg_lo;
+            k_hi = O.seg_hi;
+        }
+    } else {
+        const NtOut O = nt_out(P, q >> 1);
+        if (q & 1) {
+            lr = 0;
+            k_lo = 0;
+            k_hi = O.use_base ? P->K : 0;
+        } else {
+            lr = 1;
+            k_lo = O.seg_lo;
+            k_hi = O.seg_hi;
+        }
+    }
+}
+
+template <bool MULTI>
+__device__ __forceinline__ NtCursor nt_seek(NtPtr P, int q, int nseq) {
+    NtCursor c;
+    c.valid = 0;
+    c.q = q;
+    c.k0 = c.k_hi = c.lr = 0;
+    for (; q < nseq; ++q) {
+        int lr, lo, hi;
+        nt_part<MULTI>(P, q, lr, lo, hi);
+        if (hi > lo) {
+            c.q = q;
+            c.k0 = lo;
+            c.k_hi = hi;
+            c.lr = lr;
+            c.valid = 1;
+            break;
+        }
+    }
+    return c;
+}
+
+template <typename T, bool MULTI, bool MS>
+__global__ __launch_bounds__(256, (MULTI || MS) ? 2 : MTL_NT_LEAN_WAVES) void k_nt(const NtParams Pv) {
+    (void)Pv;
+    NtPtr P = (NtPtr)__builtin_amdgcn_kernarg_segment_ptr();
     constexpr int KE = ROWB / (int)sizeof(T);
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * TILE * LDSB];
     unsigned char* sW = smem;
     unsigned char* sA = smem + TILE * LDSB;
-    const int lane = tid & 63, wave = tid >> 6;
-    const int wn = wave >> 1, wm = wave & 1;
-    if (k_hi <= k_lo) return;
-    TileRegs<T> rg;
-    nt_load<T>(rg, tid, wgt, ld_w, w_row0, w_rows, act0, P, n_act, ld_a, a_row0, a_rows, k_lo, k_hi, mask, dc);
-    for (int k0 = k_lo; k0 < k_hi; k0 += KE) {
-        nt_store_lds<T>(rg, tid, sW, sA);
-        __syncthreads();
-        if (k0 + KE < k_hi)
-            nt_load<T>(rg, tid, wgt, ld_w, w_row0, w_rows, act0, P, n_act, ld_a, a_row0, a_rows, k0 + KE, k_hi, mask,
-                       dc);
-        nt_compute<T>(acc, sW, sA, lane, wn, wm);
-        __syncthreads();
-    }
-}
-
-template <typename T>
-__global__ __launch_bounds__(256, 2) void k_nt(const NtParams P) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * TILE * LDSB];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wn = wave >> 1, wm = wave & 1;
 
     // batched form
-    const void* act0 = P.act[0];
-    int row_off = 0, n_rows = P.n_rows;
-    bool act_mask = P.act_mask != 0;
-    if (P.nz > 0) {
-        const int z = blockIdx.z;  // static-index select chain: a dynamic index would copy P to scratch
-#pragma unroll
-        for (int q = 0; q < MAXO; ++q)
-            if (q == z) {
-                act0 = P.zact[q];
-                row_off = P.zrow0[q];
-                n_rows = P.zrows[q];
-                act_mask = P.zmask[q] != 0;
-            }
+    const void* act0 = P->act[0];
+    int row_off = 0, n_rows = P->n_rows;
+    bool act_mask = P->act_mask != 0;
+    if (P->nz > 0) {
+        const int z = blockIdx.z;
+        act0 = P->zact[z];
+        row_off = P->zrow0[z];
+        n_rows = P->zrows[z];
+        act_mask = P->zmask[z] != 0;
     }
     if (n_rows <= 0) return;
-    act_mask = act_mask && P.drop.enabled();
+    act_mask = act_mask && P->drop.thr16 != 0;
 
     // XCD-aware tile order: hardware places block b on XCD b % 8; give every XCD a contiguous run of
     // logical tiles so that the n-tiles sharing one activation row-block hit the same L2 (T1, bijective).
     const int n_tiles = (n_rows + TILE - 1) / TILE;
-    const int64_t m_tiles = (P.M + TILE - 1) / TILE;
+    const int64_t m_tiles = (P->M + TILE - 1) / TILE;
     const int64_t nwg = m_tiles * n_tiles;
     int64_t b = blockIdx.x;
     if (b >= nwg) return;
@@ -306,22 +386,52 @@ __global__ __launch_bounds__(256, 2) void k_nt(const NtParams P) {
     const int64_t m0 = bm * TILE;
     const int n0 = bn * TILE;
 
-    const T* wgt = reinterpret_cast<const T*>(P.wgt) + (int64_t)row_off * P.ld_wgt;
+    const T* wgt = reinterpret_cast<const T*>(P->wgt) + (int64_t)row_off * P->ld_wgt;
+    DropoutCfg drop;
+    drop.seed_lo = P->drop.seed_lo;
+    drop.seed_hi = P->drop.seed_hi;
+    drop.thr16 = P->drop.thr16;
+    const int nseq = MULTI ? 1 + P->n_out : 2 * P->n_out;
 
-    f32x16 base[2][2];
+    // ---- loader side of the stream (register prefetch, one wide tile ahead)
+    TileRegs<T> rg;
+    NtCursor ld = nt_seek<MULTI>(P, 0, nseq);
+    auto issue = [&](const NtCursor& c) __attribute__((always_inline)) {
+        if (c.lr)
+            nt_load<T, false>(rg, tid, reinterpret_cast<const T*>(P->Rm), P->ldR, n0, n_rows, P->L, P, 1, P->ldL, m0, P->M, c.k0,
+                              c.k_hi, false, drop);
+        else
+            nt_load<T, MS>(rg, tid, wgt, P->ld_wgt, n0, n_rows, act0, P, P->n_act, P->ld_act, m0, P->M, c.k0, c.k_hi, act_mask,
+                           drop);
+    };
+    if (ld.valid) issue(ld);
+    // consume one tile: registers -> LDS, prefetch the next tile of the stream, multiply
+    auto step = [&](f32x16(&acc)[2][2], int k_left) {
+        nt_store_lds<T>(rg, tid, sW, sA);
+        __syncthreads();
+        ld.k0 += KE;
+        if (ld.k0 >= ld.k_hi) ld = nt_seek<MULTI>(P, ld.q + 1, nseq);
+        if (ld.valid) issue(ld);
+        nt_compute<T>(acc, sW, sA, lane, wn, wm, k_left);
+        __syncthreads();
+    };
+    auto run_part = [&](int q, f32x16(&acc)[2][2]) {
+        int lr, lo, hi;
+        nt_part<MULTI>(P, q, lr, lo, hi);
+        for (int k0 = lo; k0 < hi; k0 += KE) step(acc, hi - k0);
+        return hi > lo;
+    };
+    auto zero = [](f32x16(&a)[2][2]) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) base[i][j][r] = 0.f;
-
-    if (P.K > 0)
-        nt_loop<T>(base, smem, tid, wgt, P.ld_wgt, n0, n_rows, act0, P, P.n_act, P.ld_act, m0, P.M, 0, P.K, act_mask,
-                   P.drop);
-
-    // per-column alpha / bias on the base
-    if (P.alpha || P.bias) {
+                for (int r = 0; r < 16; ++r) a[i][j][r] = 0.f;
+    };
+    // acc = acc * alpha[n] + bias[n]
+    auto affine = [&](f32x16(&a)[2][2]) {
+        if (!(P->alpha || P->bias)) return;
 #pragma unroll
         for (int sn = 0; sn < 2; ++sn)
 #pragma unroll
@@ -329,72 +439,91 @@ __global__ __launch_bounds__(256, 2) void k_nt(const NtParams P) {
                 const int n = n0 + wn * 64 + sn * 32 + 8 * q + 4 * (lane >> 5);
                 if (n < n_rows) {
                     f32x4 al = {1.f, 1.f, 1.f, 1.f}, bi = {0.f, 0.f, 0.f, 0.f};
-                    if (P.alpha) al = *reinterpret_cast<const f32x4*>(P.alpha + row_off + n);
-                    if (P.bias) bi = *reinterpret_cast<const f32x4*>(P.bias + row_off + n);
+                    if (P->alpha) al = *reinterpret_cast<const f32x4*>(P->alpha + row_off + n);
+                    if (P->bias) bi = *reinterpret_cast<const f32x4*>(P->bias + row_off + n);
 #pragma unroll
                     for (int sm = 0; sm < 2; ++sm)
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) base[sn][sm][q * 4 + e] = base[sn][sm][q * 4 + e] * al[e] + bi[e];
+                        for (int e = 0; e < 4; ++e) a[sn][sm][q * 4 + e] = a[sn][sm][q * 4 + e] * al[e] + bi[e];
                 }
             }
-    }
-
-    for (int o = 0; o < P.n_out; ++o) {
-        NtOut O = P.out[0];
-#pragma unroll
-        for (int q = 1; q < MAXO; ++q)
-            if (q == o) O = P.out[q];
-        f32x16 lr[2][2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) lr[i][j][r] = 0.f;
-        const bool has_lr = O.seg_hi > O.seg_lo;
-        if (has_lr)
-            nt_loop<T>(lr, smem, tid, reinterpret_cast<const T*>(P.Rm), P.ldR, n0, n_rows, P.L, P, 1, P.ldL, m0, P.M,
-                       O.seg_lo, O.seg_hi, false, P.drop);
-        const bool mask_lr = O.mask_lr && P.drop.enabled() && has_lr;
-        T* outp = reinterpret_cast<T*>(O.ptr);
+    };
+    // acc *= keep(m, n)
+    auto apply_mask = [&](f32x16(&a)[2][2]) {
 #pragma unroll
         for (int sm = 0; sm < 2; ++sm) {
             const int64_t m = m0 + wm * 64 + sm * 32 + (lane & 31);
-            const uint32_t rh = mask_lr ? mtl_dropout_rowhash(P.drop, 0u, (uint32_t)m) : 0u;
+            const uint32_t rh = mtl_dropout_rowhash(drop, 0u, (uint32_t)m);
 #pragma unroll
             for (int sn = 0; sn < 2; ++sn)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int n = n0 + wn * 64 + sn * 32 + 8 * q + 4 * (lane >> 5);
-                    float v[4];
+                    const uint32_t h0 = mtl_dropout_pairbits(drop, rh, (uint32_t)n);
+                    const uint32_t h1 = mtl_dropout_pairbits(drop, rh, (uint32_t)(n + 2));
+                    if ((h0 & 0xFFFFu) < drop.thr16) a[sn][sm][q * 4 + 0] = 0.f;
+                    if ((h0 >> 16) < drop.thr16) a[sn][sm][q * 4 + 1] = 0.f;
+                    if ((h1 & 0xFFFFu) < drop.thr16) a[sn][sm][q * 4 + 2] = 0.f;
+                    if ((h1 >> 16) < drop.thr16) a[sn][sm][q * 4 + 3] = 0.f;
+                }
+        }
+    };
+    auto store = [&](const f32x16(&a)[2][2], void* ptr) {
+        T* outp = reinterpret_cast<T*>(ptr);
+        if (!outp) return;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = lr[sn][sm][q * 4 + e];
-                    if (mask_lr) {
-                        const uint32_t h0 = mtl_dropout_pairbits(P.drop, rh, (uint32_t)n);
-                        const uint32_t h1 = mtl_dropout_pairbits(P.drop, rh, (uint32_t)(n + 2));
-                        if ((h0 & 0xFFFFu) < P.drop.thr16) v[0] = 0.f;
-                        if ((h0 >> 16) < P.drop.thr16) v[1] = 0.f;
-                        if ((h1 & 0xFFFFu) < P.drop.thr16) v[2] = 0.f;
-                        if ((h1 >> 16) < P.drop.thr16) v[3] = 0.f;
-                    }
-                    if (O.use_base) {
+        for (int sm = 0; sm < 2; ++sm) {
+            const int64_t m = m0 + wm * 64 + sm * 32 + (lane & 31);
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] += base[sn][sm][q * 4 + e];
-                    }
-                    if (O.fold) {
+            for (int sn = 0; sn < 2; ++sn)
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) base[sn][sm][q * 4 + e] = v[e];
-                    }
-                    if (m < P.M && n < n_rows && outp) {
-                        T* dst = outp + m * P.ld_out + row_off + n;
+                for (int q = 0; q < 4; ++q) {
+                    const int n = n0 + wn * 64 + sn * 32 + 8 * q + 4 * (lane >> 5);
+                    if (m < P->M && n < n_rows) {
+                        T* dst = outp + m * P->ld_out + row_off + n;
+                        const float v0 = a[sn][sm][q * 4], v1 = a[sn][sm][q * 4 + 1], v2 = a[sn][sm][q * 4 + 2],
+                                    v3 = a[sn][sm][q * 4 + 3];
                         if constexpr (sizeof(T) == 4) {
-                            *reinterpret_cast<f32x4*>(dst) = f32x4{v[0], v[1], v[2], v[3]};
+                            *reinterpret_cast<f32x4*>(dst) = f32x4{v0, v1, v2, v3};
                         } else {
-                            bf16x4 pk = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+                            bf16x4 pk = {(bf16)v0, (bf16)v1, (bf16)v2, (bf16)v3};
                             *reinterpret_cast<bf16x4*>(dst) = pk;
                         }
                     }
                 }
+        }
+    };
+
+    if constexpr (MULTI) {
+        f32x16 base[2][2], acc[2][2];
+        zero(base);
+        run_part(0, base);
+        affine(base);
+        for (int o = 0; o < P->n_out; ++o) {
+            const NtOut O = nt_out(P, o);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = base[i][j];
+            run_part(1 + o, acc);
+            if (O.fold) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) base[i][j] = acc[i][j];
+            }
+            store(acc, O.ptr);
+        }
+    } else {
+        f32x16 acc[2][2];
+        for (int o = 0; o < P->n_out; ++o) {
+            const NtOut O = nt_out(P, o);
+            zero(acc);
+            const bool had_lr = run_part(2 * o, acc);
+            if (had_lr && O.mask_lr && drop.enabled()) apply_mask(acc);
+            run_part(2 * o + 1, acc);
+            if (O.use_base) affine(acc);
+            store(acc, O.ptr);
         }
     }
 }
@@ -633,7 +762,14 @@ static void launch_nt(const NtParams& P, hipStream_t s, int kind, double alg_byt
     const int64_t n_tiles = mtl_ceil_div(max_rows, TILE);
     if (m_tiles * n_tiles == 0) return;
     dim3 g((unsigned)(m_tiles * n_tiles), 1, (unsigned)(P.nz > 0 ? P.nz : 1));
-    hipLaunchKernelGGL(k_nt<T>, g, dim3(256), 0, s, P);
+    int base_users = 0;
+    for (int o = 0; o < P.n_out; ++o) base_users += P.out[o].use_base ? 1 : 0;
+    if (base_users > 1)
+        hipLaunchKernelGGL((k_nt<T, true, false>), g, dim3(256), 0, s, P);
+    else if (P.n_act > 1)
+        hipLaunchKernelGGL((k_nt<T, false, true>), g, dim3(256), 0, s, P);
+    else
+        hipLaunchKernelGGL((k_nt<T, false, false>), g, dim3(256), 0, s, P);
 }
 
 template <typename T>

@@ -197,6 +197,7 @@ class AttnMeta:
     head_dim: int
     image_layout: bool
     scale: float
+    mask_value: float = -100.0
 
     def desc(self, dtype: torch.dtype) -> L.AttnDesc:
         d = L.AttnDesc()
@@ -206,36 +207,42 @@ class AttnMeta:
         d.image_layout = 1 if self.image_layout else 0
         d.dtype = L.BF16 if dtype == torch.bfloat16 else L.F32
         d.scale = self.scale
+        d.mask_value = self.mask_value
         return d
 
 
 class WindowAttentionFn(torch.autograd.Function):
     """out = softmax(scale * q k^T + bias[h] + mask[w]) v per (window, head)  (swin_transformer_mtlora.py:194-220).
-    qkv: (..., 3C) [3][nH][hd]; bias: (nH, N, N) fp32 dense; mask/mask_t: (nW, N, N) fp32 or None."""
+    qkv: (..., 3C) [3][nH][hd]; bias: (nH, N, N) fp32 dense.  The shift mask is either ``mask_ids`` (nW, N) int32
+    region ids (fast path: mask(i,j) = ids differ ? meta.mask_value : 0) or a general dense ``mask`` (nW, N, N)."""
 
     @staticmethod
-    def forward(ctx, meta: AttnMeta, qkv, bias, mask, mask_t):
-        L.require_gpu(qkv, bias, mask)
+    def forward(ctx, meta: AttnMeta, qkv, bias, mask, mask_ids):
+        L.require_gpu(qkv, bias, mask, mask_ids)
         dt = qkv.dtype
         if dt not in (torch.float32, torch.bfloat16):
             raise RuntimeError(f"mtlora_amd: window attention supports fp32/bf16, got {dt}")
         qkv_c = qkv.contiguous()
         bias_c = bias.detach().float().contiguous()
-        bias_t = bias_c.transpose(1, 2).contiguous()
+        if mask_ids is not None:
+            mask_ids = mask_ids.to(torch.int32).contiguous()
+            mask = None
+        elif mask is not None:
+            mask = mask.float().contiguous()
         C = meta.num_heads * meta.head_dim
         out = torch.empty(qkv_c.shape[:-1] + (C,), dtype=dt, device=qkv.device)
         d = meta.desc(dt)
-        st = L.lib().mtlora_window_attn_fwd(ctypes.byref(d), L.ptr(qkv_c), L.ptr(bias_t), L.ptr(mask_t), L.ptr(out),
-                                            L.stream_ptr())
+        st = L.lib().mtlora_window_attn_fwd(ctypes.byref(d), L.ptr(qkv_c), L.ptr(bias_c), L.ptr(mask), L.ptr(mask_ids),
+                                            L.ptr(out), L.stream_ptr())
         L.check(st, "mtlora_window_attn_fwd")
         ctx.meta = meta
-        ctx.save_for_backward(qkv_c, bias_c, bias_t, mask, mask_t)
+        ctx.save_for_backward(qkv_c, bias_c, mask, mask_ids)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         meta: AttnMeta = ctx.meta
-        qkv, bias, bias_t, mask, mask_t = ctx.saved_tensors
+        qkv, bias, mask, mask_ids = ctx.saved_tensors
         dout = dout.to(qkv.dtype).contiguous()
         d = meta.desc(qkv.dtype)
         lib = L.lib()
@@ -243,9 +250,8 @@ class WindowAttentionFn(torch.autograd.Function):
         scratch = torch.empty(sb, dtype=torch.uint8, device=qkv.device)
         dqkv = torch.empty_like(qkv)
         dbias = torch.empty_like(bias)
-        st = lib.mtlora_window_attn_bwd(ctypes.byref(d), L.ptr(qkv), L.ptr(bias), L.ptr(bias_t), L.ptr(mask),
-                                        L.ptr(mask_t), L.ptr(dout), L.ptr(dqkv), L.ptr(dbias), L.ptr(scratch), sb,
-                                        L.stream_ptr())
+        st = lib.mtlora_window_attn_bwd(ctypes.byref(d), L.ptr(qkv), L.ptr(bias), L.ptr(mask), L.ptr(mask_ids),
+                                        L.ptr(dout), L.ptr(dqkv), L.ptr(dbias), L.ptr(scratch), sb, L.stream_ptr())
         L.check(st, "mtlora_window_attn_bwd")
         return None, dqkv, dbias, None, None
 

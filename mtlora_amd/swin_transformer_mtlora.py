@@ -154,15 +154,11 @@ class WindowAttention(nn.Module):
         b = self.relative_position_bias_table[self.relative_position_index.view(-1)]
         return b.view(n, n, -1).permute(2, 0, 1).float()
 
-    def _core(self, qkv: Tensor, meta: Fn.AttnMeta, mask: Optional[Tensor], mask_t: Optional[Tensor]) -> Tensor:
+    def _core(self, qkv: Tensor, meta: Fn.AttnMeta, mask: Optional[Tensor], mask_ids: Optional[Tensor]) -> Tensor:
         if self.training and self.attn_drop.p > 0:
             raise NotImplementedError("mtlora_amd: attn_drop > 0 is not supported by the fused attention kernel "
                                       "(every MTLoRA config uses 0)")
-        if mask is not None:
-            mask = mask.float().contiguous()
-            if mask_t is None:
-                mask_t = mask.transpose(1, 2).contiguous()
-        return Fn.WindowAttentionFn.apply(meta, qkv, self.dense_bias(), mask, mask_t)
+        return Fn.WindowAttentionFn.apply(meta, qkv, self.dense_bias(), mask, mask_ids)
 
     def _project(self, a: Tensor):
         y, y_t = self.proj(a)
@@ -181,14 +177,14 @@ class WindowAttention(nn.Module):
                            head_dim=C // self.num_heads, image_layout=False, scale=self.scale)
         return self._project(self._core(qkv, meta, mask, None))
 
-    def forward_image(self, x, H: int, W: int, shift: int, mask=None, mask_t=None):
+    def forward_image(self, x, H: int, W: int, shift: int, mask=None, mask_ids=None):
         """x: (B, H*W, C) tokens in image order.  Equivalent to roll(-shift) -> partition -> forward ->
         merge -> roll(+shift), with the permutations folded into the attention kernel's addressing."""
         B, L, C = x.shape
         qkv, _ = self.qkv(x)
         meta = Fn.AttnMeta(B=B, H=H, W=W, window_size=self.window_size[0], shift=shift, num_heads=self.num_heads,
                            head_dim=C // self.num_heads, image_layout=True, scale=self.scale)
-        return self._project(self._core(qkv, meta, mask, mask_t))
+        return self._project(self._core(qkv, meta, mask, mask_ids))
 
     def extra_repr(self) -> str:
         return f"dim={self.dim}, window_size={self.window_size}, num_heads={self.num_heads}"
@@ -197,15 +193,20 @@ class WindowAttention(nn.Module):
         return 4 * N * self.dim * self.dim + 2 * self.num_heads * N * N * (self.dim // self.num_heads)
 
 
-def _shift_mask(H: int, W: int, ws: int, shift: int) -> Tensor:
-    """(nW, N, N) 0 / -100 mask of SW-MSA (reference :297-323): tokens of different cyclic regions do not attend."""
+def _shift_regions(H: int, W: int, ws: int, shift: int) -> Tensor:
+    """(nW, N) region id (0..8) of every token of every shifted window (the ``img_mask`` of reference :300-314)."""
     ids = torch.zeros(H, W)
     edges_h = (0, H - ws, H - shift, H)
     edges_w = (0, W - ws, W - shift, W)
     for a in range(3):
         for b in range(3):
             ids[edges_h[a]:edges_h[a + 1], edges_w[b]:edges_w[b + 1]] = 3 * a + b
-    win = ids.view(H // ws, ws, W // ws, ws).permute(0, 2, 1, 3).reshape(-1, ws * ws)
+    return ids.view(H // ws, ws, W // ws, ws).permute(0, 2, 1, 3).reshape(-1, ws * ws)
+
+
+def _shift_mask(H: int, W: int, ws: int, shift: int) -> Tensor:
+    """(nW, N, N) 0 / -100 mask of SW-MSA (reference :297-323): tokens of different cyclic regions do not attend."""
+    win = _shift_regions(H, W, ws, shift)
     diff = win[:, None, :] - win[:, :, None]
     return torch.where(diff != 0, torch.full_like(diff, -100.0), torch.zeros_like(diff))
 
@@ -238,8 +239,9 @@ class SwinTransformerBlock(nn.Module):
         H, W = self.input_resolution
         mask = _shift_mask(H, W, self.window_size, self.shift_size) if self.shift_size > 0 else None
         self.register_buffer("attn_mask", mask)
-        self.register_buffer("_attn_mask_t", None if mask is None else mask.transpose(1, 2).contiguous(),
-                             persistent=False)
+        # the same mask as per-token region ids: what the attention kernel consumes (9 ids instead of N*N floats)
+        self.register_buffer("_attn_mask_ids", None if mask is None else
+                             _shift_regions(H, W, self.window_size, self.shift_size).to(torch.int32), persistent=False)
         self.fused_window_process = fused_window_process
         self.attention_layout = "image"  # "windows": reference dataflow through the window-process kernels
 
@@ -260,7 +262,7 @@ class SwinTransformerBlock(nn.Module):
         if self.attention_layout == "windows":
             a, a_t = self._attend_windows(xn, B, H, W, C)
         else:
-            a, a_t = self.attn.forward_image(xn, H, W, self.shift_size, self.attn_mask, self._attn_mask_t)
+            a, a_t = self.attn.forward_image(xn, H, W, self.shift_size, self.attn_mask, self._attn_mask_ids)
         # residuals: an independent DropPath draw per call, like the reference (:389-392)
         x_t = None
         if a_t is not None:

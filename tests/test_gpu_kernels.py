@@ -289,6 +289,16 @@ def test_linear_errors():
 # ------------------------------------------------------------------------------------------------
 # window attention
 # ------------------------------------------------------------------------------------------------
+def _regions(H, W, ws, shift):
+    """region ids of the SW-MSA mask, derived from the ORACLE's dense mask: ids differ <=> mask == -100."""
+    from mtlora_amd.swin_transformer_mtlora import _shift_regions
+    ids = _shift_regions(H, W, ws, shift).to(torch.int32)
+    dense = O.shifted_window_mask(H, W, ws, shift)
+    rebuilt = torch.where(ids[:, None, :] != ids[:, :, None], torch.tensor(-100.0), torch.tensor(0.0))
+    assert torch.equal(rebuilt, dense)
+    return ids
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("cfg", [
     # (B, H, W, heads, ws, shift)
@@ -307,7 +317,8 @@ def test_attention_core_vs_oracle(cfg, dtype):
     mask_d = None if mask is None else mask.to(dev())
     scale = 32 ** -0.5
     meta = Fn.AttnMeta(B=B, H=H, W=W, window_size=ws, shift=shift, num_heads=nH, head_dim=32, image_layout=True, scale=scale)
-    out = Fn.WindowAttentionFn.apply(meta, qkv_img, bias, mask_d, None if mask is None else mask_d.transpose(1, 2).contiguous())
+    ids = None if mask is None else _regions(H, W, ws, shift).to(dev())
+    out = Fn.WindowAttentionFn.apply(meta, qkv_img, bias, None, ids)          # region-id fast path
     # oracle: roll + partition -> core -> merge + roll
     q64 = qkv_img.detach().double().cpu().requires_grad_(True)
     b64 = bias.detach().double().cpu().requires_grad_(True)
@@ -325,9 +336,16 @@ def test_attention_core_vs_oracle(cfg, dtype):
     nW = 1 if mask is None else mask.shape[0]
     meta_w = Fn.AttnMeta(B=qkv_win.shape[0] // nW, H=ws, W=ws * nW, window_size=ws, shift=0, num_heads=nH, head_dim=32,
                          image_layout=False, scale=scale)
-    out_w = Fn.WindowAttentionFn.apply(meta_w, qkv_win, bias.detach(), mask_d,
-                                       None if mask is None else mask_d.transpose(1, 2).contiguous())
+    out_w = Fn.WindowAttentionFn.apply(meta_w, qkv_win, bias.detach(), mask_d, None)   # general dense-mask path
     assert_close(out_w, core, dtype, "attn out (windows)")
+    if mask is not None:  # dense-mask path, image layout, forward + backward
+        q2 = qkv_img.detach().clone().requires_grad_(True)
+        b2 = bias.detach().clone().requires_grad_(True)
+        out_d = Fn.WindowAttentionFn.apply(meta, q2, b2, mask_d, None)
+        assert_close(out_d, ref, dtype, "attn out (dense mask)")
+        out_d.backward(g)
+        assert_close(q2.grad, q64.grad, dtype, "dqkv (dense mask)", mult=2)
+        assert_close(b2.grad, b64.grad, dtype, "dbias (dense mask)", mult=3)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])

@@ -168,6 +168,22 @@ int mtlora_layernorm_bwd(const void* dy, const void* x, const float* gamma, cons
                          void* scratch, int64_t scratch_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Training-mode BatchNorm + optional ReLU over a channels-last (R rows, C channels) matrix -- the decoder heads'
+ * conv1x1 -> BatchNorm2d -> ReLU (seg_hrnet.py:498-526) on the (pixels, channels) matrix; replaces
+ * aten::native_batch_norm(+backward) and the separate ReLU.  Biased variance for normalisation, unbiased for the
+ * running_var update (momentum as nn.BatchNorm2d); running_* may be NULL.  save_* are (C) fp32 buffers written by
+ * fwd and read by bwd (x is re-read by bwd; y is not needed).  dgamma / dbeta (C) fp32 are overwritten.
+ * ------------------------------------------------------------------------------------------ */
+int64_t mtlora_bn_scratch_bytes(int64_t R, int64_t C, int dtype);
+int mtlora_bn_relu_fwd(const void* x, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                       float momentum, float eps, int relu, void* y, float* save_mean, float* save_rstd,
+                       float* save_scale, float* save_shift, int64_t R, int64_t C, int dtype, void* scratch,
+                       int64_t scratch_bytes, void* stream);
+int mtlora_bn_relu_bwd(const void* dy, const void* x, const float* save_mean, const float* save_rstd,
+                       const float* save_scale, const float* save_shift, int relu, void* dx, float* dgamma, float* dbeta,
+                       int64_t R, int64_t C, int dtype, void* scratch, int64_t scratch_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Hardware self-test: writes the lane->element maps of the MFMA / LDS-transpose primitives the
  * kernels rely on into `out` (int32[4096]) so a GPU test can assert them (tests/test_gpu_layouts.py).
  * ------------------------------------------------------------------------------------------ */

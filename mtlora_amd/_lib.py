@@ -67,6 +67,12 @@ _SIGS = {
     "mtlora_layernorm_bwd_scratch_bytes": (c_int64, [c_int64, c_int64, c_int]),
     "mtlora_layernorm_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                      c_int64, c_int64, c_int, c_int, c_void_p, c_int64, c_void_p]),
+    "mtlora_bn_scratch_bytes": (c_int64, [c_int64, c_int64, c_int]),
+    "mtlora_bn_relu_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_int, c_void_p,
+                                   c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p, c_int64,
+                                   c_void_p]),
+    "mtlora_bn_relu_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
+                                   c_void_p, c_int64, c_int64, c_int, c_void_p, c_int64, c_void_p]),
     "mtlora_selftest_layouts": (c_int, [c_void_p, c_void_p]),
     "mtlora_prof_begin": (c_int, [c_int]),
     "mtlora_prof_end": (c_int, [POINTER(ProfSummary)]),

@@ -22,7 +22,7 @@ typedef __attribute__((ext_vector_type(4))) short s16x4;
         if (e__ != hipSuccess) return MTLORA_ERR_HIP;        \
     } while (0)
 
-static inline int64_t mtl_ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+__host__ __device__ static inline int64_t mtl_ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline int64_t mtl_round_up(int64_t a, int64_t b) { return mtl_ceil_div(a, b) * b; }
 static inline int mtl_elem_size(int dtype) { return dtype == MTLORA_F32 ? 4 : 2; }
 
@@ -218,6 +218,7 @@ enum MtlProfKind {
     PK_WINDOW = 9,
     PK_LN_FWD = 10,      // k_ln_fwd                      x in, y out
     PK_LN_BWD = 11,      // k_ln_bwd                      x, dy in, dx out
+    PK_BN = 12,          // k_bn_colsum / k_bn_apply      heads' BatchNorm(+ReLU)
     PK_COUNT = 16
 };
 int mtl_prof_start(int kind, double alg_bytes, hipStream_t s);

@@ -349,3 +349,46 @@ def layer_norm(mod: torch.nn.Module, x: torch.Tensor, feeds_linear: bool = True)
     else:
         out_dtype = torch.float32 if torch.is_autocast_enabled() else x.dtype
     return LayerNormFn.apply(x, mod.weight, mod.bias, mod.eps, out_dtype)
+
+
+# ----------------------------------------------------------------------------------------------
+# training-mode BatchNorm (+ReLU) over a channels-last (rows, C) matrix (decoder heads)
+# ----------------------------------------------------------------------------------------------
+class BatchNormReluFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, momentum: float, eps: float, relu: bool):
+        L.require_gpu(x, weight, bias)
+        R, C = x.shape
+        x = x.contiguous()
+        w, b = weight.detach().float().contiguous(), bias.detach().float().contiguous()
+        y = torch.empty_like(x)
+        saves = torch.empty(4, C, dtype=torch.float32, device=x.device)  # mean, rstd, scale, shift
+        lib = L.lib()
+        sb = lib.mtlora_bn_scratch_bytes(R, C, L.dtype_code(x))
+        if sb < 0:
+            raise RuntimeError(f"mtlora_amd: unsupported BatchNorm shape ({R}, {C}) {x.dtype}")
+        scratch = torch.empty(sb, dtype=torch.uint8, device=x.device)
+        st = lib.mtlora_bn_relu_fwd(L.ptr(x), L.ptr(w), L.ptr(b), L.ptr(running_mean), L.ptr(running_var), float(momentum),
+                                    float(eps), int(relu), L.ptr(y), L.ptr(saves[0]), L.ptr(saves[1]), L.ptr(saves[2]),
+                                    L.ptr(saves[3]), R, C, L.dtype_code(x), L.ptr(scratch), sb, L.stream_ptr())
+        L.check(st, "mtlora_bn_relu_fwd")
+        ctx.save_for_backward(x, saves)
+        ctx.relu = relu
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, saves = ctx.saved_tensors
+        R, C = x.shape
+        dy = dy.to(x.dtype).contiguous()
+        lib = L.lib()
+        sb = lib.mtlora_bn_scratch_bytes(R, C, L.dtype_code(x))
+        scratch = torch.empty(sb, dtype=torch.uint8, device=x.device)
+        dx = torch.empty_like(x)
+        dg = torch.empty(C, dtype=torch.float32, device=x.device)
+        db = torch.empty(C, dtype=torch.float32, device=x.device)
+        st = lib.mtlora_bn_relu_bwd(L.ptr(dy), L.ptr(x), L.ptr(saves[0]), L.ptr(saves[1]), L.ptr(saves[2]), L.ptr(saves[3]),
+                                    int(ctx.relu), L.ptr(dx), L.ptr(dg), L.ptr(db), R, C, L.dtype_code(x), L.ptr(scratch), sb,
+                                    L.stream_ptr())
+        L.check(st, "mtlora_bn_relu_bwd")
+        return dx, dg, db, None, None, None, None, None

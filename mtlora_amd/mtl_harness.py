@@ -19,6 +19,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .functional import BatchNormReluFn
 from .lora import mark_only_lora_as_trainable
 from .swin_transformer_mtlora import SwinTransformerMTLoRA
 
@@ -88,9 +89,13 @@ class HighResolutionHead(nn.Module):
         h = F.linear(t, c0.weight.view(c0.out_channels, c0.in_channels), c0.bias)
         if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
             bn.num_batches_tracked.add_(1)
-        h = F.batch_norm(h, bn.running_mean, bn.running_var, bn.weight, bn.bias, bn.training or not bn.track_running_stats,
-                         bn.momentum, bn.eps)
-        o = F.linear(F.relu(h), c3.weight.view(c3.out_channels, c3.in_channels), c3.bias)
+        if bn.training and h.is_cuda and h.dtype in (torch.float32, torch.bfloat16) and h.shape[1] % 8 == 0:
+            # fused training-mode BatchNorm + ReLU on the (pixels, channels) matrix (csrc/glue.hip)
+            h = BatchNormReluFn.apply(h, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps, True)
+        else:
+            h = F.relu(F.batch_norm(h, bn.running_mean, bn.running_var, bn.weight, bn.bias,
+                                    bn.training or not bn.track_running_stats, bn.momentum, bn.eps))
+        o = F.linear(h, c3.weight.view(c3.out_channels, c3.in_channels), c3.bias)
         return o.view(B, Hh, Ww, c3.out_channels).permute(0, 3, 1, 2)
 
 

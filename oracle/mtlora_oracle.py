@@ -96,15 +96,19 @@ def mtlora_linear(
     keep_mask: Optional[Tensor] = None,
     p: float = 0.0,
     lora_norm: Optional[Tuple[Tensor, Tensor]] = None,
+    torch_dropout: bool = False,
 ) -> Tuple[Tensor, Optional[Dict[str, Tensor]]]:
     """lora.py:253-284.  ``keep_mask`` (same shape as x, bool) stands in for
     ``self.lora_dropout`` (lora.py:258: the dropped x is re-bound, so the task
-    path sees it too when ``x_tasks`` is None)."""
+    path sees it too when ``x_tasks`` is None); ``torch_dropout`` applies
+    ``F.dropout(x, p)`` itself (what nn.Dropout does; used by the eager-GPU baseline)."""
     pretrained = F.linear(x, W, b)                                   # :255
     if A_s is None and not tasks:                                    # r == 0 -> :256
         return pretrained, None
     xd = x
-    if keep_mask is not None and p > 0.0:
+    if torch_dropout and p > 0.0:
+        xd = F.dropout(x, p, training=True)
+    elif keep_mask is not None and p > 0.0:
         xd = x * keep_mask.to(x.dtype) / (1.0 - p)                   # :258 nn.Dropout semantics
 
     def task_out(t, base):
@@ -317,8 +321,8 @@ def _lin(P, pre, x, x_tasks, tasks, stage, mt, train, rng):
     A_s, B_s = P.get(pre + ".lora_shared_A"), P.get(pre + ".lora_shared_B")
     p = mt.DROPOUT[stage] if train else 0.0
     keep = None
-    if p > 0.0:
-        keep = (torch.rand(x.shape, generator=rng, device="cpu") >= p).to(x.device)
+    if p > 0.0 and not x.is_cuda:
+        keep = torch.rand(x.shape, generator=rng, device="cpu") >= p
     ss = P[pre + ".lora_shared_scale"] if (pre + ".lora_shared_scale") in P else mt.SHARED_SCALE[stage]
     return mtlora_linear(
         x, W, b, A_s, B_s, ss,
@@ -330,6 +334,7 @@ def _lin(P, pre, x, x_tasks, tasks, stage, mt, train, rng):
         shared_mode=mt.SHARED_MODE if has_tasks else "matrix",
         keep_mask=keep, p=p,
         lora_norm=(P.get(pre + ".lora_norm.weight"), P.get(pre + ".lora_norm.bias")),
+        torch_dropout=x.is_cuda,
     )
 
 

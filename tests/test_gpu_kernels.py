@@ -476,3 +476,30 @@ def test_layernorm_vs_torch(M, C, xdt, ydt):
     assert_close(x.grad, x64.grad, xdt, "dx", mult=2)
     assert_close(w.grad, w64.grad, torch.float32 if ydt == torch.float32 else torch.bfloat16, "dgamma", mult=2)
     assert_close(b.grad, b64.grad, torch.float32 if ydt == torch.float32 else torch.bfloat16, "dbeta", mult=2)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("R,C,relu", [(5000, 1080, True), (777, 1080, False), (4096, 64, True), (100, 8, True)])
+def test_batchnorm_relu_vs_torch(R, C, relu, dtype):
+    from mtlora_amd import functional as Fn
+    torch.manual_seed(R + C)
+    x = (torch.randn(R, C, device=dev()) * 1.5 + 0.3).to(dtype).requires_grad_(True)
+    w = (torch.randn(C, device=dev()) * 0.2 + 1).requires_grad_(True)
+    b = (torch.randn(C, device=dev()) * 0.3).requires_grad_(True)
+    rm, rv = torch.zeros(C, device=dev()), torch.ones(C, device=dev())
+    y = Fn.BatchNormReluFn.apply(x, w, b, rm, rv, 0.1, 1e-5, relu)
+    x64 = x.detach().double().cpu().requires_grad_(True)
+    w64, b64 = w.detach().double().cpu().requires_grad_(True), b.detach().double().cpu().requires_grad_(True)
+    rm64, rv64 = torch.zeros(C, dtype=torch.float64), torch.ones(C, dtype=torch.float64)
+    ref = torch.nn.functional.batch_norm(x64, rm64, rv64, w64, b64, True, 0.1, 1e-5)
+    if relu:
+        ref = torch.relu(ref)
+    assert_close(y, ref, dtype, "y")
+    assert_close(rm, rm64, torch.float32, "running_mean", mult=5)
+    assert_close(rv, rv64, torch.float32, "running_var", mult=5)
+    g = torch.randn(R, C, device=dev()).to(dtype)
+    y.backward(g)
+    ref.backward(g.double().cpu())
+    assert_close(x.grad, x64.grad, dtype, "dx", mult=3)
+    assert_close(w.grad, w64.grad, dtype, "dgamma", mult=3)
+    assert_close(b.grad, b64.grad, dtype, "dbeta", mult=3)

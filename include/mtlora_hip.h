@@ -184,6 +184,18 @@ int mtlora_bn_relu_bwd(const void* dy, const void* x, const float* save_mean, co
                        int64_t R, int64_t C, int dtype, void* scratch, int64_t scratch_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * residual + DropPath for the n = 1+T tensors of a block half (swin_transformer_mtlora.py:389-392, 398-408):
+ *   out_k = res_k + scale[k][sample] * y_k      (scale = DropPath mask / keep_prob, (n, B) fp32, NULL = ones)
+ * (M, C) row-major, M = B * tokens, C % 8 == 0; res / out in res_dtype, y in y_dtype.  Backward: dy_k = scale * g_k
+ * (y_dtype) and, when the residual is shared by every k, dres = sum_k g_k (res_dtype); g[k] may be NULL.
+ * ------------------------------------------------------------------------------------------ */
+int mtlora_residual_droppath_fwd(int n, const void* const* res, const void* const* y, void* const* out,
+                                 const float* scale, int64_t M, int64_t C, int64_t B, int res_dtype, int y_dtype,
+                                 void* stream);
+int mtlora_residual_droppath_bwd(int n, const void* const* g, void* const* dy, void* dres, const float* scale,
+                                 int64_t M, int64_t C, int64_t B, int res_dtype, int y_dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Hardware self-test: writes the lane->element maps of the MFMA / LDS-transpose primitives the
  * kernels rely on into `out` (int32[4096]) so a GPU test can assert them (tests/test_gpu_layouts.py).
  * ------------------------------------------------------------------------------------------ */

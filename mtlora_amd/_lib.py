@@ -42,6 +42,7 @@ class ProfSummary(Structure):
 
 
 PtrArr = c_void_p * MAX_TASKS
+PtrArr9 = c_void_p * (MAX_TASKS + 1)
 
 _SIGS = {
     "mtlora_version": (c_int, []),
@@ -73,6 +74,10 @@ _SIGS = {
                                    c_void_p]),
     "mtlora_bn_relu_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
                                    c_void_p, c_int64, c_int64, c_int, c_void_p, c_int64, c_void_p]),
+    "mtlora_residual_droppath_fwd": (c_int, [c_int, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), c_void_p,
+                                             c_int64, c_int64, c_int64, c_int, c_int, c_void_p]),
+    "mtlora_residual_droppath_bwd": (c_int, [c_int, POINTER(c_void_p), POINTER(c_void_p), c_void_p, c_void_p, c_int64,
+                                             c_int64, c_int64, c_int, c_int, c_void_p]),
     "mtlora_selftest_layouts": (c_int, [c_void_p, c_void_p]),
     "mtlora_prof_begin": (c_int, [c_int]),
     "mtlora_prof_end": (c_int, [POINTER(ProfSummary)]),
@@ -129,6 +134,13 @@ def ptr(t) -> c_void_p:
 def ptr_array(ts) -> "PtrArr":
     a = PtrArr()
     for i in range(MAX_TASKS):
+        a[i] = 0 if (ts is None or i >= len(ts) or ts[i] is None) else ts[i].data_ptr()
+    return a
+
+
+def ptr_array9(ts) -> "PtrArr9":
+    a = PtrArr9()
+    for i in range(MAX_TASKS + 1):
         a[i] = 0 if (ts is None or i >= len(ts) or ts[i] is None) else ts[i].data_ptr()
     return a
 

@@ -218,6 +218,7 @@ enum MtlProfKind {
     PK_WINDOW = 9,
     PK_LN_FWD = 10,      // k_ln_fwd                      x in, y out
     PK_LN_BWD = 11,      // k_ln_bwd                      x, dy in, dx out
+    PK_RESIDUAL = 13,    // k_residual_fwd / _bwd         residual + DropPath over 1+T tensors
     PK_BN = 12,          // k_bn_colsum / k_bn_apply      heads' BatchNorm(+ReLU)
     PK_COUNT = 16
 };

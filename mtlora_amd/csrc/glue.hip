@@ -497,46 +497,75 @@ __global__ __launch_bounds__(512) void k_bn_colsum(const BnParams p) {
     }
 }
 
-// forward finalize: per channel combine (count, sum, sumsq) partials with Chan's formula
-__global__ __launch_bounds__(256) void k_bn_finalize(const BnParams p) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= p.C) return;
-    const int64_t rows_blk = mtl_ceil_div(p.R, p.nblk);
-    double n = 0.0, mean = 0.0, m2 = 0.0;
-    for (int b = 0; b < p.nblk; ++b) {
-        int64_t cnt = p.R - (int64_t)b * rows_blk;
-        if (cnt > rows_blk) cnt = rows_blk;
-        if (cnt <= 0) break;
-        const double s = p.part[(int64_t)b * 2 * p.C + c], q = p.part[(int64_t)b * 2 * p.C + p.C + c];
-        const double mb = s / (double)cnt;
-        const double m2b = q - s * mb;
-        const double delta = mb - mean, nn = n + (double)cnt;
-        mean += delta * (double)cnt / nn;
-        m2 += m2b + delta * delta * n * (double)cnt / nn;
-        n = nn;
+// forward finalize: per channel combine (count, sum, sumsq) partials with Chan's formula.
+// One workgroup per 64 channels: its 4 waves each fold a strided quarter of the partials (coalesced 256-byte reads),
+// then wave 0 folds the four results in a fixed order.
+struct BnAcc {
+    double n, mean, m2;
+};
+__device__ __forceinline__ void bn_fold(BnAcc& a, double cnt, double mb, double m2b) {
+    const double delta = mb - a.mean, nn = a.n + cnt;
+    if (nn > 0.0) {
+        a.mean += delta * cnt / nn;
+        a.m2 += m2b + delta * delta * a.n * cnt / nn;
+        a.n = nn;
     }
-    const double var = m2 / n;
+}
+
+__global__ __launch_bounds__(256) void k_bn_finalize(const BnParams p) {
+    __shared__ double sm[4][3][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    const int64_t rows_blk = mtl_ceil_div(p.R, p.nblk);
+    BnAcc a = {0.0, 0.0, 0.0};
+    if (c < p.C) {
+        for (int b = wave; b < p.nblk; b += 4) {
+            int64_t cnt = p.R - (int64_t)b * rows_blk;
+            if (cnt > rows_blk) cnt = rows_blk;
+            if (cnt <= 0) break;
+            const double s = p.part[(int64_t)b * 2 * p.C + c], q = p.part[(int64_t)b * 2 * p.C + p.C + c];
+            const double mb = s / (double)cnt;
+            bn_fold(a, (double)cnt, mb, q - s * mb);
+        }
+    }
+    sm[wave][0][lane] = a.n;
+    sm[wave][1][lane] = a.mean;
+    sm[wave][2][lane] = a.m2;
+    __syncthreads();
+    if (wave != 0 || c >= p.C) return;
+    BnAcc t = {0.0, 0.0, 0.0};
+    for (int w = 0; w < 4; ++w) bn_fold(t, sm[w][0][lane], sm[w][1][lane], sm[w][2][lane]);
+    const double var = t.m2 / t.n;
     const float rstd = (float)(1.0 / sqrt(var + (double)p.eps));
     const float sc = p.gamma[c] * rstd;
-    p.mean[c] = (float)mean;
+    p.mean[c] = (float)t.mean;
     p.rstd[c] = rstd;
     p.scale[c] = sc;
-    p.shift[c] = p.beta[c] - (float)mean * sc;
+    p.shift[c] = p.beta[c] - (float)t.mean * sc;
     if (p.running_mean) {
-        const double unb = n > 1.0 ? m2 / (n - 1.0) : var;
-        p.running_mean[c] = (1.f - p.momentum) * p.running_mean[c] + p.momentum * (float)mean;
+        const double unb = t.n > 1.0 ? t.m2 / (t.n - 1.0) : var;
+        p.running_mean[c] = (1.f - p.momentum) * p.running_mean[c] + p.momentum * (float)t.mean;
         p.running_var[c] = (1.f - p.momentum) * p.running_var[c] + p.momentum * (float)unb;
     }
 }
 
 __global__ __launch_bounds__(256) void k_bn_bwd_finalize(const BnParams p) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= p.C) return;
+    __shared__ double sm[4][2][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
     double s0 = 0.0, s1 = 0.0;
-    for (int b = 0; b < p.nblk; ++b) {
-        s0 += p.part[(int64_t)b * 2 * p.C + c];
-        s1 += p.part[(int64_t)b * 2 * p.C + p.C + c];
+    if (c < p.C) {
+        for (int b = wave; b < p.nblk; b += 4) {
+            s0 += p.part[(int64_t)b * 2 * p.C + c];
+            s1 += p.part[(int64_t)b * 2 * p.C + p.C + c];
+        }
     }
+    sm[wave][0][lane] = s0;
+    sm[wave][1][lane] = s1;
+    __syncthreads();
+    if (wave != 0 || c >= p.C) return;
+    s0 = (sm[0][0][lane] + sm[1][0][lane]) + (sm[2][0][lane] + sm[3][0][lane]);
+    s1 = (sm[0][1][lane] + sm[1][1][lane]) + (sm[2][1][lane] + sm[3][1][lane]);
     p.dbeta[c] = (float)s0;
     p.dgamma[c] = (float)s1;
     p.c1[c] = (float)(s0 / (double)p.R);
@@ -639,7 +668,7 @@ int mtlora_bn_relu_fwd(const void* x, const float* gamma, const float* beta, flo
         else
             hipLaunchKernelGGL((k_bn_colsum<bf16, false>), dim3(p.nblk), dim3(threads), lds, s, p);
     }
-    hipLaunchKernelGGL(k_bn_finalize, dim3((unsigned)mtl_ceil_div(C, 256)), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(k_bn_finalize, dim3((unsigned)mtl_ceil_div(C, 64)), dim3(256), 0, s, p);
     {
         MtlProfScope prof(PK_BN, (double)R * C * es * 2, s);
         if (dtype == MTLORA_F32)
@@ -685,7 +714,7 @@ int mtlora_bn_relu_bwd(const void* dy, const void* x, const float* save_mean, co
         else
             hipLaunchKernelGGL((k_bn_colsum<bf16, true>), dim3(p.nblk), dim3(threads), lds, s, p);
     }
-    hipLaunchKernelGGL(k_bn_bwd_finalize, dim3((unsigned)mtl_ceil_div(C, 256)), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(k_bn_bwd_finalize, dim3((unsigned)mtl_ceil_div(C, 64)), dim3(256), 0, s, p);
     {
         MtlProfScope prof(PK_BN, (double)R * C * es * 3, s);
         if (dtype == MTLORA_F32)
@@ -693,6 +722,185 @@ int mtlora_bn_relu_bwd(const void* dy, const void* x, const float* save_mean, co
         else
             hipLaunchKernelGGL((k_bn_apply<bf16, true>), dim3(2048), dim3(256), 0, s, p);
     }
+    MTL_CHECK_LAUNCH();
+    return MTLORA_OK;
+}
+}
+
+// =================================================================================================
+// residual + DropPath over the 1+T tensors of a block half (swin_transformer_mtlora.py:389-392, 398-408):
+//   out_k[m] = res_k[m] + s_k[sample(m)] * y_k[m]        s = DropPath mask / keep (1 when off)
+// forward : ONE launch for all k (reads res_k, y_k once, writes out_k) instead of a mul + an add per tensor;
+// backward: ONE launch: dy_k = s_k * g_k and, when the residual is SHARED by all k (attention half: every task
+//           output adds the same shortcut), d_res = sum_k g_k -- instead of T adds by the autograd engine.
+// res / out dtype may be fp32 while y is bf16 (the stage-0 residual stream is fp32 under autocast).
+// =================================================================================================
+namespace {
+
+struct ResParams {
+    const void* res[MTLORA_MAX_TASKS + 1];
+    const void* y[MTLORA_MAX_TASKS + 1];   // forward: y_k ; backward: g_k (dtype of out)
+    void* out[MTLORA_MAX_TASKS + 1];       // forward: out_k ; backward: dy_k
+    void* dres;                            // backward, shared residual: sum_k g_k
+    const float* scale;                    // [n][B] or null (all ones)
+    int64_t M;
+    int C, n, B;
+    int64_t rows_per_sample;
+};
+
+// TR: dtype of res / out / g ; TY: dtype of y / dy
+template <typename TR, typename TY>
+__global__ __launch_bounds__(256) void k_residual_fwd(const ResParams p) {
+    const int64_t nvec = p.M * p.C / 8;
+    const int k = blockIdx.y;
+    const TR* res = reinterpret_cast<const TR*>(p.res[k]);
+    const TY* y = reinterpret_cast<const TY*>(p.y[k]);
+    TR* out = reinterpret_cast<TR*>(p.out[k]);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
+        const int64_t row = (i * 8) / p.C;
+        const float s = p.scale ? p.scale[(int64_t)k * p.B + row / p.rows_per_sample] : 1.f;
+        float fr[8], fy[8], o[8];
+        if constexpr (sizeof(TR) == 4) {
+            ld_vec<TR>(res + i * 8, fr);
+            float hi[8];
+            ld_vec<TR>(res + i * 8 + 4, hi);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) fr[4 + e] = hi[e];
+        } else {
+            ld_vec<TR>(res + i * 8, fr);
+        }
+        if constexpr (sizeof(TY) == 4) {
+            ld_vec<TY>(y + i * 8, fy);
+            float hi[8];
+            ld_vec<TY>(y + i * 8 + 4, hi);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) fy[4 + e] = hi[e];
+        } else {
+            ld_vec<TY>(y + i * 8, fy);
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = fr[e] + s * fy[e];
+        st_vec<TR, 8>(out + i * 8, o);
+    }
+}
+
+template <typename TR, typename TY>
+__global__ __launch_bounds__(256) void k_residual_bwd(const ResParams p) {
+    const int64_t nvec = p.M * p.C / 8;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
+        const int64_t row = (i * 8) / p.C;
+        const int64_t b = row / p.rows_per_sample;
+        float acc[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+        for (int k = 0; k < p.n; ++k) {
+            const TR* g = reinterpret_cast<const TR*>(p.y[k]);
+            if (!g) continue;
+            float fg[8];
+            if constexpr (sizeof(TR) == 4) {
+                ld_vec<TR>(g + i * 8, fg);
+                float hi[8];
+                ld_vec<TR>(g + i * 8 + 4, hi);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) fg[4 + e] = hi[e];
+            } else {
+                ld_vec<TR>(g + i * 8, fg);
+            }
+            const float s = p.scale ? p.scale[(int64_t)k * p.B + b] : 1.f;
+            float o[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                acc[e] += fg[e];
+                o[e] = s * fg[e];
+            }
+            if (p.out[k]) st_vec<TY, 8>(reinterpret_cast<TY*>(p.out[k]) + i * 8, o);
+        }
+        if (p.dres) st_vec<TR, 8>(reinterpret_cast<TR*>(p.dres) + i * 8, acc);
+    }
+}
+
+int res_check(int n, int64_t M, int64_t C, int64_t B, int rdt, int ydt) {
+    if ((rdt != MTLORA_F32 && rdt != MTLORA_BF16) || (ydt != MTLORA_F32 && ydt != MTLORA_BF16)) return MTLORA_ERR_DTYPE;
+    if (n < 1 || n > MTLORA_MAX_TASKS + 1 || M < 0 || C <= 0 || C % 8 || B <= 0 || M % B) return MTLORA_ERR_SHAPE;
+    return MTLORA_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mtlora_residual_droppath_fwd(int n, const void* const* res, const void* const* y, void* const* out,
+                                 const float* scale, int64_t M, int64_t C, int64_t B, int res_dtype, int y_dtype,
+                                 void* stream) {
+    int st = res_check(n, M, C, B, res_dtype, y_dtype);
+    if (st != MTLORA_OK) return st;
+    if (!res || !y || !out) return MTLORA_ERR_NULL;
+    ResParams p = {};
+    for (int k = 0; k < n; ++k) {
+        if (!res[k] || !y[k] || !out[k]) return MTLORA_ERR_NULL;
+        if (((uintptr_t)res[k] | (uintptr_t)y[k] | (uintptr_t)out[k]) & 15u) return MTLORA_ERR_ALIGN;
+        p.res[k] = res[k];
+        p.y[k] = y[k];
+        p.out[k] = out[k];
+    }
+    if (M == 0) return MTLORA_OK;
+    p.scale = scale;
+    p.M = M;
+    p.C = (int)C;
+    p.n = n;
+    p.B = (int)B;
+    p.rows_per_sample = M / B;
+    hipStream_t s = (hipStream_t)stream;
+    int64_t blocks = mtl_ceil_div(M * C / 8, 256);
+    if (blocks > 2048) blocks = 2048;
+    dim3 g((unsigned)blocks, (unsigned)n);
+    const int er = mtl_elem_size(res_dtype), ey = mtl_elem_size(y_dtype);
+    MtlProfScope prof(PK_RESIDUAL, (double)n * M * C * (2 * er + ey), s);
+    if (res_dtype == MTLORA_F32 && y_dtype == MTLORA_F32)
+        hipLaunchKernelGGL((k_residual_fwd<float, float>), g, dim3(256), 0, s, p);
+    else if (res_dtype == MTLORA_F32)
+        hipLaunchKernelGGL((k_residual_fwd<float, bf16>), g, dim3(256), 0, s, p);
+    else if (y_dtype == MTLORA_F32)
+        hipLaunchKernelGGL((k_residual_fwd<bf16, float>), g, dim3(256), 0, s, p);
+    else
+        hipLaunchKernelGGL((k_residual_fwd<bf16, bf16>), g, dim3(256), 0, s, p);
+    MTL_CHECK_LAUNCH();
+    return MTLORA_OK;
+}
+
+/* g[k]: gradient of out_k (res dtype) or NULL; dy[k]: written (y dtype) where non-NULL; dres: sum_k g_k or NULL */
+int mtlora_residual_droppath_bwd(int n, const void* const* g, void* const* dy, void* dres, const float* scale,
+                                 int64_t M, int64_t C, int64_t B, int res_dtype, int y_dtype, void* stream) {
+    int st = res_check(n, M, C, B, res_dtype, y_dtype);
+    if (st != MTLORA_OK) return st;
+    if (!g || !dy) return MTLORA_ERR_NULL;
+    ResParams p = {};
+    for (int k = 0; k < n; ++k) {
+        if (((uintptr_t)g[k] | (uintptr_t)dy[k]) & 15u) return MTLORA_ERR_ALIGN;
+        p.y[k] = g[k];
+        p.out[k] = g[k] ? dy[k] : nullptr;
+    }
+    if (M == 0) return MTLORA_OK;
+    p.dres = dres;
+    p.scale = scale;
+    p.M = M;
+    p.C = (int)C;
+    p.n = n;
+    p.B = (int)B;
+    p.rows_per_sample = M / B;
+    hipStream_t s = (hipStream_t)stream;
+    int64_t blocks = mtl_ceil_div(M * C / 8, 256);
+    if (blocks > 2048) blocks = 2048;
+    const int er = mtl_elem_size(res_dtype), ey = mtl_elem_size(y_dtype);
+    MtlProfScope prof(PK_RESIDUAL, (double)M * C * (n * (er + ey) + (dres ? er : 0)), s);
+    if (res_dtype == MTLORA_F32 && y_dtype == MTLORA_F32)
+        hipLaunchKernelGGL((k_residual_bwd<float, float>), dim3((unsigned)blocks), dim3(256), 0, s, p);
+    else if (res_dtype == MTLORA_F32)
+        hipLaunchKernelGGL((k_residual_bwd<float, bf16>), dim3((unsigned)blocks), dim3(256), 0, s, p);
+    else if (y_dtype == MTLORA_F32)
+        hipLaunchKernelGGL((k_residual_bwd<bf16, float>), dim3((unsigned)blocks), dim3(256), 0, s, p);
+    else
+        hipLaunchKernelGGL((k_residual_bwd<bf16, bf16>), dim3((unsigned)blocks), dim3(256), 0, s, p);
     MTL_CHECK_LAUNCH();
     return MTLORA_OK;
 }

@@ -155,6 +155,7 @@ extern "C" const char* mtlora_prof_kind_name(int kind) {
         case PK_LN_FWD: return "k_ln_fwd";
         case PK_LN_BWD: return "k_ln_bwd";
         case PK_BN: return "k_bn";
+        case PK_RESIDUAL: return "k_residual";
         default: return "";
     }
 }

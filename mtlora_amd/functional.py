@@ -392,3 +392,71 @@ class BatchNormReluFn(torch.autograd.Function):
                                     L.stream_ptr())
         L.check(st, "mtlora_bn_relu_bwd")
         return dx, dg, db, None, None, None, None, None
+
+
+# ----------------------------------------------------------------------------------------------
+# residual + DropPath over the 1+T tensors of a block half
+# ----------------------------------------------------------------------------------------------
+class ResidualDropPathFn(torch.autograd.Function):
+    """outs[k] = res[k] + scale[k, sample] * ys[k].
+    args: scale ((n, B) fp32 or None), shared (bool: every k adds the SAME residual tensor res[0]), n,
+          *res (1 tensor if shared else n), *ys (n)."""
+
+    @staticmethod
+    def forward(ctx, scale, shared: bool, n: int, *tensors):
+        nres = 1 if shared else n
+        res, ys = list(tensors[:nres]), list(tensors[nres:nres + n])
+        L.require_gpu(*res, *ys)
+        B = res[0].shape[0]
+        C = res[0].shape[-1]
+        M = res[0].numel() // C
+        res_c = [r.contiguous() for r in res]
+        ys_c = [y.contiguous() for y in ys]
+        outs = [torch.empty_like(res_c[0]) for _ in range(n)]
+        rlist = res_c * n if shared else res_c
+        st = L.lib().mtlora_residual_droppath_fwd(n, L.ptr_array9(rlist), L.ptr_array9(ys_c), L.ptr_array9(outs), L.ptr(scale),
+                                                  M, C, B, L.dtype_code(res_c[0]), L.dtype_code(ys_c[0]), L.stream_ptr())
+        L.check(st, "mtlora_residual_droppath_fwd")
+        ctx.cfg = (shared, n, M, C, B, res_c[0].dtype, ys_c[0].dtype, res_c[0].shape)
+        ctx.save_for_backward(scale)
+        ctx.set_materialize_grads(False)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        shared, n, M, C, B, rdt, ydt, shape = ctx.cfg
+        (scale,) = ctx.saved_tensors
+        if all(g is None for g in grads):
+            return (None,) * (3 + (1 if shared else n) + n)
+        dev = next(g for g in grads if g is not None).device
+        gs = [None if g is None else g.to(rdt).contiguous() for g in grads]
+        dys = [None if g is None else torch.empty(shape, dtype=ydt, device=dev) for g in gs]
+        dres = torch.empty(shape, dtype=rdt, device=dev) if shared else None
+        st = L.lib().mtlora_residual_droppath_bwd(n, L.ptr_array9(gs), L.ptr_array9(dys), L.ptr(dres), L.ptr(scale), M, C, B,
+                                                  L.dtype_code(gs[[g is not None for g in gs].index(True)]),
+                                                  L.BF16 if ydt == torch.bfloat16 else L.F32, L.stream_ptr())
+        L.check(st, "mtlora_residual_droppath_bwd")
+        dres_out = [dres] if shared else gs          # separate residuals: identity (the incoming gradient itself)
+        return (None, None, None, *dres_out, *dys)
+
+
+def residual_droppath(res, ys, drop_prob: float, training: bool):
+    """[res_k + DropPath(ys_k)] for k in range(len(ys)) with an independent per-sample mask per k (timm DropPath,
+    scale_by_keep).  ``res``: one tensor shared by all k, or a list of len(ys) tensors."""
+    shared = not isinstance(res, (list, tuple))
+    rl = [res] if shared else list(res)
+    n = len(ys)
+    ok = (rl[0].is_cuda and rl[0].shape[-1] % 8 == 0 and all(t.dtype in (torch.float32, torch.bfloat16) for t in rl + list(ys))
+          and len({t.dtype for t in rl}) == 1 and len({t.dtype for t in ys}) == 1 and n <= L.MAX_TASKS + 1
+          and all(t.shape == rl[0].shape for t in list(ys) + rl))
+    scale = None
+    if training and drop_prob > 0.0:
+        keep = 1.0 - drop_prob
+        scale = torch.empty(n, rl[0].shape[0], dtype=torch.float32, device=rl[0].device).bernoulli_(keep).div_(keep)
+    if not ok:
+        out = []
+        for k in range(n):
+            y = ys[k] if scale is None else ys[k] * scale[k].view(-1, *([1] * (ys[k].ndim - 1))).to(ys[k].dtype)
+            out.append((rl[0] if shared else rl[k]) + y)
+        return out
+    return list(ResidualDropPathFn.apply(scale, shared, n, *rl, *ys))

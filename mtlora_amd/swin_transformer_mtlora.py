@@ -263,20 +263,25 @@ class SwinTransformerBlock(nn.Module):
             a, a_t = self._attend_windows(xn, B, H, W, C)
         else:
             a, a_t = self.attn.forward_image(xn, H, W, self.shift_size, self.attn_mask, self._attn_mask_ids)
-        # residuals: an independent DropPath draw per call, like the reference (:389-392)
+        # residuals: an independent DropPath draw per tensor, like the reference (:389-392); all 1+T of them in one
+        # fused kernel (shared shortcut -> the backward also forms d_shortcut = sum of the 1+T gradients)
+        p_dp = self.drop_path.drop_prob if isinstance(self.drop_path, DropPath) else 0.0
         x_t = None
         if a_t is not None:
-            x_t = {t: shortcut + self.drop_path(a_t[t]) for t in self.tasks}
-        x = shortcut + self.drop_path(a)
+            r = Fn.residual_droppath(shortcut, [a] + [a_t[t] for t in self.tasks], p_dp, self.training)
+            x, x_t = r[0], {t: r[1 + i] for i, t in enumerate(self.tasks)}
+        else:
+            x = Fn.residual_droppath(shortcut, [a], p_dp, self.training)[0]
         # MLP half
         m, m_t = self.mlp(Fn.layer_norm(self.norm2, x),
                           None if x_t is None else {t: Fn.layer_norm(self.norm2, x_t[t]) for t in self.tasks})
-        out = x + self.drop_path(m)
         if m_t is None:
-            return out, None
+            return Fn.residual_droppath(x, [m], p_dp, self.training)[0], None
         if x_t is None:  # INTERMEDIATE_SPECIALIZATION-style: mlp specialises but attention did not (:401-403)
+            out = Fn.residual_droppath(x, [m], p_dp, self.training)[0]
             return out, {t: self.drop_path(m_t[t]) for t in self.tasks}
-        return out, {t: x_t[t] + self.drop_path(m_t[t]) for t in self.tasks}
+        r = Fn.residual_droppath([x] + [x_t[t] for t in self.tasks], [m] + [m_t[t] for t in self.tasks], p_dp, self.training)
+        return r[0], {t: r[1 + i] for i, t in enumerate(self.tasks)}
 
     def extra_repr(self) -> str:
         return (f"dim={self.dim}, input_resolution={self.input_resolution}, num_heads={self.num_heads}, "

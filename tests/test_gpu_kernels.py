@@ -503,3 +503,32 @@ def test_batchnorm_relu_vs_torch(R, C, relu, dtype):
     assert_close(x.grad, x64.grad, dtype, "dx", mult=3)
     assert_close(w.grad, w64.grad, dtype, "dgamma", mult=3)
     assert_close(b.grad, b64.grad, dtype, "dbeta", mult=3)
+
+
+@pytest.mark.parametrize("rdt,ydt", [(torch.float32, torch.bfloat16), (torch.bfloat16, torch.bfloat16), (torch.float32, torch.float32)])
+@pytest.mark.parametrize("shared", [True, False])
+def test_residual_droppath(shared, rdt, ydt):
+    from mtlora_amd import functional as Fn
+    torch.manual_seed(5)
+    B, Ltok, C, n = 6, 49, 96, 3
+    res = [torch.randn(B, Ltok, C, device=dev()).to(rdt).requires_grad_(True) for _ in range(1 if shared else n)]
+    ys = [torch.randn(B, Ltok, C, device=dev()).to(ydt).requires_grad_(True) for _ in range(n)]
+    scale = (torch.rand(n, B, device=dev()) < 0.7).float() / 0.7
+    outs = Fn.ResidualDropPathFn.apply(scale, shared, n, *res, *ys)
+    gs = [torch.randn_like(o) for o in outs]
+    torch.autograd.backward([outs[0], outs[2]], [gs[0], gs[2]])     # output 1 gets no gradient
+    r64 = [r.detach().double().requires_grad_(True) for r in res]
+    y64 = [y.detach().double().requires_grad_(True) for y in ys]
+    ref = [(r64[0] if shared else r64[k]) + scale[k].double().view(B, 1, 1) * y64[k] for k in range(n)]
+    torch.autograd.backward([ref[0], ref[2]], [gs[0].double(), gs[2].double()])
+    for k in range(n):
+        assert outs[k].dtype == rdt
+        assert_close(outs[k], ref[k], rdt, f"out{k}")
+    for a, b in zip(res, r64):
+        if b.grad is None:
+            assert a.grad is None
+        else:
+            assert_close(a.grad, b.grad, rdt, "dres", mult=2)
+    for k in (0, 2):
+        assert_close(ys[k].grad, y64[k].grad, ydt, f"dy{k}", mult=2)
+    assert ys[1].grad is None

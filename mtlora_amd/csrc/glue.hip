@@ -12,7 +12,7 @@
 
 namespace {
 
-constexpr int LN_MAXV = 8;  // 16-byte vectors per lane per row (C <= 64 lanes * 8 vec * VEC)
+constexpr int LN_MAXV = 8;  // most 16-byte vectors per lane per row (C <= 64 lanes * 8 vec * VEC); kernels are specialised on 3 / 8
 
 template <typename T>
 __device__ __forceinline__ void ld_vec(const T* p, float (&f)[8]);
@@ -70,7 +70,7 @@ struct LnParams {
     float eps;
 };
 
-template <typename TI, typename TO, int LPR>
+template <typename TI, typename TO, int LPR, int MAXV>
 __global__ __launch_bounds__(256) void k_ln_fwd(const LnParams p) {
     constexpr int VE = ET<TI>::VEC;
     constexpr int RPW = 64 / LPR;  // rows per wave
@@ -79,9 +79,9 @@ __global__ __launch_bounds__(256) void k_ln_fwd(const LnParams p) {
     const int nvec = p.C / VE;
     const TI* x = reinterpret_cast<const TI*>(p.x);
     TO* y = reinterpret_cast<TO*>(p.y);
-    float g[LN_MAXV][VE], b[LN_MAXV][VE];
+    float g[MAXV][VE], b[MAXV][VE];
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
+    for (int i = 0; i < MAXV; ++i) {
         const int v = lr + i * LPR;
 #pragma unroll
         for (int e = 0; e < VE; ++e) {
@@ -93,10 +93,10 @@ __global__ __launch_bounds__(256) void k_ln_fwd(const LnParams p) {
     for (int64_t r0 = (int64_t)blockIdx.x * rows_per_blk; r0 < p.M; r0 += (int64_t)gridDim.x * rows_per_blk) {
         const int64_t row = r0 + wave * RPW + sub;
         const bool rv = row < p.M;
-        float f[LN_MAXV][8];
+        float f[MAXV][8];
         float s = 0.f;
 #pragma unroll
-        for (int i = 0; i < LN_MAXV; ++i) {
+        for (int i = 0; i < MAXV; ++i) {
             const int v = lr + i * LPR;
             if (rv && v < nvec) {
                 ld_vec<TI>(x + row * p.C + v * VE, f[i]);
@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256) void k_ln_fwd(const LnParams p) {
         const float mean = group_sum<LPR>(s) / p.C;
         float q = 0.f;
 #pragma unroll
-        for (int i = 0; i < LN_MAXV; ++i) {
+        for (int i = 0; i < MAXV; ++i) {
             const int v = lr + i * LPR;
             if (v < nvec) {
 #pragma unroll
@@ -127,7 +127,7 @@ __global__ __launch_bounds__(256) void k_ln_fwd(const LnParams p) {
                 p.rstd[row] = rstd;
             }
 #pragma unroll
-            for (int i = 0; i < LN_MAXV; ++i) {
+            for (int i = 0; i < MAXV; ++i) {
                 const int v = lr + i * LPR;
                 if (v < nvec) {
                     float o[8];
@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256) void k_ln_fwd(const LnParams p) {
 }
 
 // TX: dtype of x and dx; TG: dtype of dy
-template <typename TX, typename TG, int LPR>
+template <typename TX, typename TG, int LPR, int MAXV>
 __global__ __launch_bounds__(256) void k_ln_bwd(const LnParams p) {
     constexpr int VE = ET<TX>::VEC;  // elements per lane-vector (x drives the vector width; dy read with the same count)
     constexpr int RPW = 64 / LPR;
@@ -152,9 +152,9 @@ __global__ __launch_bounds__(256) void k_ln_bwd(const LnParams p) {
     const TX* x = reinterpret_cast<const TX*>(p.x);
     const TG* dy = reinterpret_cast<const TG*>(p.dy);
     TX* dx = reinterpret_cast<TX*>(p.dx);
-    float g[LN_MAXV][VE], ag[LN_MAXV][VE], ab[LN_MAXV][VE];
+    float g[MAXV][VE], ag[MAXV][VE], ab[MAXV][VE];
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
+    for (int i = 0; i < MAXV; ++i) {
         const int v = lr + i * LPR;
 #pragma unroll
         for (int e = 0; e < VE; ++e) {
@@ -168,10 +168,10 @@ __global__ __launch_bounds__(256) void k_ln_bwd(const LnParams p) {
         const int64_t row = r0 + wave * RPW + sub;
         const bool rv = row < p.M;
         const float mean = rv ? p.mean[row] : 0.f, rstd = rv ? p.rstd[row] : 0.f;
-        float xh[LN_MAXV][VE], gy[LN_MAXV][VE];
+        float xh[MAXV][VE], gy[MAXV][VE];
         float c1 = 0.f, c2 = 0.f;
 #pragma unroll
-        for (int i = 0; i < LN_MAXV; ++i) {
+        for (int i = 0; i < MAXV; ++i) {
             const int v = lr + i * LPR;
             if (rv && v < nvec) {
                 float fx[8], fg[8];
@@ -214,7 +214,7 @@ __global__ __launch_bounds__(256) void k_ln_bwd(const LnParams p) {
         c2 = group_sum<LPR>(c2) / p.C;
         if (rv) {
 #pragma unroll
-            for (int i = 0; i < LN_MAXV; ++i) {
+            for (int i = 0; i < MAXV; ++i) {
                 const int v = lr + i * LPR;
                 if (v < nvec) {
                     float o[8];
@@ -229,7 +229,7 @@ __global__ __launch_bounds__(256) void k_ln_bwd(const LnParams p) {
     // group writes its own LDS slab and the slabs are summed in a fixed order (deterministic, no float atomics)
     float* mine = sm + (size_t)(wave * RPW + sub) * 2 * p.C;
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
+    for (int i = 0; i < MAXV; ++i) {
         const int v = lr + i * LPR;
         if (v < nvec) {
 #pragma unroll
@@ -282,10 +282,10 @@ int pick_lpr(int nvec) {
     return lpr;
 }
 
-int ln_grid(int64_t M, int lpr) {
+int ln_grid(int64_t M, int lpr, int cap = 256 * 2) {
     const int64_t rows_per_blk = 4 * (64 / lpr);
     int64_t g = mtl_ceil_div(M, rows_per_blk);
-    if (g > 256 * 2) g = 256 * 2;  // also the number of dgamma/dbeta partials the second stage sums
+    if (g > cap) g = cap;  // also the number of dgamma/dbeta partials the second stage sums
     return (int)(g < 1 ? 1 : g);
 }
 
@@ -307,12 +307,17 @@ int64_t mtlora_layernorm_bwd_scratch_bytes(int64_t M, int64_t C, int x_dtype) {
     return (int64_t)ln_grid(M, lpr) * 2 * C * 4 + 256;
 }
 
-#define LN_DISPATCH_LPR(KERNEL, ...)                                                          \
-    switch (lpr) {                                                                            \
-        case 8: hipLaunchKernelGGL((KERNEL<__VA_ARGS__, 8>), dim3(grid), dim3(256), lds, s, p); break;   \
-        case 16: hipLaunchKernelGGL((KERNEL<__VA_ARGS__, 16>), dim3(grid), dim3(256), lds, s, p); break; \
-        case 32: hipLaunchKernelGGL((KERNEL<__VA_ARGS__, 32>), dim3(grid), dim3(256), lds, s, p); break; \
-        default: hipLaunchKernelGGL((KERNEL<__VA_ARGS__, 64>), dim3(grid), dim3(256), lds, s, p); break; \
+#define LN_LAUNCH(KERNEL, L_, ...)                                                                        \
+    if (vpl <= 3)                                                                                           \
+        hipLaunchKernelGGL((KERNEL<__VA_ARGS__, L_, 3>), dim3(grid), dim3(256), lds, s, p);                  \
+    else                                                                                                    \
+        hipLaunchKernelGGL((KERNEL<__VA_ARGS__, L_, LN_MAXV>), dim3(grid), dim3(256), lds, s, p);
+#define LN_DISPATCH_LPR(KERNEL, ...)                       \
+    switch (lpr) {                                         \
+        case 8: LN_LAUNCH(KERNEL, 8, __VA_ARGS__) break;   \
+        case 16: LN_LAUNCH(KERNEL, 16, __VA_ARGS__) break; \
+        case 32: LN_LAUNCH(KERNEL, 32, __VA_ARGS__) break; \
+        default: LN_LAUNCH(KERNEL, 64, __VA_ARGS__) break; \
     }
 
 int mtlora_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
@@ -332,8 +337,10 @@ int mtlora_layernorm_fwd(const void* x, const float* gamma, const float* beta, v
     p.M = M;
     p.C = (int)C;
     p.eps = eps;
-    const int lpr = pick_lpr((int)(C / (x_dtype == MTLORA_F32 ? 4 : 8)));
-    const int grid = ln_grid(M, lpr);
+    const int nvec_h = (int)(C / (x_dtype == MTLORA_F32 ? 4 : 8));
+    const int lpr = pick_lpr(nvec_h);
+    const int vpl = (nvec_h + lpr - 1) / lpr;
+    const int grid = ln_grid(M, lpr, 256 * 8);
     const size_t lds = 0;
     hipStream_t s = (hipStream_t)stream;
     const int es_x = mtl_elem_size(x_dtype), es_y = mtl_elem_size(y_dtype);
@@ -375,7 +382,9 @@ int mtlora_layernorm_bwd(const void* dy, const void* x, const float* gamma, cons
     p.part = reinterpret_cast<float*>(scratch);
     p.M = M;
     p.C = (int)C;
-    const int lpr = pick_lpr((int)(C / (x_dtype == MTLORA_F32 ? 4 : 8)));
+    const int nvec_h = (int)(C / (x_dtype == MTLORA_F32 ? 4 : 8));
+    const int lpr = pick_lpr(nvec_h);
+    const int vpl = (nvec_h + lpr - 1) / lpr;
     const int grid = ln_grid(M, lpr);
     const size_t lds = (size_t)4 * (64 / lpr) * 2 * C * 4;
     const int es_x = mtl_elem_size(x_dtype), es_g = mtl_elem_size(dy_dtype);

@@ -20,15 +20,20 @@
 //
 // Forward  = k_pack, k_nt (P = alpha D(X) A^T, per source), k_nt (all 1+T outputs, base shared).
 // Backward = k_nt (Q = alpha dY_o B_o per output), k_nt (dX [+ dX_t]), k_tn (+ k_reduce) for dA/dB.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
 
 constexpr int TILE = 128;    // rows per CTA tile, both operands
-constexpr int SUBT = 3;             // 64-byte MFMA sub-tiles per staged k-tile: a tile covers K = 96 bf16 in ONE round trip
+constexpr int SUBT = 3;             // 64-byte MFMA sub-tiles per staged k-tile: K = 96 bf16 is ONE round trip (k_nt 17.5 vs 18.8 ms/step with 1)
 constexpr int ROWB = 64 * SUBT;     // payload bytes per row per k-tile (96 bf16 / 48 f32)
 constexpr int LDSB = ROWB + 16;     // padded LDS row stride (conflict-free ds_read_b128, 16-B aligned)
-constexpr int VPT = SUBT;           // 16-byte vectors per thread per row-half per operand (4 * SUBT vectors / 4 lanes)
+constexpr int VPT = SUBT;
+constexpr int EPI_ROW = 64 * 2 + 8;                      // row stride of a wave's bf16 output image (epilogue)
+constexpr int EPI_BYTES = 4 * 64 * EPI_ROW;               // four waves
+constexpr int STAGE_BYTES = 2 * TILE * LDSB > EPI_BYTES ? 2 * TILE * LDSB : EPI_BYTES;  // staging / epilogue region           // 16-byte vectors per thread per row-half per operand (4 * SUBT vectors / 4 lanes)
 constexpr int MAXO = MTLORA_MAX_TASKS + 1;
 #ifndef MTL_NT_LEAN_WAVES
 #define MTL_NT_LEAN_WAVES 2
@@ -156,6 +161,16 @@ struct NtParams {
     int nz;
     const void* zact[MAXO];
     int zrow0[MAXO], zrows[MAXO], zmask[MAXO];
+    // fused low-rank projection (forward): P = alpha * D(src) A_cat^T is formed by the workgroup itself into an
+    // LDS image [128 m][pR] before the base GEMM; the rank-segment parts then read their activation operand from
+    // that image instead of a global P.  np sources (shared x, then x_t per task), each owning rank rows [lo,hi).
+    int np;
+    const void* pact[MAXO];
+    int pseg_lo[MAXO], pseg_hi[MAXO], pmask[MAXO];
+    const void* pA;        // A_cat (pR x pK)
+    int pK, pR;
+    const float* palpha;   // (pR)
+    void* pout;            // global P (M x pR), written by the n-tile-0 workgroups for the backward
     DropoutCfg drop;
 };
 
@@ -172,7 +187,8 @@ struct TileRegs {
 template <typename T, bool MS>
 __device__ __forceinline__ void nt_load(TileRegs<T>& rg, int tid, const T* wgt, int64_t ld_w, int w_row0, int w_rows,
                                         const void* act0, NtPtr P, int n_act, int64_t ld_a, int64_t a_row0,
-                                        int64_t a_rows, int k0, int k_hi, bool mask, const DropoutCfg& dc) {
+                                        int64_t a_rows, int k0, int k_hi, bool mask, const DropoutCfg& dc,
+                                        int w_lo = 0) {
     constexpr int VEC = ET<T>::VEC;
 #pragma unroll
     for (int j = 0; j < VPT; ++j) {
@@ -184,11 +200,11 @@ __device__ __forceinline__ void nt_load(TileRegs<T>& rg, int tid, const T* wgt, 
             const int r = (tid >> 2) + i * 64;
             // weights
             const int wr = w_row0 + r;
-            rg.w[i][j] = (kin && wr < w_rows) ? *reinterpret_cast<const u32x4*>(wgt + (int64_t)wr * ld_w + k)
+            rg.w[i][j] = (kin && wr < w_rows && wr >= w_lo) ? *reinterpret_cast<const u32x4*>(wgt + (int64_t)wr * ld_w + k)
                                               : u32x4{0u, 0u, 0u, 0u};
             // activations
             const int64_t ar = a_row0 + r;
-            if (kin && ar < a_rows) {
+            if (kin && ar < a_rows && act0) {
                 u32x4 x = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(act0) + ar * ld_a + k);
                 if (MS && n_act > 1) {
                     if constexpr (sizeof(T) == 4) {
@@ -226,7 +242,8 @@ __device__ __forceinline__ void nt_load(TileRegs<T>& rg, int tid, const T* wgt, 
 }
 
 template <typename T>
-__device__ __forceinline__ void nt_store_lds(const TileRegs<T>& rg, int tid, unsigned char* sW, unsigned char* sA) {
+__device__ __forceinline__ void nt_store_lds(const TileRegs<T>& rg, int tid, unsigned char* sW, unsigned char* sA,
+                                             bool with_act = true) {
 #pragma unroll
     for (int j = 0; j < VPT; ++j) {
         const int v = (tid & 3) + 4 * j;
@@ -234,7 +251,7 @@ __device__ __forceinline__ void nt_store_lds(const TileRegs<T>& rg, int tid, uns
         for (int i = 0; i < 2; ++i) {
             const int r = (tid >> 2) + i * 64;
             *reinterpret_cast<u32x4*>(sW + r * LDSB + v * 16) = rg.w[i][j];
-            *reinterpret_cast<u32x4*>(sA + r * LDSB + v * 16) = rg.a[i][j];
+            if (with_act) *reinterpret_cast<u32x4*>(sA + r * LDSB + v * 16) = rg.a[i][j];
         }
     }
 }
@@ -243,7 +260,7 @@ __device__ __forceinline__ void nt_store_lds(const TileRegs<T>& rg, int tid, uns
 // and skipped -- wave-uniform)
 template <typename T>
 __device__ __forceinline__ void nt_compute(f32x16 (&acc)[2][2], const unsigned char* sW, const unsigned char* sA,
-                                           int lane, int wn, int wm, int k_left) {
+                                           int lane, int wn, int wm, int k_left, int a_stride = LDSB) {
     constexpr int KS = 64 / (int)sizeof(T);  // elements per 64-byte sub-tile
     const int h = lane >> 5, rl = lane & 31;
 #pragma unroll
@@ -253,7 +270,7 @@ __device__ __forceinline__ void nt_compute(f32x16 (&acc)[2][2], const unsigned c
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             const unsigned char* pw = sW + (wn * 64 + s * 32 + rl) * LDSB + t * 64;
-            const unsigned char* pa = sA + (wm * 64 + s * 32 + rl) * LDSB + t * 64;
+            const unsigned char* pa = sA + (wm * 64 + s * 32 + rl) * a_stride + t * 64;
             fw[s].v[0] = *reinterpret_cast<const u32x4*>(pw + h * 16);
             fw[s].v[1] = *reinterpret_cast<const u32x4*>(pw + (2 + h) * 16);
             fa[s].v[0] = *reinterpret_cast<const u32x4*>(pa + h * 16);
@@ -297,8 +314,16 @@ __device__ __forceinline__ NtOut nt_out(NtPtr P, int o) {
 
 // k range of part q.  MULTI: q = 0 base, q = 1 + o rank segment of output o.
 // lean: q = 2 o rank segment of output o, q = 2 o + 1 base (if that output uses it).
-template <bool MULTI>
+template <bool MULTI, bool FUSE>
 __device__ __forceinline__ void nt_part(NtPtr P, int q, int& lr, int& k_lo, int& k_hi) {
+    const int np = FUSE ? P->np : 0;
+    if (q < np) {  // fused low-rank projection of source q
+        lr = 2;
+        k_lo = 0;
+        k_hi = P->pK;
+        return;
+    }
+    q -= np;
     if (MULTI) {
         if (q == 0) {
             lr = 0;
@@ -324,7 +349,7 @@ __device__ __forceinline__ void nt_part(NtPtr P, int q, int& lr, int& k_lo, int&
     }
 }
 
-template <bool MULTI>
+template <bool MULTI, bool FUSE>
 __device__ __forceinline__ NtCursor nt_seek(NtPtr P, int q, int nseq) {
     NtCursor c;
     c.valid = 0;
@@ -332,7 +357,7 @@ __device__ __forceinline__ NtCursor nt_seek(NtPtr P, int q, int nseq) {
     c.k0 = c.k_hi = c.lr = 0;
     for (; q < nseq; ++q) {
         int lr, lo, hi;
-        nt_part<MULTI>(P, q, lr, lo, hi);
+        nt_part<MULTI, FUSE>(P, q, lr, lo, hi);
         if (hi > lo) {
             c.q = q;
             c.k0 = lo;
@@ -345,14 +370,15 @@ __device__ __forceinline__ NtCursor nt_seek(NtPtr P, int q, int nseq) {
     return c;
 }
 
-template <typename T, bool MULTI, bool MS>
-__global__ __launch_bounds__(256, (MULTI || MS) ? 2 : MTL_NT_LEAN_WAVES) void k_nt(const NtParams Pv) {
+template <typename T, bool MULTI, bool MS, bool FUSE>
+__global__ __launch_bounds__(256, 2) void k_nt(const NtParams Pv) {
     (void)Pv;
     NtPtr P = (NtPtr)__builtin_amdgcn_kernarg_segment_ptr();
     constexpr int KE = ROWB / (int)sizeof(T);
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * TILE * LDSB];
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // staging (2 x 128 x LDSB) [+ P image]
     unsigned char* sW = smem;
     unsigned char* sA = smem + TILE * LDSB;
+    unsigned char* sP = smem + STAGE_BYTES;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wn = wave >> 1, wm = wave & 1;
 
@@ -391,37 +417,47 @@ __global__ __launch_bounds__(256, (MULTI || MS) ? 2 : MTL_NT_LEAN_WAVES) void k_
     drop.seed_lo = P->drop.seed_lo;
     drop.seed_hi = P->drop.seed_hi;
     drop.thr16 = P->drop.thr16;
-    const int nseq = MULTI ? 1 + P->n_out : 2 * P->n_out;
+    const int np = FUSE ? P->np : 0;
+    const int PRS = P->pR * (int)sizeof(T) + 80;  // row stride of the LDS P image: pR columns + 64 zeroed bytes (a
+                                                  // 64-byte sub-tile may start 32 B before the end) + 16 B of skew
+    const int nseq = np + (MULTI ? 1 + P->n_out : 2 * P->n_out);
 
     // ---- loader side of the stream (register prefetch, one wide tile ahead)
     TileRegs<T> rg;
-    NtCursor ld = nt_seek<MULTI>(P, 0, nseq);
+    NtCursor ld = nt_seek<MULTI, FUSE>(P, 0, nseq);
     auto issue = [&](const NtCursor& c) __attribute__((always_inline)) {
-        if (c.lr)
-            nt_load<T, false>(rg, tid, reinterpret_cast<const T*>(P->Rm), P->ldR, n0, n_rows, P->L, P, 1, P->ldL, m0, P->M, c.k0,
-                              c.k_hi, false, drop);
+        if (FUSE && c.lr == 2)  // fused projection: weights = A_cat rows of source c.q, activation = that source
+            nt_load<T, false>(rg, tid, reinterpret_cast<const T*>(P->pA), P->pK, 0, P->pseg_hi[c.q], P->pact[c.q], P, 1,
+                              P->pK, m0, P->M, c.k0, c.k_hi, P->pmask[c.q] != 0 && drop.thr16 != 0, drop, P->pseg_lo[c.q]);
+        else if (c.lr)  // rank segment: weights = Rm; activation = L, or the LDS P image when the projection is fused
+            nt_load<T, false>(rg, tid, reinterpret_cast<const T*>(P->Rm), P->ldR, n0, n_rows, np > 0 ? nullptr : P->L, P, 1,
+                              P->ldL, m0, P->M, c.k0, c.k_hi, false, drop);
         else
             nt_load<T, MS>(rg, tid, wgt, P->ld_wgt, n0, n_rows, act0, P, P->n_act, P->ld_act, m0, P->M, c.k0, c.k_hi, act_mask,
                            drop);
     };
     if (ld.valid) issue(ld);
     // consume one tile: registers -> LDS, prefetch the next tile of the stream, multiply
-    auto step = [&](f32x16(&acc)[2][2], int k_left) {
-        nt_store_lds<T>(rg, tid, sW, sA);
+    auto step = [&](f32x16(&acc)[2][2], int k_left, int from_p, int k0) __attribute__((always_inline)) {
+        nt_store_lds<T>(rg, tid, sW, sA, !from_p);
         __syncthreads();
         ld.k0 += KE;
-        if (ld.k0 >= ld.k_hi) ld = nt_seek<MULTI>(P, ld.q + 1, nseq);
+        if (ld.k0 >= ld.k_hi) ld = nt_seek<MULTI, FUSE>(P, ld.q + 1, nseq);
         if (ld.valid) issue(ld);
-        nt_compute<T>(acc, sW, sA, lane, wn, wm, k_left);
+        if (from_p)
+            nt_compute<T>(acc, sW, sP + k0 * (int)sizeof(T), lane, wn, wm, k_left, PRS);
+        else
+            nt_compute<T>(acc, sW, sA, lane, wn, wm, k_left);
         __syncthreads();
     };
-    auto run_part = [&](int q, f32x16(&acc)[2][2]) {
+    auto run_part = [&](int q, f32x16(&acc)[2][2]) __attribute__((always_inline)) {
         int lr, lo, hi;
-        nt_part<MULTI>(P, q, lr, lo, hi);
-        for (int k0 = lo; k0 < hi; k0 += KE) step(acc, hi - k0);
+        nt_part<MULTI, FUSE>(P, q, lr, lo, hi);
+        const int from_p = (FUSE && lr == 1 && np > 0) ? 1 : 0;
+        for (int k0 = lo; k0 < hi; k0 += KE) step(acc, hi - k0, from_p, k0);
         return hi > lo;
     };
-    auto zero = [](f32x16(&a)[2][2]) {
+    auto zero = [](f32x16(&a)[2][2]) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -430,7 +466,7 @@ __global__ __launch_bounds__(256, (MULTI || MS) ? 2 : MTL_NT_LEAN_WAVES) void k_
                 for (int r = 0; r < 16; ++r) a[i][j][r] = 0.f;
     };
     // acc = acc * alpha[n] + bias[n]
-    auto affine = [&](f32x16(&a)[2][2]) {
+    auto affine = [&](f32x16(&a)[2][2]) __attribute__((always_inline)) {
         if (!(P->alpha || P->bias)) return;
 #pragma unroll
         for (int sn = 0; sn < 2; ++sn)
@@ -449,7 +485,7 @@ __global__ __launch_bounds__(256, (MULTI || MS) ? 2 : MTL_NT_LEAN_WAVES) void k_
             }
     };
     // acc *= keep(m, n)
-    auto apply_mask = [&](f32x16(&a)[2][2]) {
+    auto apply_mask = [&](f32x16(&a)[2][2]) __attribute__((always_inline)) {
 #pragma unroll
         for (int sm = 0; sm < 2; ++sm) {
             const int64_t m = m0 + wm * 64 + sm * 32 + (lane & 31);
@@ -468,36 +504,98 @@ __global__ __launch_bounds__(256, (MULTI || MS) ? 2 : MTL_NT_LEAN_WAVES) void k_
                 }
         }
     };
-    auto store = [&](const f32x16(&a)[2][2], void* ptr) {
+    auto store = [&](const f32x16(&a)[2][2], void* ptr) __attribute__((always_inline)) {
         T* outp = reinterpret_cast<T*>(ptr);
         if (!outp) return;
+        if constexpr (sizeof(T) == 2) {
+            // bf16: transpose the wave's 64(n) x 64(m) accumulator tile through LDS so that every store instruction
+            // writes whole 128-byte row segments (8 lanes x 16 B) instead of 16-byte pieces of 32 different rows.
+            // The staging buffers are idle here (the trailing barrier of the last tile has passed).
+            constexpr int ORS = EPI_ROW;  // row stride of the per-wave image (bytes): 2-way conflicts at most
+            unsigned char* img = smem + wave * (64 * ORS);
+#pragma unroll
+            for (int sm = 0; sm < 2; ++sm)
+#pragma unroll
+                for (int sn = 0; sn < 2; ++sn)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int ml = sm * 32 + (lane & 31), nl = sn * 32 + 8 * q + 4 * (lane >> 5);
+                        u32x2 pk = {mtl_pack_bf16(a[sn][sm][q * 4], a[sn][sm][q * 4 + 1]),
+                                    mtl_pack_bf16(a[sn][sm][q * 4 + 2], a[sn][sm][q * 4 + 3])};
+                        *reinterpret_cast<u32x2*>(img + ml * ORS + nl * 2) = pk;
+                    }
+            __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the image is private to this wave, no barrier needed
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int ml = it * 8 + (lane >> 3), c16 = lane & 7;
+                const int64_t m = m0 + wm * 64 + ml;
+                const int n = n0 + wn * 64 + c16 * 8;
+                const u32x4 v = *reinterpret_cast<const u32x4*>(img + ml * ORS + c16 * 16);
+                if (m < P->M && n < n_rows) *reinterpret_cast<u32x4*>(outp + m * P->ld_out + row_off + n) = v;
+            }
+            __builtin_amdgcn_wave_barrier();
+        } else {
+#pragma unroll
+            for (int sm = 0; sm < 2; ++sm) {
+                const int64_t m = m0 + wm * 64 + sm * 32 + (lane & 31);
+#pragma unroll
+                for (int sn = 0; sn < 2; ++sn)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int n = n0 + wn * 64 + sn * 32 + 8 * q + 4 * (lane >> 5);
+                        if (m < P->M && n < n_rows) {
+                            T* dst = outp + m * P->ld_out + row_off + n;
+                            *reinterpret_cast<f32x4*>(dst) =
+                                f32x4{a[sn][sm][q * 4], a[sn][sm][q * 4 + 1], a[sn][sm][q * 4 + 2], a[sn][sm][q * 4 + 3]};
+                        }
+                    }
+            }
+        }
+    };
+
+    // park the projected tile: acc holds P^T [rank r][m]; scale by alpha, write the LDS image [m][r] (and the global
+    // copy for the backward from the n-tile-0 workgroups)
+    auto park_p = [&](f32x16(&a)[2][2]) __attribute__((always_inline)) {
+        T* pg = reinterpret_cast<T*>(P->pout);
+        for (int i = tid; i < TILE * 4; i += 256)  // zero the 64-byte tail of every row (0 * garbage could be NaN)
+            *reinterpret_cast<u32x4*>(sP + (i >> 2) * PRS + P->pR * (int)sizeof(T) + (i & 3) * 16) = u32x4{0u, 0u, 0u, 0u};
 #pragma unroll
         for (int sm = 0; sm < 2; ++sm) {
-            const int64_t m = m0 + wm * 64 + sm * 32 + (lane & 31);
+            const int ml = wm * 64 + sm * 32 + (lane & 31);
+            const int64_t m = m0 + ml;
 #pragma unroll
             for (int sn = 0; sn < 2; ++sn)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const int n = n0 + wn * 64 + sn * 32 + 8 * q + 4 * (lane >> 5);
-                    if (m < P->M && n < n_rows) {
-                        T* dst = outp + m * P->ld_out + row_off + n;
-                        const float v0 = a[sn][sm][q * 4], v1 = a[sn][sm][q * 4 + 1], v2 = a[sn][sm][q * 4 + 2],
-                                    v3 = a[sn][sm][q * 4 + 3];
+                    const int r = wn * 64 + sn * 32 + 8 * q + 4 * (lane >> 5);
+                    if (r < P->pR) {
+                        const f32x4 al = *reinterpret_cast<const f32x4*>(P->palpha + r);
+                        const float v0 = a[sn][sm][q * 4] * al[0], v1 = a[sn][sm][q * 4 + 1] * al[1],
+                                    v2 = a[sn][sm][q * 4 + 2] * al[2], v3 = a[sn][sm][q * 4 + 3] * al[3];
                         if constexpr (sizeof(T) == 4) {
-                            *reinterpret_cast<f32x4*>(dst) = f32x4{v0, v1, v2, v3};
+                            *reinterpret_cast<f32x4*>(sP + ml * PRS + r * 4) = f32x4{v0, v1, v2, v3};
+                            if (pg && bn == 0 && m < P->M) *reinterpret_cast<f32x4*>(pg + m * P->pR + r) = f32x4{v0, v1, v2, v3};
                         } else {
-                            bf16x4 pk = {(bf16)v0, (bf16)v1, (bf16)v2, (bf16)v3};
-                            *reinterpret_cast<bf16x4*>(dst) = pk;
+                            const u32x2 pk = {mtl_pack_bf16(v0, v1), mtl_pack_bf16(v2, v3)};
+                            *reinterpret_cast<u32x2*>(sP + ml * PRS + r * 2) = pk;
+                            if (pg && bn == 0 && m < P->M) *reinterpret_cast<u32x2*>(pg + m * P->pR + r) = pk;
                         }
                     }
                 }
         }
+        __syncthreads();
     };
 
     if constexpr (MULTI) {
         f32x16 base[2][2], acc[2][2];
+        if constexpr (FUSE) {
+            zero(acc);
+            for (int q = 0; q < np; ++q) run_part(q, acc);
+            if (np > 0) park_p(acc);
+        }
         zero(base);
-        run_part(0, base);
+        run_part(np, base);
         affine(base);
         for (int o = 0; o < P->n_out; ++o) {
             const NtOut O = nt_out(P, o);
@@ -505,7 +603,7 @@ __global__ __launch_bounds__(256, (MULTI || MS) ? 2 : MTL_NT_LEAN_WAVES) void k_
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[i][j] = base[i][j];
-            run_part(1 + o, acc);
+            run_part(np + 1 + o, acc);
             if (O.fold) {
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
@@ -513,17 +611,24 @@ __global__ __launch_bounds__(256, (MULTI || MS) ? 2 : MTL_NT_LEAN_WAVES) void k_
                     for (int j = 0; j < 2; ++j) base[i][j] = acc[i][j];
             }
             store(acc, O.ptr);
+            __syncthreads();  // the output image lives in the staging buffers
         }
     } else {
         f32x16 acc[2][2];
+        if constexpr (FUSE) {
+            zero(acc);
+            for (int q = 0; q < np; ++q) run_part(q, acc);
+            if (np > 0) park_p(acc);
+        }
         for (int o = 0; o < P->n_out; ++o) {
             const NtOut O = nt_out(P, o);
             zero(acc);
-            const bool had_lr = run_part(2 * o, acc);
+            const bool had_lr = run_part(np + 2 * o, acc);
             if (had_lr && O.mask_lr && drop.enabled()) apply_mask(acc);
-            run_part(2 * o + 1, acc);
+            run_part(np + 2 * o + 1, acc);
             if (O.use_base) affine(acc);
             store(acc, O.ptr);
+            __syncthreads();  // the output image lives in the staging buffers
         }
     }
 }
@@ -764,12 +869,42 @@ static void launch_nt(const NtParams& P, hipStream_t s, int kind, double alg_byt
     dim3 g((unsigned)(m_tiles * n_tiles), 1, (unsigned)(P.nz > 0 ? P.nz : 1));
     int base_users = 0;
     for (int o = 0; o < P.n_out; ++o) base_users += P.out[o].use_base ? 1 : 0;
-    if (base_users > 1)
-        hipLaunchKernelGGL((k_nt<T, true, false>), g, dim3(256), 0, s, P);
-    else if (P.n_act > 1)
-        hipLaunchKernelGGL((k_nt<T, false, true>), g, dim3(256), 0, s, P);
-    else
-        hipLaunchKernelGGL((k_nt<T, false, false>), g, dim3(256), 0, s, P);
+    const size_t lds = (size_t)STAGE_BYTES + (P.np > 0 ? (size_t)TILE * (P.pR * sizeof(T) + 80) : 0);
+    // (> 64 KiB of dynamic LDS must be opted into once per kernel)
+    const int variant = base_users > 1 ? 0 : (P.n_act > 1 ? 1 : 2);
+    const bool fuse = P.np > 0;
+#define MTL_NT_LAUNCH(MU, MSRC, FU)                                                                              \
+    do {                                                                                                       \
+        static bool raised = false;                                                                            \
+        if (lds > 64 * 1024 && !raised) {                                                                      \
+            (void)hipFuncSetAttribute((const void*)k_nt<T, MU, MSRC, FU>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                      160 * 1024 - 512);                                                       \
+            raised = true;                                                                                     \
+        }                                                                                                      \
+        hipLaunchKernelGGL((k_nt<T, MU, MSRC, FU>), g, dim3(256), lds, s, P);                                    \
+    } while (0)
+    if (variant == 0) {
+        if (fuse)
+            MTL_NT_LAUNCH(true, false, true);
+        else
+            MTL_NT_LAUNCH(true, false, false);
+    } else if (variant == 1) {
+        MTL_NT_LAUNCH(false, true, false);
+    } else {
+        if (fuse)
+            MTL_NT_LAUNCH(false, false, true);
+        else
+            MTL_NT_LAUNCH(false, false, false);
+    }
+#undef MTL_NT_LAUNCH
+}
+
+static bool fuse_p_enabled() {
+    static const bool on = [] {
+        const char* e = getenv("MTLORA_FUSE_P");
+        return e && e[0] == '1';
+    }();
+    return on;
 }
 
 template <typename T>
@@ -787,6 +922,7 @@ static int fwd_impl(const mtlora_linear_desc* d, const void* x, const void* cons
     T* Pm = reinterpret_cast<T*>(c + L.p);
     const DropoutCfg dc = mtl_make_dropout(d->dropout_p, d->seed);
     const float keep_scale = dc.enabled() ? 1.f / (1.f - d->dropout_p) : 1.f;
+    bool fuse = false;
 
     if (sg.R > 0) {
         PackParams pp;
@@ -815,38 +951,45 @@ static int fwd_impl(const mtlora_linear_desc* d, const void* x, const void* cons
                                alpha);
         }
 
-        // P = alpha * D(X) A^T  (per source)
-        NtParams q = {};
-        q.n_act = 1;
-        q.ld_act = d->K;
-        q.wgt = a_cat;
-        q.ld_wgt = d->K;
-        q.M = d->M;
-        q.K = (int)d->K;
-        q.alpha = alpha;
-        q.n_out = 1;
-        q.out[0].ptr = Pm;
-        q.out[0].use_base = 1;
-        q.ld_out = sg.R;
-        q.drop = dc;
-        if (d->T > 0 && d->has_x_tasks) {
-            q.nz = 0;
-            for (int o = 0; o < sg.n; ++o) {
-                if (sg.rp[o] == 0) continue;
-                q.zact[q.nz] = (o == 0) ? x : x_t[o - 1];
-                q.zrow0[q.nz] = sg.off[o];
-                q.zrows[q.nz] = sg.rp[o];
-                q.zmask[q.nz] = (o == 0) ? 1 : 0;
-                ++q.nz;
+        // EXPERIMENTAL (MTLORA_FUSE_P=1): form the projection inside the output kernel (LDS-resident P, no P-pass
+        // launch, no P re-read).  Correct (tests/test_gpu_kernels.py::test_linear_fused_projection) but, with the
+        // projection recomputed by every n-tile workgroup, 1.7 ms/step SLOWER than the two-pass form at C2 -- the
+        // serialized extra tile-steps cost more than the saved traffic.  Default: two passes.
+        fuse = fuse_p_enabled() && sg.R <= 128 && mtl_ceil_div(d->N, TILE) <= 6;
+        if (!fuse) {
+            // P = alpha * D(X) A^T  (per source)
+            NtParams q = {};
+            q.n_act = 1;
+            q.ld_act = d->K;
+            q.wgt = a_cat;
+            q.ld_wgt = d->K;
+            q.M = d->M;
+            q.K = (int)d->K;
+            q.alpha = alpha;
+            q.n_out = 1;
+            q.out[0].ptr = Pm;
+            q.out[0].use_base = 1;
+            q.ld_out = sg.R;
+            q.drop = dc;
+            if (d->T > 0 && d->has_x_tasks) {
+                q.nz = 0;
+                for (int o = 0; o < sg.n; ++o) {
+                    if (sg.rp[o] == 0) continue;
+                    q.zact[q.nz] = (o == 0) ? x : x_t[o - 1];
+                    q.zrow0[q.nz] = sg.off[o];
+                    q.zrows[q.nz] = sg.rp[o];
+                    q.zmask[q.nz] = (o == 0) ? 1 : 0;
+                    ++q.nz;
+                }
+                q.n_rows = 0;
+            } else {
+                q.act[0] = x;
+                q.act_mask = 1;
+                q.n_rows = sg.R;
+                q.nz = 0;
             }
-            q.n_rows = 0;
-        } else {
-            q.act[0] = x;
-            q.act_mask = 1;
-            q.n_rows = sg.R;
-            q.nz = 0;
+            launch_nt<T>(q, s, PK_NT_FWD_P, (double)sizeof(T) * (d->has_x_tasks ? d->T : 0) * d->M * d->K);
         }
-        launch_nt<T>(q, s, PK_NT_FWD_P, (double)sizeof(T) * (d->has_x_tasks ? d->T : 0) * d->M * d->K);
     }
 
     // all outputs
@@ -876,7 +1019,32 @@ static int fwd_impl(const mtlora_linear_desc* d, const void* x, const void* cons
         O.mask_lr = 0;
         O.fold = (o == 0 && d->mode == 1 && d->T > 0) ? 1 : 0;
     }
-    launch_nt<T>(m, s, PK_NT_FWD_MAIN, (double)sizeof(T) * d->M * (d->K + (double)(1 + d->T) * d->N));
+    if (fuse) {
+        m.pA = a_cat;
+        m.pK = (int)d->K;
+        m.pR = sg.R;
+        m.palpha = alpha;
+        m.pout = Pm;
+        m.np = 0;
+        if (d->T > 0 && d->has_x_tasks) {
+            for (int o = 0; o < sg.n; ++o) {
+                if (sg.rp[o] == 0) continue;
+                m.pact[m.np] = (o == 0) ? x : x_t[o - 1];
+                m.pseg_lo[m.np] = sg.off[o];
+                m.pseg_hi[m.np] = sg.off[o] + sg.rp[o];
+                m.pmask[m.np] = (o == 0) ? 1 : 0;
+                ++m.np;
+            }
+        } else {
+            m.pact[0] = x;
+            m.pseg_lo[0] = 0;
+            m.pseg_hi[0] = sg.R;
+            m.pmask[0] = 1;
+            m.np = 1;
+        }
+    }
+    const double xt_bytes = fuse ? (double)sizeof(T) * (d->has_x_tasks ? d->T : 0) * d->M * d->K : 0.0;
+    launch_nt<T>(m, s, PK_NT_FWD_MAIN, (double)sizeof(T) * d->M * (d->K + (double)(1 + d->T) * d->N) + xt_bytes);
     return MTLORA_OK;
 }
 

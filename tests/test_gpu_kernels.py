@@ -532,3 +532,45 @@ def test_residual_droppath(shared, rdt, ydt):
     for k in (0, 2):
         assert_close(ys[k].grad, y64[k].grad, ydt, f"dy{k}", mult=2)
     assert ys[1].grad is None
+
+
+def test_linear_fused_projection():
+    """MTLORA_FUSE_P=1: the experimental LDS-resident projection path of the forward kernel, in a subprocess (the
+    switch is read once per process), against the default two-pass path and the oracle."""
+    import os, subprocess, sys
+    code = r'''
+import sys, torch
+sys.path.insert(0, %r)
+from mtlora_amd.lora import MTLoRALinear
+torch.manual_seed(0)
+dev = torch.device("cuda")
+outs = []
+for (M, K, N, T, xt, dt) in [(777, 96, 288, 0, False, torch.bfloat16), (520, 96, 384, 4, True, torch.bfloat16),
+                             (300, 192, 192, 4, False, torch.float32), (260, 384, 96, 2, True, torch.bfloat16)]:
+    tasks = [f"t{i}" for i in range(T)] or None
+    m = MTLoRALinear(K, N, r={"shared": 64, **{t: 4 for t in (tasks or [])}}, lora_shared_scale=4.0,
+                     lora_task_scale={t: 4.0 for t in (tasks or [])} if tasks else 1.0, lora_dropout=0.1, tasks=tasks).to(dev)
+    g = torch.Generator(device="cuda").manual_seed(M)
+    with torch.no_grad():
+        for p in m.parameters():
+            p.copy_(torch.randn(p.shape, device=dev, generator=g) * 0.05)
+    m.train()
+    x = torch.randn(M, K, device=dev, generator=g).to(dt)
+    xts = {t: torch.randn(M, K, device=dev, generator=g).to(dt) for t in tasks} if (tasks and xt) else None
+    from mtlora_amd import functional as Fn
+    Fn._seed_counter = 100
+    y, yt = m(x, xts)
+    outs.append(y.float().cpu())
+    outs += [yt[t].float().cpu() for t in (tasks or [])]
+torch.save(outs, sys.argv[1])
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    import tempfile
+    res = {}
+    for flag in ("0", "1"):
+        with tempfile.NamedTemporaryFile(suffix=".pt") as f:
+            env = dict(os.environ, MTLORA_FUSE_P=flag)
+            r = subprocess.run([sys.executable, "-c", code, f.name], env=env, capture_output=True, text=True, timeout=300)
+            assert r.returncode == 0, r.stderr[-2000:]
+            res[flag] = torch.load(f.name)
+    for a, b in zip(res["0"], res["1"]):
+        assert ((a - b).abs().max() / a.abs().max()).item() < 2e-2   # same dropout seed, same math, bf16 rounding of P

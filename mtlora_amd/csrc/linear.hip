@@ -634,9 +634,15 @@ __global__ __launch_bounds__(256, 2) void k_nt(const NtParams Pv) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_tn : Out[a][b] = sum_m SrcA[m][a0 + a] * SrcB[m][b0 + b]   (64 x 64 tiles, split over m)
+// k_tn : Out[a][b] = sum_m SrcA[m][a0 + a] * SrcB[m][b0 + b], split over m.
+// SrcA is always the NARROW (rank-side) operand (Q or P, <= 64 columns per tile) and SrcB the WIDE one
+// (X or dY, 256 columns per tile), so a workgroup streams 64 + 256 columns per row and the wide matrix is
+// read ~once (x1.25 with the narrow slab) instead of twice with square tiles.  dB = dY^T P is computed as
+// its transpose P^T dY and written back transposed by k_tn_reduce.
 // ------------------------------------------------------------------------------------------------
-constexpr int TN_T = 64;
+constexpr int TN_A = 64;
+constexpr int TN_B = 256;
+constexpr int TN_TILE = TN_A * TN_B;
 struct TnProblem {
     const void* A;
     const void* B;
@@ -644,9 +650,9 @@ struct TnProblem {
     int a0, Na, b0, Nb;  // column windows
     int b_mask;          // dropout keep-mask on SrcB (keyed by (m, b0 + b))
     int tiles_a, tiles_b;
-    float* part;         // [nsplit][tiles_a*tiles_b][64*64]
-    float* out;          // (Na_valid x Nb_valid) fp32, ld = ldo
-    int out_rows, out_cols, ldo;
+    float* part;         // [nsplit][tiles_a*tiles_b][64*256]
+    float* out;          // fp32; element (a, b) at out[a*ldo + b], or out[b*ldo + a] when transpose
+    int out_a, out_b, ldo, transpose;
 };
 struct TnParams {
     TnProblem p[2 * MAXO];
@@ -661,17 +667,15 @@ template <typename T>
 struct TnCfg;
 template <>
 struct TnCfg<bf16> {
-    static constexpr int KE = 32;      // rows (m) per chunk
-    static constexpr int LDS_ROW = 144;  // bytes: 64 cols * 2 + 16 pad
+    static constexpr int SUB = 32;  // rows (m) per MFMA k-tile
 };
 template <>
 struct TnCfg<float> {
-    static constexpr int KE = 16;
-    static constexpr int LDS_ROW = 272;  // 64 * 4 + 16
+    static constexpr int SUB = 16;
 };
 
-// transposed fragment: lane (i = l & 31, h = l >> 5) gets Src[m = slot(h, e)][col0 + i]
-__device__ __forceinline__ Frag<bf16> tn_frag(const unsigned char* s, int col0, int lane, bf16*) {
+// transposed fragment: lane (i = l & 31, h = l >> 5) gets Src[m = slot(h, e)][col0 + i]; ``lr`` = LDS row bytes
+__device__ __forceinline__ Frag<bf16> tn_frag(const unsigned char* s, int col0, int lane, int lr, bf16*) {
     // ds_read_b64_tr_b16: within each 16-lane group, lane i supplies the 8-byte address of row (i>>2),
     // columns 4*(i&3)..+3 of a [4][16] block and receives column i of that block (4 rows).
     const int g = lane >> 4, i = lane & 15, h = g >> 1;
@@ -681,7 +685,7 @@ __device__ __forceinline__ Frag<bf16> tn_frag(const unsigned char* s, int col0, 
 #pragma unroll
     for (int j = 0; j < 4; ++j) {  // rows: {8h+0..3}, {8h+4..7}, {16+8h+0..3}, {16+8h+4..7}
         const int row = ((j >> 1) * 16) + 8 * h + 4 * (j & 1) + (i >> 2);
-        const unsigned char* p = s + row * TnCfg<bf16>::LDS_ROW + col * 2;
+        const unsigned char* p = s + row * lr + col * 2;
         s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
             (__attribute__((address_space(3))) s16x4*)(p));
         u32x2 u = __builtin_bit_cast(u32x2, v);
@@ -692,14 +696,14 @@ __device__ __forceinline__ Frag<bf16> tn_frag(const unsigned char* s, int col0, 
     f.v[1] = u32x4{w[4], w[5], w[6], w[7]};
     return f;
 }
-__device__ __forceinline__ Frag<float> tn_frag(const unsigned char* s, int col0, int lane, float*) {
+__device__ __forceinline__ Frag<float> tn_frag(const unsigned char* s, int col0, int lane, int lr, float*) {
     const int h = lane >> 5, i = lane & 31;
     Frag<float> f;
     uint32_t w[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {  // rows {4h..4h+3} U {8+4h..8+4h+3}
         const int row = (e >> 2) * 8 + 4 * h + (e & 3);
-        w[e] = *reinterpret_cast<const uint32_t*>(s + row * TnCfg<float>::LDS_ROW + (col0 + i) * 4);
+        w[e] = *reinterpret_cast<const uint32_t*>(s + row * lr + (col0 + i) * 4);
     }
     f.v[0] = u32x4{w[0], w[1], w[2], w[3]};
     f.v[1] = u32x4{w[4], w[5], w[6], w[7]};
@@ -707,90 +711,142 @@ __device__ __forceinline__ Frag<float> tn_frag(const unsigned char* s, int col0,
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void k_tn(const TnParams P) {
-    constexpr int KE = TnCfg<T>::KE;
-    constexpr int LR = TnCfg<T>::LDS_ROW;
+__global__ __launch_bounds__(256, 2) void k_tn(const TnParams P) {
+    constexpr int SUB = TnCfg<T>::SUB;
+    constexpr int KE = 2 * SUB;  // rows per staged chunk
+    constexpr int ES = (int)sizeof(T);
     constexpr int VEC = ET<T>::VEC;
-    constexpr int VPR = TN_T / VEC;  // 16-byte vectors per tile row
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * KE * LR];
+    constexpr int LRA = TN_A * ES + 16, LRB = TN_B * ES + 16;  // padded LDS rows
+    constexpr int VPA = TN_A / VEC, VPB = TN_B / VEC;          // 16-byte vectors per tile row
+    constexpr int RSA = 256 / VPA, RSB = 256 / VPB;            // rows covered by one sweep of the workgroup
+    constexpr int NLA = KE / RSA, NLB = KE / RSB;              // loads per thread per chunk (2 and 8)
+    __shared__ __attribute__((aligned(16))) unsigned char smem[KE * (LRA + LRB)];
     unsigned char* sA = smem;
-    unsigned char* sB = smem + KE * LR;
+    unsigned char* sB = smem + KE * LRA;
     const TnProblem& pr = P.p[blockIdx.z];
     const int tile = blockIdx.y;
     if (tile >= pr.tiles_a * pr.tiles_b) return;
     const int ta = tile / pr.tiles_b, tb = tile % pr.tiles_b;
     const int split = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int sa = wave >> 1, sb = wave & 1;
 
     const int64_t m_lo = (int64_t)split * P.rows_per_split;
     int64_t m_hi = m_lo + P.rows_per_split;
     if (m_hi > P.M) m_hi = P.M;
 
-    f32x16 acc;
+    f32x16 acc[2][2];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    // loader coordinates: one 16-byte vector per operand per thread (f32: KE*VPR = 256 too)
-    const int lrow = tid / VPR, lvec = tid % VPR;
-    const int ca = ta * TN_T + lvec * VEC;  // column inside the A window
-    const int cb = tb * TN_T + lvec * VEC;
+    const int rowA = tid / VPA, vecA = tid % VPA, rowB = tid / VPB, vecB = tid % VPB;
+    const int ca = ta * TN_A + vecA * VEC;  // column inside the A window
+    const int cb = tb * TN_B + vecB * VEC;
     const bool a_in = ca < pr.Na, b_in = cb < pr.Nb;
+    const bool wave_on = tb * TN_B + wave * 64 < pr.Nb;  // this wave's 64 wide columns hold data
     const T* Ap = reinterpret_cast<const T*>(pr.A) + pr.a0 + ca;
     const T* Bp = reinterpret_cast<const T*>(pr.B) + pr.b0 + cb;
     const bool bmask = pr.b_mask && P.drop.enabled();
 
-    auto load = [&](int64_t mrow, u32x4& ra, u32x4& rb) {
-        const int64_t m = mrow + lrow;
-        ra = (a_in && m < m_hi) ? *reinterpret_cast<const u32x4*>(Ap + m * pr.lda) : u32x4{0u, 0u, 0u, 0u};
-        if (b_in && m < m_hi) {
-            Vec16<T> x = mtl_ld16<T>(Bp + m * pr.ldb);
-            if (bmask) {
-                const uint32_t rh = mtl_dropout_rowhash(P.drop, 0u, (uint32_t)m);
+    // two register sets = prefetch distance 2 chunks (the grid is sized to 2 workgroups per CU, i.e. 256 VGPRs per
+    // wave, and a workgroup's streaming rate is bounded by bytes in flight / load latency)
+    u32x4 ra0[NLA], rb0[NLB], ra1[NLA], rb1[NLB];
+    auto load = [&](u32x4* ra, u32x4* rb, int64_t mrow) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < NLA; ++j) {
+            const int64_t m = mrow + rowA + j * RSA;
+            ra[j] = (a_in && m < m_hi) ? *reinterpret_cast<const u32x4*>(Ap + m * pr.lda) : u32x4{0u, 0u, 0u, 0u};
+        }
+#pragma unroll
+        for (int j = 0; j < NLB; ++j) {
+            const int64_t m = mrow + rowB + j * RSB;
+            rb[j] = (b_in && m < m_hi) ? *reinterpret_cast<const u32x4*>(Bp + m * pr.ldb) : u32x4{0u, 0u, 0u, 0u};
+        }
+    };
+    auto stage = [&](u32x4* ra, u32x4* rb, int64_t mrow) __attribute__((always_inline)) {
+        if (bmask && b_in) {  // dropout keep-mask, applied just before the LDS store
+#pragma unroll
+            for (int j = 0; j < NLB; ++j) {
+                const uint32_t rh = mtl_dropout_rowhash(P.drop, 0u, (uint32_t)(mrow + rowB + j * RSB));
+                Vec16<T> x;
+                x.raw = rb[j];
 #pragma unroll
                 for (int e = 0; e < VEC; e += 2) {
                     const uint32_t h = mtl_dropout_pairbits(P.drop, rh, (uint32_t)(pr.b0 + cb + e));
                     if ((h & 0xFFFFu) < P.drop.thr16) x.e[e] = mtl_from_f32<T>(0.f);
                     if ((h >> 16) < P.drop.thr16) x.e[e + 1] = mtl_from_f32<T>(0.f);
                 }
+                rb[j] = x.raw;
             }
-            rb = x.raw;
-        } else {
-            rb = u32x4{0u, 0u, 0u, 0u};
+        }
+#pragma unroll
+        for (int j = 0; j < NLA; ++j) *reinterpret_cast<u32x4*>(sA + (rowA + j * RSA) * LRA + vecA * 16) = ra[j];
+#pragma unroll
+        for (int j = 0; j < NLB; ++j) *reinterpret_cast<u32x4*>(sB + (rowB + j * RSB) * LRB + vecB * 16) = rb[j];
+    };
+    auto compute = [&]() __attribute__((always_inline)) {
+        if (!wave_on) return;
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            const unsigned char* a_s = sA + sub * SUB * LRA;
+            const unsigned char* b_s = sB + sub * SUB * LRB;
+            Frag<T> fa0 = tn_frag(a_s, 0, lane, LRA, (T*)nullptr);
+            Frag<T> fa1 = tn_frag(a_s, 32, lane, LRA, (T*)nullptr);
+            Frag<T> fb0 = tn_frag(b_s, wave * 64, lane, LRB, (T*)nullptr);
+            Frag<T> fb1 = tn_frag(b_s, wave * 64 + 32, lane, LRB, (T*)nullptr);
+            mtl_mma(fa0, fb0, acc[0][0]);
+            mtl_mma(fa0, fb1, acc[0][1]);
+            mtl_mma(fa1, fb0, acc[1][0]);
+            mtl_mma(fa1, fb1, acc[1][1]);
         }
     };
 
-    u32x4 ra, rb;
-    if (m_lo < m_hi) load(m_lo, ra, rb);
-    for (int64_t mrow = m_lo; mrow < m_hi; mrow += KE) {
-        *reinterpret_cast<u32x4*>(sA + lrow * LR + lvec * 16) = ra;
-        *reinterpret_cast<u32x4*>(sB + lrow * LR + lvec * 16) = rb;
+    if (m_lo < m_hi) load(ra0, rb0, m_lo);
+    if (m_lo + KE < m_hi) load(ra1, rb1, m_lo + KE);
+    for (int64_t mrow = m_lo; mrow < m_hi; mrow += 2 * KE) {
+        stage(ra0, rb0, mrow);
         __syncthreads();
-        if (mrow + KE < m_hi) load(mrow + KE, ra, rb);
-        Frag<T> fa = tn_frag(sA, sa * 32, lane, (T*)nullptr);
-        Frag<T> fb = tn_frag(sB, sb * 32, lane, (T*)nullptr);
-        mtl_mma(fa, fb, acc);
+        if (mrow + 2 * KE < m_hi) load(ra0, rb0, mrow + 2 * KE);
+        compute();
         __syncthreads();
+        if (mrow + KE < m_hi) {
+            stage(ra1, rb1, mrow + KE);
+            __syncthreads();
+            if (mrow + 3 * KE < m_hi) load(ra1, rb1, mrow + 3 * KE);
+            compute();
+            __syncthreads();
+        }
     }
 
-    float* dst = pr.part + ((int64_t)split * (pr.tiles_a * pr.tiles_b) + tile) * (TN_T * TN_T);
+    if (!wave_on) return;  // k_tn_reduce never reads columns outside the B window
+    float* dst = pr.part + ((int64_t)split * (pr.tiles_a * pr.tiles_b) + tile) * TN_TILE;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int i = sa * 32 + mtl_d_row(lane, r), j = sb * 32 + mtl_d_col(lane);
-        dst[i * TN_T + j] = acc[r];
-    }
+    for (int ia = 0; ia < 2; ++ia)
+#pragma unroll
+        for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int i = ia * 32 + mtl_d_row(lane, r), j = wave * 64 + jb * 32 + mtl_d_col(lane);
+                dst[i * TN_B + j] = acc[ia][jb][r];
+            }
 }
 
 __global__ __launch_bounds__(256) void k_tn_reduce(const TnParams P) {
-    // one workgroup per (problem, tile, quarter): 1024 outputs, 4 per thread (one 16-byte load per split,
+    // one workgroup per (problem, tile, 1024-element block): 4 outputs per thread (one 16-byte load per split,
     // coalesced across the wave), splits summed in a fixed order with 4 independent chains in flight
     const TnProblem& pr = P.p[blockIdx.z];
     const int ntile = pr.tiles_a * pr.tiles_b;
     const int tile = blockIdx.y;
     if (tile >= ntile) return;
-    const int e0 = blockIdx.x * 1024 + threadIdx.x * 4;  // element inside the 64x64 tile
-    const float* src = pr.part + (int64_t)tile * (TN_T * TN_T) + e0;
-    const int64_t stride = (int64_t)ntile * (TN_T * TN_T);
+    const int e0 = blockIdx.x * 1024 + threadIdx.x * 4;  // element inside the 64x256 tile
+    const int ta = tile / pr.tiles_b, tb = tile % pr.tiles_b;
+    const int a = ta * TN_A + e0 / TN_B, b0 = tb * TN_B + e0 % TN_B;
+    if (a >= pr.out_a || b0 >= pr.out_b) return;
+    const float* src = pr.part + (int64_t)tile * TN_TILE + e0;
+    const int64_t stride = (int64_t)ntile * TN_TILE;
     f32x4 acc[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -801,13 +857,12 @@ __global__ __launch_bounds__(256) void k_tn_reduce(const TnParams P) {
     }
     for (; sp < P.nsplit; ++sp) acc[0] += *reinterpret_cast<const f32x4*>(src + (int64_t)sp * stride);
     const f32x4 t = (acc[0] + acc[1]) + (acc[2] + acc[3]);
-    const int ta = tile / pr.tiles_b, tb = tile % pr.tiles_b;
-    const int a = ta * TN_T + e0 / TN_T, b0 = tb * TN_T + e0 % TN_T;
-    if (a < pr.out_rows) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-            if (b0 + e < pr.out_cols) pr.out[(int64_t)a * pr.ldo + b0 + e] = t[e];
-    }
+    for (int e = 0; e < 4; ++e)
+        if (b0 + e < pr.out_b) {
+            const int64_t at = pr.transpose ? (int64_t)(b0 + e) * pr.ldo + a : (int64_t)a * pr.ldo + b0 + e;
+            pr.out[at] = t[e];
+        }
 }
 
 // elementwise sum of up to MAXO tensors (matrixv2 backward: G for the shared factors)
@@ -1048,6 +1103,7 @@ static int fwd_impl(const mtlora_linear_desc* d, const void* x, const void* cons
     return MTLORA_OK;
 }
 
+constexpr int64_t TN_TARGET_CTAS = 512;
 struct BwdScratch {
     int64_t q, g, part, total;
     int nsplit;
@@ -1064,26 +1120,27 @@ static BwdScratch bwd_scratch(const mtlora_linear_desc* d, const Segs& sg) {
     };
     S.q = take(d->M * sg.R * es);
     S.g = take((d->mode == 1 && d->T > 0) ? d->M * d->N * es : 0);
-    // TN tiles
+    // TN tiles (rank side x wide side), dB and dA per output
     int64_t tiles = 0;
     for (int oo = 0; oo < sg.n; ++oo) {
         if (sg.rp[oo] == 0) continue;
-        tiles += mtl_ceil_div(d->N, TN_T) * mtl_ceil_div(sg.rp[oo], TN_T);  // dB
-        tiles += mtl_ceil_div(sg.rp[oo], TN_T) * mtl_ceil_div(d->K, TN_T);  // dA
+        tiles += mtl_ceil_div(sg.rp[oo], TN_A) * mtl_ceil_div(d->N, TN_B);  // dB (as P^T dY)
+        tiles += mtl_ceil_div(sg.rp[oo], TN_A) * mtl_ceil_div(d->K, TN_B);  // dA
     }
+    // <= 512 workgroups = 2 per CU, all resident; >= 256 rows per split so that the fp32 partial tiles stay a small part of the traffic
     int nsplit = 1;
     if (tiles > 0) {
-        nsplit = (int)(2048 / tiles);
-        const int64_t max_by_rows = mtl_ceil_div(d->M, 256);  // at least 256 rows per split
+        nsplit = (int)(TN_TARGET_CTAS / tiles);  // floor: the whole grid is resident at once (no second round)
+        const int64_t max_by_rows = mtl_ceil_div(d->M, 256);
         if (nsplit > max_by_rows) nsplit = (int)max_by_rows;
-        if (nsplit > 128) nsplit = 128;
+        if (nsplit > 256) nsplit = 256;
         if (nsplit < 1) nsplit = 1;
     }
     S.nsplit = nsplit;
     int64_t rps = mtl_ceil_div(d->M > 0 ? d->M : 1, nsplit);
-    rps = mtl_round_up(rps, 32);
+    rps = mtl_round_up(rps, 64);
     S.rows_per_split = rps;
-    S.part = take(tiles * nsplit * (int64_t)(TN_T * TN_T) * 4);
+    S.part = take(tiles * nsplit * (int64_t)TN_TILE * 4);
     S.total = o;
     return S;
 }
@@ -1223,25 +1280,26 @@ static int bwd_impl(const mtlora_linear_desc* d, const void* x, const void* cons
             if (sg.rp[o] == 0 || !dyo[o]) continue;
             float* dAo = (o == 0) ? dA_s : (dA_t ? dA_t[o - 1] : nullptr);
             float* dBo = (o == 0) ? dB_s : (dB_t ? dB_t[o - 1] : nullptr);
-            if (dBo) {  // (N x r_o) = dY_o^T (M x N)  .  P[:, seg_o]
+            if (dBo) {  // (N x r_o) = dY_o^T P[:, seg_o], evaluated as its transpose P[:, seg_o]^T dY_o
                 TnProblem& p = tp.p[tp.n_prob++];
-                p.A = dyo[o];
-                p.lda = d->N;
-                p.a0 = 0;
-                p.Na = (int)d->N;
-                p.B = Pm;
-                p.ldb = sg.R;
-                p.b0 = sg.off[o];
-                p.Nb = sg.rp[o];
+                p.A = Pm;
+                p.lda = sg.R;
+                p.a0 = sg.off[o];
+                p.Na = sg.rp[o];
+                p.B = dyo[o];
+                p.ldb = d->N;
+                p.b0 = 0;
+                p.Nb = (int)d->N;
                 p.b_mask = 0;
-                p.tiles_a = (int)mtl_ceil_div(p.Na, TN_T);
-                p.tiles_b = (int)mtl_ceil_div(p.Nb, TN_T);
+                p.tiles_a = (int)mtl_ceil_div(p.Na, TN_A);
+                p.tiles_b = (int)mtl_ceil_div(p.Nb, TN_B);
                 p.part = pp;
-                pp += (int64_t)p.tiles_a * p.tiles_b * S.nsplit * (TN_T * TN_T);
+                pp += (int64_t)p.tiles_a * p.tiles_b * S.nsplit * TN_TILE;
                 p.out = dBo;
-                p.out_rows = (int)d->N;
-                p.out_cols = sg.r[o];
+                p.out_a = sg.r[o];
+                p.out_b = (int)d->N;
                 p.ldo = sg.r[o];
+                p.transpose = 1;
                 if (p.tiles_a * p.tiles_b > max_tiles) max_tiles = p.tiles_a * p.tiles_b;
             }
             if (dAo) {  // (r_o x K) = Q[:, seg_o]^T . D(X_o)
@@ -1256,14 +1314,15 @@ static int bwd_impl(const mtlora_linear_desc* d, const void* x, const void* cons
                 p.b0 = 0;
                 p.Nb = (int)d->K;
                 p.b_mask = own_x ? 0 : 1;
-                p.tiles_a = (int)mtl_ceil_div(p.Na, TN_T);
-                p.tiles_b = (int)mtl_ceil_div(p.Nb, TN_T);
+                p.tiles_a = (int)mtl_ceil_div(p.Na, TN_A);
+                p.tiles_b = (int)mtl_ceil_div(p.Nb, TN_B);
                 p.part = pp;
-                pp += (int64_t)p.tiles_a * p.tiles_b * S.nsplit * (TN_T * TN_T);
+                pp += (int64_t)p.tiles_a * p.tiles_b * S.nsplit * TN_TILE;
                 p.out = dAo;
-                p.out_rows = sg.r[o];
-                p.out_cols = (int)d->K;
+                p.out_a = sg.r[o];
+                p.out_b = (int)d->K;
                 p.ldo = (int)d->K;
+                p.transpose = 0;
                 if (p.tiles_a * p.tiles_b > max_tiles) max_tiles = p.tiles_a * p.tiles_b;
             }
         }
@@ -1274,7 +1333,7 @@ static int bwd_impl(const mtlora_linear_desc* d, const void* x, const void* cons
                                    dim3(256), 0, s, tp);
             }
             MtlProfScope prof(PK_REDUCE, 0.0, s);
-            hipLaunchKernelGGL(k_tn_reduce, dim3(4, (unsigned)max_tiles, (unsigned)tp.n_prob), dim3(256), 0, s, tp);
+            hipLaunchKernelGGL(k_tn_reduce, dim3(TN_TILE / 1024, (unsigned)max_tiles, (unsigned)tp.n_prob), dim3(256), 0, s, tp);
         }
     }
     return MTLORA_OK;

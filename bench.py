@@ -110,9 +110,18 @@ def roofline(step_fn, steps):
     ms = sum(s.ms[k] for k in nt)
     by = sum(s.alg_bytes[k] for k in nt)
     achieved = (by / 1e9) / (ms / 1e3) if ms > 0 else 0.0
+    # HBM bytes per launch from the committed PMC passes of this same workload (separate `--pmc` runs cannot be
+    # collected from inside the timed process): profiles/r01_pmc_traffic.json, FETCH_SIZE corrected for gfx950.
+    traffic, traffic_src = None, None
+    try:
+        pm = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")))
+        if abs(pm["k_nt"]["launches_per_step"] - n / steps) < 0.5:  # same launch structure as the profiled run
+            traffic, traffic_src = round(pm["k_nt"]["traffic_bytes_per_launch"]), "profiles/r01_pmc_traffic.json"
+    except Exception:
+        pass
     return {"bound": "hbm", "kernel": "k_nt<bf16> (fused MTLoRALinear GEMM: fwd outputs, low-rank P/Q, bwd dX)",
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-            "traffic": None, "launches_per_step": n / steps, "avg_launch_us": round(1e3 * ms / max(n, 1), 2),
+            "traffic": traffic, "traffic_source": traffic_src, "launches_per_step": n / steps, "avg_launch_us": round(1e3 * ms / max(n, 1), 2),
             "alg_bytes_per_launch": by / max(n, 1), "kernel_ms_per_step": round(ms / steps, 3),
             "all_kernels": kinds}
 

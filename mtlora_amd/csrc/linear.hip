@@ -181,15 +181,32 @@ typedef const __attribute__((address_space(4))) NtParams* NtPtr;
 template <typename T>
 struct TileRegs {
     u32x4 w[2][VPT], a[2][VPT];
+    int mask;  // dropout keep-mask still to be applied to a[][] (done at LDS-store time: applying it at load time
+    int k0;    // would put an s_waitcnt vmcnt(0) behind every single load and serialise the tile's loads)
 };
 
-// stage one 128-row x 64-byte k-tile of the weight-like and activation-like operands into registers
+// stage one 128-row x ROWB-byte k-tile of the weight-like and activation-like operands into registers
 template <typename T, bool MS>
 __device__ __forceinline__ void nt_load(TileRegs<T>& rg, int tid, const T* wgt, int64_t ld_w, int w_row0, int w_rows,
                                         const void* act0, NtPtr P, int n_act, int64_t ld_a, int64_t a_row0,
-                                        int64_t a_rows, int k0, int k_hi, bool mask, const DropoutCfg& dc,
-                                        int w_lo = 0) {
+                                        int64_t a_rows, int k0, int k_hi, bool mask, int w_lo = 0) {
     constexpr int VEC = ET<T>::VEC;
+    rg.mask = mask ? 1 : 0;
+    rg.k0 = k0;
+    // row bases once per tile (two rows per thread), the k offset is added per vector
+    const T* wp[2];
+    int64_t aoff[2];
+    bool wok[2], aok[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = (tid >> 2) + i * 64;
+        const int wr = w_row0 + r;
+        wok[i] = wr < w_rows && wr >= w_lo;
+        wp[i] = wgt + (int64_t)wr * ld_w;
+        const int64_t ar = a_row0 + r;
+        aok[i] = ar < a_rows && act0 != nullptr;
+        aoff[i] = ar * ld_a;
+    }
 #pragma unroll
     for (int j = 0; j < VPT; ++j) {
         const int v = (tid & 3) + 4 * j;
@@ -197,22 +214,16 @@ __device__ __forceinline__ void nt_load(TileRegs<T>& rg, int tid, const T* wgt, 
         const bool kin = k < k_hi;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const int r = (tid >> 2) + i * 64;
-            // weights
-            const int wr = w_row0 + r;
-            rg.w[i][j] = (kin && wr < w_rows && wr >= w_lo) ? *reinterpret_cast<const u32x4*>(wgt + (int64_t)wr * ld_w + k)
-                                              : u32x4{0u, 0u, 0u, 0u};
-            // activations
-            const int64_t ar = a_row0 + r;
-            if (kin && ar < a_rows && act0) {
-                u32x4 x = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(act0) + ar * ld_a + k);
+            rg.w[i][j] = (kin && wok[i]) ? *reinterpret_cast<const u32x4*>(wp[i] + k) : u32x4{0u, 0u, 0u, 0u};
+            if (kin && aok[i]) {
+                u32x4 x = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(act0) + aoff[i] + k);
                 if (MS && n_act > 1) {
                     if constexpr (sizeof(T) == 4) {
                         f32x4 fx = __builtin_bit_cast(f32x4, x);
 #pragma unroll
                         for (int s = 1; s < MAXO; ++s) {
                             if (s < n_act)
-                                fx += *reinterpret_cast<const f32x4*>(reinterpret_cast<const T*>(P->act[s]) + ar * ld_a + k);
+                                fx += *reinterpret_cast<const f32x4*>(reinterpret_cast<const T*>(P->act[s]) + aoff[i] + k);
                         }
                         x = __builtin_bit_cast(u32x4, fx);
                     } else {
@@ -222,7 +233,7 @@ __device__ __forceinline__ void nt_load(TileRegs<T>& rg, int tid, const T* wgt, 
                         for (int s = 1; s < MAXO; ++s) {
                             if (s < n_act) {
                                 const u32x4 y =
-                                    *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(P->act[s]) + ar * ld_a + k);
+                                    *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(P->act[s]) + aoff[i] + k);
                                 float g[8];
                                 VOps<T>::unpack(y, g);
 #pragma unroll
@@ -232,7 +243,6 @@ __device__ __forceinline__ void nt_load(TileRegs<T>& rg, int tid, const T* wgt, 
                         x = VOps<T>::pack(f);
                     }
                 }
-                if (mask) VOps<T>::drop(x, dc, mtl_dropout_rowhash(dc, 0u, (uint32_t)ar), (uint32_t)k);
                 rg.a[i][j] = x;
             } else {
                 rg.a[i][j] = u32x4{0u, 0u, 0u, 0u};
@@ -242,8 +252,17 @@ __device__ __forceinline__ void nt_load(TileRegs<T>& rg, int tid, const T* wgt, 
 }
 
 template <typename T>
-__device__ __forceinline__ void nt_store_lds(const TileRegs<T>& rg, int tid, unsigned char* sW, unsigned char* sA,
-                                             bool with_act = true) {
+__device__ __forceinline__ void nt_store_lds(TileRegs<T>& rg, int tid, unsigned char* sW, unsigned char* sA,
+                                             const DropoutCfg& dc, int64_t a_row0, bool with_act = true) {
+    constexpr int VEC = ET<T>::VEC;
+    if (rg.mask) {  // wave-uniform
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const uint32_t rh = mtl_dropout_rowhash(dc, 0u, (uint32_t)(a_row0 + (tid >> 2) + i * 64));
+#pragma unroll
+            for (int j = 0; j < VPT; ++j) VOps<T>::drop(rg.a[i][j], dc, rh, (uint32_t)(rg.k0 + ((tid & 3) + 4 * j) * VEC));
+        }
+    }
 #pragma unroll
     for (int j = 0; j < VPT; ++j) {
         const int v = (tid & 3) + 4 * j;
@@ -370,7 +389,10 @@ __device__ __forceinline__ NtCursor nt_seek(NtPtr P, int q, int nseq) {
     return c;
 }
 
-template <typename T, bool MULTI, bool MS, bool FUSE>
+// MLR: some output masks its low-rank part (dX = G W + keep .* (Q A)).  A template parameter, not a runtime test: the
+// keep-mask hashes depend only on (m, n), so the compiler hoists all 64 of them (+ their SGPR-pair results, spilled to
+// VGPR lanes) to the top of the kernel -- ~700 instructions per workgroup that the forward / P / Q launches never use.
+template <typename T, bool MULTI, bool MS, bool FUSE, bool MLR>
 __global__ __launch_bounds__(256, 2) void k_nt(const NtParams Pv) {
     (void)Pv;
     NtPtr P = (NtPtr)__builtin_amdgcn_kernarg_segment_ptr();
@@ -428,18 +450,17 @@ __global__ __launch_bounds__(256, 2) void k_nt(const NtParams Pv) {
     auto issue = [&](const NtCursor& c) __attribute__((always_inline)) {
         if (FUSE && c.lr == 2)  // fused projection: weights = A_cat rows of source c.q, activation = that source
             nt_load<T, false>(rg, tid, reinterpret_cast<const T*>(P->pA), P->pK, 0, P->pseg_hi[c.q], P->pact[c.q], P, 1,
-                              P->pK, m0, P->M, c.k0, c.k_hi, P->pmask[c.q] != 0 && drop.thr16 != 0, drop, P->pseg_lo[c.q]);
+                              P->pK, m0, P->M, c.k0, c.k_hi, P->pmask[c.q] != 0 && drop.thr16 != 0, P->pseg_lo[c.q]);
         else if (c.lr)  // rank segment: weights = Rm; activation = L, or the LDS P image when the projection is fused
             nt_load<T, false>(rg, tid, reinterpret_cast<const T*>(P->Rm), P->ldR, n0, n_rows, np > 0 ? nullptr : P->L, P, 1,
-                              P->ldL, m0, P->M, c.k0, c.k_hi, false, drop);
+                              P->ldL, m0, P->M, c.k0, c.k_hi, false);
         else
-            nt_load<T, MS>(rg, tid, wgt, P->ld_wgt, n0, n_rows, act0, P, P->n_act, P->ld_act, m0, P->M, c.k0, c.k_hi, act_mask,
-                           drop);
+            nt_load<T, MS>(rg, tid, wgt, P->ld_wgt, n0, n_rows, act0, P, P->n_act, P->ld_act, m0, P->M, c.k0, c.k_hi, act_mask);
     };
     if (ld.valid) issue(ld);
     // consume one tile: registers -> LDS, prefetch the next tile of the stream, multiply
     auto step = [&](f32x16(&acc)[2][2], int k_left, int from_p, int k0) __attribute__((always_inline)) {
-        nt_store_lds<T>(rg, tid, sW, sA, !from_p);
+        nt_store_lds<T>(rg, tid, sW, sA, drop, m0, !from_p);
         __syncthreads();
         ld.k0 += KE;
         if (ld.k0 >= ld.k_hi) ld = nt_seek<MULTI, FUSE>(P, ld.q + 1, nseq);
@@ -624,7 +645,11 @@ __global__ __launch_bounds__(256, 2) void k_nt(const NtParams Pv) {
             const NtOut O = nt_out(P, o);
             zero(acc);
             const bool had_lr = run_part(np + 2 * o, acc);
-            if (had_lr && O.mask_lr && drop.enabled()) apply_mask(acc);
+            if constexpr (MLR) {
+                if (had_lr && O.mask_lr && drop.enabled()) apply_mask(acc);
+            } else {
+                (void)had_lr;
+            }
             run_part(np + 2 * o + 1, acc);
             if (O.use_base) affine(acc);
             store(acc, O.ptr);
@@ -928,28 +953,33 @@ static void launch_nt(const NtParams& P, hipStream_t s, int kind, double alg_byt
     // (> 64 KiB of dynamic LDS must be opted into once per kernel)
     const int variant = base_users > 1 ? 0 : (P.n_act > 1 ? 1 : 2);
     const bool fuse = P.np > 0;
-#define MTL_NT_LAUNCH(MU, MSRC, FU)                                                                              \
+#define MTL_NT_LAUNCH(MU, MSRC, FU, ML)                                                                          \
     do {                                                                                                       \
         static bool raised = false;                                                                            \
         if (lds > 64 * 1024 && !raised) {                                                                      \
-            (void)hipFuncSetAttribute((const void*)k_nt<T, MU, MSRC, FU>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+            (void)hipFuncSetAttribute((const void*)k_nt<T, MU, MSRC, FU, ML>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                       160 * 1024 - 512);                                                       \
             raised = true;                                                                                     \
         }                                                                                                      \
-        hipLaunchKernelGGL((k_nt<T, MU, MSRC, FU>), g, dim3(256), lds, s, P);                                    \
+        hipLaunchKernelGGL((k_nt<T, MU, MSRC, FU, ML>), g, dim3(256), lds, s, P);                                 \
     } while (0)
+    bool mlr = false;
+    for (int o = 0; o < P.n_out; ++o) mlr = mlr || P.out[o].mask_lr != 0;
+    mlr = mlr && P.drop.enabled();
     if (variant == 0) {
         if (fuse)
-            MTL_NT_LAUNCH(true, false, true);
+            MTL_NT_LAUNCH(true, false, true, false);
         else
-            MTL_NT_LAUNCH(true, false, false);
+            MTL_NT_LAUNCH(true, false, false, false);
     } else if (variant == 1) {
-        MTL_NT_LAUNCH(false, true, false);
+        MTL_NT_LAUNCH(false, true, false, true);  // multi-source = the dX launch
     } else {
         if (fuse)
-            MTL_NT_LAUNCH(false, false, true);
+            MTL_NT_LAUNCH(false, false, true, false);
+        else if (mlr)
+            MTL_NT_LAUNCH(false, false, false, true);
         else
-            MTL_NT_LAUNCH(false, false, false);
+            MTL_NT_LAUNCH(false, false, false, false);
     }
 #undef MTL_NT_LAUNCH
 }

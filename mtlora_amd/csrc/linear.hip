@@ -170,7 +170,8 @@ struct NtParams {
     const void* pA;        // A_cat (pR x pK)
     int pK, pR;
     const float* palpha;   // (pR)
-    void* pout;            // global P (M x pR), written by the n-tile-0 workgroups for the backward
+    void* pout;            // global P (M x pR), written by the n-group-0 workgroups for the backward
+    int n_groups;          // fused form: a workgroup owns a 128-row panel and 1/n_groups of its n-tiles (it loops over them)
     DropoutCfg drop;
 };
 
@@ -318,6 +319,7 @@ struct NtCursor {
     int k_hi;      // end of the part's k range
     int lr;        // 1: rank-segment part (L x Rm), 0: base part (act x wgt)
     int valid;
+    int bn;        // n-tile the part belongs to (fused form: the stream runs on across the workgroup's n-tiles)
 };
 
 __device__ __forceinline__ NtOut nt_out(NtPtr P, int o) {
@@ -369,22 +371,30 @@ __device__ __forceinline__ void nt_part(NtPtr P, int q, int& lr, int& k_lo, int&
 }
 
 template <bool MULTI, bool FUSE>
-__device__ __forceinline__ NtCursor nt_seek(NtPtr P, int q, int nseq) {
+__device__ __forceinline__ NtCursor nt_seek(NtPtr P, int q, int nseq, int bn, int bn_hi) {
     NtCursor c;
     c.valid = 0;
     c.q = q;
     c.k0 = c.k_hi = c.lr = 0;
-    for (; q < nseq; ++q) {
-        int lr, lo, hi;
-        nt_part<MULTI, FUSE>(P, q, lr, lo, hi);
-        if (hi > lo) {
-            c.q = q;
-            c.k0 = lo;
-            c.k_hi = hi;
-            c.lr = lr;
-            c.valid = 1;
-            break;
+    c.bn = bn;
+    const int np = FUSE ? P->np : 0;
+    for (;;) {
+        for (; q < nseq; ++q) {
+            int lr, lo, hi;
+            nt_part<MULTI, FUSE>(P, q, lr, lo, hi);
+            if (hi > lo) {
+                c.q = q;
+                c.k0 = lo;
+                c.k_hi = hi;
+                c.lr = lr;
+                c.valid = 1;
+                c.bn = bn;
+                return c;
+            }
         }
+        if (!FUSE || bn + 1 >= bn_hi) break;
+        ++bn;  // next n-tile of the panel: the projection parts are not repeated
+        q = np;
     }
     return c;
 }
@@ -420,19 +430,28 @@ __global__ __launch_bounds__(256, 2) void k_nt(const NtParams Pv) {
 
     // XCD-aware tile order: hardware places block b on XCD b % 8; give every XCD a contiguous run of
     // logical tiles so that the n-tiles sharing one activation row-block hit the same L2 (T1, bijective).
+    // Fused form: a workgroup = (row panel, n-group) and walks the n-tiles of its group itself.
     const int n_tiles = (n_rows + TILE - 1) / TILE;
+    const int G = FUSE ? P->n_groups : n_tiles;
     const int64_t m_tiles = (P->M + TILE - 1) / TILE;
-    const int64_t nwg = m_tiles * n_tiles;
+    const int64_t nwg = m_tiles * G;
     int64_t b = blockIdx.x;
     if (b >= nwg) return;
     {
         const int64_t q = nwg / 8, r = nwg % 8, xcd = b % 8;
         b = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + b / 8;
     }
-    const int64_t bm = b / n_tiles;
-    const int bn = (int)(b % n_tiles);
+    const int64_t bm = b / G;
+    const int grp = (int)(b % G);
+    int bn_lo = grp, bn_hi = grp + 1;
+    if (FUSE) {
+        const int per = (n_tiles + G - 1) / G;
+        bn_lo = grp * per;
+        bn_hi = bn_lo + per < n_tiles ? bn_lo + per : n_tiles;
+        if (bn_lo >= bn_hi) return;
+    }
     const int64_t m0 = bm * TILE;
-    const int n0 = bn * TILE;
+    int n0 = bn_lo * TILE;
 
     const T* wgt = reinterpret_cast<const T*>(P->wgt) + (int64_t)row_off * P->ld_wgt;
     DropoutCfg drop;
@@ -446,16 +465,16 @@ __global__ __launch_bounds__(256, 2) void k_nt(const NtParams Pv) {
 
     // ---- loader side of the stream (register prefetch, one wide tile ahead)
     TileRegs<T> rg;
-    NtCursor ld = nt_seek<MULTI, FUSE>(P, 0, nseq);
+    NtCursor ld = nt_seek<MULTI, FUSE>(P, 0, nseq, bn_lo, bn_hi);
     auto issue = [&](const NtCursor& c) __attribute__((always_inline)) {
         if (FUSE && c.lr == 2)  // fused projection: weights = A_cat rows of source c.q, activation = that source
             nt_load<T, false>(rg, tid, reinterpret_cast<const T*>(P->pA), P->pK, 0, P->pseg_hi[c.q], P->pact[c.q], P, 1,
                               P->pK, m0, P->M, c.k0, c.k_hi, P->pmask[c.q] != 0 && drop.thr16 != 0, P->pseg_lo[c.q]);
         else if (c.lr)  // rank segment: weights = Rm; activation = L, or the LDS P image when the projection is fused
-            nt_load<T, false>(rg, tid, reinterpret_cast<const T*>(P->Rm), P->ldR, n0, n_rows, np > 0 ? nullptr : P->L, P, 1,
+            nt_load<T, false>(rg, tid, reinterpret_cast<const T*>(P->Rm), P->ldR, c.bn * TILE, n_rows, np > 0 ? nullptr : P->L, P, 1,
                               P->ldL, m0, P->M, c.k0, c.k_hi, false);
         else
-            nt_load<T, MS>(rg, tid, wgt, P->ld_wgt, n0, n_rows, act0, P, P->n_act, P->ld_act, m0, P->M, c.k0, c.k_hi, act_mask);
+            nt_load<T, MS>(rg, tid, wgt, P->ld_wgt, c.bn * TILE, n_rows, act0, P, P->n_act, P->ld_act, m0, P->M, c.k0, c.k_hi, act_mask);
     };
     if (ld.valid) issue(ld);
     // consume one tile: registers -> LDS, prefetch the next tile of the stream, multiply
@@ -463,7 +482,7 @@ __global__ __launch_bounds__(256, 2) void k_nt(const NtParams Pv) {
         nt_store_lds<T>(rg, tid, sW, sA, drop, m0, !from_p);
         __syncthreads();
         ld.k0 += KE;
-        if (ld.k0 >= ld.k_hi) ld = nt_seek<MULTI, FUSE>(P, ld.q + 1, nseq);
+        if (ld.k0 >= ld.k_hi) ld = nt_seek<MULTI, FUSE>(P, ld.q + 1, nseq, ld.bn, bn_hi);
         if (ld.valid) issue(ld);
         if (from_p)
             nt_compute<T>(acc, sW, sP + k0 * (int)sizeof(T), lane, wn, wm, k_left, PRS);
@@ -596,11 +615,11 @@ __global__ __launch_bounds__(256, 2) void k_nt(const NtParams Pv) {
                                     v2 = a[sn][sm][q * 4 + 2] * al[2], v3 = a[sn][sm][q * 4 + 3] * al[3];
                         if constexpr (sizeof(T) == 4) {
                             *reinterpret_cast<f32x4*>(sP + ml * PRS + r * 4) = f32x4{v0, v1, v2, v3};
-                            if (pg && bn == 0 && m < P->M) *reinterpret_cast<f32x4*>(pg + m * P->pR + r) = f32x4{v0, v1, v2, v3};
+                            if (pg && grp == 0 && m < P->M) *reinterpret_cast<f32x4*>(pg + m * P->pR + r) = f32x4{v0, v1, v2, v3};
                         } else {
                             const u32x2 pk = {mtl_pack_bf16(v0, v1), mtl_pack_bf16(v2, v3)};
                             *reinterpret_cast<u32x2*>(sP + ml * PRS + r * 2) = pk;
-                            if (pg && bn == 0 && m < P->M) *reinterpret_cast<u32x2*>(pg + m * P->pR + r) = pk;
+                            if (pg && grp == 0 && m < P->M) *reinterpret_cast<u32x2*>(pg + m * P->pR + r) = pk;
                         }
                     }
                 }
@@ -615,24 +634,27 @@ __global__ __launch_bounds__(256, 2) void k_nt(const NtParams Pv) {
             for (int q = 0; q < np; ++q) run_part(q, acc);
             if (np > 0) park_p(acc);
         }
-        zero(base);
-        run_part(np, base);
-        affine(base);
-        for (int o = 0; o < P->n_out; ++o) {
-            const NtOut O = nt_out(P, o);
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = base[i][j];
-            run_part(np + 1 + o, acc);
-            if (O.fold) {
+        for (int bn = bn_lo; bn < bn_hi; ++bn) {
+            n0 = bn * TILE;
+            zero(base);
+            run_part(np, base);
+            affine(base);
+            for (int o = 0; o < P->n_out; ++o) {
+                const NtOut O = nt_out(P, o);
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) base[i][j] = acc[i][j];
+                    for (int j = 0; j < 2; ++j) acc[i][j] = base[i][j];
+                run_part(np + 1 + o, acc);
+                if (O.fold) {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) base[i][j] = acc[i][j];
+                }
+                store(acc, O.ptr);
+                __syncthreads();  // the output image lives in the staging buffers
             }
-            store(acc, O.ptr);
-            __syncthreads();  // the output image lives in the staging buffers
         }
     } else {
         f32x16 acc[2][2];
@@ -641,19 +663,22 @@ __global__ __launch_bounds__(256, 2) void k_nt(const NtParams Pv) {
             for (int q = 0; q < np; ++q) run_part(q, acc);
             if (np > 0) park_p(acc);
         }
-        for (int o = 0; o < P->n_out; ++o) {
-            const NtOut O = nt_out(P, o);
-            zero(acc);
-            const bool had_lr = run_part(np + 2 * o, acc);
-            if constexpr (MLR) {
-                if (had_lr && O.mask_lr && drop.enabled()) apply_mask(acc);
-            } else {
-                (void)had_lr;
+        for (int bn = bn_lo; bn < bn_hi; ++bn) {
+            n0 = bn * TILE;
+            for (int o = 0; o < P->n_out; ++o) {
+                const NtOut O = nt_out(P, o);
+                zero(acc);
+                const bool had_lr = run_part(np + 2 * o, acc);
+                if constexpr (MLR) {
+                    if (had_lr && O.mask_lr && drop.enabled()) apply_mask(acc);
+                } else {
+                    (void)had_lr;
+                }
+                run_part(np + 2 * o + 1, acc);
+                if (O.use_base) affine(acc);
+                store(acc, O.ptr);
+                __syncthreads();  // the output image lives in the staging buffers
             }
-            run_part(np + 2 * o + 1, acc);
-            if (O.use_base) affine(acc);
-            store(acc, O.ptr);
-            __syncthreads();  // the output image lives in the staging buffers
         }
     }
 }
@@ -946,13 +971,13 @@ static void launch_nt(const NtParams& P, hipStream_t s, int kind, double alg_byt
     const int64_t m_tiles = mtl_ceil_div(P.M, TILE);
     const int64_t n_tiles = mtl_ceil_div(max_rows, TILE);
     if (m_tiles * n_tiles == 0) return;
-    dim3 g((unsigned)(m_tiles * n_tiles), 1, (unsigned)(P.nz > 0 ? P.nz : 1));
+    const bool fuse = P.np > 0;
+    dim3 g((unsigned)(m_tiles * (fuse ? P.n_groups : n_tiles)), 1, (unsigned)(P.nz > 0 ? P.nz : 1));
     int base_users = 0;
     for (int o = 0; o < P.n_out; ++o) base_users += P.out[o].use_base ? 1 : 0;
     const size_t lds = (size_t)STAGE_BYTES + (P.np > 0 ? (size_t)TILE * (P.pR * sizeof(T) + 80) : 0);
     // (> 64 KiB of dynamic LDS must be opted into once per kernel)
     const int variant = base_users > 1 ? 0 : (P.n_act > 1 ? 1 : 2);
-    const bool fuse = P.np > 0;
 #define MTL_NT_LAUNCH(MU, MSRC, FU, ML)                                                                          \
     do {                                                                                                       \
         static bool raised = false;                                                                            \
@@ -974,7 +999,9 @@ static void launch_nt(const NtParams& P, hipStream_t s, int kind, double alg_byt
     } else if (variant == 1) {
         MTL_NT_LAUNCH(false, true, false, true);  // multi-source = the dX launch
     } else {
-        if (fuse)
+        if (fuse && mlr)
+            MTL_NT_LAUNCH(false, false, true, true);
+        else if (fuse)
             MTL_NT_LAUNCH(false, false, true, false);
         else if (mlr)
             MTL_NT_LAUNCH(false, false, false, true);
@@ -984,12 +1011,31 @@ static void launch_nt(const NtParams& P, hipStream_t s, int kind, double alg_byt
 #undef MTL_NT_LAUNCH
 }
 
-static bool fuse_p_enabled() {
+// Row-panel ("fused") form, OPT-IN (MTLORA_FUSE_P=1): the workgroup that owns 128 rows forms their low-rank
+// projection itself (P forward, Q backward) into LDS, then walks the n-tiles of the output: no separate P / Q pass,
+// no re-read of X / dY for it, and the tile stream pipelines across n-tiles.  Eligible when (a) the LDS image leaves
+// room for 2 workgroups per CU (R <= 64), (b) there is one output (T = 0: the lean variant) and (c) there are enough
+// row panels to fill the GPU; n_groups > 1 splits a panel's n-tiles over several workgroups (each repeats the
+// projection).  Parity-tested forward and backward (test_linear_fused_projection).  Measured at C2 (10 eligible
+// layers of 48): the P / Q launches it removes are worth 1.06 ms/step, but the fused variants need 256 VGPRs plus
+// 80-96 B of scratch and their forward / dX launches grow by 1.7 ms/step (k_nt 16.98 vs 16.33 ms/step with n_groups
+// = 1, worse with more groups), so the two-pass form stays the default.
+static bool fuse_p_allowed() {
     static const bool on = [] {
         const char* e = getenv("MTLORA_FUSE_P");
         return e && e[0] == '1';
     }();
     return on;
+}
+static int fuse_groups(const mtlora_linear_desc* d, const Segs& sg, int64_t out_cols) {  // 0 = do not fuse
+    if (!fuse_p_allowed() || d->T != 0 || sg.R <= 0 || sg.R > 64) return 0;
+    static const int64_t min_tiles = [] { const char* e = getenv("MTLORA_FUSE_MIN_TILES"); return e ? atoll(e) : 384ll; }();
+    static const int64_t target = [] { const char* e = getenv("MTLORA_FUSE_TARGET"); return e ? atoll(e) : 1536ll; }();
+    const int64_t m_tiles = mtl_ceil_div(d->M, TILE), n_tiles = mtl_ceil_div(out_cols, TILE);
+    if (m_tiles < min_tiles) return 0;
+    int g = 1;
+    while (m_tiles * g < target && g < n_tiles) ++g;
+    return g;
 }
 
 template <typename T>
@@ -1008,6 +1054,7 @@ static int fwd_impl(const mtlora_linear_desc* d, const void* x, const void* cons
     const DropoutCfg dc = mtl_make_dropout(d->dropout_p, d->seed);
     const float keep_scale = dc.enabled() ? 1.f / (1.f - d->dropout_p) : 1.f;
     bool fuse = false;
+    int groups = 0;
 
     if (sg.R > 0) {
         PackParams pp;
@@ -1036,11 +1083,8 @@ static int fwd_impl(const mtlora_linear_desc* d, const void* x, const void* cons
                                alpha);
         }
 
-        // EXPERIMENTAL (MTLORA_FUSE_P=1): form the projection inside the output kernel (LDS-resident P, no P-pass
-        // launch, no P re-read).  Correct (tests/test_gpu_kernels.py::test_linear_fused_projection) but, with the
-        // projection recomputed by every n-tile workgroup, 1.7 ms/step SLOWER than the two-pass form at C2 -- the
-        // serialized extra tile-steps cost more than the saved traffic.  Default: two passes.
-        fuse = fuse_p_enabled() && sg.R <= 128 && mtl_ceil_div(d->N, TILE) <= 6;
+        groups = fuse_groups(d, sg, d->N);
+        fuse = groups > 0;
         if (!fuse) {
             // P = alpha * D(X) A^T  (per source)
             NtParams q = {};
@@ -1110,6 +1154,7 @@ static int fwd_impl(const mtlora_linear_desc* d, const void* x, const void* cons
         m.pR = sg.R;
         m.palpha = alpha;
         m.pout = Pm;
+        m.n_groups = groups;
         m.np = 0;
         if (d->T > 0 && d->has_x_tasks) {
             for (int o = 0; o < sg.n; ++o) {
@@ -1223,7 +1268,8 @@ static int bwd_impl(const mtlora_linear_desc* d, const void* x, const void* cons
     for (int o = 0; o < sg.n; ++o) dyo[o] = (o == 0) ? dy_shared : dy[o];
 
     // Q[:, seg_o] = alpha_o * dY_o B_o   (zero where the output got no gradient)
-    if (sg.R > 0) {
+    const int groups = (dx && dyo[0]) ? fuse_groups(d, sg, d->K) : 0;  // row-panel form: Q is formed inside the dX kernel
+    if (sg.R > 0 && groups == 0) {
         bool any_missing = false;
         for (int o = 0; o < sg.n; ++o)
             if (sg.rp[o] > 0 && !dyo[o]) any_missing = true;
@@ -1275,6 +1321,19 @@ static int bwd_impl(const mtlora_linear_desc* d, const void* x, const void* cons
         O.ptr = dx;
         O.use_base = 1;
         O.mask_lr = 1;
+        if (groups > 0) {  // T == 0: one gradient source, one rank segment
+            m.np = 1;
+            m.pact[0] = dyo[0];
+            m.pseg_lo[0] = 0;
+            m.pseg_hi[0] = sg.R;
+            m.pmask[0] = 0;
+            m.pA = bt_cat;
+            m.pK = (int)d->N;
+            m.pR = sg.R;
+            m.palpha = alpha;
+            m.pout = Qm;
+            m.n_groups = groups;
+        }
         if (d->T > 0 && d->has_x_tasks) {
             O.seg_lo = sg.off[0];
             O.seg_hi = sg.off[0] + sg.rp[0];

@@ -535,42 +535,48 @@ def test_residual_droppath(shared, rdt, ydt):
 
 
 def test_linear_fused_projection():
-    """MTLORA_FUSE_P=1: the experimental LDS-resident projection path of the forward kernel, in a subprocess (the
-    switch is read once per process), against the default two-pass path and the oracle."""
+    """Row-panel form of k_nt (projection P / Q formed inside the output kernel, workgroup loops over its n-tiles):
+    forward AND backward against the two-pass form, in subprocesses (the switches are read once per process).
+    Production enables it only for M >= 49k rows; MTLORA_FUSE_MIN_TILES=1 forces it at test sizes, and
+    MTLORA_FUSE_TARGET selects one workgroup per panel (n-loop, G = 1) or one per n-tile (G = n_tiles)."""
     import os, subprocess, sys
     code = r'''
 import sys, torch
 sys.path.insert(0, %r)
 from mtlora_amd.lora import MTLoRALinear
+from mtlora_amd import functional as Fn
 torch.manual_seed(0)
 dev = torch.device("cuda")
 outs = []
-for (M, K, N, T, xt, dt) in [(777, 96, 288, 0, False, torch.bfloat16), (520, 96, 384, 4, True, torch.bfloat16),
-                             (300, 192, 192, 4, False, torch.float32), (260, 384, 96, 2, True, torch.bfloat16)]:
-    tasks = [f"t{i}" for i in range(T)] or None
-    m = MTLoRALinear(K, N, r={"shared": 64, **{t: 4 for t in (tasks or [])}}, lora_shared_scale=4.0,
-                     lora_task_scale={t: 4.0 for t in (tasks or [])} if tasks else 1.0, lora_dropout=0.1, tasks=tasks).to(dev)
+for (M, K, N, dt, p) in [(777, 96, 288, torch.bfloat16, 0.1), (1000, 96, 384, torch.bfloat16, 0.05), (515, 384, 96, torch.bfloat16, 0.1),
+                        (300, 192, 576, torch.float32, 0.1), (260, 96, 96, torch.float32, 0.0), (129, 768, 200, torch.bfloat16, 0.1)]:
+    m = MTLoRALinear(K, N, r={"shared": 64}, lora_shared_scale=4.0, lora_task_scale=1.0, lora_dropout=p, tasks=None).to(dev)
     g = torch.Generator(device="cuda").manual_seed(M)
     with torch.no_grad():
-        for p in m.parameters():
-            p.copy_(torch.randn(p.shape, device=dev, generator=g) * 0.05)
+        for q in m.parameters():
+            q.copy_(torch.randn(q.shape, device=dev, generator=g) * 0.05)
+    m.linear.weight.requires_grad_(False)
     m.train()
-    x = torch.randn(M, K, device=dev, generator=g).to(dt)
-    xts = {t: torch.randn(M, K, device=dev, generator=g).to(dt) for t in tasks} if (tasks and xt) else None
-    from mtlora_amd import functional as Fn
+    x = torch.randn(M, K, device=dev, generator=g).to(dt).requires_grad_(True)
     Fn._seed_counter = 100
-    y, yt = m(x, xts)
-    outs.append(y.float().cpu())
-    outs += [yt[t].float().cpu() for t in (tasks or [])]
+    y, _ = m(x, None)
+    gy = torch.randn(M, N, device=dev, generator=g).to(dt)
+    y.backward(gy)
+    outs += [y.float().cpu(), x.grad.float().cpu(), m.lora_shared_A.grad.float().cpu(), m.lora_shared_B.grad.float().cpu()]
 torch.save(outs, sys.argv[1])
 ''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     import tempfile
     res = {}
-    for flag in ("0", "1"):
+    for tag, extra in (("two_pass", {"MTLORA_FUSE_P": "0"}),
+                       ("panel_g1", {"MTLORA_FUSE_P": "1", "MTLORA_FUSE_MIN_TILES": "1", "MTLORA_FUSE_TARGET": "1"}),
+                       ("panel_gn", {"MTLORA_FUSE_P": "1", "MTLORA_FUSE_MIN_TILES": "1", "MTLORA_FUSE_TARGET": "1000000"})):
         with tempfile.NamedTemporaryFile(suffix=".pt") as f:
-            env = dict(os.environ, MTLORA_FUSE_P=flag)
-            r = subprocess.run([sys.executable, "-c", code, f.name], env=env, capture_output=True, text=True, timeout=300)
+            r = subprocess.run([sys.executable, "-c", code, f.name], env=dict(os.environ, **extra), capture_output=True,
+                               text=True, timeout=300)
             assert r.returncode == 0, r.stderr[-2000:]
-            res[flag] = torch.load(f.name)
-    for a, b in zip(res["0"], res["1"]):
-        assert ((a - b).abs().max() / a.abs().max()).item() < 2e-2   # same dropout seed, same math, bf16 rounding of P
+            res[tag] = torch.load(f.name)
+    for tag in ("panel_g1", "panel_gn"):
+        for i, (a, b) in enumerate(zip(res["two_pass"], res[tag])):
+            assert torch.isfinite(b).all(), (tag, i)
+            err = ((a - b).abs().max() / a.abs().max().clamp_min(1e-12)).item()
+            assert err < 2e-2, (tag, i, err)   # same dropout seed, same math; bf16 rounding of P / Q differs in order only

@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--img", type=int, default=448)
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fused-loss", action="store_true", help="final upsample + losses through ATen instead of csrc/loss.hip")
     return ap.parse_args()
 
 
@@ -197,7 +198,8 @@ def main():
         torch.manual_seed(1234 + rank)
 
         def step():
-            H.train_step(model, crit, opt, img, tg, clip_grad=5.0, reducer=reducer, amp_dtype=torch.bfloat16)
+            H.train_step(model, crit, opt, img, tg, clip_grad=5.0, reducer=reducer, amp_dtype=torch.bfloat16,
+                         fused_loss=not args.no_fused_loss)
 
         dt = time_steps(step, args.steps, args.warmup, world)
         ips = args.batch * world * args.steps / dt

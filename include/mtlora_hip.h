@@ -196,6 +196,24 @@ int mtlora_residual_droppath_bwd(int n, const void* const* g, void* const* dy, v
                                  int64_t M, int64_t C, int64_t B, int res_dtype, int y_dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Loss end of the train step, fused (callers): replaces the final
+ * F.interpolate(pred, img_size, mode="bilinear") of models/swin_mtl.py:245 TOGETHER WITH the per-task loss of
+ * mtl_loss_schemes.py and their autograd backward.
+ *   kind 0  SoftMaxwithLoss (:22-39): cross entropy over C classes, ignore_index, mean over valid pixels;
+ *           label (B,1,H,W) float class ids; stat[0] = number of valid pixels
+ *   kind 1  NormalsLoss(normalize=True, L1, size_average) (:162-220): label (B,C,H,W), C <= 4;
+ *           stat[0] = sum of the validity mask (label != ignore_index)
+ *   kind 2  BalancedCrossEntropyLoss(size_average) (:42-89): C = 1, label (B,1,H,W);
+ *           stat[0] = w = mean(1 - (label >= 0.5))
+ * low (B,h,w,C) is the channels-last low-resolution prediction, H = scale*h, W = scale*w (integer scale,
+ * align_corners=False).  Writes dlow = d loss / d low (dtype of low) and `mtlora_upsample_loss_partials`
+ * fp32 partial loss values whose sum is the loss.  `stat` is a device pointer (label-only statistics).
+ * ------------------------------------------------------------------------------------------ */
+int64_t mtlora_upsample_loss_partials(int64_t B, int h, int w);
+int mtlora_upsample_loss(int kind, const void* low, const float* label, const float* stat, void* dlow, float* partials,
+                         int64_t B, int h, int w, int C, int scale, int dtype, float ignore_index, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Hardware self-test: writes the lane->element maps of the MFMA / LDS-transpose primitives the
  * kernels rely on into `out` (int32[4096]) so a GPU test can assert them (tests/test_gpu_layouts.py).
  * ------------------------------------------------------------------------------------------ */

@@ -78,6 +78,9 @@ _SIGS = {
                                              c_int64, c_int64, c_int64, c_int, c_int, c_void_p]),
     "mtlora_residual_droppath_bwd": (c_int, [c_int, POINTER(c_void_p), POINTER(c_void_p), c_void_p, c_void_p, c_int64,
                                              c_int64, c_int64, c_int, c_int, c_void_p]),
+    "mtlora_upsample_loss_partials": (c_int64, [c_int64, c_int, c_int]),
+    "mtlora_upsample_loss": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int,
+                                     c_int, c_int, ctypes.c_float, c_void_p]),
     "mtlora_selftest_layouts": (c_int, [c_void_p, c_void_p]),
     "mtlora_prof_begin": (c_int, [c_int]),
     "mtlora_prof_end": (c_int, [POINTER(ProfSummary)]),

@@ -460,3 +460,52 @@ def residual_droppath(res, ys, drop_prob: float, training: bool):
             out.append((rl[0] if shared else rl[k]) + y)
         return out
     return list(ResidualDropPathFn.apply(scale, shared, n, *rl, *ys))
+
+
+# ----------------------------------------------------------------------------------------------
+# loss end of the train step: bilinear upsample (integer scale, align_corners=False) + per-task loss, fused
+# ----------------------------------------------------------------------------------------------
+LOSS_KINDS = {"softmax": 0, "normals": 1, "balanced_bce": 2}
+
+
+class UpsampleLossFn(torch.autograd.Function):
+    """loss_kind( F.interpolate(low.permute(0,3,1,2), scale_factor=scale, mode="bilinear"), label ) as ONE kernel that also
+    produces d loss / d low (csrc/loss.hip); the upsampled prediction never exists.  ``low`` is (B, h, w, C)
+    channels-last (fp32 / bf16), ``label`` (B, 1 | C, scale*h, scale*w)."""
+
+    @staticmethod
+    def forward(ctx, kind: str, low, label, scale: int, ignore_index: float = 255.0):
+        L.require_gpu(low, label)
+        B, h, w, C = low.shape
+        H, W = h * scale, w * scale
+        lab = label.detach().float().contiguous()
+        exp_c = C if kind == "normals" else 1
+        if tuple(lab.shape) != (B, exp_c, H, W):
+            raise RuntimeError(f"mtlora_amd: label shape {tuple(lab.shape)} does not match prediction {(B, exp_c, H, W)}")
+        lo = low.detach().contiguous()
+        if lo.dtype not in (torch.float32, torch.bfloat16):
+            lo = lo.float()
+        # label-only statistics (independent of the prediction)
+        if kind == "softmax":
+            stat = (lab != ignore_index).sum().float().reshape(1)
+        elif kind == "normals":
+            stat = (lab != ignore_index).sum().float().reshape(1)
+        elif kind == "balanced_bce":
+            stat = (1.0 - (lab >= 0.5).float()).mean().reshape(1)
+        else:
+            raise RuntimeError(f"mtlora_amd: unknown fused loss kind {kind!r}")
+        lib = L.lib()
+        n = lib.mtlora_upsample_loss_partials(B, h, w)
+        part = torch.empty(max(n, 1), dtype=torch.float32, device=lo.device)
+        dlow = torch.empty_like(lo)
+        st = lib.mtlora_upsample_loss(LOSS_KINDS[kind], L.ptr(lo), L.ptr(lab), L.ptr(stat), L.ptr(dlow), L.ptr(part), B, h, w,
+                                      C, int(scale), L.dtype_code(lo), float(ignore_index), L.stream_ptr())
+        L.check(st, "mtlora_upsample_loss")
+        ctx.save_for_backward(dlow)
+        ctx.in_dtype = low.dtype
+        return part[:n].sum() if n > 0 else part.sum() * 0
+
+    @staticmethod
+    def backward(ctx, g):
+        (dlow,) = ctx.saved_tensors
+        return None, (dlow * g.to(dlow.dtype)).to(ctx.in_dtype), None, None, None

@@ -19,7 +19,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .functional import BatchNormReluFn
+from .functional import BatchNormReluFn, UpsampleLossFn
 from .lora import mark_only_lora_as_trainable
 from .swin_transformer_mtlora import SwinTransformerMTLoRA
 
@@ -81,7 +81,7 @@ class HighResolutionHead(nn.Module):
         self.last_layer = nn.Sequential(nn.Conv2d(c, 4 * c, 1), nn.BatchNorm2d(4 * c, momentum=0.1),
                                         nn.ReLU(inplace=False), nn.Conv2d(4 * c, num_outputs, 1))
 
-    def forward(self, x):
+    def forward(self, x, channels_last_out: bool = False):
         B, _, Hh, Ww = x[0].shape
         cat = torch.cat([x[0]] + [F.interpolate(m, (Hh, Ww), mode="bilinear") for m in x[1:]], 1)
         c0, bn, _, c3 = self.last_layer
@@ -95,8 +95,8 @@ class HighResolutionHead(nn.Module):
         else:
             h = F.relu(F.batch_norm(h, bn.running_mean, bn.running_var, bn.weight, bn.bias,
                                     bn.training or not bn.track_running_stats, bn.momentum, bn.eps))
-        o = F.linear(h, c3.weight.view(c3.out_channels, c3.in_channels), c3.bias)
-        return o.view(B, Hh, Ww, c3.out_channels).permute(0, 3, 1, 2)
+        o = F.linear(h, c3.weight.view(c3.out_channels, c3.in_channels), c3.bias).view(B, Hh, Ww, c3.out_channels)
+        return o if channels_last_out else o.permute(0, 3, 1, 2)
 
 
 class DecoderGroup(nn.Module):
@@ -105,7 +105,11 @@ class DecoderGroup(nn.Module):
         self.tasks, self.out_size = tasks, out_size
         self.decoders = nn.ModuleDict({t: HighResolutionHead(channels, num_outputs[t]) for t in tasks})
 
-    def forward(self, x):
+    def forward(self, x, upsample: bool = True):
+        """upsample=False: the low-resolution (B, h, w, C) predictions, for ``MultiTaskLoss.forward_low`` (the final
+        bilinear upsample is fused into the loss kernels and never materialised)."""
+        if not upsample:
+            return {t: self.decoders[t](x[t], channels_last_out=True) for t in self.tasks}
         return {t: F.interpolate(self.decoders[t](x[t]), self.out_size, mode="bilinear") for t in self.tasks}
 
 
@@ -126,10 +130,10 @@ class MultiTaskSwin(nn.Module):
         self.downsampler = nn.ModuleDict({t: Downsampler(self.dims, decoder_channels, self.input_res) for t in self.tasks})
         self.decoders = DecoderGroup(self.tasks, num_outputs, decoder_channels, self.img_size)
 
-    def forward(self, x):
+    def forward(self, x, upsample: bool = True):
         stages = self.backbone(x, return_stages=True)
         feats = {t: self.downsampler[t]([tl[t] for _, tl in stages]) for t in self.tasks}
-        return self.decoders(feats)
+        return self.decoders(feats, upsample=upsample)
 
 
 # --------------------------------------------------------------------------------------------------
@@ -165,6 +169,26 @@ class MultiTaskLoss(nn.Module):
 
     def forward(self, pred, gt):
         per = {t: task_loss(t, pred[t], gt[t]) for t in self.tasks}
+        total = torch.stack([self.loss_weights[t] * per[t] for t in self.tasks]).sum()
+        per["total"] = total
+        return total, per
+
+    FUSED_KIND = {"semseg": "softmax", "human_parts": "softmax", "normals": "normals", "sal": "balanced_bce"}
+
+    def forward_low(self, low, gt):
+        """same value and gradients as ``forward(upsampled prediction, gt)`` from the LOW-resolution (B, h, w, C)
+        predictions of ``model(x, upsample=False)``: bilinear upsample + loss + backward fused (csrc/loss.hip).
+        Tasks without a fused kernel (depth, edge) and non-integer scales take the plain path."""
+        per = {}
+        for t in self.tasks:
+            lo, lab = low[t], gt[t]
+            h, w = lo.shape[1:3]
+            H, W = lab.shape[-2:]
+            kind = self.FUSED_KIND.get(t)
+            if kind is not None and lo.is_cuda and H % h == 0 and W % w == 0 and H // h == W // w:
+                per[t] = UpsampleLossFn.apply(kind, lo, lab, H // h)
+            else:
+                per[t] = task_loss(t, F.interpolate(lo.permute(0, 3, 1, 2), (H, W), mode="bilinear"), lab)
         total = torch.stack([self.loss_weights[t] * per[t] for t in self.tasks]).sum()
         per["total"] = total
         return total, per
@@ -237,17 +261,20 @@ def synthetic_batch(B: int, S: int, tasks: Sequence[str], seed: int, device="cpu
 
 
 def train_step(model, criterion, optimizer, images, targets, clip_grad: float = 5.0, reducer=None,
-               amp_dtype: Optional[torch.dtype] = torch.bfloat16):
+               amp_dtype: Optional[torch.dtype] = torch.bfloat16, fused_loss: bool = True):
     """one reference train step (main.py:329-354): autocast fwd + weighted multi-task loss, backward,
     [gradient all-reduce], clip_grad_norm_(5.0), AdamW, zero_grad.  bf16 autocast needs no GradScaler
     (the reference's scaler exists for its fp16 default)."""
+    def fwd():
+        if fused_loss:  # final upsample + losses (+ their backward) as one kernel per task
+            return criterion.forward_low(model(images, upsample=False), targets)
+        return criterion(model(images), targets)
+
     if amp_dtype is not None:
         with torch.autocast("cuda", dtype=amp_dtype):
-            out = model(images)
-            loss, per = criterion(out, targets)
+            loss, per = fwd()
     else:
-        out = model(images)
-        loss, per = criterion(out, targets)
+        loss, per = fwd()
     if reducer is not None:
         reducer.prepare()
     loss.backward()

@@ -580,3 +580,69 @@ torch.save(outs, sys.argv[1])
             assert torch.isfinite(b).all(), (tag, i)
             err = ((a - b).abs().max() / a.abs().max().clamp_min(1e-12)).item()
             assert err < 2e-2, (tag, i, err)   # same dropout seed, same math; bf16 rounding of P / Q differs in order only
+
+
+# ------------------------------------------------------------------------------------------------
+# fused bilinear upsample + loss (+ backward)
+# ------------------------------------------------------------------------------------------------
+def _loss_case(task, B, h, w, S, seed):
+    g = torch.Generator().manual_seed(seed)
+    C = O.NUM_OUTPUT[task]
+    low = torch.randn(B, h, w, C, generator=g) * 2.0
+    H, W = h * S, w * S
+    if task in ("semseg", "human_parts"):
+        lab = torch.randint(0, C, (B, 1, H, W), generator=g).float()
+        lab[torch.rand(B, 1, H, W, generator=g) < 0.07] = 255.0
+    elif task == "normals":
+        lab = torch.nn.functional.normalize(torch.randn(B, 3, H, W, generator=g), dim=1)
+        lab[torch.rand(B, 3, H, W, generator=g) < 0.05] = 255.0
+    else:
+        lab = (torch.rand(B, 1, H, W, generator=g) < 0.3).float()
+    return low, lab
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("task,B,h,w,S", [("semseg", 2, 20, 20, 4), ("human_parts", 3, 18, 33, 4), ("normals", 2, 37, 16, 4),
+                                          ("sal", 2, 16, 16, 4), ("semseg", 1, 7, 9, 2), ("sal", 2, 5, 40, 3),
+                                          ("normals", 1, 16, 16, 1)])
+def test_upsample_loss_vs_oracle(task, B, h, w, S, dtype):
+    """value and gradient of loss(interpolate(low)) against the oracle's task_loss on torch's own bilinear upsample
+    (fp64 on the CPU), incl. partial 16x16 tiles, h != w, borders, ignore_index pixels and scales 1..4."""
+    from mtlora_amd import functional as Fn
+    from mtlora_amd.mtl_harness import MultiTaskLoss
+    low, lab = _loss_case(task, B, h, w, S, seed=h * 100 + w)
+    low_q = low.to(dtype)
+    ref_in = low_q.double().requires_grad_(True)
+    up = torch.nn.functional.interpolate(ref_in.permute(0, 3, 1, 2), scale_factor=S, mode="bilinear")
+    ref = O.task_loss(task, up, lab.double())
+    ref.backward()
+    x = low_q.to(dev()).requires_grad_(True)
+    got = Fn.UpsampleLossFn.apply(MultiTaskLoss.FUSED_KIND[task], x, lab.to(dev()), S)
+    (got * 3.0).backward()
+    tol = 2e-5 if dtype == torch.float32 else 1e-2
+    assert abs(got.item() - ref.item()) <= tol * max(1.0, abs(ref.item())), (got.item(), ref.item())
+    e = rel_err(x.grad.float() / 3.0, ref_in.grad)
+    assert e <= (1e-4 if dtype == torch.float32 else 1e-2), e
+
+
+def test_fused_loss_path_equals_plain_path():
+    """MultiTaskLoss.forward_low(low) == MultiTaskLoss.forward(F.interpolate(low)) (value and gradient) on the GPU."""
+    from mtlora_amd.mtl_harness import MultiTaskLoss
+    tasks = ["semseg", "normals", "sal", "human_parts"]
+    crit = MultiTaskLoss(tasks)
+    low, gt = {}, {}
+    for i, t in enumerate(tasks):
+        lo, lab = _loss_case(t, 2, 24, 24, 4, seed=i)
+        low[t], gt[t] = lo.to(dev()).requires_grad_(True), lab.to(dev())
+    total, per = crit.forward_low(low, gt)
+    total.backward()
+    g_fused = {t: low[t].grad.clone() for t in tasks}
+    for t in tasks:
+        low[t].grad = None
+    pred = {t: torch.nn.functional.interpolate(low[t].permute(0, 3, 1, 2), scale_factor=4, mode="bilinear") for t in tasks}
+    total2, per2 = crit(pred, gt)
+    total2.backward()
+    assert abs(total.item() - total2.item()) <= 1e-4 * abs(total2.item())
+    for t in tasks:
+        assert abs(per[t].item() - per2[t].item()) <= 1e-4 * max(1.0, abs(per2[t].item())), t
+        assert rel_err(g_fused[t], low[t].grad) <= 1e-4, t

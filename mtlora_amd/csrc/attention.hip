@@ -56,16 +56,40 @@ struct AttnParams {
     float scale;
 };
 
-__device__ __forceinline__ int64_t token_index(const AttnParams& p, int64_t w, int t) {
-    if (!p.image_layout) return w * p.N + t;
-    const int wx = (int)(w % p.nWx);
-    const int64_t r = w / p.nWx;
-    const int wy = (int)(r % p.nWy);
-    const int64_t b = r / p.nWy;
-    const int ty = t / p.ws, tx = t - ty * p.ws;
-    const int y = (wy * p.ws + ty + p.shift) % p.H;
-    const int x = (wx * p.ws + tx + p.shift) % p.W;
-    return (b * p.H + y) * p.W + x;
+// Token addressing without per-token divisions.  A window id is decomposed ONCE per window (wave-uniform, 32-bit);
+// a token's (ty, tx) inside the window is a per-lane constant computed before the persistent loop; the cyclic shift
+// wraps with one conditional subtract (wy*ws + ty + shift < H + ws).  [64-bit div / mod per token per window was
+// ~800 instructions a call.]
+struct WinPos {
+    int64_t base;  // windows layout: first token of the window; image layout: b * H * W
+    int y0, x0;    // image layout: wy*ws + shift, wx*ws + shift
+};
+__device__ __forceinline__ WinPos win_pos(const AttnParams& p, int64_t w) {
+    WinPos q;
+    if (!p.image_layout) {
+        q.base = w * p.N;
+        q.y0 = q.x0 = 0;
+        return q;
+    }
+    const uint32_t wu = (uint32_t)w;  // n_windows < 2^31 (checked by the host)
+    const uint32_t wx = wu % (uint32_t)p.nWx, r = wu / (uint32_t)p.nWx;
+    const uint32_t wy = r % (uint32_t)p.nWy, b = r / (uint32_t)p.nWy;
+    q.base = (int64_t)b * p.H * p.W;
+    q.y0 = (int)wy * p.ws + p.shift;
+    q.x0 = (int)wx * p.ws + p.shift;
+    return q;
+}
+// t = ty * ws + tx  (tyx packs ty << 8 | tx; t itself is kept for the windows layout)
+__device__ __forceinline__ int pack_tyx(const AttnParams& p, int t) {
+    const int ty = t / p.ws;
+    return (ty << 8) | (t - ty * p.ws);
+}
+__device__ __forceinline__ int64_t token_at(const AttnParams& p, const WinPos& q, int t, int tyx) {
+    if (!p.image_layout) return q.base + t;
+    int y = q.y0 + (tyx >> 8), x = q.x0 + (tyx & 255);
+    y = y >= p.H ? y - p.H : y;
+    x = x >= p.W ? x - p.W : x;
+    return q.base + (int64_t)y * p.W + x;
 }
 
 // The LDS image of a (window, head) operand holds its N token rows plus ONE shared zero row (index N): every
@@ -89,6 +113,55 @@ __device__ __forceinline__ void stage_rows(unsigned char* s, const T* base, int6
             if (row < n) v = *reinterpret_cast<const u32x4*>(base + (int64_t)tok[row] * stride + vec * VEC);
             *reinterpret_cast<u32x4*>(s + row * RS + vec * 16) = v;
         }
+    }
+}
+
+// the same copy split in two, for the software pipeline of the persistent kernels: the next window's rows are loaded
+// into registers while the current window is being multiplied, and written to the images at the next iteration
+template <typename T>
+struct RowRegs {
+    u32x4 v[AC<T>::VPR];
+};
+template <typename T>
+struct RowIds {
+    int t[AC<T>::VPR], tyx[AC<T>::VPR];  // token (row) this lane copies in iteration it, -1 = none
+};
+template <typename T>
+__device__ __forceinline__ RowIds<T> row_ids(const AttnParams& p, int lane) {
+    RowIds<T> r;
+#pragma unroll
+    for (int it = 0; it < AC<T>::VPR; ++it) {
+        const int row = (it * 64 + lane) / AC<T>::VPR;
+        r.t[it] = row < p.N ? row : -1;
+        r.tyx[it] = row < p.N ? pack_tyx(p, row) : 0;
+    }
+    return r;
+}
+template <typename T>
+__device__ __forceinline__ void row_offsets(int64_t (&off)[AC<T>::VPR], const AttnParams& p, const WinPos& q,
+                                            const RowIds<T>& ids) {
+#pragma unroll
+    for (int it = 0; it < AC<T>::VPR; ++it) off[it] = ids.t[it] >= 0 ? token_at(p, q, ids.t[it], ids.tyx[it]) : -1;
+}
+template <typename T>
+__device__ __forceinline__ void load_rows(RowRegs<T>& r, const T* base, int64_t stride, const int64_t (&off)[AC<T>::VPR],
+                                          int lane) {
+    constexpr int VPR = AC<T>::VPR, VEC = ET<T>::VEC;
+#pragma unroll
+    for (int it = 0; it < VPR; ++it) {
+        const int vec = (it * 64 + lane) % VPR;
+        r.v[it] = off[it] >= 0 ? *reinterpret_cast<const u32x4*>(base + off[it] * stride + vec * VEC) : u32x4{0u, 0u, 0u, 0u};
+    }
+}
+template <typename T>
+__device__ __forceinline__ void store_rows(unsigned char* s, const RowRegs<T>& r, int n, int lane) {
+    constexpr int VPR = AC<T>::VPR, RS = AC<T>::RS;
+    const int rows = img_rows(n);
+#pragma unroll
+    for (int it = 0; it < VPR; ++it) {
+        const int idx = it * 64 + lane;
+        const int row = idx / VPR, vec = idx % VPR;
+        if (row < rows) *reinterpret_cast<u32x4*>(s + row * RS + vec * 16) = r.v[it];
     }
 }
 
@@ -291,17 +364,28 @@ __global__ __launch_bounds__(64) void k_attn_fwd(const AttnParams p) {
     T* out = reinterpret_cast<T*>(p.out);
     const int64_t C3 = 3 * (int64_t)p.C;
     stage_bias(sBias, p.bias, head, p.N, lane);
+    const RowIds<T> ids = row_ids<T>(p, lane);
+    const int lane_tyx = pack_tyx(p, lane < p.N ? lane : 0);
+    RowRegs<T> rq, rk, rv;
+    auto prefetch = [&](int64_t w) __attribute__((always_inline)) {
+        int64_t off[AC<T>::VPR];
+        row_offsets<T>(off, p, win_pos(p, w), ids);
+        load_rows<T>(rq, qkv + head * HD, C3, off, lane);
+        load_rows<T>(rk, qkv + p.C + head * HD, C3, off, lane);
+        load_rows<T>(rv, qkv + 2 * p.C + head * HD, C3, off, lane);
+    };
+    if (g < p.n_windows) prefetch(g);
 
     for (int64_t w = g; w < p.n_windows; w += p.G) {
         const int wm = (int)(w % nWimg);
         __syncthreads();  // previous item's LDS reads are done
-        tok[lane] = lane < p.N ? (int)token_index(p, w, lane) : 0;
+        tok[lane] = lane < p.N ? (int)token_at(p, win_pos(p, w), lane, lane_tyx) : 0;
         if (p.mask_ids) srid[lane] = lane < p.N ? p.mask_ids[wm * p.N + lane] : 0;
+        store_rows<T>(sQ, rq, p.N, lane);
+        store_rows<T>(sK, rk, p.N, lane);
+        store_rows<T>(sV, rv, p.N, lane);
         __syncthreads();
-        stage_rows<T>(sQ, qkv + head * HD, C3, tok, p.N, lane);
-        stage_rows<T>(sK, qkv + p.C + head * HD, C3, tok, p.N, lane);
-        stage_rows<T>(sV, qkv + 2 * p.C + head * HD, C3, tok, p.N, lane);
-        __syncthreads();
+        if (w + p.G < p.n_windows) prefetch(w + p.G);  // next window's rows fly while this one is multiplied
 #pragma unroll 1
         for (int si = 0; si < 2; ++si) {
             if (si * 32 >= p.N) break;
@@ -323,8 +407,10 @@ __global__ __launch_bounds__(64) void k_attn_fwd(const AttnParams p) {
     }
 }
 
+// One wave per workgroup and (LDS-limited) one workgroup per SIMD: the whole 512-entry register file is this wave's,
+// so the next window's Q / K / V / dO rows are prefetched into registers while the current window is multiplied.
 template <typename T>
-__global__ __launch_bounds__(64) void k_attn_bwd(const AttnParams p) {
+__global__ __launch_bounds__(64, 1) void k_attn_bwd(const AttnParams p) {
     constexpr int RS = AC<T>::RS;
     // Q, K, V, dO images + token table + row stats (m, 1/l, D) + dbias accumulator [N][64]
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -354,17 +440,29 @@ __global__ __launch_bounds__(64) void k_attn_bwd(const AttnParams p) {
     stage_bias(sBias, p.bias, head, p.N, lane);
     for (int idx = lane; idx < p.N * DBS; idx += 64) sDB[idx] = 0.f;
 
+    const RowIds<T> ids = row_ids<T>(p, lane);
+    const int lane_tyx = pack_tyx(p, lane < p.N ? lane : 0);
+    RowRegs<T> rq, rk, rv, ro;
+    auto prefetch = [&](int64_t w) __attribute__((always_inline)) {
+        int64_t off[AC<T>::VPR];
+        row_offsets<T>(off, p, win_pos(p, w), ids);
+        load_rows<T>(rq, qkv + head * HD, C3, off, lane);
+        load_rows<T>(rk, qkv + p.C + head * HD, C3, off, lane);
+        load_rows<T>(rv, qkv + 2 * p.C + head * HD, C3, off, lane);
+        load_rows<T>(ro, dout + head * HD, (int64_t)p.C, off, lane);
+    };
+    if (g < p.n_windows) prefetch(g);
     for (int64_t w = g; w < p.n_windows; w += p.G) {
         const int wm = (int)(w % nWimg);
         __syncthreads();
-        tok[lane] = lane < p.N ? (int)token_index(p, w, lane) : 0;
+        tok[lane] = lane < p.N ? (int)token_at(p, win_pos(p, w), lane, lane_tyx) : 0;
         if (p.mask_ids) srid[lane] = lane < p.N ? p.mask_ids[wm * p.N + lane] : 0;
+        store_rows<T>(sQ, rq, p.N, lane);
+        store_rows<T>(sK, rk, p.N, lane);
+        store_rows<T>(sV, rv, p.N, lane);
+        store_rows<T>(sO, ro, p.N, lane);
         __syncthreads();
-        stage_rows<T>(sQ, qkv + head * HD, C3, tok, p.N, lane);
-        stage_rows<T>(sK, qkv + p.C + head * HD, C3, tok, p.N, lane);
-        stage_rows<T>(sV, qkv + 2 * p.C + head * HD, C3, tok, p.N, lane);
-        stage_rows<T>(sO, dout + head * HD, (int64_t)p.C, tok, p.N, lane);
-        __syncthreads();
+        if (w + p.G < p.n_windows) prefetch(w + p.G);
 
         // ---- pass 1: query-owned ------------------------------------------------------------
 #pragma unroll 1

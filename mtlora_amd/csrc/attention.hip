@@ -271,7 +271,7 @@ __device__ __forceinline__ void stage_bias(float* sBias, const float* bias, int 
 }
 
 // scores for query half `si` in the query-owned orientation: st[sj][r] = S^T[key][query]
-template <typename T>
+template <typename T, bool DENSE>
 __device__ __forceinline__ void scores_t(f32x16 (&st)[2], const unsigned char* sK, const unsigned char* sQ, int si,
                                          const AttnParams& p, const float* sBias, const int* srid, int wm, int lane) {
     zero(st[0]);
@@ -285,31 +285,33 @@ __device__ __forceinline__ void scores_t(f32x16 (&st)[2], const unsigned char* s
             mtl_mma(fk, fq, st[sj]);
         }
     }
+    // bias + mask, branch-free: clamped indices + selects, so the 32 LDS reads of a lane are issued back to back
+    // (per-element branches made every read its own wait -- the kernel spent its time in exposed LDS latency)
     const int i = si * 32 + (lane & 31);
     const bool iv = i < p.N;
-    const int bs = bias_stride(p.N);
-    const int rid_i = (p.mask_ids && iv) ? srid[i] : 0;
-    const float* mg = (p.mask && !p.mask_ids) ? p.mask + (int64_t)wm * p.N * p.N : nullptr;
+    const int ic = iv ? i : p.N - 1;
+    const float* brow = sBias + ic * bias_stride(p.N);
+    const int rid_i = srid[ic];  // 0 everywhere when there is no region-id mask
+    const bool use_ids = p.mask_ids != nullptr;
+    const float* mrow = DENSE ? p.mask + ((int64_t)wm * p.N + ic) * p.N : nullptr;  // dense additive mask: slow path
+    const int h4 = 4 * (lane >> 5);
 #pragma unroll
-    for (int sj = 0; sj < 2; ++sj)
+    for (int sj = 0; sj < 2; ++sj) {
+        __builtin_amdgcn_sched_barrier(0);  // 16 elements' LDS reads in flight at a time, not 64 (register pressure)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int j = sj * 32 + mtl_d_row(lane, r);
-            float v = st[sj][r] * p.scale;
-            if (j < p.N) {
-                if (iv) {
-                    v += sBias[i * bs + j];
-                    if (p.mask_ids) {
-                        if (srid[j] != rid_i) v += p.mask_value;
-                    } else if (mg) {
-                        v += mg[i * p.N + j];
-                    }
-                }
-            } else {
-                v = NEG_BIG;
-            }
-            st[sj][r] = v;
+            const int j = sj * 32 + (r & 3) + 8 * (r >> 2) + h4;
+            const int jc = j < p.N ? j : p.N - 1;
+            float add = brow[jc];
+            if constexpr (DENSE)
+                add += mrow[jc];
+            else if (use_ids)
+                add += srid[jc] != rid_i ? p.mask_value : 0.f;
+            const float v = st[sj][r] * p.scale + (iv ? add : 0.f);
+            st[sj][r] = j < p.N ? v : NEG_BIG;
         }
+    }
+    __builtin_amdgcn_sched_barrier(0);
 }
 
 // in-place softmax over the 64 keys of a query column (32 in this lane, 32 in lane^32)
@@ -344,8 +346,8 @@ __device__ __forceinline__ int64_t xcd_remap(int64_t b, int64_t n) {
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + b / 8;
 }
 
-template <typename T>
-__global__ __launch_bounds__(64) void k_attn_fwd(const AttnParams p) {
+template <typename T, bool DENSE>
+__global__ __launch_bounds__(64, 2) void k_attn_fwd(const AttnParams p) {
     constexpr int RS = AC<T>::RS;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int IB = ((img_rows(p.N) * RS + 15) / 16) * 16;  // bytes per image
@@ -380,7 +382,7 @@ __global__ __launch_bounds__(64) void k_attn_fwd(const AttnParams p) {
         const int wm = (int)(w % nWimg);
         __syncthreads();  // previous item's LDS reads are done
         tok[lane] = lane < p.N ? (int)token_at(p, win_pos(p, w), lane, lane_tyx) : 0;
-        if (p.mask_ids) srid[lane] = lane < p.N ? p.mask_ids[wm * p.N + lane] : 0;
+        srid[lane] = (p.mask_ids && lane < p.N) ? p.mask_ids[wm * p.N + lane] : 0;
         store_rows<T>(sQ, rq, p.N, lane);
         store_rows<T>(sK, rk, p.N, lane);
         store_rows<T>(sV, rv, p.N, lane);
@@ -390,7 +392,7 @@ __global__ __launch_bounds__(64) void k_attn_fwd(const AttnParams p) {
         for (int si = 0; si < 2; ++si) {
             if (si * 32 >= p.N) break;
             f32x16 st[2];
-            scores_t<T>(st, sK, sQ, si, p, sBias, srid, wm, lane);
+            scores_t<T, DENSE>(st, sK, sQ, si, p, sBias, srid, wm, lane);
             float m, inv_l;
             softmax_t(st, m, inv_l);
             f32x16 o;
@@ -409,24 +411,20 @@ __global__ __launch_bounds__(64) void k_attn_fwd(const AttnParams p) {
 
 // One wave per workgroup and (LDS-limited) one workgroup per SIMD: the whole 512-entry register file is this wave's,
 // so the next window's Q / K / V / dO rows are prefetched into registers while the current window is multiplied.
-template <typename T>
+template <typename T, bool DENSE>
 __global__ __launch_bounds__(64, 1) void k_attn_bwd(const AttnParams p) {
     constexpr int RS = AC<T>::RS;
-    // Q, K, V, dO images + token table + row stats (m, 1/l, D) + dbias accumulator [N][64]
+    // Q, K, V, dO images + token table + region ids + row stats {m, 1/l, D, region id} + bias[head]
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int IB = ((img_rows(p.N) * RS + 15) / 16) * 16;  // bytes per image
-    const int DBS = p.N + 1;                                 // dbias accumulator row stride
     unsigned char* sQ = smem;
     unsigned char* sK = smem + IB;
     unsigned char* sV = smem + 2 * IB;
     unsigned char* sO = smem + 3 * IB;
-    int* tok = reinterpret_cast<int*>(smem + 4 * IB);
+    f32x4* sst = reinterpret_cast<f32x4*>(smem + 4 * IB);  // [AN], 16-byte aligned (IB is)
+    int* tok = reinterpret_cast<int*>(sst + AN);
     int* srid = tok + AN;
-    float* st_m = reinterpret_cast<float*>(srid + AN);
-    float* st_il = st_m + AN;
-    float* st_D = st_il + AN;
-    float* sDB = st_D + AN;             // [N][N + 1]
-    float* sBias = sDB + p.N * DBS;     // [N][bias_stride(N)]
+    float* sBias = reinterpret_cast<float*>(srid + AN);  // [N][bias_stride(N)]
     const int lane = threadIdx.x;
     const int64_t L = xcd_remap(blockIdx.x, gridDim.x);
     const int head = (int)(L % p.nH);
@@ -438,7 +436,15 @@ __global__ __launch_bounds__(64, 1) void k_attn_bwd(const AttnParams p) {
     const int64_t C3 = 3 * (int64_t)p.C;
     const int bs = bias_stride(p.N);
     stage_bias(sBias, p.bias, head, p.N, lane);
-    for (int idx = lane; idx < p.N * DBS; idx += 64) sDB[idx] = 0.f;
+    // dbias accumulator in REGISTERS: element (sj, r) of lane l is always (key j = 32 sj + row(l, r), query i = 32 si + l % 32),
+    // the same pair for every window this wave visits
+    f32x16 dbacc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) zero(dbacc[a][b]);
+    const bool use_ids = p.mask_ids != nullptr;
+    const int h4 = 4 * (lane >> 5);
 
     const RowIds<T> ids = row_ids<T>(p, lane);
     const int lane_tyx = pack_tyx(p, lane < p.N ? lane : 0);
@@ -456,7 +462,7 @@ __global__ __launch_bounds__(64, 1) void k_attn_bwd(const AttnParams p) {
         const int wm = (int)(w % nWimg);
         __syncthreads();
         tok[lane] = lane < p.N ? (int)token_at(p, win_pos(p, w), lane, lane_tyx) : 0;
-        if (p.mask_ids) srid[lane] = lane < p.N ? p.mask_ids[wm * p.N + lane] : 0;
+        srid[lane] = (p.mask_ids && lane < p.N) ? p.mask_ids[wm * p.N + lane] : 0;
         store_rows<T>(sQ, rq, p.N, lane);
         store_rows<T>(sK, rk, p.N, lane);
         store_rows<T>(sV, rv, p.N, lane);
@@ -465,11 +471,11 @@ __global__ __launch_bounds__(64, 1) void k_attn_bwd(const AttnParams p) {
         if (w + p.G < p.n_windows) prefetch(w + p.G);
 
         // ---- pass 1: query-owned ------------------------------------------------------------
-#pragma unroll 1
+#pragma unroll
         for (int si = 0; si < 2; ++si) {
             if (si * 32 >= p.N) break;
             f32x16 pt[2];
-            scores_t<T>(pt, sK, sQ, si, p, sBias, srid, wm, lane);
+            scores_t<T, DENSE>(pt, sK, sQ, si, p, sBias, srid, wm, lane);
             float m, inv_l;
             softmax_t(pt, m, inv_l);
             // dP^T[j][i] = sum_d V[j][d] dO[i][d]
@@ -492,20 +498,15 @@ __global__ __launch_bounds__(64, 1) void k_attn_bwd(const AttnParams p) {
                 for (int r = 0; r < 16; ++r) D += pt[sj][r] * dp[sj][r];
             D += __shfl_xor(D, 32);
             const int i = si * 32 + (lane & 31);
-            if (lane < 32) {
-                st_m[i] = m;
-                st_il[i] = inv_l;
-                st_D[i] = D;
-            }
-            // dS^T in place of dp; accumulate dbias
+            if (lane < 32) sst[i] = f32x4{m, inv_l, D, __int_as_float(srid[i < p.N ? i : p.N - 1])};
+            // dS^T in place of dp; dbias accumulates in registers (padded keys have P = 0, padded queries are never written)
 #pragma unroll
             for (int sj = 0; sj < 2; ++sj)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const float ds = pt[sj][r] * (dp[sj][r] - D);
                     dp[sj][r] = ds;
-                    const int j = sj * 32 + mtl_d_row(lane, r);
-                    if (j < p.N && i < p.N) sDB[j * DBS + i] += ds;
+                    dbacc[si][sj][r] += ds;
                 }
             // dQ^T[d][i] = scale * sum_j K[j][d] dS^T[j][i]
             f32x16 dq;
@@ -543,27 +544,33 @@ __global__ __launch_bounds__(64, 1) void k_attn_bwd(const AttnParams p) {
                     mtl_mma(fo, fv, dp[si]);
                 }
             }
-            const float* mn = (p.mask && !p.mask_ids) ? p.mask + (int64_t)wm * p.N * p.N : nullptr;
-            const int rid_j = (p.mask_ids && jv) ? srid[j] : 0;
+            // recompute P and dS in the key-owned orientation, branch-free (clamped indices, one 16-byte stats read per
+            // query row, selects at the end)
+            const int jc = jv ? j : p.N - 1;
+            const int rid_j = srid[jc];
+            const int bs = bias_stride(p.N);
+            const float* mn = DENSE ? p.mask + (int64_t)wm * p.N * p.N + jc : nullptr;
 #pragma unroll
-            for (int si = 0; si < 2; ++si)
+            for (int si = 0; si < 2; ++si) {
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int i = si * 32 + mtl_d_row(lane, r);
-                    float pv = 0.f, ds = 0.f;
-                    if (i < p.N && jv) {
-                        float s = pp[si][r] * p.scale + sBias[i * bs + j];
-                        if (p.mask_ids) {
-                            if (srid[i] != rid_j) s += p.mask_value;
-                        } else if (mn) {
-                            s += mn[i * p.N + j];
-                        }
-                        pv = __expf(s - st_m[i]) * st_il[i];
-                        ds = pv * (dp[si][r] - st_D[i]);
-                    }
-                    pp[si][r] = pv;
-                    dp[si][r] = ds;
+                    const int i = si * 32 + (r & 3) + 8 * (r >> 2) + h4;
+                    const int ic = i < p.N ? i : p.N - 1;
+                    const f32x4 sv = sst[ic];
+                    float sc = pp[si][r] * p.scale + sBias[ic * bs + jc];
+                    if constexpr (DENSE)
+                        sc += mn[ic * p.N];
+                    else if (use_ids)
+                        sc += __float_as_int(sv[3]) != rid_j ? p.mask_value : 0.f;
+                    const float pv = __expf(sc - sv[0]) * sv[1];
+                    const float ds = pv * (dp[si][r] - sv[2]);
+                    const bool ok = i < p.N && jv;
+                    pp[si][r] = ok ? pv : 0.f;
+                    dp[si][r] = ok ? ds : 0.f;
                 }
+            }
+            __builtin_amdgcn_sched_barrier(0);
             f32x16 dk, dv;
             zero(dk);
             zero(dv);
@@ -582,12 +589,16 @@ __global__ __launch_bounds__(64, 1) void k_attn_bwd(const AttnParams p) {
             }
         }
     }
-    __syncthreads();
-    float* dst = p.dbias_part + ((int64_t)g * p.nH + head) * p.N * p.N;
-    for (int idx = lane; idx < p.N * p.N; idx += 64) {
-        const int j = idx / p.N, i = idx % p.N;
-        dst[idx] = sDB[j * DBS + i];
-    }
+    float* dst = p.dbias_part + ((int64_t)g * p.nH + head) * p.N * p.N;  // [j][i]
+#pragma unroll
+    for (int si = 0; si < 2; ++si)
+#pragma unroll
+        for (int sj = 0; sj < 2; ++sj)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int i = si * 32 + (lane & 31), j = sj * 32 + (r & 3) + 8 * (r >> 2) + h4;
+                if (i < p.N && j < p.N) dst[j * p.N + i] = dbacc[si][sj][r];
+            }
 }
 
 // dbias[h][i][j] = sum_g part[g][h][j][i]: one workgroup per 64 outputs, 4 waves stride over g, fixed-order combine
@@ -644,12 +655,13 @@ static size_t bwd_lds_bytes(const mtlora_attn_desc* d) {
     const int N = d->window_size * d->window_size;
     const int rs = d->dtype == MTLORA_F32 ? AC<float>::RS : AC<bf16>::RS;
     const size_t ib = (size_t)((img_rows_h(N) * rs + 15) / 16) * 16;
-    return 4 * ib + 5 * AN * 4 + (size_t)N * (N + 1) * 4 + (size_t)N * bias_stride_host(N) * 4;
+    return 4 * ib + AN * 16 + 2 * AN * 4 + (size_t)N * bias_stride_host(N) * 4;
 }
 
 int bwd_groups(const mtlora_attn_desc* d) {
     const int64_t nwin = d->B * (d->H / d->window_size) * (d->W / d->window_size);
-    return groups_for(bwd_lds_bytes(d), 8, d->num_heads, nwin);
+    // one single-wave workgroup per SIMD (the kernel is compiled for the full register file): 4 per CU
+    return groups_for(bwd_lds_bytes(d), 4, d->num_heads, nwin);
 }
 
 AttnParams make_params(const mtlora_attn_desc* d) {
@@ -700,10 +712,18 @@ int mtlora_window_attn_fwd(const mtlora_attn_desc* d, const void* qkv, const flo
     const unsigned grid = (unsigned)(p.G * p.nH);
     hipStream_t s = (hipStream_t)stream;
     MtlProfScope prof(PK_ATTN_FWD, 4.0 * mtl_elem_size(d->dtype) * (double)p.n_windows * p.N * p.C, s);
-    if (d->dtype == MTLORA_F32)
-        hipLaunchKernelGGL(k_attn_fwd<float>, dim3(grid), dim3(64), lds, s, p);
-    else
-        hipLaunchKernelGGL(k_attn_fwd<bf16>, dim3(grid), dim3(64), lds, s, p);
+    const bool dense = p.mask && !p.mask_ids;
+    if (d->dtype == MTLORA_F32) {
+        if (dense)
+            hipLaunchKernelGGL((k_attn_fwd<float, true>), dim3(grid), dim3(64), lds, s, p);
+        else
+            hipLaunchKernelGGL((k_attn_fwd<float, false>), dim3(grid), dim3(64), lds, s, p);
+    } else {
+        if (dense)
+            hipLaunchKernelGGL((k_attn_fwd<bf16, true>), dim3(grid), dim3(64), lds, s, p);
+        else
+            hipLaunchKernelGGL((k_attn_fwd<bf16, false>), dim3(grid), dim3(64), lds, s, p);
+    }
     MTL_CHECK_LAUNCH();
     return MTLORA_OK;
 }
@@ -735,10 +755,18 @@ int mtlora_window_attn_bwd(const mtlora_attn_desc* d, const void* qkv, const flo
     const size_t lds = bwd_lds_bytes(d);
     {
         MtlProfScope prof(PK_ATTN_BWD, 7.0 * mtl_elem_size(d->dtype) * (double)p.n_windows * p.N * p.C, s);
-        if (d->dtype == MTLORA_F32)
-            hipLaunchKernelGGL(k_attn_bwd<float>, dim3(grid), dim3(64), lds, s, p);
-        else
-            hipLaunchKernelGGL(k_attn_bwd<bf16>, dim3(grid), dim3(64), lds, s, p);
+        const bool dense = p.mask && !p.mask_ids;
+        if (d->dtype == MTLORA_F32) {
+            if (dense)
+                hipLaunchKernelGGL((k_attn_bwd<float, true>), dim3(grid), dim3(64), lds, s, p);
+            else
+                hipLaunchKernelGGL((k_attn_bwd<float, false>), dim3(grid), dim3(64), lds, s, p);
+        } else {
+            if (dense)
+                hipLaunchKernelGGL((k_attn_bwd<bf16, true>), dim3(grid), dim3(64), lds, s, p);
+            else
+                hipLaunchKernelGGL((k_attn_bwd<bf16, false>), dim3(grid), dim3(64), lds, s, p);
+        }
     }
     const int total = p.nH * p.N * p.N;
     hipLaunchKernelGGL(k_dbias_reduce, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, s, (const float*)p.dbias_part,

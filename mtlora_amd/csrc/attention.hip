@@ -292,7 +292,6 @@ __device__ __forceinline__ void scores_t(f32x16 (&st)[2], const unsigned char* s
     const int ic = iv ? i : p.N - 1;
     const float* brow = sBias + ic * bias_stride(p.N);
     const int rid_i = srid[ic];  // 0 everywhere when there is no region-id mask
-    const bool use_ids = p.mask_ids != nullptr;
     const float* mrow = DENSE ? p.mask + ((int64_t)wm * p.N + ic) * p.N : nullptr;  // dense additive mask: slow path
     const int h4 = 4 * (lane >> 5);
 #pragma unroll
@@ -305,7 +304,7 @@ __device__ __forceinline__ void scores_t(f32x16 (&st)[2], const unsigned char* s
             float add = brow[jc];
             if constexpr (DENSE)
                 add += mrow[jc];
-            else if (use_ids)
+            else  // region ids are all 0 when there is no mask: the compare is then never true (no per-element branch)
                 add += srid[jc] != rid_i ? p.mask_value : 0.f;
             const float v = st[sj][r] * p.scale + (iv ? add : 0.f);
             st[sj][r] = j < p.N ? v : NEG_BIG;
@@ -443,7 +442,6 @@ __global__ __launch_bounds__(64, 1) void k_attn_bwd(const AttnParams p) {
     for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int b = 0; b < 2; ++b) zero(dbacc[a][b]);
-    const bool use_ids = p.mask_ids != nullptr;
     const int h4 = 4 * (lane >> 5);
 
     const RowIds<T> ids = row_ids<T>(p, lane);
@@ -561,7 +559,7 @@ __global__ __launch_bounds__(64, 1) void k_attn_bwd(const AttnParams p) {
                     float sc = pp[si][r] * p.scale + sBias[ic * bs + jc];
                     if constexpr (DENSE)
                         sc += mn[ic * p.N];
-                    else if (use_ids)
+                    else
                         sc += __float_as_int(sv[3]) != rid_j ? p.mask_value : 0.f;
                     const float pv = __expf(sc - sv[0]) * sv[1];
                     const float ds = pv * (dp[si][r] - sv[2]);

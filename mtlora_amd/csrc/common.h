@@ -221,6 +221,7 @@ enum MtlProfKind {
     PK_RESIDUAL = 13,    // k_residual_fwd / _bwd         residual + DropPath over 1+T tensors
     PK_BN = 12,          // k_bn_colsum / k_bn_apply      heads' BatchNorm(+ReLU)
     PK_LOSS = 14,        // k_up_loss                     low-res logits in, gradient out, labels in
+    PK_SUM = 15,         // k_sum: G = sum of the output gradients (matrixv2 / pre-summed dX operand)
     PK_COUNT = 16
 };
 int mtl_prof_start(int kind, double alg_bytes, hipStream_t s);

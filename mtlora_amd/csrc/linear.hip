@@ -766,7 +766,10 @@ __global__ __launch_bounds__(256, 2) void k_tn(const TnParams P) {
     constexpr int KE = 2 * SUB;  // rows per staged chunk
     constexpr int ES = (int)sizeof(T);
     constexpr int VEC = ET<T>::VEC;
-    constexpr int LRA = TN_A * ES + 16, LRB = TN_B * ES + 16;  // padded LDS rows
+    // padded LDS rows.  bf16: a ds_read_b64_tr_b16 cycle serves 32 lanes = 4 rows x 2 column halves of 32 B; the 8
+    // segments fall in distinct bank groups iff the row stride is 16 dwords (mod 64): 320 B / 576 B (strides of
+    // 144 B / 528 B cost 42 % of the LDS cycles in conflicts).  f32 (scalar 4-byte reads across 32 columns): +16 B.
+    constexpr int LRA = ES == 2 ? 320 : TN_A * ES + 16, LRB = ES == 2 ? 576 : TN_B * ES + 16;
     constexpr int VPA = TN_A / VEC, VPB = TN_B / VEC;          // 16-byte vectors per tile row
     constexpr int RSA = 256 / VPA, RSB = 256 / VPB;            // rows covered by one sweep of the workgroup
     constexpr int NLA = KE / RSA, NLB = KE / RSB;              // loads per thread per chunk (2 and 8)
@@ -1194,7 +1197,7 @@ static BwdScratch bwd_scratch(const mtlora_linear_desc* d, const Segs& sg) {
         return at;
     };
     S.q = take(d->M * sg.R * es);
-    S.g = take((d->mode == 1 && d->T > 0) ? d->M * d->N * es : 0);
+    S.g = take(d->T > 0 ? d->M * d->N * es : 0);  // G = sum of the output gradients (matrixv2 factors; pre-summed dX operand)
     // TN tiles (rank side x wide side), dB and dA per output
     int64_t tiles = 0;
     for (int oo = 0; oo < sg.n; ++oo) {
@@ -1248,22 +1251,28 @@ static int bwd_impl(const mtlora_linear_desc* d, const void* x, const void* cons
     for (int o = 0; o < sg.n; ++o)
         if (dy[o]) dy_all[n_dy++] = dy[o];
 
-    // matrixv2: the shared factors see G = sum of every output gradient
+    // G = sum of every output gradient, materialised when
+    //  * matrixv2: the shared factors see G, or
+    //  * the dX kernel would otherwise re-sum the n_dy sources once per output n-tile (it re-reads every dY panel for
+    //    each of the ceil(K/128) n-tiles: 3..24x for fc2): one k_sum pass + the single-source kernel moves
+    //    (n_dy + 1 + n_tiles) MN bytes instead of n_dy * n_tiles * MN.
     const void* dy_shared = dy[0];
-    if (v2 && n_dy > 0) {
-        if (n_dy == 1) {
-            dy_shared = dy_all[0];
-        } else {
-            SumParams sp;
-            sp.n = n_dy;
-            for (int i = 0; i < n_dy; ++i) sp.src[i] = dy_all[i];
-            sp.nvec = d->M * d->N / ET<T>::VEC;
-            int64_t blocks = mtl_ceil_div(sp.nvec, 256);
-            if (blocks > 4096) blocks = 4096;
+    const bool presum = n_dy > 1 && dx && mtl_ceil_div(d->K, TILE) >= 3;
+    bool have_g = false;
+    if ((v2 || presum) && n_dy > 1) {
+        SumParams sp;
+        sp.n = n_dy;
+        for (int i = 0; i < n_dy; ++i) sp.src[i] = dy_all[i];
+        sp.nvec = d->M * d->N / ET<T>::VEC;
+        int64_t blocks = mtl_ceil_div(sp.nvec, 256);
+        if (blocks > 4096) blocks = 4096;
+        if (blocks > 0) {
+            MtlProfScope prof(PK_SUM, (double)sizeof(T) * d->M * d->N * (n_dy + 1), s);
             hipLaunchKernelGGL(k_sum<T>, dim3((unsigned)blocks), dim3(256), 0, s, sp, Gm);
-            dy_shared = Gm;
         }
+        have_g = true;
     }
+    if (v2 && n_dy > 0) dy_shared = have_g ? (const void*)Gm : dy_all[0];
     const void* dyo[MAXO];  // gradient feeding factor o
     for (int o = 0; o < sg.n; ++o) dyo[o] = (o == 0) ? dy_shared : dy[o];
 
@@ -1302,8 +1311,13 @@ static int bwd_impl(const mtlora_linear_desc* d, const void* x, const void* cons
     // dX = G W + keep .* (Q_s A_s [+ sum_t Q_t A_t]),  dX_t = Q_t A_t
     {
         NtParams m = {};
-        m.n_act = n_dy;
-        for (int i = 0; i < n_dy; ++i) m.act[i] = dy_all[i];
+        if (presum && have_g) {
+            m.n_act = 1;
+            m.act[0] = Gm;
+        } else {
+            m.n_act = n_dy;
+            for (int i = 0; i < n_dy; ++i) m.act[i] = dy_all[i];
+        }
         m.ld_act = d->N;
         m.wgt = Wt;
         m.ld_wgt = d->N;

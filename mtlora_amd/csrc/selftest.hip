@@ -157,6 +157,7 @@ extern "C" const char* mtlora_prof_kind_name(int kind) {
         case PK_BN: return "k_bn";
         case PK_RESIDUAL: return "k_residual";
         case PK_LOSS: return "k_up_loss";
+        case PK_SUM: return "k_sum";
         default: return "";
     }
 }

@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--img", type=int, default=448)
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-reducer", action="store_true", help="run the gradient pack / RCCL all-reduce / unpack path even at 1 rank")
     ap.add_argument("--no-fused-loss", action="store_true", help="final upsample + losses through ATen instead of csrc/loss.hip")
     return ap.parse_args()
 
@@ -166,7 +167,8 @@ def cpu_baseline():
     t0 = time.perf_counter()
     step()
     warm = time.perf_counter() - t0
-    k = 2 if warm < 15.0 else (1 if warm < 60.0 else 0)  # keep the default bench run bounded
+    # ~10-20 s of CPU work in total, bounded whatever the host is
+    k = max(2, min(8, int(12.0 / max(warm, 1e-3)))) if warm < 15.0 else (1 if warm < 60.0 else 0)
     if k:
         t0 = time.perf_counter()
         for _ in range(k):
@@ -193,7 +195,8 @@ def main():
         model.train()
         crit = H.MultiTaskLoss(TASKS)
         opt = H.build_optimizer(model, lr=5e-4 * args.batch * world / 512.0)  # main.py:578-583 linear LR scaling
-        reducer = GradReducer(model.parameters(), bucket_mb=16.0) if world > 1 else None
+        reducer = (GradReducer(model.parameters(), bucket_mb=16.0, force=args.force_reducer)
+                   if (world > 1 or args.force_reducer) else None)
         img, tg = H.synthetic_batch(args.batch, args.img, TASKS, seed=1234 + rank, device=dev)
         torch.manual_seed(1234 + rank)
 

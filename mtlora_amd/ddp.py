@@ -24,7 +24,7 @@ import torch.distributed as dist
 
 
 class _Bucket:
-    __slots__ = ("params", "offsets", "flat", "pending", "handle", "seen")
+    __slots__ = ("params", "offsets", "flat", "pending", "handle", "seen", "arrived")
 
     def __init__(self, params: List[torch.nn.Parameter]):
         self.params = params
@@ -36,7 +36,8 @@ class _Bucket:
         self.flat = torch.zeros(n, dtype=torch.float32, device=params[0].device)
         self.pending = len(params)
         self.handle = None
-        self.seen = [False] * len(params)
+        self.seen = [False] * len(params)      # has a gradient this step
+        self.arrived = [False] * len(params)   # its accumulation node ran (possibly with an undefined gradient)
 
 
 class GradReducer:
@@ -47,9 +48,11 @@ class GradReducer:
     """
 
     def __init__(self, params: Iterable[torch.nn.Parameter], bucket_mb: float = 16.0,
-                 process_group: Optional[dist.ProcessGroup] = None):
+                 process_group: Optional[dist.ProcessGroup] = None, force: bool = False):
+        """force=True runs the pack / all-reduce / unpack path even on a single rank (hardware test of the RCCL path)."""
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.active = self.world > 1 or (force and dist.is_initialized())
         plist = [p for p in params if p.requires_grad]
         plist.reverse()  # approximate backward completion order
         cap = int(bucket_mb * 1024 * 1024 / 4)
@@ -81,10 +84,25 @@ class GradReducer:
             b.pending = len(b.params)
             b.handle = None
             b.seen = [False] * len(b.params)
+            b.arrived = [False] * len(b.params)
         self._armed = True
 
+    def _pack(self, b: _Bucket) -> None:
+        """gather the bucket's gradients into its flat buffer: ONE multi-tensor copy (not one kernel per parameter)."""
+        dst, src = [], []
+        for pi, p in enumerate(b.params):
+            view = b.flat[b.offsets[pi]:b.offsets[pi] + p.numel()]
+            if b.seen[pi]:
+                dst.append(view)
+                src.append(p.grad.reshape(-1))
+            else:  # no gradient on this rank this step: counts as zero
+                view.zero_()
+        if dst:
+            torch._foreach_copy_(dst, src)
+
     def _launch(self, b: _Bucket) -> None:
-        if self.world > 1:
+        self._pack(b)
+        if self.active:
             b.handle = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def _on_grad(self, p: torch.nn.Parameter) -> None:
@@ -92,11 +110,12 @@ class GradReducer:
             return
         bi, pi = self._where[p]
         b = self.buckets[bi]
-        if b.seen[pi]:
+        if b.arrived[pi]:
             return  # gradient accumulation touching the same parameter twice in one backward
-        n = p.numel()
-        b.flat[b.offsets[pi]:b.offsets[pi] + n].copy_(p.grad.reshape(-1))
-        b.seen[pi] = True
+        b.arrived[pi] = True
+        # the hook also fires when the incoming gradient is undefined (an unused output of a custom Function, e.g. the
+        # final stage's shared fc2 factors): such a parameter has arrived but contributes zeros and keeps grad None
+        b.seen[pi] = p.grad is not None
         b.pending -= 1
         if b.pending == 0:
             self._launch(b)
@@ -106,22 +125,20 @@ class GradReducer:
         self._armed = False
         for b in self.buckets:
             if b.pending > 0:  # some parameters produced no gradient on this rank this step: they count as zero
-                for pi, p in enumerate(b.params):
-                    if not b.seen[pi]:
-                        b.flat[b.offsets[pi]:b.offsets[pi] + p.numel()].zero_()
+                b.pending = 0
                 self._launch(b)
         inv = 1.0 / self.world
         for b in self.buckets:
             if b.handle is not None:
                 b.handle.wait()
-            if self.world > 1:
+            if self.active:
                 b.flat.mul_(inv)
             dst, src = [], []
             for pi, p in enumerate(b.params):
                 if b.seen[pi]:  # parameters without a local gradient keep grad None (all ranks agree on the set)
                     dst.append(p.grad)
                     src.append(b.flat[b.offsets[pi]:b.offsets[pi] + p.numel()].view_as(p.grad))
-            if dst and self.world > 1:
+            if dst and self.active:
                 torch._foreach_copy_(dst, src)
 
     def remove(self) -> None:

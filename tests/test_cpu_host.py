@@ -140,7 +140,20 @@ torch.manual_seed(0)
 net = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.ReLU(), torch.nn.Linear(16, 4), torch.nn.Linear(4, 4))
 net[0].weight.requires_grad_(False)            # frozen parameters never enter a bucket
 unused = torch.nn.Parameter(torch.zeros(3))     # trainable but never used -> grad stays None
-params = list(net.parameters()) + [unused]
+class _Half(torch.autograd.Function):          # like MTLoRALinearFn for an unused output: returns an UNDEFINED gradient for
+    @staticmethod                              # `b`; torch still runs b's accumulation node and its post-accumulate hook
+    def forward(ctx, x, a, b):
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(x)
+        return x * a
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        return g, (g * x).sum(0), None
+ha, hb = torch.nn.Parameter(torch.ones(4)), torch.nn.Parameter(torch.ones(4))
+_fwd = net.forward
+net.forward = lambda x: _Half.apply(_fwd(x), ha, hb)
+params = list(net.parameters()) + [unused, ha, hb]
 red = GradReducer(params, bucket_mb=0.0002)     # several buckets
 assert red.nbytes == 4 * sum(p.numel() for p in params if p.requires_grad)
 g = torch.Generator().manual_seed(100)
@@ -155,7 +168,7 @@ for (n, p), q in zip(net.named_parameters(), ref.parameters()):
         assert torch.allclose(p.grad, q.grad / world, rtol=1e-5, atol=1e-6), n
     else:
         assert p.grad is None
-assert unused.grad is None
+assert unused.grad is None and hb.grad is None and ha.grad is not None
 # second step reuses the buckets
 net.zero_grad(); red.prepare(); net(xs[rank] * 2).pow(2).sum().backward(); red.finish()
 t = torch.stack([p.grad.sum() for p in net.parameters() if p.requires_grad]).sum().reshape(1)

@@ -179,27 +179,28 @@ struct NtParams {
 // by-value struct argument would make the compiler copy the whole struct to scratch
 typedef const __attribute__((address_space(4))) NtParams* NtPtr;
 
-template <typename T>
+// RI = tile rows per thread per operand: 2 with 256 threads (4 waves), 1 with 512 threads (8 waves)
+template <typename T, int RI>
 struct TileRegs {
-    u32x4 w[2][VPT], a[2][VPT];
+    u32x4 w[RI][VPT], a[RI][VPT];
     int mask;  // dropout keep-mask still to be applied to a[][] (done at LDS-store time: applying it at load time
     int k0;    // would put an s_waitcnt vmcnt(0) behind every single load and serialise the tile's loads)
 };
 
 // stage one 128-row x ROWB-byte k-tile of the weight-like and activation-like operands into registers
-template <typename T, bool MS>
-__device__ __forceinline__ void nt_load(TileRegs<T>& rg, int tid, const T* wgt, int64_t ld_w, int w_row0, int w_rows,
+template <typename T, bool MS, int RI>
+__device__ __forceinline__ void nt_load(TileRegs<T, RI>& rg, int tid, const T* wgt, int64_t ld_w, int w_row0, int w_rows,
                                         const void* act0, NtPtr P, int n_act, int64_t ld_a, int64_t a_row0,
                                         int64_t a_rows, int k0, int k_hi, bool mask, int w_lo = 0) {
     constexpr int VEC = ET<T>::VEC;
     rg.mask = mask ? 1 : 0;
     rg.k0 = k0;
     // row bases once per tile (two rows per thread), the k offset is added per vector
-    const T* wp[2];
-    int64_t aoff[2];
-    bool wok[2], aok[2];
+    const T* wp[RI];
+    int64_t aoff[RI];
+    bool wok[RI], aok[RI];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < RI; ++i) {
         const int r = (tid >> 2) + i * 64;
         const int wr = w_row0 + r;
         wok[i] = wr < w_rows && wr >= w_lo;
@@ -214,7 +215,7 @@ __device__ __forceinline__ void nt_load(TileRegs<T>& rg, int tid, const T* wgt, 
         const int k = k0 + v * VEC;
         const bool kin = k < k_hi;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < RI; ++i) {
             rg.w[i][j] = (kin && wok[i]) ? *reinterpret_cast<const u32x4*>(wp[i] + k) : u32x4{0u, 0u, 0u, 0u};
             if (kin && aok[i]) {
                 u32x4 x = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(act0) + aoff[i] + k);
@@ -252,13 +253,13 @@ __device__ __forceinline__ void nt_load(TileRegs<T>& rg, int tid, const T* wgt, 
     }
 }
 
-template <typename T>
-__device__ __forceinline__ void nt_store_lds(TileRegs<T>& rg, int tid, unsigned char* sW, unsigned char* sA,
+template <typename T, int RI>
+__device__ __forceinline__ void nt_store_lds(TileRegs<T, RI>& rg, int tid, unsigned char* sW, unsigned char* sA,
                                              const DropoutCfg& dc, int64_t a_row0, bool with_act = true) {
     constexpr int VEC = ET<T>::VEC;
     if (rg.mask) {  // wave-uniform
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < RI; ++i) {
             const uint32_t rh = mtl_dropout_rowhash(dc, 0u, (uint32_t)(a_row0 + (tid >> 2) + i * 64));
 #pragma unroll
             for (int j = 0; j < VPT; ++j) VOps<T>::drop(rg.a[i][j], dc, rh, (uint32_t)(rg.k0 + ((tid & 3) + 4 * j) * VEC));
@@ -268,7 +269,7 @@ __device__ __forceinline__ void nt_store_lds(TileRegs<T>& rg, int tid, unsigned 
     for (int j = 0; j < VPT; ++j) {
         const int v = (tid & 3) + 4 * j;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < RI; ++i) {
             const int r = (tid >> 2) + i * 64;
             *reinterpret_cast<u32x4*>(sW + r * LDSB + v * 16) = rg.w[i][j];
             if (with_act) *reinterpret_cast<u32x4*>(sA + r * LDSB + v * 16) = rg.a[i][j];
@@ -278,28 +279,32 @@ __device__ __forceinline__ void nt_store_lds(TileRegs<T>& rg, int tid, unsigned 
 
 // multiply the staged tile; k_left = elements of the part's k range still ahead (sub-tiles past it are all zero
 // and skipped -- wave-uniform)
-template <typename T>
-__device__ __forceinline__ void nt_compute(f32x16 (&acc)[2][2], const unsigned char* sW, const unsigned char* sA,
+// SM = 32-row m sub-blocks per wave: 2 (4 waves, wave tile 64 n x 64 m) or 1 (8 waves, wave tile 64 n x 32 m)
+template <typename T, int SM>
+__device__ __forceinline__ void nt_compute(f32x16 (&acc)[2][SM], const unsigned char* sW, const unsigned char* sA,
                                            int lane, int wn, int wm, int k_left, int a_stride = LDSB) {
     constexpr int KS = 64 / (int)sizeof(T);  // elements per 64-byte sub-tile
     const int h = lane >> 5, rl = lane & 31;
 #pragma unroll
     for (int t = 0; t < SUBT; ++t) {
         if (t * KS >= k_left) break;
-        Frag<T> fw[2], fa[2];
+        Frag<T> fw[2], fa[SM];
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             const unsigned char* pw = sW + (wn * 64 + s * 32 + rl) * LDSB + t * 64;
-            const unsigned char* pa = sA + (wm * 64 + s * 32 + rl) * a_stride + t * 64;
             fw[s].v[0] = *reinterpret_cast<const u32x4*>(pw + h * 16);
             fw[s].v[1] = *reinterpret_cast<const u32x4*>(pw + (2 + h) * 16);
+        }
+#pragma unroll
+        for (int s = 0; s < SM; ++s) {
+            const unsigned char* pa = sA + (wm * (32 * SM) + s * 32 + rl) * a_stride + t * 64;
             fa[s].v[0] = *reinterpret_cast<const u32x4*>(pa + h * 16);
             fa[s].v[1] = *reinterpret_cast<const u32x4*>(pa + (2 + h) * 16);
         }
 #pragma unroll
         for (int sn = 0; sn < 2; ++sn)
 #pragma unroll
-            for (int sm = 0; sm < 2; ++sm) mtl_mma(fw[sn], fa[sm], acc[sn][sm]);
+            for (int sm = 0; sm < SM; ++sm) mtl_mma(fw[sn], fa[sm], acc[sn][sm]);
     }
 }
 
@@ -402,8 +407,14 @@ __device__ __forceinline__ NtCursor nt_seek(NtPtr P, int q, int nseq, int bn, in
 // MLR: some output masks its low-rank part (dX = G W + keep .* (Q A)).  A template parameter, not a runtime test: the
 // keep-mask hashes depend only on (m, n), so the compiler hoists all 64 of them (+ their SGPR-pair results, spilled to
 // VGPR lanes) to the top of the kernel -- ~700 instructions per workgroup that the forward / P / Q launches never use.
-template <typename T, bool MULTI, bool MS, bool FUSE, bool MLR>
-__global__ __launch_bounds__(256, 2) void k_nt(const NtParams Pv) {
+// NW = waves per workgroup.  The 128 x 128 tile is unchanged; with 8 waves a wave owns 64 n x 32 m (half the
+// accumulators, half the staging registers, half the loads / LDS traffic / MFMAs per step), fits 128 VGPRs and runs
+// 4 waves per SIMD instead of 2 -- the kernel is latency- and issue-bound, not bandwidth-bound.
+template <typename T, bool MULTI, bool MS, bool FUSE, bool MLR, int NW>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void k_nt(const NtParams Pv) {
+    constexpr int SM = 8 / NW;       // 32-row m sub-blocks per wave
+    constexpr int MW = 32 * SM;      // m rows per wave
+    constexpr int NT = 64 * NW;      // threads
     (void)Pv;
     NtPtr P = (NtPtr)__builtin_amdgcn_kernarg_segment_ptr();
     constexpr int KE = ROWB / (int)sizeof(T);
@@ -412,7 +423,7 @@ __global__ __launch_bounds__(256, 2) void k_nt(const NtParams Pv) {
     unsigned char* sA = smem + TILE * LDSB;
     unsigned char* sP = smem + STAGE_BYTES;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wn = wave >> 1, wm = wave & 1;
+    const int wn = NW == 4 ? wave >> 1 : wave >> 2, wm = NW == 4 ? wave & 1 : wave & 3;
 
     // batched form
     const void* act0 = P->act[0];
@@ -464,49 +475,49 @@ __global__ __launch_bounds__(256, 2) void k_nt(const NtParams Pv) {
     const int nseq = np + (MULTI ? 1 + P->n_out : 2 * P->n_out);
 
     // ---- loader side of the stream (register prefetch, one wide tile ahead)
-    TileRegs<T> rg;
+    TileRegs<T, SM> rg;
     NtCursor ld = nt_seek<MULTI, FUSE>(P, 0, nseq, bn_lo, bn_hi);
     auto issue = [&](const NtCursor& c) __attribute__((always_inline)) {
         if (FUSE && c.lr == 2)  // fused projection: weights = A_cat rows of source c.q, activation = that source
-            nt_load<T, false>(rg, tid, reinterpret_cast<const T*>(P->pA), P->pK, 0, P->pseg_hi[c.q], P->pact[c.q], P, 1,
+            nt_load<T, false, SM>(rg, tid, reinterpret_cast<const T*>(P->pA), P->pK, 0, P->pseg_hi[c.q], P->pact[c.q], P, 1,
                               P->pK, m0, P->M, c.k0, c.k_hi, P->pmask[c.q] != 0 && drop.thr16 != 0, P->pseg_lo[c.q]);
         else if (c.lr)  // rank segment: weights = Rm; activation = L, or the LDS P image when the projection is fused
-            nt_load<T, false>(rg, tid, reinterpret_cast<const T*>(P->Rm), P->ldR, c.bn * TILE, n_rows, np > 0 ? nullptr : P->L, P, 1,
+            nt_load<T, false, SM>(rg, tid, reinterpret_cast<const T*>(P->Rm), P->ldR, c.bn * TILE, n_rows, np > 0 ? nullptr : P->L, P, 1,
                               P->ldL, m0, P->M, c.k0, c.k_hi, false);
         else
-            nt_load<T, MS>(rg, tid, wgt, P->ld_wgt, c.bn * TILE, n_rows, act0, P, P->n_act, P->ld_act, m0, P->M, c.k0, c.k_hi, act_mask);
+            nt_load<T, MS, SM>(rg, tid, wgt, P->ld_wgt, c.bn * TILE, n_rows, act0, P, P->n_act, P->ld_act, m0, P->M, c.k0, c.k_hi, act_mask);
     };
     if (ld.valid) issue(ld);
     // consume one tile: registers -> LDS, prefetch the next tile of the stream, multiply
-    auto step = [&](f32x16(&acc)[2][2], int k_left, int from_p, int k0) __attribute__((always_inline)) {
-        nt_store_lds<T>(rg, tid, sW, sA, drop, m0, !from_p);
+    auto step = [&](f32x16(&acc)[2][SM], int k_left, int from_p, int k0) __attribute__((always_inline)) {
+        nt_store_lds<T, SM>(rg, tid, sW, sA, drop, m0, !from_p);
         __syncthreads();
         ld.k0 += KE;
         if (ld.k0 >= ld.k_hi) ld = nt_seek<MULTI, FUSE>(P, ld.q + 1, nseq, ld.bn, bn_hi);
         if (ld.valid) issue(ld);
         if (from_p)
-            nt_compute<T>(acc, sW, sP + k0 * (int)sizeof(T), lane, wn, wm, k_left, PRS);
+            nt_compute<T, SM>(acc, sW, sP + k0 * (int)sizeof(T), lane, wn, wm, k_left, PRS);
         else
-            nt_compute<T>(acc, sW, sA, lane, wn, wm, k_left);
+            nt_compute<T, SM>(acc, sW, sA, lane, wn, wm, k_left);
         __syncthreads();
     };
-    auto run_part = [&](int q, f32x16(&acc)[2][2]) __attribute__((always_inline)) {
+    auto run_part = [&](int q, f32x16(&acc)[2][SM]) __attribute__((always_inline)) {
         int lr, lo, hi;
         nt_part<MULTI, FUSE>(P, q, lr, lo, hi);
         const int from_p = (FUSE && lr == 1 && np > 0) ? 1 : 0;
         for (int k0 = lo; k0 < hi; k0 += KE) step(acc, hi - k0, from_p, k0);
         return hi > lo;
     };
-    auto zero = [](f32x16(&a)[2][2]) __attribute__((always_inline)) {
+    auto zero = [](f32x16(&a)[2][SM]) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < SM; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) a[i][j][r] = 0.f;
     };
     // acc = acc * alpha[n] + bias[n]
-    auto affine = [&](f32x16(&a)[2][2]) __attribute__((always_inline)) {
+    auto affine = [&](f32x16(&a)[2][SM]) __attribute__((always_inline)) {
         if (!(P->alpha || P->bias)) return;
 #pragma unroll
         for (int sn = 0; sn < 2; ++sn)
@@ -518,17 +529,17 @@ __global__ __launch_bounds__(256, 2) void k_nt(const NtParams Pv) {
                     if (P->alpha) al = *reinterpret_cast<const f32x4*>(P->alpha + row_off + n);
                     if (P->bias) bi = *reinterpret_cast<const f32x4*>(P->bias + row_off + n);
 #pragma unroll
-                    for (int sm = 0; sm < 2; ++sm)
+                    for (int sm = 0; sm < SM; ++sm)
 #pragma unroll
                         for (int e = 0; e < 4; ++e) a[sn][sm][q * 4 + e] = a[sn][sm][q * 4 + e] * al[e] + bi[e];
                 }
             }
     };
     // acc *= keep(m, n)
-    auto apply_mask = [&](f32x16(&a)[2][2]) __attribute__((always_inline)) {
+    auto apply_mask = [&](f32x16(&a)[2][SM]) __attribute__((always_inline)) {
 #pragma unroll
-        for (int sm = 0; sm < 2; ++sm) {
-            const int64_t m = m0 + wm * 64 + sm * 32 + (lane & 31);
+        for (int sm = 0; sm < SM; ++sm) {
+            const int64_t m = m0 + wm * MW + sm * 32 + (lane & 31);
             const uint32_t rh = mtl_dropout_rowhash(drop, 0u, (uint32_t)m);
 #pragma unroll
             for (int sn = 0; sn < 2; ++sn)
@@ -544,7 +555,7 @@ __global__ __launch_bounds__(256, 2) void k_nt(const NtParams Pv) {
                 }
         }
     };
-    auto store = [&](const f32x16(&a)[2][2], void* ptr) __attribute__((always_inline)) {
+    auto store = [&](const f32x16(&a)[2][SM], void* ptr) __attribute__((always_inline)) {
         T* outp = reinterpret_cast<T*>(ptr);
         if (!outp) return;
         if constexpr (sizeof(T) == 2) {
@@ -552,9 +563,9 @@ __global__ __launch_bounds__(256, 2) void k_nt(const NtParams Pv) {
             // writes whole 128-byte row segments (8 lanes x 16 B) instead of 16-byte pieces of 32 different rows.
             // The staging buffers are idle here (the trailing barrier of the last tile has passed).
             constexpr int ORS = EPI_ROW;  // row stride of the per-wave image (bytes): 2-way conflicts at most
-            unsigned char* img = smem + wave * (64 * ORS);
+            unsigned char* img = smem + wave * (MW * ORS);
 #pragma unroll
-            for (int sm = 0; sm < 2; ++sm)
+            for (int sm = 0; sm < SM; ++sm)
 #pragma unroll
                 for (int sn = 0; sn < 2; ++sn)
 #pragma unroll
@@ -567,9 +578,9 @@ __global__ __launch_bounds__(256, 2) void k_nt(const NtParams Pv) {
             __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the image is private to this wave, no barrier needed
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (int it = 0; it < 8; ++it) {
+            for (int it = 0; it < 4 * SM; ++it) {
                 const int ml = it * 8 + (lane >> 3), c16 = lane & 7;
-                const int64_t m = m0 + wm * 64 + ml;
+                const int64_t m = m0 + wm * MW + ml;
                 const int n = n0 + wn * 64 + c16 * 8;
                 const u32x4 v = *reinterpret_cast<const u32x4*>(img + ml * ORS + c16 * 16);
                 if (m < P->M && n < n_rows) *reinterpret_cast<u32x4*>(outp + m * P->ld_out + row_off + n) = v;
@@ -577,8 +588,8 @@ __global__ __launch_bounds__(256, 2) void k_nt(const NtParams Pv) {
             __builtin_amdgcn_wave_barrier();
         } else {
 #pragma unroll
-            for (int sm = 0; sm < 2; ++sm) {
-                const int64_t m = m0 + wm * 64 + sm * 32 + (lane & 31);
+            for (int sm = 0; sm < SM; ++sm) {
+                const int64_t m = m0 + wm * MW + sm * 32 + (lane & 31);
 #pragma unroll
                 for (int sn = 0; sn < 2; ++sn)
 #pragma unroll
@@ -596,13 +607,13 @@ __global__ __launch_bounds__(256, 2) void k_nt(const NtParams Pv) {
 
     // park the projected tile: acc holds P^T [rank r][m]; scale by alpha, write the LDS image [m][r] (and the global
     // copy for the backward from the n-tile-0 workgroups)
-    auto park_p = [&](f32x16(&a)[2][2]) __attribute__((always_inline)) {
+    auto park_p = [&](f32x16(&a)[2][SM]) __attribute__((always_inline)) {
         T* pg = reinterpret_cast<T*>(P->pout);
-        for (int i = tid; i < TILE * 4; i += 256)  // zero the 64-byte tail of every row (0 * garbage could be NaN)
+        for (int i = tid; i < TILE * 4; i += NT)  // zero the 64-byte tail of every row (0 * garbage could be NaN)
             *reinterpret_cast<u32x4*>(sP + (i >> 2) * PRS + P->pR * (int)sizeof(T) + (i & 3) * 16) = u32x4{0u, 0u, 0u, 0u};
 #pragma unroll
-        for (int sm = 0; sm < 2; ++sm) {
-            const int ml = wm * 64 + sm * 32 + (lane & 31);
+        for (int sm = 0; sm < SM; ++sm) {
+            const int ml = wm * MW + sm * 32 + (lane & 31);
             const int64_t m = m0 + ml;
 #pragma unroll
             for (int sn = 0; sn < 2; ++sn)
@@ -628,7 +639,7 @@ __global__ __launch_bounds__(256, 2) void k_nt(const NtParams Pv) {
     };
 
     if constexpr (MULTI) {
-        f32x16 base[2][2], acc[2][2];
+        f32x16 base[2][SM], acc[2][SM];
         if constexpr (FUSE) {
             zero(acc);
             for (int q = 0; q < np; ++q) run_part(q, acc);
@@ -644,20 +655,20 @@ __global__ __launch_bounds__(256, 2) void k_nt(const NtParams Pv) {
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) acc[i][j] = base[i][j];
+                    for (int j = 0; j < SM; ++j) acc[i][j] = base[i][j];
                 run_part(np + 1 + o, acc);
                 if (O.fold) {
 #pragma unroll
                     for (int i = 0; i < 2; ++i)
 #pragma unroll
-                        for (int j = 0; j < 2; ++j) base[i][j] = acc[i][j];
+                        for (int j = 0; j < SM; ++j) base[i][j] = acc[i][j];
                 }
                 store(acc, O.ptr);
                 __syncthreads();  // the output image lives in the staging buffers
             }
         }
     } else {
-        f32x16 acc[2][2];
+        f32x16 acc[2][SM];
         if constexpr (FUSE) {
             zero(acc);
             for (int q = 0; q < np; ++q) run_part(q, acc);
@@ -963,6 +974,14 @@ static int check_desc(const mtlora_linear_desc* d) {
 
 static bool misaligned(const void* p) { return ((uintptr_t)p & 15u) != 0; }
 
+static int nt_waves() {
+    static const int w = [] {
+        const char* e = getenv("MTLORA_NT_WAVES");
+        return (e && e[0] == '4') ? 4 : 8;
+    }();
+    return w;
+}
+
 template <typename T>
 static void launch_nt(const NtParams& P, hipStream_t s, int kind, double alg_bytes) {
     MtlProfScope prof(kind, alg_bytes, s);
@@ -981,15 +1000,24 @@ static void launch_nt(const NtParams& P, hipStream_t s, int kind, double alg_byt
     const size_t lds = (size_t)STAGE_BYTES + (P.np > 0 ? (size_t)TILE * (P.pR * sizeof(T) + 80) : 0);
     // (> 64 KiB of dynamic LDS must be opted into once per kernel)
     const int variant = base_users > 1 ? 0 : (P.n_act > 1 ? 1 : 2);
-#define MTL_NT_LAUNCH(MU, MSRC, FU, ML)                                                                          \
+#define MTL_NT_LAUNCH_W(MU, MSRC, FU, ML, W)                                                                      \
     do {                                                                                                       \
         static bool raised = false;                                                                            \
         if (lds > 64 * 1024 && !raised) {                                                                      \
-            (void)hipFuncSetAttribute((const void*)k_nt<T, MU, MSRC, FU, ML>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                      160 * 1024 - 512);                                                       \
+            (void)hipFuncSetAttribute((const void*)k_nt<T, MU, MSRC, FU, ML, W>,                                \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);            \
             raised = true;                                                                                     \
         }                                                                                                      \
-        hipLaunchKernelGGL((k_nt<T, MU, MSRC, FU, ML>), g, dim3(256), lds, s, P);                                 \
+        hipLaunchKernelGGL((k_nt<T, MU, MSRC, FU, ML, W>), g, dim3(64 * W), lds, s, P);                         \
+    } while (0)
+    // bf16 single-accumulator-set variants: 8 waves per workgroup (<= 128 VGPRs, 4 waves per SIMD) unless
+    // MTLORA_NT_WAVES=4; MULTI (two accumulator sets), the row-panel form and f32 (wider fragments) would spill at 128
+#define MTL_NT_LAUNCH(MU, MSRC, FU, ML)                                                                          \
+    do {                                                                                                       \
+        if (sizeof(T) == 2 && !(MU) && !(FU) && nt_waves() == 8)                                               \
+            MTL_NT_LAUNCH_W(false, MSRC, false, ML, 8);                                                        \
+        else                                                                                                   \
+            MTL_NT_LAUNCH_W(MU, MSRC, FU, ML, 4);                                                              \
     } while (0)
     bool mlr = false;
     for (int o = 0; o < P.n_out; ++o) mlr = mlr || P.out[o].mask_lr != 0;
@@ -1011,6 +1039,7 @@ static void launch_nt(const NtParams& P, hipStream_t s, int kind, double alg_byt
         else
             MTL_NT_LAUNCH(false, false, false, false);
     }
+#undef MTL_NT_LAUNCH_W
 #undef MTL_NT_LAUNCH
 }
 

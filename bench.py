@@ -45,6 +45,11 @@ def parse():
     ap.add_argument("--img", type=int, default=448)
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph", action="store_true",
+                    help="EXPERIMENTAL: replay the step as captured HIP graph(s).  Off by default: with this ROCm stack a "
+                         "captured small hipMemsetAsync (ATen uses them for reduction semaphores) stops taking effect from "
+                         "the second replay on, so a whole-step graph computes garbage (tests/test_gpu_kernels.py::"
+                         "test_library_is_hip_graph_safe documents the hazard; the library itself avoids memset nodes)")
     ap.add_argument("--force-reducer", action="store_true", help="run the gradient pack / RCCL all-reduce / unpack path even at 1 rank")
     ap.add_argument("--no-fused-loss", action="store_true", help="final upsample + losses through ATen instead of csrc/loss.hip")
     return ap.parse_args()
@@ -194,15 +199,27 @@ def main():
         model = H.build_model(img_size=args.img, tasks=TASKS, r_shared=64, r_task=4, drop_path_rate=0.2, seed=0).to(dev)
         model.train()
         crit = H.MultiTaskLoss(TASKS)
-        opt = H.build_optimizer(model, lr=5e-4 * args.batch * world / 512.0)  # main.py:578-583 linear LR scaling
+        opt = H.build_optimizer(model, lr=5e-4 * args.batch * world / 512.0,  # main.py:578-583 linear LR scaling
+                                capturable=args.graph)
         reducer = (GradReducer(model.parameters(), bucket_mb=16.0, force=args.force_reducer)
                    if (world > 1 or args.force_reducer) else None)
         img, tg = H.synthetic_batch(args.batch, args.img, TASKS, seed=1234 + rank, device=dev)
         torch.manual_seed(1234 + rank)
 
-        def step():
+        def eager_step():
             H.train_step(model, crit, opt, img, tg, clip_grad=5.0, reducer=reducer, amp_dtype=torch.bfloat16,
                          fused_loss=not args.no_fused_loss)
+
+        graph_info = {"enabled": False, "why": "eager (default); --graph is experimental, see its help"}
+        step = eager_step
+        if args.graph:
+            # the whole step (fwd + losses + bwd + clip + AdamW) captured as HIP graph(s); RCCL stays outside the graphs
+            gstep = H.GraphedTrainStep(model, crit, opt, img, tg, clip_grad=5.0, reducer=reducer, amp_dtype=torch.bfloat16,
+                                       fused_loss=not args.no_fused_loss)
+            graph_info = {"enabled": gstep.graphed, "why": gstep.why}
+            if not gstep.graphed and rank == 0:
+                print(f"bench: HIP-graph capture failed, running eagerly: {gstep.why}", file=sys.stderr)
+            step = gstep
 
         dt = time_steps(step, args.steps, args.warmup, world)
         ips = args.batch * world * args.steps / dt
@@ -215,13 +232,14 @@ def main():
                                    "r_shared=64 r_task=4 scale4, train step (fwd+loss+bwd+clip+AdamW), dropout .05, "
                                    "drop_path .2", "per_gpu_batch": args.batch, "global_batch": args.batch * world,
                        "img_size": args.img, "parallelism": f"dp{world}", "trainable_params": n_train,
-                       "allreduce_bytes": reducer.nbytes if reducer else 0},
+                       "allreduce_bytes": reducer.nbytes if reducer else 0, "hip_graph": graph_info},
         }
         if rank == 0 and not args.no_roofline:
-            result["roofline"] = roofline(step, max(2, min(args.steps, 5)))
+            # profiled EAGERLY: the library's HIP-event brackets are recorded at launch time (same kernels as the graph)
+            result["roofline"] = roofline(eager_step, max(2, min(args.steps, 5)))
         elif not args.no_roofline and world > 1:
             for _ in range(max(2, min(args.steps, 5))):  # keep ranks in lock-step with rank 0's profiled steps
-                step()
+                eager_step()
         del model, opt
         torch.cuda.empty_cache()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define MTLORA_ABI_VERSION 1
+#define MTLORA_ABI_VERSION 2
 #define MTLORA_MAX_TASKS 8
 
 typedef enum mtlora_dtype {
@@ -95,6 +95,9 @@ typedef struct mtlora_linear_desc {
     int32_t has_x_tasks; /* 1: task t reads x_t[t] undropped; 0: task t reads D(X) (lora.py:262-263) */
     float dropout_p;     /* 0 in eval */
     uint64_t seed;       /* dropout seed of this call (same value for fwd and bwd) */
+    const uint64_t* seed_offset; /* optional DEVICE pointer (null = none): the kernels use seed + *seed_offset (mod 2^64),
+                                    read when they run -- a captured HIP graph draws fresh masks on every replay by
+                                    bumping that one device word between replays (ABI v2) */
 } mtlora_linear_desc;
 
 /* bytes of the context buffer written by fwd and read by bwd (packed low-rank factors + P). */

@@ -737,7 +737,7 @@ int mtlora_window_attn_bwd(const mtlora_attn_desc* d, const void* qkv, const flo
     AttnParams p = make_params(d);
     hipStream_t s = (hipStream_t)stream;
     if (p.n_windows == 0) {
-        hipMemsetAsync(dbias, 0, (size_t)p.nH * p.N * p.N * 4, s);
+        mtl_zero_async(dbias, (size_t)p.nH * p.N * p.N * 4, s);
         return MTLORA_OK;
     }
     p.qkv = qkv;

@@ -22,6 +22,20 @@ typedef __attribute__((ext_vector_type(4))) short s16x4;
         if (e__ != hipSuccess) return MTLORA_ERR_HIP;        \
     } while (0)
 
+// Zero-fill as a KERNEL, not hipMemsetAsync: the buffers this library clears are consumed inside HIP graphs captured by
+// the host framework, and a captured memset node was observed not to take effect on replay (stale pool memory showed
+// through from the second replay on); kernel nodes replay reliably.  `bytes` must be a multiple of 4.
+static __global__ void mtl_k_zero(uint32_t* p, size_t n_words) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_words; i += (size_t)gridDim.x * blockDim.x) p[i] = 0u;
+}
+static inline void mtl_zero_async(void* p, size_t bytes, hipStream_t s) {
+    const size_t n = bytes / 4;
+    if (n == 0) return;
+    size_t blocks = (n + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(mtl_k_zero, dim3((unsigned)blocks), dim3(256), 0, s, reinterpret_cast<uint32_t*>(p), n);
+}
+
 __host__ __device__ static inline int64_t mtl_ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline int64_t mtl_round_up(int64_t a, int64_t b) { return mtl_ceil_div(a, b) * b; }
 static inline int mtl_elem_size(int dtype) { return dtype == MTLORA_F32 ? 4 : 2; }
@@ -43,11 +57,13 @@ __host__ __device__ __forceinline__ uint32_t mtl_mix32(uint32_t x) {
 
 struct DropoutCfg {
     uint32_t seed_lo, seed_hi, thr16;  // thr16 == 0 -> disabled
+    const unsigned long long* off;     // optional device word added to the seed at kernel start (graph replays)
     __host__ __device__ bool enabled() const { return thr16 != 0; }
 };
 
-static inline DropoutCfg mtl_make_dropout(float p, uint64_t seed) {
+static inline DropoutCfg mtl_make_dropout(float p, uint64_t seed, const uint64_t* seed_offset = nullptr) {
     DropoutCfg c;
+    c.off = reinterpret_cast<const unsigned long long*>(seed_offset);
     c.seed_lo = (uint32_t)(seed & 0xFFFFFFFFu);
     c.seed_hi = (uint32_t)(seed >> 32);
     double t = (double)p * 65536.0;
@@ -55,6 +71,15 @@ static inline DropoutCfg mtl_make_dropout(float p, uint64_t seed) {
     return c;
 }
 
+// effective seed = seed + *off (mod 2^64), resolved once per kernel (one scalar load)
+__device__ __forceinline__ void mtl_dropout_resolve(DropoutCfg& c) {
+    if (c.off && c.thr16) {
+        const unsigned long long e = (((unsigned long long)c.seed_hi << 32) | c.seed_lo) + *c.off;
+        c.seed_lo = (uint32_t)e;
+        c.seed_hi = (uint32_t)(e >> 32);
+    }
+    c.off = nullptr;
+}
 __device__ __forceinline__ uint32_t mtl_dropout_rowhash(const DropoutCfg& c, uint32_t stream, uint32_t m) {
     return mtl_mix32(m * 0x9E3779B1u + c.seed_lo + stream * 0x85EBCA77u);
 }

@@ -368,8 +368,8 @@ int mtlora_layernorm_bwd(const void* dy, const void* x, const float* gamma, cons
     if (scratch_bytes < mtlora_layernorm_bwd_scratch_bytes(M, C, x_dtype) - 256) return MTLORA_ERR_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
     if (M == 0) {
-        hipMemsetAsync(dgamma, 0, (size_t)C * 4, s);
-        hipMemsetAsync(dbeta, 0, (size_t)C * 4, s);
+        mtl_zero_async(dgamma, (size_t)C * 4, s);
+        mtl_zero_async(dbeta, (size_t)C * 4, s);
         return MTLORA_OK;
     }
     LnParams p = {};

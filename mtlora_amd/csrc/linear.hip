@@ -469,6 +469,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void k_nt(const NtParams 
     drop.seed_lo = P->drop.seed_lo;
     drop.seed_hi = P->drop.seed_hi;
     drop.thr16 = P->drop.thr16;
+    drop.off = P->drop.off;
+    mtl_dropout_resolve(drop);
     const int np = FUSE ? P->np : 0;
     const int PRS = P->pR * (int)sizeof(T) + 80;  // row stride of the LDS P image: pR columns + 64 zeroed bytes (a
                                                   // 64-byte sub-tile may start 32 B before the end) + 16 B of skew
@@ -813,7 +815,9 @@ __global__ __launch_bounds__(256, 2) void k_tn(const TnParams P) {
     const bool wave_on = tb * TN_B + wave * 64 < pr.Nb;  // this wave's 64 wide columns hold data
     const T* Ap = reinterpret_cast<const T*>(pr.A) + pr.a0 + ca;
     const T* Bp = reinterpret_cast<const T*>(pr.B) + pr.b0 + cb;
-    const bool bmask = pr.b_mask && P.drop.enabled();
+    DropoutCfg drop = P.drop;
+    mtl_dropout_resolve(drop);
+    const bool bmask = pr.b_mask && drop.enabled();
 
     // two register sets = prefetch distance 2 chunks (the grid is sized to 2 workgroups per CU, i.e. 256 VGPRs per
     // wave, and a workgroup's streaming rate is bounded by bytes in flight / load latency)
@@ -834,14 +838,14 @@ __global__ __launch_bounds__(256, 2) void k_tn(const TnParams P) {
         if (bmask && b_in) {  // dropout keep-mask, applied just before the LDS store
 #pragma unroll
             for (int j = 0; j < NLB; ++j) {
-                const uint32_t rh = mtl_dropout_rowhash(P.drop, 0u, (uint32_t)(mrow + rowB + j * RSB));
+                const uint32_t rh = mtl_dropout_rowhash(drop, 0u, (uint32_t)(mrow + rowB + j * RSB));
                 Vec16<T> x;
                 x.raw = rb[j];
 #pragma unroll
                 for (int e = 0; e < VEC; e += 2) {
-                    const uint32_t h = mtl_dropout_pairbits(P.drop, rh, (uint32_t)(pr.b0 + cb + e));
-                    if ((h & 0xFFFFu) < P.drop.thr16) x.e[e] = mtl_from_f32<T>(0.f);
-                    if ((h >> 16) < P.drop.thr16) x.e[e + 1] = mtl_from_f32<T>(0.f);
+                    const uint32_t h = mtl_dropout_pairbits(drop, rh, (uint32_t)(pr.b0 + cb + e));
+                    if ((h & 0xFFFFu) < drop.thr16) x.e[e] = mtl_from_f32<T>(0.f);
+                    if ((h >> 16) < drop.thr16) x.e[e + 1] = mtl_from_f32<T>(0.f);
                 }
                 rb[j] = x.raw;
             }
@@ -1083,7 +1087,7 @@ static int fwd_impl(const mtlora_linear_desc* d, const void* x, const void* cons
     T* bt_cat = reinterpret_cast<T*>(c + L.bt_cat);
     float* alpha = reinterpret_cast<float*>(c + L.alpha);
     T* Pm = reinterpret_cast<T*>(c + L.p);
-    const DropoutCfg dc = mtl_make_dropout(d->dropout_p, d->seed);
+    const DropoutCfg dc = mtl_make_dropout(d->dropout_p, d->seed, d->seed_offset);
     const float keep_scale = dc.enabled() ? 1.f / (1.f - d->dropout_p) : 1.f;
     bool fuse = false;
     int groups = 0;
@@ -1268,7 +1272,7 @@ static int bwd_impl(const mtlora_linear_desc* d, const void* x, const void* cons
     T* Qm = reinterpret_cast<T*>(sc + S.q);
     T* Gm = reinterpret_cast<T*>(sc + S.g);
     float* part = reinterpret_cast<float*>(sc + S.part);
-    const DropoutCfg dc = mtl_make_dropout(d->dropout_p, d->seed);
+    const DropoutCfg dc = mtl_make_dropout(d->dropout_p, d->seed, d->seed_offset);
     const bool v2 = d->mode == 1 && d->T > 0;
 
     // gradient sources per output
@@ -1311,7 +1315,7 @@ static int bwd_impl(const mtlora_linear_desc* d, const void* x, const void* cons
         bool any_missing = false;
         for (int o = 0; o < sg.n; ++o)
             if (sg.rp[o] > 0 && !dyo[o]) any_missing = true;
-        if (any_missing) hipMemsetAsync(Qm, 0, (size_t)(d->M * sg.R * sizeof(T)), s);
+        if (any_missing) mtl_zero_async(Qm, (size_t)(d->M * sg.R * sizeof(T)), s);
         NtParams q = {};
         q.n_act = 1;
         q.ld_act = d->N;

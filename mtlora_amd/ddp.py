@@ -78,8 +78,11 @@ class GradReducer:
     def nbytes(self) -> int:
         return sum(b.flat.numel() * 4 for b in self.buckets)
 
-    def prepare(self) -> None:
-        """call before backward."""
+    def prepare(self, defer: bool = False) -> None:
+        """call before backward.  defer=True (graphed step): buckets are only PACKED as their gradients arrive (those
+        copies are captured with the backward graph); the collectives are issued afterwards by ``all_reduce_packed``
+        outside any graph, and ``unpack`` (capturable) writes the means back."""
+        self._defer = defer
         for b in self.buckets:
             b.pending = len(b.params)
             b.handle = None
@@ -102,7 +105,7 @@ class GradReducer:
 
     def _launch(self, b: _Bucket) -> None:
         self._pack(b)
-        if self.active:
+        if self.active and not getattr(self, "_defer", False):
             b.handle = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def _on_grad(self, p: torch.nn.Parameter) -> None:
@@ -139,6 +142,35 @@ class GradReducer:
                     dst.append(p.grad)
                     src.append(b.flat[b.offsets[pi]:b.offsets[pi] + p.numel()].view_as(p.grad))
             if dst and self.active:
+                torch._foreach_copy_(dst, src)
+
+    # ---- graphed step: backward graph (packs) -> all_reduce_packed (eager RCCL) -> optimizer graph (unpack first)
+    def flush_packs(self) -> None:
+        """after backward, inside the backward capture: pack the buckets whose last gradient never arrived."""
+        self._armed = False
+        for b in self.buckets:
+            if b.pending > 0:
+                b.pending = 0
+                self._pack(b)
+
+    def all_reduce_packed(self) -> None:
+        if self.active:
+            for b in self.buckets:
+                dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group)
+
+    def unpack(self) -> None:
+        """capturable: mean = sum / world, written back into the gradients that exist."""
+        if not self.active:
+            return
+        inv = 1.0 / self.world
+        for b in self.buckets:
+            b.flat.mul_(inv)
+            dst, src = [], []
+            for pi, p in enumerate(b.params):
+                if b.seen[pi] and p.grad is not None:
+                    dst.append(p.grad)
+                    src.append(b.flat[b.offsets[pi]:b.offsets[pi] + p.numel()].view_as(p.grad))
+            if dst:
                 torch._foreach_copy_(dst, src)
 
     def remove(self) -> None:

@@ -20,6 +20,19 @@ from . import _lib as L
 _seed_counter = 0
 
 
+# optional device-resident offset added to every dropout seed when the kernels RUN (mtlora_linear_desc.seed_offset):
+# a captured HIP graph bakes the host-side seeds in, so a graphed train step bumps this one int64 between replays.
+_seed_offset: Optional[torch.Tensor] = None
+
+
+def set_seed_offset(t: Optional[torch.Tensor]) -> None:
+    """install (or clear) the device int64[1] tensor whose value is added to the dropout seeds at kernel time."""
+    global _seed_offset
+    if t is not None and not (t.is_cuda and t.dtype == torch.int64 and t.numel() == 1):
+        raise RuntimeError("mtlora_amd: the seed offset must be a CUDA int64 tensor with one element")
+    _seed_offset = t
+
+
 def next_seed() -> int:
     global _seed_counter
     _seed_counter += 1
@@ -77,6 +90,7 @@ class LinearMeta:
         d.has_x_tasks = 1 if self.has_x_tasks else 0
         d.dropout_p = self.dropout_p
         d.seed = self.seed
+        d.seed_offset = 0 if _seed_offset is None else _seed_offset.data_ptr()
         return d
 
 

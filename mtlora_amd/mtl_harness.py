@@ -13,12 +13,15 @@ main.py:192-204 (loss weights), main.py:329-354 + utils.py:348-375 (train step).
 """
 from __future__ import annotations
 
+import contextlib
+
 from typing import Dict, List, Mapping, Optional, Sequence
 
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import functional as Fn
 from .functional import BatchNormReluFn, UpsampleLossFn
 from .lora import mark_only_lora_as_trainable
 from .swin_transformer_mtlora import SwinTransformerMTLoRA
@@ -218,7 +221,8 @@ def build_model(img_size=448, tasks=("semseg", "normals", "sal", "human_parts"),
     return model
 
 
-def build_optimizer(model: nn.Module, lr=5e-4, weight_decay=0.05, fused: Optional[bool] = None) -> torch.optim.Optimizer:
+def build_optimizer(model: nn.Module, lr=5e-4, weight_decay=0.05, fused: Optional[bool] = None,
+                    capturable: bool = False) -> torch.optim.Optimizer:
     """AdamW(betas .9/.999, eps 1e-8, wd .05) with the no-decay set of optimizer.py:71-85 (1-D tensors, biases,
     relative_position_bias_table); only trainable tensors are handed over (frozen ones never get a grad in the
     reference either)."""
@@ -233,7 +237,8 @@ def build_optimizer(model: nn.Module, lr=5e-4, weight_decay=0.05, fused: Optiona
     groups = [{"params": decay}, {"params": no_decay, "weight_decay": 0.0}]
     if fused is None:
         fused = all(p.is_cuda for p in decay + no_decay)
-    return torch.optim.AdamW(groups, lr=lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=weight_decay, fused=fused)
+    return torch.optim.AdamW(groups, lr=lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=weight_decay, fused=fused,
+                             capturable=bool(capturable and fused))
 
 
 def synthetic_batch(B: int, S: int, tasks: Sequence[str], seed: int, device="cpu"):
@@ -285,3 +290,110 @@ def train_step(model, criterion, optimizer, images, targets, clip_grad: float = 
     optimizer.step()
     optimizer.zero_grad(set_to_none=True)
     return loss.detach(), norm
+
+
+class GraphedTrainStep:
+    """The SAME train step as ``train_step``, captured once as HIP graph(s) and replayed: the step issues ~1500 kernel
+    launches plus the Python / autograd / ctypes work behind them (~50 ms of host time against ~55 ms of GPU time at
+    C2), so eagerly it is nearly launch-bound -- and 8 ranks share one host.  A replay costs the host microseconds.
+
+    * one graph = autocast forward + fused losses + backward + clip + AdamW + zero_grad (single rank), or
+      backward graph (bucket packs captured) -> RCCL all-reduce of the flat buckets, EAGER, outside any graph ->
+      optimizer graph (unpack + clip + AdamW) with a reducer (the collectives are deliberately not captured);
+    * dropout: the MTLoRALinear seeds are baked into the graph, so a device int64 (``Fn.set_seed_offset``) is bumped
+      by a captured add at the start of every replay and added to the seeds by the kernels at run time; DropPath
+      uses torch's graph-safe generator;
+    * data: ``images`` / ``targets`` are static buffers -- ``copy_`` the next batch into them before calling;
+    * optimizer: must be ``capturable`` (``build_optimizer(..., capturable=True)``).
+    Falls back to the eager step (``self.graphed = False``, reason in ``self.why``) if capture fails.
+
+    EXPERIMENTAL -- NOT used by bench.py by default.  On the ROCm 7.0 / PyTorch 2.10 stack of this image a captured SMALL
+    ``hipMemsetAsync`` stops taking effect from the second replay on (4 KB: stale data shows through; 4 MB is fine).
+    This library no longer issues memsets (common.h:mtl_zero_async), but ATen does (reduction semaphores, ...), so a graph
+    of the WHOLE step, which mixes both, returns garbage after the first replay.  Kept because capture itself works
+    (~1500 launches, same speed as eager while the step is GPU-bound) and only the upstream memset nodes are in the way."""
+
+    SEED_STEP = 0x1E3779B97F4A7C15  # odd: a full-period walk of the 64-bit seed offset
+
+    def __init__(self, model, criterion, optimizer, images, targets, clip_grad: float = 5.0, reducer=None,
+                 amp_dtype: Optional[torch.dtype] = torch.bfloat16, fused_loss: bool = True, warmup: int = 3):
+        self.model, self.criterion, self.optimizer = model, criterion, optimizer
+        self.images, self.targets = images, targets
+        self.clip_grad, self.reducer, self.amp_dtype, self.fused_loss = clip_grad, reducer, amp_dtype, fused_loss
+        self.graphed, self.why = False, ""
+        self.seed = torch.zeros(1, dtype=torch.int64, device=images.device)
+        Fn.set_seed_offset(self.seed)
+        self.g_bwd = self.g_opt = None
+        self.loss = None
+        try:
+            self._capture(warmup)
+            self.graphed = True
+        except Exception as e:  # noqa: BLE001 -- any capture problem means: run eagerly, loudly
+            self.why = f"{type(e).__name__}: {e}"
+            torch.cuda.synchronize()
+            self.g_bwd = self.g_opt = None
+            optimizer.zero_grad(set_to_none=True)
+
+    # -- pieces of the step (shared by the eager fallback and the capture)
+    def _forward_backward(self):
+        self.seed.add_(self.SEED_STEP)
+        ctx = (torch.autocast("cuda", dtype=self.amp_dtype, cache_enabled=False) if self.amp_dtype is not None
+               else contextlib.nullcontext())
+        with ctx:
+            if self.fused_loss:
+                loss, _ = self.criterion.forward_low(self.model(self.images, upsample=False), self.targets)
+            else:
+                loss, _ = self.criterion(self.model(self.images), self.targets)
+        if self.reducer is not None:
+            self.reducer.prepare(defer=True)
+        loss.backward()
+        if self.reducer is not None:
+            self.reducer.flush_packs()
+        return loss.detach()
+
+    def _optimize(self):
+        if self.reducer is not None:
+            self.reducer.unpack()
+        params = [p for g in self.optimizer.param_groups for p in g["params"] if p.grad is not None]
+        if self.clip_grad:
+            torch.nn.utils.clip_grad_norm_(params, self.clip_grad, foreach=True)
+        self.optimizer.step()
+        self.optimizer.zero_grad(set_to_none=True)
+
+    def _eager(self):
+        loss = self._forward_backward()
+        if self.reducer is not None:
+            self.reducer.all_reduce_packed()
+        self._optimize()
+        return loss
+
+    def _capture(self, warmup: int):
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):  # allocator / autotune / lazy-init warm-up off the capture stream
+            for _ in range(max(1, warmup)):
+                self._eager()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.optimizer.zero_grad(set_to_none=True)
+        self.g_bwd = torch.cuda.CUDAGraph()
+        if self.reducer is None:
+            with torch.cuda.graph(self.g_bwd):
+                self.loss = self._forward_backward()
+                self._optimize()
+        else:
+            with torch.cuda.graph(self.g_bwd):
+                self.loss = self._forward_backward()
+            self.g_opt = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.g_opt, pool=self.g_bwd.pool()):
+                self._optimize()
+        torch.cuda.synchronize()
+
+    def __call__(self):
+        if not self.graphed:
+            return self._eager()
+        self.g_bwd.replay()
+        if self.g_opt is not None:
+            self.reducer.all_reduce_packed()
+            self.g_opt.replay()
+        return self.loss

@@ -646,3 +646,104 @@ def test_fused_loss_path_equals_plain_path():
     for t in tasks:
         assert abs(per[t].item() - per2[t].item()) <= 1e-4 * max(1.0, abs(per2[t].item())), t
         assert rel_err(g_fused[t], low[t].grad) <= 1e-4, t
+
+
+# ------------------------------------------------------------------------------------------------
+# device-side seed offset (ABI v2) and the HIP-graph train step
+# ------------------------------------------------------------------------------------------------
+def test_linear_seed_offset_is_added_on_device():
+    """mtlora_linear_desc.seed_offset: the kernels use seed + *offset (mod 2^64), forward and backward."""
+    from mtlora_amd.lora import MTLoRALinear
+    from mtlora_amd import functional as Fn
+    M, K, N = 257, 96, 128
+    torch.manual_seed(5)
+    m = MTLoRALinear(K, N, r={"shared": 16}, lora_shared_scale=2.0, lora_task_scale=1.0, lora_dropout=0.25, tasks=None).to(dev())
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            p.copy_(torch.randn_like(p) * 0.05)
+    m.linear.weight.requires_grad_(False)
+    m.linear.bias.requires_grad_(False)
+    m.train()
+    x = torch.randn(M, K, device=dev(), requires_grad=True)
+    off = torch.tensor([0x1E3779B97F4A7C15 * 3 % (1 << 63)], dtype=torch.int64, device=dev())
+    try:
+        Fn.set_seed_offset(off)
+        c0 = Fn._seed_counter
+        y, _ = m(x, None)
+        Fn._seed_counter = c0
+        seed = (Fn.next_seed() + int(off.item())) & 0xFFFFFFFFFFFFFFFF
+        keep = O.dropout_keep_mask(seed, 0, M, K, 0.25)
+        P, xs, _, yo, _ = _oracle_linear(m, x, None, keep=keep, p=0.25)
+        assert_close(y, yo, torch.float32, "y")
+        y.sum().backward()
+        yo.sum().backward()
+        assert_close(x.grad, xs.grad, torch.float32, "dx", mult=2)
+        for n, p in m.named_parameters():
+            if p.requires_grad:
+                assert_close(p.grad, P[n].grad, torch.float32, f"grad {n}", mult=3)
+        # a different offset -> a different mask
+        off.add_(12345)
+        y2, _ = m(x, None)   # NB: draws the next host seed as well; only checks that the result moved
+        assert not torch.allclose(y2, y)
+    finally:
+        Fn.set_seed_offset(None)
+
+
+def test_library_is_hip_graph_safe():
+    """The library's launches can be captured into a HIP graph and replayed: MTLoRALinear forward + backward with an
+    UNUSED task output (the backward must zero that output's slice of Q) inside torch.cuda.graph, with the graph's
+    private pool dirtied between uses.  Guards the zero-fill-as-a-kernel rule (common.h:mtl_zero_async): a captured
+    small hipMemsetAsync does not take effect from the second replay on with this ROCm stack (stale pool memory shows
+    through), which is also why bench.py does not replay the whole train step as a graph by default."""
+    from mtlora_amd.lora import MTLoRALinear
+    M, K, N = 640, 96, 192
+    tasks = ["a", "b"]
+    torch.manual_seed(11)
+    m = MTLoRALinear(K, N, r={"shared": 16, "a": 4, "b": 4}, lora_shared_scale=2.0, lora_task_scale={"a": 1.0, "b": 1.0},
+                     lora_dropout=0.0, tasks=tasks).to(dev())
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            p.copy_(torch.randn_like(p) * 0.05)
+    m.linear.weight.requires_grad_(False)
+    m.linear.bias.requires_grad_(False)
+    m.train()
+    x = torch.randn(M, K, device=dev(), dtype=torch.bfloat16, requires_grad=True)
+    xt = {t: torch.randn(M, K, device=dev(), dtype=torch.bfloat16, requires_grad=True) for t in tasks}
+    gy = torch.randn(M, N, device=dev(), dtype=torch.bfloat16)
+
+    def run():
+        junk = torch.full((1 << 16,), float("nan"), device=dev())  # dirty a pool block the scratch buffers may reuse
+        del junk
+        y, yt = m(x, xt)
+        (y * gy).sum().backward(inputs=[x, xt["a"], xt["b"]] + [p for p in m.parameters() if p.requires_grad])
+        # yt["a"], yt["b"] unused: their gradients are undefined -> zero-filled slices inside the library
+
+    grads = lambda: [x.grad, xt["a"].grad, xt["b"].grad] + [p.grad for p in m.parameters() if p.requires_grad]  # noqa: E731
+
+    def clear():
+        x.grad = None
+        for t in tasks:
+            xt[t].grad = None
+        for p in m.parameters():
+            p.grad = None
+
+    run()
+    ref = [None if g is None else g.clone() for g in grads()]
+    clear()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        run()
+    torch.cuda.current_stream().wait_stream(side)
+    clear()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        run()
+    for _ in range(4):
+        g.replay()
+        torch.cuda.synchronize()
+        for a_, b_ in zip(grads(), ref):
+            assert (a_ is None) == (b_ is None)
+            if a_ is not None:
+                assert torch.isfinite(a_).all()
+                assert torch.equal(a_, b_)

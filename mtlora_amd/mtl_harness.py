@@ -68,7 +68,8 @@ class Downsampler(nn.Module):
         for i, (f, r, d) in enumerate(zip(feats, self.input_res, self.dims)):
             if self.enabled:
                 conv = getattr(self, f"downsample_{i}")
-                f = F.linear(f, conv.weight.view(conv.out_channels, d), conv.bias)
+                B_, L_, _ = f.shape
+                f = Fn.linear_big_m(f.reshape(B_ * L_, d), conv.weight.view(conv.out_channels, d), conv.bias).view(B_, L_, -1)
             maps.append(f.view(-1, r, r, f.shape[-1]).permute(0, 3, 1, 2))
         return maps
 
@@ -89,7 +90,7 @@ class HighResolutionHead(nn.Module):
         cat = torch.cat([x[0]] + [F.interpolate(m, (Hh, Ww), mode="bilinear") for m in x[1:]], 1)
         c0, bn, _, c3 = self.last_layer
         t = cat.permute(0, 2, 3, 1).reshape(B * Hh * Ww, cat.shape[1])
-        h = F.linear(t, c0.weight.view(c0.out_channels, c0.in_channels), c0.bias)
+        h = Fn.linear_big_m(t, c0.weight.view(c0.out_channels, c0.in_channels), c0.bias)
         if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
             bn.num_batches_tracked.add_(1)
         if bn.training and h.is_cuda and h.dtype in (torch.float32, torch.bfloat16) and h.shape[1] % 8 == 0:

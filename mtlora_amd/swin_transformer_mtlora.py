@@ -65,6 +65,10 @@ class CompatLinear(nn.Linear):
     """plain linear with the tuple calling convention (reference :36-41); stays on rocBLAS/hipBLASLt."""
 
     def forward(self, input: Tensor, x_tasks: dict = None):
+        if input.is_cuda and self.weight.requires_grad:  # huge-M trained linear (PatchMerging.reduction): split-K wgrad
+            sh = input.shape
+            y = Fn.linear_big_m(input.reshape(-1, sh[-1]), self.weight, self.bias)
+            return y.view(*sh[:-1], y.shape[-1]), None
         return super().forward(input), None
 
 
@@ -385,7 +389,9 @@ class PatchEmbed(nn.Module):
         # (same `proj.weight` / `proj.bias` parameters and values as the reference's Conv2d, no MIOpen find)
         ph, pw = self.patch_size
         p = x.view(B, C, H // ph, ph, W // pw, pw).permute(0, 2, 4, 1, 3, 5).reshape(B, -1, C * ph * pw)
-        x = nn.functional.linear(p, self.proj.weight.view(self.embed_dim, -1), self.proj.bias)
+        sh = p.shape
+        x = Fn.linear_big_m(p.reshape(-1, sh[-1]), self.proj.weight.view(self.embed_dim, -1), self.proj.bias)
+        x = x.view(*sh[:-1], self.embed_dim)
         return x if self.norm is None else Fn.layer_norm(self.norm, x, feeds_linear=False)
 
     def flops(self):

@@ -217,6 +217,18 @@ int mtlora_upsample_loss(int kind, const void* low, const float* label, const fl
                          int64_t B, int h, int w, int C, int scale, int dtype, float ignore_index, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Channels-last bilinear upsampling by an integer factor (align_corners=False) for the HRNet head of the callers
+ * (models/seg_hrnet.py:498-526: F.interpolate of the coarse maps + torch.cat).  coarse (B,h,w,C) contiguous; the fine
+ * tensor (B, scale*h, scale*w, .) is addressed with `ld_fine` elements per pixel, its pointer already offset to the
+ * first channel of this map -- i.e. a channel slice of the concatenated matrix.  C and ld_fine multiples of 4,
+ * pointers 8-byte (bf16) / 16-byte (fp32) aligned.  bwd = exact transpose (gather form, deterministic).
+ * ------------------------------------------------------------------------------------------ */
+int mtlora_upsample_cl_fwd(const void* coarse, void* fine, int64_t B, int h, int w, int C, int scale, int64_t ld_fine,
+                           int dtype, void* stream);
+int mtlora_upsample_cl_bwd(const void* grad_fine, void* grad_coarse, int64_t B, int h, int w, int C, int scale,
+                           int64_t ld_fine, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Hardware self-test: writes the lane->element maps of the MFMA / LDS-transpose primitives the
  * kernels rely on into `out` (int32[4096]) so a GPU test can assert them (tests/test_gpu_layouts.py).
  * ------------------------------------------------------------------------------------------ */
@@ -229,7 +241,7 @@ int mtlora_selftest_layouts(int32_t* out, void* stream);
  * were synchronised.  A process-wide diagnostic switch -- the only global state in the library; the
  * compute entry points stay re-entrant.
  * ------------------------------------------------------------------------------------------ */
-#define MTLORA_PROF_KINDS 16
+#define MTLORA_PROF_KINDS 24
 typedef struct mtlora_prof_summary {
     int64_t count[MTLORA_PROF_KINDS];
     double ms[MTLORA_PROF_KINDS];        /* sum of launch durations */

@@ -33,7 +33,7 @@ class AttnDesc(Structure):
                 ("scale", c_float), ("mask_value", c_float)]
 
 
-PROF_KINDS = 16
+PROF_KINDS = 24
 
 
 class ProfSummary(Structure):
@@ -81,6 +81,8 @@ _SIGS = {
     "mtlora_upsample_loss_partials": (c_int64, [c_int64, c_int, c_int]),
     "mtlora_upsample_loss": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int,
                                      c_int, c_int, ctypes.c_float, c_void_p]),
+    "mtlora_upsample_cl_fwd": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int64, c_int, c_void_p]),
+    "mtlora_upsample_cl_bwd": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int64, c_int, c_void_p]),
     "mtlora_selftest_layouts": (c_int, [c_void_p, c_void_p]),
     "mtlora_prof_begin": (c_int, [c_int]),
     "mtlora_prof_end": (c_int, [POINTER(ProfSummary)]),

@@ -247,7 +247,8 @@ enum MtlProfKind {
     PK_BN = 12,          // k_bn_colsum / k_bn_apply      heads' BatchNorm(+ReLU)
     PK_LOSS = 14,        // k_up_loss                     low-res logits in, gradient out, labels in
     PK_SUM = 15,         // k_sum: G = sum of the output gradients (matrixv2 / pre-summed dX operand)
-    PK_COUNT = 16
+    PK_UPSAMPLE = 16,    // k_up_fwd / k_up_bwd: head's coarse -> fine bilinear maps
+    PK_COUNT = 24
 };
 int mtl_prof_start(int kind, double alg_bytes, hipStream_t s);
 void mtl_prof_stop(int idx, hipStream_t s);

@@ -158,6 +158,7 @@ extern "C" const char* mtlora_prof_kind_name(int kind) {
         case PK_RESIDUAL: return "k_residual";
         case PK_LOSS: return "k_up_loss";
         case PK_SUM: return "k_sum";
+        case PK_UPSAMPLE: return "k_upsample";
         default: return "";
     }
 }

@@ -568,3 +568,70 @@ def linear_big_m(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Ten
                     return SplitKLinearFn.apply(x.to(dt), weight.to(dt), None if bias is None else bias.to(dt), S)
             return SplitKLinearFn.apply(x, weight, bias, S)
     return torch.nn.functional.linear(x, weight, bias)
+
+
+# ----------------------------------------------------------------------------------------------
+# HRNet head input: [finest map | upsampled coarse maps] concatenated along channels, without the copies
+# ----------------------------------------------------------------------------------------------
+def _pad4(c: int) -> int:
+    return (c + 3) // 4 * 4
+
+
+class ConcatUpsampleFn(torch.autograd.Function):
+    """maps[i]: (B, h_i, w_i, C_i) channels-last, h_0 = H the finest, H = s_i * h_i.  Returns the (B*H*W, ld) matrix
+    [maps[0] | pad | up(maps[1]) | up(maps[2]) | ...] (bilinear, align_corners=False) whose slices start at multiples of
+    4 channels (``ConcatUpsampleFn.layout(channels)`` gives offsets and ld): the upsample kernels write / read the slices
+    of the concatenated matrix directly (csrc/upsample.hip), replacing F.interpolate x3 + torch.cat and their backward."""
+
+    @staticmethod
+    def layout(channels):
+        offs, o = [], 0
+        for c in channels:
+            offs.append(o)
+            o += _pad4(c)
+        return offs, (o + 7) // 8 * 8
+
+    @staticmethod
+    def forward(ctx, *maps):
+        L.require_gpu(*maps)
+        B, H, W, _ = maps[0].shape
+        chans = [m.shape[3] for m in maps]
+        offs, ld = ConcatUpsampleFn.layout(chans)
+        dt = maps[0].dtype
+        out = torch.empty(B * H * W, ld, dtype=dt, device=maps[0].device)
+        o3 = out.view(B, H, W, ld)
+        o3[..., :chans[0]].copy_(maps[0])
+        lib = L.lib()
+        end = chans[0]
+        for i in range(1, len(maps)):
+            if offs[i] > end:
+                o3[..., end:offs[i]].zero_()
+            m = maps[i].contiguous()
+            _, h, w, C = m.shape
+            if H % h or W % w or H // h != W // w or C % 4 or m.dtype != dt:
+                raise RuntimeError("mtlora_amd: ConcatUpsampleFn needs integer scales, C % 4 == 0 and one dtype")
+            st = lib.mtlora_upsample_cl_fwd(L.ptr(m), ctypes.c_void_p(out.data_ptr() + offs[i] * out.element_size()), B, h, w, C,
+                                            H // h, ld, L.dtype_code(m), L.stream_ptr())
+            L.check(st, "mtlora_upsample_cl_fwd")
+            end = offs[i] + C
+        if ld > end:
+            o3[..., end:].zero_()
+        ctx.shapes = [tuple(m.shape) for m in maps]
+        ctx.offs, ctx.ld = offs, ld
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        B, H, W, C0 = ctx.shapes[0]
+        ld = ctx.ld
+        grads = [g.view(B, H, W, ld)[..., :C0]]
+        lib = L.lib()
+        for i in range(1, len(ctx.shapes)):
+            _, h, w, C = ctx.shapes[i]
+            d = torch.empty(ctx.shapes[i], dtype=g.dtype, device=g.device)
+            st = lib.mtlora_upsample_cl_bwd(ctypes.c_void_p(g.data_ptr() + ctx.offs[i] * g.element_size()), L.ptr(d), B, h, w, C,
+                                            H // h, ld, L.dtype_code(g), L.stream_ptr())
+            L.check(st, "mtlora_upsample_cl_bwd")
+            grads.append(d)
+        return tuple(grads)

@@ -87,10 +87,31 @@ class HighResolutionHead(nn.Module):
 
     def forward(self, x, channels_last_out: bool = False):
         B, _, Hh, Ww = x[0].shape
-        cat = torch.cat([x[0]] + [F.interpolate(m, (Hh, Ww), mode="bilinear") for m in x[1:]], 1)
         c0, bn, _, c3 = self.last_layer
-        t = cat.permute(0, 2, 3, 1).reshape(B * Hh * Ww, cat.shape[1])
-        h = Fn.linear_big_m(t, c0.weight.view(c0.out_channels, c0.in_channels), c0.bias)
+        w2d = c0.weight.view(c0.out_channels, c0.in_channels)
+        xc = [m.permute(0, 2, 3, 1) for m in x]  # the Downsampler's maps are channels-last views
+        chans = [t.shape[3] for t in xc]
+        if (x[0].is_cuda and all(t.is_contiguous() for t in xc) and all(c % 4 == 0 for c in chans[1:])
+                and len({t.dtype for t in xc}) == 1 and xc[0].dtype in (torch.float32, torch.bfloat16)
+                and all(Hh % t.shape[1] == 0 and Ww % t.shape[2] == 0 and Hh // t.shape[1] == Ww // t.shape[2] for t in xc)):
+            # upsample kernels write straight into the channel slices of the concatenated pixel matrix (padded so that
+            # every slice starts at a multiple of 4 channels and rows are 16-byte aligned); the 1x1 conv weight gets the
+            # matching zero columns
+            t = Fn.ConcatUpsampleFn.apply(*xc)
+            offs, ld = Fn.ConcatUpsampleFn.layout(chans)
+            cols, src, end = [], 0, 0
+            for o, c in zip(offs, chans):
+                if o > end:
+                    cols.append(w2d.new_zeros(w2d.shape[0], o - end))
+                cols.append(w2d[:, src:src + c])
+                src, end = src + c, o + c
+            if ld > end:
+                cols.append(w2d.new_zeros(w2d.shape[0], ld - end))
+            w2d = torch.cat(cols, 1)
+        else:
+            cat = torch.cat([x[0]] + [F.interpolate(m, (Hh, Ww), mode="bilinear") for m in x[1:]], 1)
+            t = cat.permute(0, 2, 3, 1).reshape(B * Hh * Ww, cat.shape[1])
+        h = Fn.linear_big_m(t, w2d, c0.bias)
         if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
             bn.num_batches_tracked.add_(1)
         if bn.training and h.is_cuda and h.dtype in (torch.float32, torch.bfloat16) and h.shape[1] % 8 == 0:

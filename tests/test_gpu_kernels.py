@@ -747,3 +747,32 @@ def test_library_is_hip_graph_safe():
             if a_ is not None:
                 assert torch.isfinite(a_).all()
                 assert torch.equal(a_, b_)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_concat_upsample_vs_torch(dtype):
+    """ConcatUpsampleFn == torch.cat([x0, F.interpolate(x1), F.interpolate(x2), ...], channels) on the padded layout,
+    values and gradients (scales 2 / 4 / 8, H != W)."""
+    from mtlora_amd import functional as Fn
+    B, H, W = 2, 16, 24
+    chans = [18, 36, 72, 144]
+    torch.manual_seed(0)
+    maps = [torch.randn(B, H >> i, W >> i, c, device=dev()).to(dtype).requires_grad_(True) for i, c in enumerate(chans)]
+    out = Fn.ConcatUpsampleFn.apply(*maps)
+    offs, ld = Fn.ConcatUpsampleFn.layout(chans)
+    assert out.shape == (B * H * W, ld) and ld % 8 == 0
+    refs = [m.detach().double().requires_grad_(True) for m in maps]
+    ups = [refs[0]] + [torch.nn.functional.interpolate(r.permute(0, 3, 1, 2), (H, W), mode="bilinear").permute(0, 2, 3, 1)
+                       for r in refs[1:]]
+    o3 = out.view(B, H, W, ld)
+    used = torch.zeros(ld, dtype=torch.bool)
+    for o, c, u in zip(offs, chans, ups):
+        assert_close(o3[..., o:o + c], u, dtype, f"slice@{o}")
+        used[o:o + c] = True
+    assert (o3[..., ~used.to(o3.device)] == 0).all()   # pad channels are zero
+    g = torch.randn(B * H * W, ld, device=dev()).to(dtype)
+    out.backward(g)
+    g3 = g.view(B, H, W, ld).double().cpu()
+    sum((u.cpu() * g3[..., o:o + c]).sum() for o, c, u in zip(offs, chans, ups)).backward()
+    for m, r in zip(maps, refs):
+        assert_close(m.grad, r.grad, dtype, "grad", mult=2)

@@ -497,10 +497,14 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void k_nt(const NtParams 
         ld.k0 += KE;
         if (ld.k0 >= ld.k_hi) ld = nt_seek<MULTI, FUSE>(P, ld.q + 1, nseq, ld.bn, bn_hi);
         if (ld.valid) issue(ld);
-        if (from_p)
-            nt_compute<T, SM>(acc, sW, sP + k0 * (int)sizeof(T), lane, wn, wm, k_left, PRS);
-        else
-            nt_compute<T, SM>(acc, sW, sA, lane, wn, wm, k_left);
+        // a wave whose 64 output columns lie entirely past n_rows (P / Q passes: <= 64 of the tile's 128 columns exist)
+        // only helps staging: no LDS fragment reads, no MFMAs (wave-uniform test)
+        if (n0 + wn * 64 < n_rows) {
+            if (from_p)
+                nt_compute<T, SM>(acc, sW, sP + k0 * (int)sizeof(T), lane, wn, wm, k_left, PRS);
+            else
+                nt_compute<T, SM>(acc, sW, sA, lane, wn, wm, k_left);
+        }
         __syncthreads();
     };
     auto run_part = [&](int q, f32x16(&acc)[2][SM]) __attribute__((always_inline)) {
@@ -559,7 +563,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void k_nt(const NtParams 
     };
     auto store = [&](const f32x16(&a)[2][SM], void* ptr) __attribute__((always_inline)) {
         T* outp = reinterpret_cast<T*>(ptr);
-        if (!outp) return;
+        if (!outp || n0 + wn * 64 >= n_rows) return;  // (the per-wave LDS image needs no workgroup barrier)
         if constexpr (sizeof(T) == 2) {
             // bf16: transpose the wave's 64(n) x 64(m) accumulator tile through LDS so that every store instruction
             // writes whole 128-byte row segments (8 lanes x 16 B) instead of 16-byte pieces of 32 different rows.

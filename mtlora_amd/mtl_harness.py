@@ -120,7 +120,7 @@ class HighResolutionHead(nn.Module):
         else:
             h = F.relu(F.batch_norm(h, bn.running_mean, bn.running_var, bn.weight, bn.bias,
                                     bn.training or not bn.track_running_stats, bn.momentum, bn.eps))
-        o = F.linear(h, c3.weight.view(c3.out_channels, c3.in_channels), c3.bias).view(B, Hh, Ww, c3.out_channels)
+        o = Fn.linear_big_m(h, c3.weight.view(c3.out_channels, c3.in_channels), c3.bias).view(B, Hh, Ww, c3.out_channels)
         return o if channels_last_out else o.permute(0, 3, 1, 2)
 
 

@@ -70,10 +70,33 @@ struct LnParams {
     float eps;
 };
 
+// raw 16-byte vector -> floats
+template <typename T>
+__device__ __forceinline__ void cvt_vec(const u32x4& r, float (&f)[8]);
+template <>
+__device__ __forceinline__ void cvt_vec<float>(const u32x4& r, float (&f)[8]) {
+    const f32x4 v = __builtin_bit_cast(f32x4, r);
+    f[0] = v[0];
+    f[1] = v[1];
+    f[2] = v[2];
+    f[3] = v[3];
+}
+template <>
+__device__ __forceinline__ void cvt_vec<bf16>(const u32x4& r, float (&f)[8]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        f[2 * q] = __builtin_bit_cast(float, r[q] << 16);
+        f[2 * q + 1] = __builtin_bit_cast(float, r[q] & 0xFFFF0000u);
+    }
+}
+
+// UNR row groups per wave iteration: their loads are issued back to back and kept as raw 16-byte vectors (a wave with a
+// single 1.5 KB row group in flight per iteration ran at 1.5-2.8 TB/s for the stage-1..3 shapes)
 template <typename TI, typename TO, int LPR, int MAXV>
 __global__ __launch_bounds__(256) void k_ln_fwd(const LnParams p) {
     constexpr int VE = ET<TI>::VEC;
-    constexpr int RPW = 64 / LPR;  // rows per wave
+    constexpr int RPW = 64 / LPR;  // rows per wave per group
+    constexpr int UNR = MAXV <= 3 ? 4 : 1;  // (the wide-row specialisation already holds 8 vectors per lane)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int sub = lane / LPR, lr = lane % LPR;
     const int nvec = p.C / VE;
@@ -89,51 +112,60 @@ __global__ __launch_bounds__(256) void k_ln_fwd(const LnParams p) {
             b[i][e] = v < nvec ? p.beta[v * VE + e] : 0.f;
         }
     }
-    const int64_t rows_per_blk = 4 * RPW;
+    const float inv_c = 1.f / (float)p.C;
+    const int64_t rows_per_blk = 4 * RPW * UNR;
     for (int64_t r0 = (int64_t)blockIdx.x * rows_per_blk; r0 < p.M; r0 += (int64_t)gridDim.x * rows_per_blk) {
-        const int64_t row = r0 + wave * RPW + sub;
-        const bool rv = row < p.M;
-        float f[MAXV][8];
-        float s = 0.f;
+        u32x4 raw[UNR][MAXV];
+        int64_t row[UNR];
 #pragma unroll
-        for (int i = 0; i < MAXV; ++i) {
-            const int v = lr + i * LPR;
-            if (rv && v < nvec) {
-                ld_vec<TI>(x + row * p.C + v * VE, f[i]);
-#pragma unroll
-                for (int e = 0; e < VE; ++e) s += f[i][e];
-            } else {
-#pragma unroll
-                for (int e = 0; e < VE; ++e) f[i][e] = 0.f;
-            }
-        }
-        const float mean = group_sum<LPR>(s) / p.C;
-        float q = 0.f;
-#pragma unroll
-        for (int i = 0; i < MAXV; ++i) {
-            const int v = lr + i * LPR;
-            if (v < nvec) {
-#pragma unroll
-                for (int e = 0; e < VE; ++e) {
-                    const float d = f[i][e] - mean;
-                    q += d * d;
-                }
-            }
-        }
-        const float rstd = rsqrtf(group_sum<LPR>(q) / p.C + p.eps);
-        if (rv) {
-            if (lr == 0) {
-                p.mean[row] = mean;
-                p.rstd[row] = rstd;
-            }
+        for (int u = 0; u < UNR; ++u) {
+            row[u] = r0 + (int64_t)(wave * UNR + u) * RPW + sub;
 #pragma unroll
             for (int i = 0; i < MAXV; ++i) {
                 const int v = lr + i * LPR;
-                if (v < nvec) {
-                    float o[8];
+                raw[u][i] = (row[u] < p.M && v < nvec) ? *reinterpret_cast<const u32x4*>(x + row[u] * p.C + v * VE)
+                                                      : u32x4{0u, 0u, 0u, 0u};
+            }
+        }
 #pragma unroll
-                    for (int e = 0; e < VE; ++e) o[e] = (f[i][e] - mean) * rstd * g[i][e] + b[i][e];
-                    st_vec<TO, VE>(y + row * p.C + v * VE, o);
+        for (int u = 0; u < UNR; ++u) {
+            float f[8];
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < MAXV; ++i) {
+                cvt_vec<TI>(raw[u][i], f);
+#pragma unroll
+                for (int e = 0; e < VE; ++e) s += f[e];  // out-of-range vectors are zero
+            }
+            const float mean = group_sum<LPR>(s) * inv_c;
+            float q = 0.f;
+#pragma unroll
+            for (int i = 0; i < MAXV; ++i) {
+                if (lr + i * LPR < nvec) {
+                    cvt_vec<TI>(raw[u][i], f);
+#pragma unroll
+                    for (int e = 0; e < VE; ++e) {
+                        const float d = f[e] - mean;
+                        q += d * d;
+                    }
+                }
+            }
+            const float rstd = rsqrtf(group_sum<LPR>(q) * inv_c + p.eps);
+            if (row[u] < p.M) {
+                if (lr == 0) {
+                    p.mean[row[u]] = mean;
+                    p.rstd[row[u]] = rstd;
+                }
+#pragma unroll
+                for (int i = 0; i < MAXV; ++i) {
+                    const int v = lr + i * LPR;
+                    if (v < nvec) {
+                        cvt_vec<TI>(raw[u][i], f);
+                        float o[8];
+#pragma unroll
+                        for (int e = 0; e < VE; ++e) o[e] = (f[e] - mean) * rstd * g[i][e] + b[i][e];
+                        st_vec<TO, VE>(y + row[u] * p.C + v * VE, o);
+                    }
                 }
             }
         }
@@ -340,7 +372,9 @@ int mtlora_layernorm_fwd(const void* x, const float* gamma, const float* beta, v
     const int nvec_h = (int)(C / (x_dtype == MTLORA_F32 ? 4 : 8));
     const int lpr = pick_lpr(nvec_h);
     const int vpl = (nvec_h + lpr - 1) / lpr;
-    const int grid = ln_grid(M, lpr, 256 * 8);
+    const int grid = (int)mtl_ceil_div(ln_grid(M, lpr, 1 << 30), vpl <= 3 ? 4 : 1) < 256 * 8
+                         ? (int)mtl_ceil_div(ln_grid(M, lpr, 1 << 30), vpl <= 3 ? 4 : 1)
+                         : 256 * 8;  // 4 row groups per wave iteration in the narrow-row kernels
     const size_t lds = 0;
     hipStream_t s = (hipStream_t)stream;
     const int es_x = mtl_elem_size(x_dtype), es_y = mtl_elem_size(y_dtype);

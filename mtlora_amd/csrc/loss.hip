@@ -44,7 +44,9 @@ __global__ __launch_bounds__(256) void k_up_loss(const UpLossParams p) {
     const int b = blockIdx.x / (tiles_x * tiles_y);
     const int trem = blockIdx.x % (tiles_x * tiles_y);
     const int qy0 = (trem / tiles_x) * UQ, qx0 = (trem % tiles_x) * UQ;
-    const int C = p.C, Cs = C | 1;  // odd stride: neighbouring pixels hit different banks
+    const int C = p.C, Cs = C | 1;  // odd pixel stride: the 16 pixels of a tile row hit 16 different banks
+    // tile-row pitch == 16 (mod 32) words: the two tile rows a 32-lane half touches land in the complementary banks
+    const int RP = (UQ + 2) * Cs + ((16 - (UQ + 2) * Cs) & 31);
     const int H = p.h * p.S, W = p.w * p.S, S = p.S;
     const T* low = reinterpret_cast<const T*>(p.low);
 
@@ -53,7 +55,7 @@ __global__ __launch_bounds__(256) void k_up_loss(const UpLossParams p) {
         int gy = qy0 - 1 + pix / (UQ + 2), gx = qx0 - 1 + pix % (UQ + 2);
         gy = gy < 0 ? 0 : (gy > p.h - 1 ? p.h - 1 : gy);
         gx = gx < 0 ? 0 : (gx > p.w - 1 ? p.w - 1 : gx);
-        sm[pix * Cs + c] = mtl_to_f32(low[(((int64_t)b * p.h + gy) * p.w + gx) * C + c]);
+        sm[(pix / (UQ + 2)) * RP + (pix % (UQ + 2)) * Cs + c] = mtl_to_f32(low[(((int64_t)b * p.h + gy) * p.w + gx) * C + c]);
     }
     __syncthreads();
 
@@ -84,8 +86,8 @@ __global__ __launch_bounds__(256) void k_up_loss(const UpLossParams p) {
             const float fy = sy - (float)iy0;
             const float wy = (iy0 == qy ? 1.f - fy : 0.f) + (iy1 == qy ? fy : 0.f);
             if (wy == 0.f) continue;
-            const float* r0 = sm + ((iy0 - qy0 + 1) * (UQ + 2) + lx) * Cs;
-            const float* r1 = sm + ((iy1 - qy0 + 1) * (UQ + 2) + lx) * Cs;
+            const float* r0 = sm + (iy0 - qy0 + 1) * RP + lx * Cs;
+            const float* r1 = sm + (iy1 - qy0 + 1) * RP + lx * Cs;
             float v[3][CMAX];  // vertical lerp at columns qx-1, qx, qx+1
 #pragma unroll
             for (int j = 0; j < 3; ++j)
@@ -179,7 +181,8 @@ __global__ __launch_bounds__(256) void k_up_loss(const UpLossParams p) {
 
 template <typename T, int KIND, int CMAX>
 static void launch_up(const UpLossParams& p, int64_t blocks, hipStream_t s) {
-    const size_t lds = (size_t)(UQ + 2) * (UQ + 2) * (p.C | 1) * sizeof(float);
+    const int cs = p.C | 1, rp = (UQ + 2) * cs + ((16 - (UQ + 2) * cs) & 31);
+    const size_t lds = (size_t)(UQ + 2) * rp * sizeof(float);
     hipLaunchKernelGGL((k_up_loss<T, KIND, CMAX>), dim3((unsigned)blocks), dim3(256), lds, s, p);
 }
 

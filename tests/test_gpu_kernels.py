@@ -177,6 +177,16 @@ def _oracle_linear(m, x, xt, keep=None, p=0.0):
     (260, 768, 3072, 64, 4, 0, False),    # fc1 stage 3
     (130, 3072, 768, 128, 128, 2, True),  # C4-like ranks
     (1, 96, 96, 16, 4, 1, True),          # single row
+    # BASELINE configs[3]: Swin-B (C = 128 -> 1024), r = 128 shared and per task, 4 tasks
+    (640, 128, 384, 128, 128, 4, True),   # qkv-like / fc1 stage 0 of Swin-B, R = 640 rank columns
+    (384, 512, 128, 128, 128, 4, True),   # fc2 stage 0 of Swin-B
+    (200, 1024, 1024, 128, 128, 4, False),  # proj stage 3 of Swin-B, tasks read D(x)
+    # BASELINE configs[4]: 8 task heads, r swept over {4, 16, 64, 256}
+    (500, 96, 384, 4, 4, 8, True),
+    (500, 96, 384, 16, 16, 8, True),
+    (333, 384, 96, 64, 64, 8, True),
+    (260, 192, 192, 256, 256, 8, True),   # R = 9 * 256 rank columns
+    (260, 96, 288, 256, 4, 8, False),
 ])
 def test_linear_random_vs_oracle(shape, dtype):
     from mtlora_amd.lora import MTLoRALinear
@@ -776,3 +786,86 @@ def test_concat_upsample_vs_torch(dtype):
     sum((u.cpu() * g3[..., o:o + c]).sum() for o, c, u in zip(offs, chans, ups)).backward()
     for m, r in zip(maps, refs):
         assert_close(m.grad, r.grad, dtype, "grad", mult=2)
+
+
+# ------------------------------------------------------------------------------------------------
+# BASELINE configs[1] FULL sizes (B = 32, 448 x 448 -> M = 32 * 112 * 112 rows at stage 0): size-independent properties
+# ------------------------------------------------------------------------------------------------
+def test_full_size_linear_rows_vs_oracle():
+    """MTLoRALinear at the full stage-0 size (M = 401 408, K = 96, N = 384, 4 tasks reading their own x_t, bf16):
+    rows are independent, so (a) 2 048 sampled rows must match the oracle evaluated on those rows alone, forward and
+    dX, and (b) the eval-mode map minus its bias is linear: f(x1 + x2) = f(x1) + f(x2)."""
+    from mtlora_amd.lora import MTLoRALinear
+    M, K, N = 32 * 112 * 112, 96, 384
+    tasks = ["semseg", "normals", "sal", "human_parts"]
+    dtype = torch.bfloat16
+    torch.manual_seed(1)
+    m = MTLoRALinear(K, N, r={"shared": 64, **{t: 4 for t in tasks}}, lora_shared_scale=4.0,
+                     lora_task_scale={t: 4.0 for t in tasks}, lora_dropout=0.0, tasks=tasks).to(dev())
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            p.copy_((torch.randn_like(p) * (0.05 if "lora" in n else 0.02)).to(dtype).float())
+    m.linear.weight.requires_grad_(False)
+    m.linear.bias.requires_grad_(False)
+    x = (torch.randn(M, K, device=dev()) * 0.5).to(dtype).requires_grad_(True)
+    xt = {t: (torch.randn(M, K, device=dev()) * 0.5).to(dtype).requires_grad_(True) for t in tasks}
+    y, yt = m(x, xt)
+    idx = torch.randperm(M, device=dev())[:2048].sort().values
+    gy = torch.zeros(M, N, device=dev(), dtype=dtype)
+    gy[idx] = torch.randn(2048, N, device=dev()).to(dtype)
+    gt = {t: torch.zeros(M, N, device=dev(), dtype=dtype) for t in tasks}
+    for t in tasks:
+        gt[t][idx] = torch.randn(2048, N, device=dev()).to(dtype)
+    loss = (y.float() * gy.float()).sum() + sum((yt[t].float() * gt[t].float()).sum() for t in tasks)
+    loss.backward(inputs=[x] + [xt[t] for t in tasks])
+    # oracle on the sampled rows only
+    xs = x.detach()[idx].clone().requires_grad_(True)
+    xts = {t: xt[t].detach()[idx].clone().requires_grad_(True) for t in tasks}
+    P, xo, xto, yo, yto = _oracle_linear(m, xs, xts)
+    assert_close(y[idx], yo, dtype, "y rows")
+    lo = (yo * gy[idx].double().cpu()).sum()
+    for t in tasks:
+        assert_close(yt[t][idx], yto[t], dtype, f"y[{t}] rows")
+        lo = lo + (yto[t] * gt[t][idx].double().cpu()).sum()
+    lo.backward()
+    assert_close(x.grad[idx], xo.grad, dtype, "dx rows", mult=2)
+    for t in tasks:
+        assert_close(xt[t].grad[idx], xto[t].grad, dtype, f"dx[{t}] rows", mult=2)
+    keep = torch.ones(M, dtype=torch.bool, device=dev())
+    keep[idx] = False
+    assert x.grad[keep].abs().max().item() == 0.0   # rows without an output gradient get an exactly zero dX
+    # linearity in eval mode (bias removed), full size
+    m.eval()
+    with torch.no_grad():
+        x1, x2 = x.detach()[: M // 2], x.detach()[M // 2:]
+        f = lambda v: m(v, None)[0].float() - m.linear.bias.float()  # noqa: E731
+        lhs, rhs = f((x1.float() + x2.float()).to(dtype)), f(x1) + f(x2)
+        assert ((lhs - rhs).abs().max() / rhs.abs().max()).item() < 2e-2
+
+
+def test_full_size_attention_windows_vs_oracle():
+    """window attention at the full stage-0 size (B = 32, 112 x 112, 3 heads, shifted): windows are independent, so the
+    first and last image of the batch must match the oracle run on those two images alone (forward and dqkv)."""
+    from mtlora_amd import functional as Fn
+    B, H, W, nH, ws, shift = 32, 112, 112, 3, 7, 3
+    C, N = nH * 32, ws * ws
+    dtype = torch.bfloat16
+    torch.manual_seed(2)
+    qkv = (torch.randn(B, H, W, 3 * C, device=dev()) * 0.7).to(dtype).requires_grad_(True)
+    bias = (torch.randn(nH, N, N, device=dev()) * 0.5)
+    ids = _regions(H, W, ws, shift).to(dev())
+    scale = 32 ** -0.5
+    meta = Fn.AttnMeta(B=B, H=H, W=W, window_size=ws, shift=shift, num_heads=nH, head_dim=32, image_layout=True, scale=scale)
+    out = Fn.WindowAttentionFn.apply(meta, qkv, bias, None, ids)
+    sel = [0, B - 1]
+    g = torch.zeros_like(out)
+    g[sel] = torch.randn(2, H, W, C, device=dev()).to(dtype)
+    out.backward(g)
+    q64 = qkv.detach()[sel].double().cpu().requires_grad_(True)
+    win = O.roll_and_window_partition(q64, shift, ws).reshape(-1, N, 3 * C)
+    core = O.window_attention_core(win, bias.double().cpu(), O.shifted_window_mask(H, W, ws, shift).double(), nH, scale)
+    ref = O.window_merge_and_roll(core.reshape(-1, ws, ws, C), shift, ws, H, W)
+    assert_close(out[sel], ref, dtype, "attn out (2 of 32 images)")
+    ref.backward(g[sel].double().cpu())
+    assert_close(qkv.grad[sel], q64.grad, dtype, "dqkv", mult=2)
+    assert qkv.grad[1:B - 1].abs().max().item() == 0.0

@@ -11,9 +11,14 @@
 //            softmax over keys = in-lane reduction + one exchange with lane^32
 //            O^T[d][i]  = V^T P^T : V^T operand via ds_read_b64_tr_b16 on the row-major LDS image,
 //                                   P^T operand straight from the accumulator registers.
-// backward:  pass 1 (query-owned):  P^T, dP^T = V dO^T, D_i, dS^T -> dbias (LDS accumulate), dQ^T = K^T dS^T
+// backward:  pass 1 (query-owned):  P^T, dP^T = V dO^T, D_i, dS^T -> dbias (REGISTER accumulate: the (key, query) a
+//                                   lane's accumulator element maps to is the same for every window), dQ^T = K^T dS^T
 //            pass 2 (key-owned):    S, P, dP recomputed in the other orientation from the row stats of
 //                                   pass 1 -> dK^T = Q^T dS, dV^T = dO^T P
+// Both kernels are persistent (grid = resident workgroups) and software-pipelined: the NEXT window's Q/K/V(/dO) rows
+// are loaded into registers while the current window is multiplied; token addresses use a per-window decomposition
+// plus per-lane constants (no per-token division); the per-element sections are branch-free (clamped indices +
+// selects) so that their LDS reads are issued back to back; the dense-mask path is a separate template variant.
 // The k-slot <-> key assignment of every register-fed operand follows the accumulator layout
 // (row = (r&3) + 8(r>>2) + 4(lane>>5)); the LDS-fed partner operand is gathered in the same order.
 #include "common.h"

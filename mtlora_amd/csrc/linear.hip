@@ -1,25 +1,30 @@
 // linear.hip -- MTLoRALinear forward / backward on CDNA4 (gfx950).
 // Replaces the ATen sequence of models/lora.py:253-284 and its autograd backward.
 //
-// Kernel families (all hand-written MFMA, 64-wide waves, 256-thread workgroups):
+// Kernel families (all hand-written MFMA, 64-wide waves):
 //
 //   k_pack   fp32 LoRA masters -> compute-dtype packed factors, every rank padded to 16:
 //              A_cat (R x K), B_cat (N x R), At_cat (K x R), Bt_cat (R x N), alpha (R)   R = sum_o rp(o)
-//   k_nt     "NT" tile GEMM  D[n][m] = sum_k Wgt[n][k] * Act[m][k]  with
+//   k_nt     "NT" tile GEMM  D[n][m] = sum_k Wgt[n][k] * Act[m][k]  (128 x 128 tile, 4 or 8 waves per workgroup) run
+//            as ONE software-pipelined stream of k-tiles over the base GEMM and every output's rank segment, with
 //              - multi-source activation (sum of up to 1+T tensors formed while staging: G = dY_s + sum dY_t)
-//              - optional dropout mask applied to the staged activation (P = alpha * D(X) A^T)
+//              - optional dropout mask applied to the staged activation at LDS-store time (P = alpha * D(X) A^T)
 //              - bias / per-row alpha epilogue
-//              - multi-output low-rank epilogue: for each output o, extra k-steps over the o-th rank
-//                segment of L (M x R) and R (N x R) chained onto the shared base accumulator
-//                (Y_o = base + L_o R_o^T), optionally masked (dX = G W + keep .* (Q A)).
-//            The MFMA "A" operand is the weight tile and "B" the activation tile, so a lane's four
-//            consecutive accumulator registers are four consecutive output COLUMNS -> 8/16-byte stores.
-//   k_tn     "TN" split-M reduction  Out[a][b] = sum_m SrcA[m][a] * SrcB[m][b]  (dA = Q^T D(X), dB = dY^T P):
-//            both operands are read with the LDS transpose load (ds_read_b64_tr_b16) for bf16;
-//            per-split partials (deterministic) + k_reduce.
+//              - multi-output low-rank parts: for each output o, extra k-tiles over the o-th rank segment of
+//                L (M x R) and R (N x R) chained onto the base accumulator (Y_o = base + L_o R_o^T), optionally
+//                masked (dX = G W + keep .* (Q A))
+//              - optional row-panel form (FUSE): the projection L is formed by the workgroup itself in LDS
+//            The MFMA "A" operand is the weight tile and "B" the activation tile, so a lane's four consecutive
+//            accumulator registers are four consecutive output COLUMNS; the bf16 epilogue goes through LDS so that
+//            stores are whole 128-byte row segments.
+//   k_tn     "TN" split-M reduction  Out[a][b] = sum_m SrcA[m][a] * SrcB[m][b]  (dA = Q^T D(X), dB^T = P^T dY) with
+//            64 (rank side) x 256 (wide side) tiles: both operands are read with the LDS transpose load
+//            (ds_read_b64_tr_b16) for bf16; per-split partials (deterministic) + k_tn_reduce.
+//   k_sum    G = sum of the output gradients (matrixv2 factors; pre-summed dX operand of wide outputs).
 //
 // Forward  = k_pack, k_nt (P = alpha D(X) A^T, per source), k_nt (all 1+T outputs, base shared).
-// Backward = k_nt (Q = alpha dY_o B_o per output), k_nt (dX [+ dX_t]), k_tn (+ k_reduce) for dA/dB.
+// Backward = [k_sum], k_nt (Q = alpha dY_o B_o per output), k_nt (dX [+ dX_t]), k_tn + k_tn_reduce for dA / dB.
+// DESIGN.md section 4.1 / 4.3 has the measurements and the experiments that were tried and dropped.
 #include <stdlib.h>
 
 #include "common.h"
@@ -27,17 +32,14 @@
 namespace {
 
 constexpr int TILE = 128;    // rows per CTA tile, both operands
-constexpr int SUBT = 3;             // 64-byte MFMA sub-tiles per staged k-tile: K = 96 bf16 is ONE round trip (k_nt 17.5 vs 18.8 ms/step with 1)
+constexpr int SUBT = 3;             // 64-byte MFMA sub-tiles per staged k-tile: K = 96 bf16 is ONE round trip
+constexpr int VPT = SUBT;           // 16-byte vectors per thread per tile row
 constexpr int ROWB = 64 * SUBT;     // payload bytes per row per k-tile (96 bf16 / 48 f32)
 constexpr int LDSB = ROWB + 16;     // padded LDS row stride (conflict-free ds_read_b128, 16-B aligned)
-constexpr int VPT = SUBT;
 constexpr int EPI_ROW = 64 * 2 + 8;                      // row stride of a wave's bf16 output image (epilogue)
-constexpr int EPI_BYTES = 4 * 64 * EPI_ROW;               // four waves
-constexpr int STAGE_BYTES = 2 * TILE * LDSB > EPI_BYTES ? 2 * TILE * LDSB : EPI_BYTES;  // staging / epilogue region           // 16-byte vectors per thread per row-half per operand (4 * SUBT vectors / 4 lanes)
+constexpr int EPI_BYTES = 4 * 64 * EPI_ROW;               // 4 waves x 64 rows = 8 waves x 32 rows
+constexpr int STAGE_BYTES = 2 * TILE * LDSB > EPI_BYTES ? 2 * TILE * LDSB : EPI_BYTES;  // staging / epilogue region
 constexpr int MAXO = MTLORA_MAX_TASKS + 1;
-#ifndef MTL_NT_LEAN_WAVES
-#define MTL_NT_LEAN_WAVES 2
-#endif
 
 // ------------------------------------------------------------------------------------------------
 // segment table: output o (0 = shared, 1..T = tasks) owns columns [off, off + rp) of the rank axis

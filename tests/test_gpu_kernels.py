@@ -869,3 +869,56 @@ def test_full_size_attention_windows_vs_oracle():
     ref.backward(g[sel].double().cpu())
     assert_close(qkv.grad[sel], q64.grad, dtype, "dqkv", mult=2)
     assert qkv.grad[1:B - 1].abs().max().item() == 0.0
+
+
+# ------------------------------------------------------------------------------------------------
+# whole model: backbone + Downsampler + HRNet heads + losses through every custom path vs the oracle's full model
+# ------------------------------------------------------------------------------------------------
+def test_full_model_loss_and_gradients_vs_oracle():
+    """MultiTaskSwin (HIP linears / attention / LN / residual, concat-upsample head input, split-reduction head linears,
+    fused BatchNorm+ReLU, fused upsample+loss) against oracle.full_model + multi_task_loss in fp64 on the same
+    parameters and batch: loss, per-task losses and the gradients of backbone AND head parameters (fp32, train-mode
+    BatchNorm statistics, dropout / DropPath off so both sides are deterministic)."""
+    from mtlora_amd import mtl_harness as H
+    tasks = ["semseg", "normals", "sal", "human_parts"]
+    model = H.build_model(img_size=224, tasks=tasks, depths=(2, 2, 2, 2), r_shared=16, r_task=4, drop_path_rate=0.0, seed=3,
+                          DROPOUT=[0.0] * 4).to(dev())
+    model.train()
+    crit = H.MultiTaskLoss(tasks)
+    img, tg = H.synthetic_batch(2, 224, tasks, seed=5, device=dev())
+    loss, per = crit.forward_low(model(img, upsample=False), tg)
+    loss.backward()
+    # oracle on the CPU, fp64, same state dict
+    cfg = O.swin_t_cfg(img_size=224, tasks=tasks, r_shared=16, r_task=4, depths=(2, 2, 2, 2), drop_path_rate=0.0, dropout=0.0)
+    sd = model.state_dict()
+    P = {k: v.detach().double().cpu().clone() for k, v in sd.items()}
+    trainable = {n for n, p in model.named_parameters() if p.requires_grad}
+    for k in P:
+        if k in trainable:
+            P[k].requires_grad_(True)
+    # running statistics were updated by the forward above; the oracle's train-mode BN only reads batch statistics
+    out = O.full_model(P, img.double().cpu(), cfg, train=True, rng=torch.Generator().manual_seed(0))
+    rl, rper = O.multi_task_loss(out, {t: v.double().cpu() for t, v in tg.items()}, tasks)
+    rl.backward()
+    assert abs(loss.item() - rl.item()) <= 1e-3 * abs(rl.item()), (loss.item(), rl.item())
+    for t in tasks:
+        assert abs(per[t].item() - rper[t].item()) <= 1e-3 * max(1.0, abs(rper[t].item())), t
+    named = dict(model.named_parameters())
+    gmax = max(P[n].grad.abs().max().item() for n in trainable if P[n].grad is not None)
+    checked = 0
+    for n in sorted(trainable):
+        g, r = named[n].grad, P[n].grad
+        if r is None:
+            assert g is None, n
+            continue
+        assert g is not None, n
+        if n.endswith("last_layer.0.bias"):
+            # the bias in front of a BatchNorm: its gradient is the column sum of the BN-backward output, analytically 0;
+            # both sides only hold rounding noise
+            assert g.abs().max().item() <= 1e-4 * gmax and r.abs().max().item() <= 1e-4 * gmax, n
+            continue
+        scale = max(r.abs().max().item(), 1e-6 * gmax)
+        err = (g.double().cpu() - r).abs().max().item() / scale
+        assert err <= 5e-3, (n, err)
+        checked += 1
+    assert checked > 200

@@ -534,10 +534,11 @@ class SplitKLinearFn(torch.autograd.Function):
     17-34 workgroups of the 256 CUs (568 us for 1080x270 over 401k rows), the batched form fills the GPU."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, splits: int):
+    def forward(ctx, x, weight, bias, splits: int, zero_bias_grad: bool = False):
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
         ctx.splits = splits
+        ctx.zero_bias_grad = zero_bias_grad
         return torch.nn.functional.linear(x, weight, bias)
 
     @staticmethod
@@ -552,12 +553,19 @@ class SplitKLinearFn(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             part = torch.bmm(gy.view(S, M // S, N).transpose(1, 2), x.view(S, M // S, K))  # (S, N, K)
             dw = part.float().sum(0).to(w.dtype)
-        db = gy.sum(0) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
-        return dx, dw, db, None
+        db = None
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            # zero_bias_grad: the output feeds a training-mode BatchNorm, whose backward returns columns that sum to zero
+            # EXACTLY (dx = scale (dy' - mean(dy') - xhat mean(dy' xhat)), sum(xhat) = 0): the bias gradient is 0, and
+            # summing 400k x 1080 elements only to obtain rounding noise costs a full pass over the gradient
+            db = torch.zeros(N, dtype=gy.dtype, device=gy.device) if ctx.zero_bias_grad else gy.sum(0)
+        return dx, dw, db, None, None
 
 
-def linear_big_m(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
-    """F.linear for (M, K) inputs; switches to SplitKLinearFn when M is large and the weight is trained."""
+def linear_big_m(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor],
+                 feeds_batchnorm: bool = False) -> torch.Tensor:
+    """F.linear for (M, K) inputs; switches to SplitKLinearFn when M is large and the weight is trained.
+    feeds_batchnorm=True: the output goes straight into a training-mode BatchNorm -> the bias gradient is exactly 0."""
     M = x.shape[0]
     if x.dim() == 2 and x.is_cuda and weight.requires_grad and torch.is_grad_enabled() and M >= 16384:
         S = 16 if M >= 262144 else (8 if M >= 65536 else 4)
@@ -565,8 +573,8 @@ def linear_big_m(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Ten
             if torch.is_autocast_enabled("cuda"):
                 dt = torch.get_autocast_dtype("cuda")
                 with torch.autocast("cuda", enabled=False):
-                    return SplitKLinearFn.apply(x.to(dt), weight.to(dt), None if bias is None else bias.to(dt), S)
-            return SplitKLinearFn.apply(x, weight, bias, S)
+                    return SplitKLinearFn.apply(x.to(dt), weight.to(dt), None if bias is None else bias.to(dt), S, feeds_batchnorm)
+            return SplitKLinearFn.apply(x, weight, bias, S, feeds_batchnorm)
     return torch.nn.functional.linear(x, weight, bias)
 
 

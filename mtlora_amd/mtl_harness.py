@@ -111,7 +111,7 @@ class HighResolutionHead(nn.Module):
         else:
             cat = torch.cat([x[0]] + [F.interpolate(m, (Hh, Ww), mode="bilinear") for m in x[1:]], 1)
             t = cat.permute(0, 2, 3, 1).reshape(B * Hh * Ww, cat.shape[1])
-        h = Fn.linear_big_m(t, w2d, c0.bias)
+        h = Fn.linear_big_m(t, w2d, c0.bias, feeds_batchnorm=bn.training)
         if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
             bn.num_batches_tracked.add_(1)
         if bn.training and h.is_cuda and h.dtype in (torch.float32, torch.bfloat16) and h.shape[1] % 8 == 0:

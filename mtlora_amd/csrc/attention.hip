@@ -219,6 +219,70 @@ __device__ __forceinline__ Frag<float> colfrag(const unsigned char* s, int kt, i
     return f;
 }
 
+// P / dS hand-over images of the backward ([32 query rows][64 keys], row stride IMG_RS): the accumulators hold them
+// query-per-lane; dK / dV need them key-per-lane with the queries along k, i.e. transposed -- written row-wise, read back
+// with the transposing load exactly like colfrag (same slot <-> row order as the Q / dO operand they are paired with)
+template <typename T>
+struct IMG;
+template <>
+struct IMG<bf16> {
+    static constexpr int RS = 64 * 2 + 16;
+};
+template <>
+struct IMG<float> {
+    static constexpr int RS = 64 * 4 + 16;
+};
+// lane (i = lane & 31, h = lane >> 5) writes query row i: for each key block sj its 4 runs of 4 consecutive keys
+template <typename T>
+__device__ __forceinline__ void img_store(unsigned char* img, const f32x16 (&a)[2], int lane) {
+    const int il = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int sj = 0; sj < 2; ++sj)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int j0 = sj * 32 + 8 * q + 4 * h;
+            if constexpr (sizeof(T) == 4) {
+                *reinterpret_cast<f32x4*>(img + il * IMG<float>::RS + j0 * 4) =
+                    f32x4{a[sj][4 * q], a[sj][4 * q + 1], a[sj][4 * q + 2], a[sj][4 * q + 3]};
+            } else {
+                *reinterpret_cast<bf16x4*>(img + il * IMG<bf16>::RS + j0 * 2) =
+                    bf16x4{(bf16)a[sj][4 * q], (bf16)a[sj][4 * q + 1], (bf16)a[sj][4 * q + 2], (bf16)a[sj][4 * q + 3]};
+            }
+        }
+}
+// MFMA rows = image columns [col0, col0 + 32), k = image rows of k-tile kt
+__device__ __forceinline__ Frag<bf16> imgfrag(const unsigned char* s, int col0, int kt, int lane, bf16*) {
+    const int g = lane >> 4, i = lane & 15, h = g >> 1;
+    const int col = col0 + 16 * (g & 1) + 4 * (i & 3);
+    uint32_t w[8];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int row = kt * 32 + 8 * q + 4 * h + (i >> 2);
+        const unsigned char* p = s + row * IMG<bf16>::RS + col * 2;
+        s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
+        u32x2 u = __builtin_bit_cast(u32x2, v);
+        w[2 * q] = u[0];
+        w[2 * q + 1] = u[1];
+    }
+    Frag<bf16> f;
+    f.v[0] = u32x4{w[0], w[1], w[2], w[3]};
+    f.v[1] = u32x4{w[4], w[5], w[6], w[7]};
+    return f;
+}
+__device__ __forceinline__ Frag<float> imgfrag(const unsigned char* s, int col0, int kt, int lane, float*) {
+    const int h = lane >> 5, d = lane & 31;
+    uint32_t w[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int row = kt * 16 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        w[e] = *reinterpret_cast<const uint32_t*>(s + row * IMG<float>::RS + (col0 + d) * 4);
+    }
+    Frag<float> f;
+    f.v[0] = u32x4{w[0], w[1], w[2], w[3]};
+    f.v[1] = u32x4{w[4], w[5], w[6], w[7]};
+    return f;
+}
+
 // operand fed from accumulator registers: acc[0..1] are the two 32-row subtiles along the k axis
 __device__ __forceinline__ uint32_t pack_bf16(float a, float b) {
     bf16 x = (bf16)a, y = (bf16)b;
@@ -415,18 +479,24 @@ __global__ __launch_bounds__(64, 2) void k_attn_fwd(const AttnParams p) {
 
 // One wave per workgroup and (LDS-limited) one workgroup per SIMD: the whole 512-entry register file is this wave's,
 // so the next window's Q / K / V / dO rows are prefetched into registers while the current window is multiplied.
+// Single pass over the two 32-query halves: S^T, P^T, dP^T, D, dS^T, dbias, dQ as before (query per lane), then P^T and
+// dS^T of the half are handed over through two small LDS images and read back TRANSPOSED (key per lane, queries along k)
+// to accumulate dK^T += Q^T dS and dV^T += dO^T P -- instead of a second, key-owned pass that recomputed S, P and dP from
+// the row statistics (16 MFMAs, 64 exps per lane and a long element-wise section per window).
 template <typename T, bool DENSE>
 __global__ __launch_bounds__(64, 1) void k_attn_bwd(const AttnParams p) {
     constexpr int RS = AC<T>::RS;
-    // Q, K, V, dO images + token table + region ids + row stats {m, 1/l, D, region id} + bias[head]
+    constexpr int KQ = 32 / (AC<T>::KT_N == 2 ? 32 : 16);  // k-tiles per 32-query half (bf16: 1, f32: 2)
+    // Q, K, V, dO images + P / dS hand-over images + token table + region ids + bias[head]
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int IB = ((img_rows(p.N) * RS + 15) / 16) * 16;  // bytes per image
     unsigned char* sQ = smem;
     unsigned char* sK = smem + IB;
     unsigned char* sV = smem + 2 * IB;
     unsigned char* sO = smem + 3 * IB;
-    f32x4* sst = reinterpret_cast<f32x4*>(smem + 4 * IB);  // [AN], 16-byte aligned (IB is)
-    int* tok = reinterpret_cast<int*>(sst + AN);
+    unsigned char* sPi = smem + 4 * IB;                 // [32][64] P of the current query half
+    unsigned char* sDi = sPi + 32 * IMG<T>::RS;         // [32][64] dS
+    int* tok = reinterpret_cast<int*>(sDi + 32 * IMG<T>::RS);
     int* srid = tok + AN;
     float* sBias = reinterpret_cast<float*>(srid + AN);  // [N][bias_stride(N)]
     const int lane = threadIdx.x;
@@ -438,7 +508,6 @@ __global__ __launch_bounds__(64, 1) void k_attn_bwd(const AttnParams p) {
     const T* dout = reinterpret_cast<const T*>(p.dout);
     T* dqkv = reinterpret_cast<T*>(p.dqkv);
     const int64_t C3 = 3 * (int64_t)p.C;
-    const int bs = bias_stride(p.N);
     stage_bias(sBias, p.bias, head, p.N, lane);
     // dbias accumulator in REGISTERS: element (sj, r) of lane l is always (key j = 32 sj + row(l, r), query i = 32 si + l % 32),
     // the same pair for every window this wave visits
@@ -473,7 +542,11 @@ __global__ __launch_bounds__(64, 1) void k_attn_bwd(const AttnParams p) {
         __syncthreads();
         if (w + p.G < p.n_windows) prefetch(w + p.G);
 
-        // ---- pass 1: query-owned ------------------------------------------------------------
+        f32x16 dk[2], dv[2];  // [sj]: dK^T / dV^T [d][key], accumulated over the query halves
+        zero(dk[0]);
+        zero(dk[1]);
+        zero(dv[0]);
+        zero(dv[1]);
 #pragma unroll
         for (int si = 0; si < 2; ++si) {
             if (si * 32 >= p.N) break;
@@ -500,8 +573,6 @@ __global__ __launch_bounds__(64, 1) void k_attn_bwd(const AttnParams p) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) D += pt[sj][r] * dp[sj][r];
             D += __shfl_xor(D, 32);
-            const int i = si * 32 + (lane & 31);
-            if (lane < 32) sst[i] = f32x4{m, inv_l, D, __int_as_float(srid[i < p.N ? i : p.N - 1])};
             // dS^T in place of dp; dbias accumulates in registers (padded keys have P = 0, padded queries are never written)
 #pragma unroll
             for (int sj = 0; sj < 2; ++sj)
@@ -511,6 +582,11 @@ __global__ __launch_bounds__(64, 1) void k_attn_bwd(const AttnParams p) {
                     dp[sj][r] = ds;
                     dbacc[si][sj][r] += ds;
                 }
+            // hand P^T / dS^T of this half over for the key-owned products (previous half's reads are complete: the
+            // wave executes in order and the MFMAs below consumed their fragments)
+            __builtin_amdgcn_wave_barrier();
+            img_store<T>(sPi, pt, lane);
+            img_store<T>(sDi, dp, lane);
             // dQ^T[d][i] = scale * sum_j K[j][d] dS^T[j][i]
             f32x16 dq;
             zero(dq);
@@ -520,75 +596,31 @@ __global__ __launch_bounds__(64, 1) void k_attn_bwd(const AttnParams p) {
                 Frag<T> fs = regfrag(dp, kt, (T*)nullptr);
                 mtl_mma(fk, fs, dq);
             }
+            const int i = si * 32 + (lane & 31);
             if (i < p.N) store_dt<T>(dqkv, (int64_t)tok[i] * C3 + head * HD, dq, p.scale, lane);
+            __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the image stores have landed (single wave: no barrier needed)
+            __builtin_amdgcn_wave_barrier();
+            // dK^T[d][j] += sum_{i in half} Q[i][d] dS[i][j],  dV^T[d][j] += sum_i dO[i][d] P[i][j]
+            // (padded queries: their Q / dO rows are the shared zero row, so whatever P / dS hold there drops out)
+#pragma unroll
+            for (int kq = 0; kq < KQ; ++kq) {
+                Frag<T> fq = colfrag(sQ, si * KQ + kq, lane, p.N, (T*)nullptr);
+                Frag<T> fo = colfrag(sO, si * KQ + kq, lane, p.N, (T*)nullptr);
+#pragma unroll
+                for (int sj = 0; sj < 2; ++sj) {
+                    Frag<T> fds = imgfrag(sDi, sj * 32, kq, lane, (T*)nullptr);
+                    Frag<T> fp = imgfrag(sPi, sj * 32, kq, lane, (T*)nullptr);
+                    mtl_mma(fq, fds, dk[sj]);
+                    mtl_mma(fo, fp, dv[sj]);
+                }
+            }
         }
-        __syncthreads();
-
-        // ---- pass 2: key-owned ----------------------------------------------------------------
-#pragma unroll 1
+#pragma unroll
         for (int sj = 0; sj < 2; ++sj) {
-            if (sj * 32 >= p.N) break;
             const int j = sj * 32 + (lane & 31);
-            const bool jv = j < p.N;
-            f32x16 pp[2], dp[2];  // [si]: P[i][j], dP[i][j]
-            zero(pp[0]);
-            zero(pp[1]);
-            zero(dp[0]);
-            zero(dp[1]);
-#pragma unroll
-            for (int kt = 0; kt < AC<T>::KT_D; ++kt) {
-                Frag<T> fk = rowfrag<T>(sK, sj, kt, lane, p.N);
-                Frag<T> fv = rowfrag<T>(sV, sj, kt, lane, p.N);
-#pragma unroll
-                for (int si = 0; si < 2; ++si) {
-                    Frag<T> fq = rowfrag<T>(sQ, si, kt, lane, p.N);
-                    Frag<T> fo = rowfrag<T>(sO, si, kt, lane, p.N);
-                    mtl_mma(fq, fk, pp[si]);
-                    mtl_mma(fo, fv, dp[si]);
-                }
-            }
-            // recompute P and dS in the key-owned orientation, branch-free (clamped indices, one 16-byte stats read per
-            // query row, selects at the end)
-            const int jc = jv ? j : p.N - 1;
-            const int rid_j = srid[jc];
-            const int bs = bias_stride(p.N);
-            const float* mn = DENSE ? p.mask + (int64_t)wm * p.N * p.N + jc : nullptr;
-#pragma unroll
-            for (int si = 0; si < 2; ++si) {
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int i = si * 32 + (r & 3) + 8 * (r >> 2) + h4;
-                    const int ic = i < p.N ? i : p.N - 1;
-                    const f32x4 sv = sst[ic];
-                    float sc = pp[si][r] * p.scale + sBias[ic * bs + jc];
-                    if constexpr (DENSE)
-                        sc += mn[ic * p.N];
-                    else
-                        sc += __float_as_int(sv[3]) != rid_j ? p.mask_value : 0.f;
-                    const float pv = __expf(sc - sv[0]) * sv[1];
-                    const float ds = pv * (dp[si][r] - sv[2]);
-                    const bool ok = i < p.N && jv;
-                    pp[si][r] = ok ? pv : 0.f;
-                    dp[si][r] = ok ? ds : 0.f;
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            f32x16 dk, dv;
-            zero(dk);
-            zero(dv);
-#pragma unroll
-            for (int kt = 0; kt < AC<T>::KT_N; ++kt) {
-                Frag<T> fq = colfrag(sQ, kt, lane, p.N, (T*)nullptr);
-                Frag<T> fo = colfrag(sO, kt, lane, p.N, (T*)nullptr);
-                Frag<T> fds = regfrag(dp, kt, (T*)nullptr);
-                Frag<T> fp = regfrag(pp, kt, (T*)nullptr);
-                mtl_mma(fq, fds, dk);
-                mtl_mma(fo, fp, dv);
-            }
-            if (jv) {
-                store_dt<T>(dqkv, (int64_t)tok[j] * C3 + p.C + head * HD, dk, p.scale, lane);
-                store_dt<T>(dqkv, (int64_t)tok[j] * C3 + 2 * p.C + head * HD, dv, 1.f, lane);
+            if (j < p.N) {
+                store_dt<T>(dqkv, (int64_t)tok[j] * C3 + p.C + head * HD, dk[sj], p.scale, lane);
+                store_dt<T>(dqkv, (int64_t)tok[j] * C3 + 2 * p.C + head * HD, dv[sj], 1.f, lane);
             }
         }
     }
@@ -658,7 +690,8 @@ static size_t bwd_lds_bytes(const mtlora_attn_desc* d) {
     const int N = d->window_size * d->window_size;
     const int rs = d->dtype == MTLORA_F32 ? AC<float>::RS : AC<bf16>::RS;
     const size_t ib = (size_t)((img_rows_h(N) * rs + 15) / 16) * 16;
-    return 4 * ib + AN * 16 + 2 * AN * 4 + (size_t)N * bias_stride_host(N) * 4;
+    const size_t img = d->dtype == MTLORA_F32 ? IMG<float>::RS : IMG<bf16>::RS;  // P / dS hand-over images
+    return 4 * ib + 2 * 32 * img + 2 * AN * 4 + (size_t)N * bias_stride_host(N) * 4;
 }
 
 int bwd_groups(const mtlora_attn_desc* d) {

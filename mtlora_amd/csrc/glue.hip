@@ -280,27 +280,31 @@ __global__ __launch_bounds__(256) void k_ln_bwd(const LnParams p) {
     }
 }
 
-// second stage: one workgroup per 64 columns; its 4 waves stride over the partial rows (coalesced 256-byte
-// reads), then a fixed-order LDS combine -> deterministic
-__global__ __launch_bounds__(256) void k_ln_reduce(const float* part, float* dgamma, float* dbeta, int nblk, int C) {
-    __shared__ float sm[4][64];
+// second stage: one workgroup per 64 columns; its 16 waves stride over the partial rows (coalesced 256-byte reads, 4
+// independent chains each: 8 dependent iterations for 512 partials instead of 32), then a fixed-order LDS combine ->
+// deterministic
+constexpr int LN_RW = 16;
+__global__ __launch_bounds__(64 * LN_RW) void k_ln_reduce(const float* part, float* dgamma, float* dbeta, int nblk, int C) {
+    __shared__ float sm[LN_RW][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + lane;  // column in [0, 2C)
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
     if (c < 2 * C) {
         int b = wave;
-        for (; b + 12 < nblk; b += 16) {
+        for (; b + 3 * LN_RW < nblk; b += 4 * LN_RW) {
             a0 += part[(int64_t)b * 2 * C + c];
-            a1 += part[(int64_t)(b + 4) * 2 * C + c];
-            a2 += part[(int64_t)(b + 8) * 2 * C + c];
-            a3 += part[(int64_t)(b + 12) * 2 * C + c];
+            a1 += part[(int64_t)(b + LN_RW) * 2 * C + c];
+            a2 += part[(int64_t)(b + 2 * LN_RW) * 2 * C + c];
+            a3 += part[(int64_t)(b + 3 * LN_RW) * 2 * C + c];
         }
-        for (; b < nblk; b += 4) a0 += part[(int64_t)b * 2 * C + c];
+        for (; b < nblk; b += LN_RW) a0 += part[(int64_t)b * 2 * C + c];
     }
     sm[wave][lane] = (a0 + a1) + (a2 + a3);
     __syncthreads();
     if (wave == 0 && c < 2 * C) {
-        const float t = (sm[0][lane] + sm[1][lane]) + (sm[2][lane] + sm[3][lane]);
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < LN_RW; ++w) t += sm[w][lane];
         if (c < C)
             dgamma[c] = t;
         else
@@ -434,7 +438,7 @@ int mtlora_layernorm_bwd(const void* dy, const void* x, const float* gamma, cons
             LN_DISPATCH_LPR(k_ln_bwd, bf16, bf16)
         }
     }
-    hipLaunchKernelGGL(k_ln_reduce, dim3((unsigned)mtl_ceil_div(2 * C, 64)), dim3(256), 0, s, (const float*)p.part, dgamma,
+    hipLaunchKernelGGL(k_ln_reduce, dim3((unsigned)mtl_ceil_div(2 * C, 64)), dim3(64 * LN_RW), 0, s, (const float*)p.part, dgamma,
                        dbeta, grid, (int)C);
     MTL_CHECK_LAUNCH();
     return MTLORA_OK;

@@ -908,34 +908,45 @@ __global__ __launch_bounds__(256, 2) void k_tn(const TnParams P) {
             }
 }
 
-__global__ __launch_bounds__(256) void k_tn_reduce(const TnParams P) {
-    // one workgroup per (problem, tile, 1024-element block): 4 outputs per thread (one 16-byte load per split,
-    // coalesced across the wave), splits summed in a fixed order with 4 independent chains in flight
+constexpr int TN_RG = 4;  // thread groups that share the splits of a 1024-element block
+__global__ __launch_bounds__(256 * TN_RG) void k_tn_reduce(const TnParams P) {
+    // one workgroup per (problem, tile, 1024-element block): 4 outputs per thread (one 16-byte load per split, coalesced
+    // across the wave); the splits are dealt round-robin to TN_RG groups of 256 threads, each summing its share in a
+    // fixed order with 4 independent chains, then a fixed-order LDS combine (deterministic)
+    __shared__ f32x4 sm[TN_RG][256];
     const TnProblem& pr = P.p[blockIdx.z];
     const int ntile = pr.tiles_a * pr.tiles_b;
     const int tile = blockIdx.y;
     if (tile >= ntile) return;
-    const int e0 = blockIdx.x * 1024 + threadIdx.x * 4;  // element inside the 64x256 tile
+    const int t = threadIdx.x & 255, grp = threadIdx.x >> 8;
+    const int e0 = blockIdx.x * 1024 + t * 4;  // element inside the 64x256 tile
     const int ta = tile / pr.tiles_b, tb = tile % pr.tiles_b;
     const int a = ta * TN_A + e0 / TN_B, b0 = tb * TN_B + e0 % TN_B;
-    if (a >= pr.out_a || b0 >= pr.out_b) return;
-    const float* src = pr.part + (int64_t)tile * TN_TILE + e0;
-    const int64_t stride = (int64_t)ntile * TN_TILE;
+    const bool live = a < pr.out_a && b0 < pr.out_b;
     f32x4 acc[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-    int sp = 0;
-    for (; sp + 4 <= P.nsplit; sp += 4) {
+    if (live) {
+        const float* src = pr.part + (int64_t)tile * TN_TILE + e0;
+        const int64_t stride = (int64_t)ntile * TN_TILE;
+        int sp = grp;
+        for (; sp + 3 * TN_RG < P.nsplit; sp += 4 * TN_RG) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) acc[u] += *reinterpret_cast<const f32x4*>(src + (int64_t)(sp + u) * stride);
+            for (int u = 0; u < 4; ++u) acc[u] += *reinterpret_cast<const f32x4*>(src + (int64_t)(sp + u * TN_RG) * stride);
+        }
+        for (; sp < P.nsplit; sp += TN_RG) acc[0] += *reinterpret_cast<const f32x4*>(src + (int64_t)sp * stride);
     }
-    for (; sp < P.nsplit; ++sp) acc[0] += *reinterpret_cast<const f32x4*>(src + (int64_t)sp * stride);
-    const f32x4 t = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+    sm[grp][t] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+    __syncthreads();
+    if (grp != 0 || !live) return;
+    f32x4 tsum = sm[0][t];
+#pragma unroll
+    for (int gI = 1; gI < TN_RG; ++gI) tsum += sm[gI][t];
 #pragma unroll
     for (int e = 0; e < 4; ++e)
         if (b0 + e < pr.out_b) {
             const int64_t at = pr.transpose ? (int64_t)(b0 + e) * pr.ldo + a : (int64_t)a * pr.ldo + b0 + e;
-            pr.out[at] = t[e];
+            pr.out[at] = tsum[e];
         }
 }
 
@@ -1475,7 +1486,7 @@ static int bwd_impl(const mtlora_linear_desc* d, const void* x, const void* cons
                                    dim3(256), 0, s, tp);
             }
             MtlProfScope prof(PK_REDUCE, 0.0, s);
-            hipLaunchKernelGGL(k_tn_reduce, dim3(TN_TILE / 1024, (unsigned)max_tiles, (unsigned)tp.n_prob), dim3(256), 0, s, tp);
+            hipLaunchKernelGGL(k_tn_reduce, dim3(TN_TILE / 1024, (unsigned)max_tiles, (unsigned)tp.n_prob), dim3(256 * TN_RG), 0, s, tp);
         }
     }
     return MTLORA_OK;

@@ -547,73 +547,82 @@ __global__ __launch_bounds__(512) void k_bn_colsum(const BnParams p) {
 // forward finalize: per channel combine (count, sum, sumsq) partials with Chan's formula.
 // One workgroup per 64 channels: its 4 waves each fold a strided quarter of the partials (coalesced 256-byte reads),
 // then wave 0 folds the four results in a fixed order.
-struct BnAcc {
-    double n, mean, m2;
-};
-__device__ __forceinline__ void bn_fold(BnAcc& a, double cnt, double mb, double m2b) {
-    const double delta = mb - a.mean, nn = a.n + cnt;
-    if (nn > 0.0) {
-        a.mean += delta * cnt / nn;
-        a.m2 += m2b + delta * delta * a.n * cnt / nn;
-        a.n = nn;
-    }
-}
-
-constexpr int BN_FW = 16;  // waves folding the per-workgroup partials of 64 columns (serial fp64 Chan folds: 67 us with 4)
+// Finalize kernels: the per-workgroup partials (fp32 sums of x and x^2, resp. of dy' and dy' xhat) are summed in fp64 by
+// 16 waves with two independent chains each and combined in a fixed order (deterministic).  Plain fp64 sums carry the
+// same information as a Chan fold of the fp32 partials (var = (Q - S^2/R)/R loses < 1e-12 relative in fp64) without the
+// two fp64 divisions per partial that made the fold take 29-67 us.
+constexpr int BN_FW = 16;
 __global__ __launch_bounds__(64 * BN_FW) void k_bn_finalize(const BnParams p) {
-    __shared__ double sm[BN_FW][3][64];
+    __shared__ double sm[BN_FW][2][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + lane;
-    const int64_t rows_blk = mtl_ceil_div(p.R, p.nblk);
-    BnAcc a = {0.0, 0.0, 0.0};
+    double s0 = 0.0, q0 = 0.0, s1 = 0.0, q1 = 0.0;
     if (c < p.C) {
-        for (int b = wave; b < p.nblk; b += BN_FW) {
-            int64_t cnt = p.R - (int64_t)b * rows_blk;
-            if (cnt > rows_blk) cnt = rows_blk;
-            if (cnt <= 0) break;
-            const double s = p.part[(int64_t)b * 2 * p.C + c], q = p.part[(int64_t)b * 2 * p.C + p.C + c];
-            const double mb = s / (double)cnt;
-            bn_fold(a, (double)cnt, mb, q - s * mb);
+        int b = wave;
+        for (; b + BN_FW < p.nblk; b += 2 * BN_FW) {
+            s0 += p.part[(int64_t)b * 2 * p.C + c];
+            q0 += p.part[(int64_t)b * 2 * p.C + p.C + c];
+            s1 += p.part[(int64_t)(b + BN_FW) * 2 * p.C + c];
+            q1 += p.part[(int64_t)(b + BN_FW) * 2 * p.C + p.C + c];
+        }
+        for (; b < p.nblk; b += BN_FW) {
+            s0 += p.part[(int64_t)b * 2 * p.C + c];
+            q0 += p.part[(int64_t)b * 2 * p.C + p.C + c];
         }
     }
-    sm[wave][0][lane] = a.n;
-    sm[wave][1][lane] = a.mean;
-    sm[wave][2][lane] = a.m2;
+    sm[wave][0][lane] = s0 + s1;
+    sm[wave][1][lane] = q0 + q1;
     __syncthreads();
     if (wave != 0 || c >= p.C) return;
-    BnAcc t = {0.0, 0.0, 0.0};
-    for (int w = 0; w < BN_FW; ++w) bn_fold(t, sm[w][0][lane], sm[w][1][lane], sm[w][2][lane]);
-    const double var = t.m2 / t.n;
+    double S = 0.0, Q = 0.0;
+    for (int w = 0; w < BN_FW; ++w) {
+        S += sm[w][0][lane];
+        Q += sm[w][1][lane];
+    }
+    const double n = (double)p.R, mean = S / n;
+    double m2 = Q - S * mean;
+    m2 = m2 < 0.0 ? 0.0 : m2;
+    const double var = m2 / n;
     const float rstd = (float)(1.0 / sqrt(var + (double)p.eps));
     const float sc = p.gamma[c] * rstd;
-    p.mean[c] = (float)t.mean;
+    p.mean[c] = (float)mean;
     p.rstd[c] = rstd;
     p.scale[c] = sc;
-    p.shift[c] = p.beta[c] - (float)t.mean * sc;
+    p.shift[c] = p.beta[c] - (float)mean * sc;
     if (p.running_mean) {
-        const double unb = t.n > 1.0 ? t.m2 / (t.n - 1.0) : var;
-        p.running_mean[c] = (1.f - p.momentum) * p.running_mean[c] + p.momentum * (float)t.mean;
+        const double unb = n > 1.0 ? m2 / (n - 1.0) : var;
+        p.running_mean[c] = (1.f - p.momentum) * p.running_mean[c] + p.momentum * (float)mean;
         p.running_var[c] = (1.f - p.momentum) * p.running_var[c] + p.momentum * (float)unb;
     }
 }
 
-__global__ __launch_bounds__(256) void k_bn_bwd_finalize(const BnParams p) {
-    __shared__ double sm[4][2][64];
+__global__ __launch_bounds__(64 * BN_FW) void k_bn_bwd_finalize(const BnParams p) {
+    __shared__ double sm[BN_FW][2][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + lane;
-    double s0 = 0.0, s1 = 0.0;
+    double s0 = 0.0, s1 = 0.0, t0 = 0.0, t1 = 0.0;
     if (c < p.C) {
-        for (int b = wave; b < p.nblk; b += 4) {
+        int b = wave;
+        for (; b + BN_FW < p.nblk; b += 2 * BN_FW) {
+            s0 += p.part[(int64_t)b * 2 * p.C + c];
+            s1 += p.part[(int64_t)b * 2 * p.C + p.C + c];
+            t0 += p.part[(int64_t)(b + BN_FW) * 2 * p.C + c];
+            t1 += p.part[(int64_t)(b + BN_FW) * 2 * p.C + p.C + c];
+        }
+        for (; b < p.nblk; b += BN_FW) {
             s0 += p.part[(int64_t)b * 2 * p.C + c];
             s1 += p.part[(int64_t)b * 2 * p.C + p.C + c];
         }
     }
-    sm[wave][0][lane] = s0;
-    sm[wave][1][lane] = s1;
+    sm[wave][0][lane] = s0 + t0;
+    sm[wave][1][lane] = s1 + t1;
     __syncthreads();
     if (wave != 0 || c >= p.C) return;
-    s0 = (sm[0][0][lane] + sm[1][0][lane]) + (sm[2][0][lane] + sm[3][0][lane]);
-    s1 = (sm[0][1][lane] + sm[1][1][lane]) + (sm[2][1][lane] + sm[3][1][lane]);
+    s0 = s1 = 0.0;
+    for (int w = 0; w < BN_FW; ++w) {
+        s0 += sm[w][0][lane];
+        s1 += sm[w][1][lane];
+    }
     p.dbeta[c] = (float)s0;
     p.dgamma[c] = (float)s1;
     p.c1[c] = (float)(s0 / (double)p.R);
@@ -762,7 +771,7 @@ int mtlora_bn_relu_bwd(const void* dy, const void* x, const float* save_mean, co
         else
             hipLaunchKernelGGL((k_bn_colsum<bf16, true>), dim3(p.nblk), dim3(threads), lds, s, p);
     }
-    hipLaunchKernelGGL(k_bn_bwd_finalize, dim3((unsigned)mtl_ceil_div(C, 64)), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(k_bn_bwd_finalize, dim3((unsigned)mtl_ceil_div(C, 64)), dim3(64 * BN_FW), 0, s, p);
     {
         MtlProfScope prof(PK_BN, (double)R * C * es * 3, s);
         if (dtype == MTLORA_F32)

@@ -31,6 +31,41 @@ def test_header_symbols_exported(built_lib):
         assert f" T {s}" in nm, s
 
 
+def test_header_prototypes_match_ctypes_signatures():
+    """every prototype of include/mtlora_hip.h has as many parameters as the ctypes signature that binds it, and the
+    two descriptor structs have the sizes the header implies (ABI drift check, no GPU needed)."""
+    import ctypes
+    from mtlora_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "mtlora_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    protos = dict(re.findall(r"\b(mtlora_[a-z0-9_]+)\s*\(([^;{}]*?)\)\s*;", hdr))
+    for name, (_, argtypes) in _lib._SIGS.items():
+        assert name in protos, name
+        params = protos[name].strip()
+        n = 0 if params in ("", "void") else params.count(",") + 1
+        assert n == len(argtypes), (name, n, len(argtypes))
+    # struct layouts as the C compiler sees them (gcc on the header) == the ctypes mirrors
+    import tempfile
+    src = '''#include <stdio.h>
+#include <stddef.h>
+#include "mtlora_hip.h"
+int main(void) {
+    printf("%zu %zu %zu %zu %zu %zu\\n", sizeof(mtlora_linear_desc), offsetof(mtlora_linear_desc, scale_t),
+           offsetof(mtlora_linear_desc, seed), offsetof(mtlora_linear_desc, seed_offset), sizeof(mtlora_attn_desc),
+           offsetof(mtlora_attn_desc, mask_value));
+    return 0;
+}
+'''
+    with tempfile.TemporaryDirectory() as td:
+        c, exe = os.path.join(td, "l.c"), os.path.join(td, "l")
+        open(c, "w").write(src)
+        subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), c, "-o", exe], check=True)
+        got = [int(v) for v in subprocess.run([exe], capture_output=True, text=True, check=True).stdout.split()]
+    LD, AD = _lib.LinearDesc, _lib.AttnDesc
+    assert got == [ctypes.sizeof(LD), LD.scale_t.offset, LD.seed.offset, LD.seed_offset.offset, ctypes.sizeof(AD),
+                   AD.mask_value.offset], got
+
+
 def test_size_queries_and_validation(built_lib):
     """pure host calls (no GPU): shape validation and workspace sizing of the C ABI."""
     import ctypes

@@ -922,3 +922,32 @@ def test_full_model_loss_and_gradients_vs_oracle():
         assert err <= 5e-3, (n, err)
         checked += 1
     assert checked > 200
+
+
+@pytest.mark.parametrize("autocast", [False, True])
+def test_split_reduction_linear_vs_f_linear(autocast):
+    """functional.linear_big_m (hipBLASLt, weight gradient as a batched GEMM over row chunks, two-stage bias sum) ==
+    F.linear, values and gradients; feeds_batchnorm=True returns an exactly zero bias gradient."""
+    from mtlora_amd import functional as Fn
+    M, K, N = 32768, 72, 40
+    torch.manual_seed(4)
+    x = torch.randn(M, K, device=dev(), requires_grad=True)
+    w = (torch.randn(N, K, device=dev()) * 0.1).requires_grad_(True)
+    b = torch.randn(N, device=dev()).requires_grad_(True)
+    gy = torch.randn(M, N, device=dev())
+    dt = torch.bfloat16 if autocast else torch.float32
+    with torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
+        y = Fn.linear_big_m(x, w, b)
+    assert y.dtype == dt
+    y.backward(gy.to(dt))
+    xr, wr, br = (t.detach().double().cpu().requires_grad_(True) for t in (x, w, b))
+    yr = torch.nn.functional.linear(xr, wr, br)
+    yr.backward(gy.double().cpu())
+    assert_close(y, yr, dt, "y")
+    assert_close(x.grad, xr.grad, dt, "dx", mult=2)
+    assert_close(w.grad, wr.grad, dt, "dw", mult=3)
+    assert_close(b.grad, br.grad, dt, "db", mult=3)
+    b.grad = None
+    with torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
+        Fn.linear_big_m(x, w, b, feeds_batchnorm=True).backward(gy.to(dt))
+    assert b.grad is not None and b.grad.abs().max().item() == 0.0

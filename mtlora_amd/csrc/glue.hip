@@ -64,6 +64,7 @@ struct LnParams {
     // backward
     const void* dy;
     void* dx;
+    const void* add;  // optional (dtype of x): dx = add + LayerNorm-backward(dy) -- the gradient of the skip path that forks off x
     float* part;  // [gridDim.x][2][C]
     int64_t M;
     int C;
@@ -184,6 +185,7 @@ __global__ __launch_bounds__(256) void k_ln_bwd(const LnParams p) {
     const TX* x = reinterpret_cast<const TX*>(p.x);
     const TG* dy = reinterpret_cast<const TG*>(p.dy);
     TX* dx = reinterpret_cast<TX*>(p.dx);
+    const TX* addp = reinterpret_cast<const TX*>(p.add);
     float g[MAXV][VE], ag[MAXV][VE], ab[MAXV][VE];
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
@@ -252,6 +254,12 @@ __global__ __launch_bounds__(256) void k_ln_bwd(const LnParams p) {
                     float o[8];
 #pragma unroll
                     for (int e = 0; e < VE; ++e) o[e] = rstd * (gy[i][e] - c1 - xh[i][e] * c2);
+                    if (addp) {
+                        float fa[8];
+                        ld_vec<TX>(addp + row * p.C + v * VE, fa);
+#pragma unroll
+                        for (int e = 0; e < VE; ++e) o[e] += fa[e];
+                    }
                     st_vec<TX, VE>(dx + row * p.C + v * VE, o);
                 }
             }
@@ -398,11 +406,11 @@ int mtlora_layernorm_fwd(const void* x, const float* gamma, const float* beta, v
 
 int mtlora_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
                          void* dx, float* dgamma, float* dbeta, int64_t M, int64_t C, int x_dtype, int dy_dtype,
-                         void* scratch, int64_t scratch_bytes, void* stream) {
+                         void* scratch, int64_t scratch_bytes, const void* dx_addend, void* stream) {
     int st = ln_check(M, C, x_dtype, dy_dtype);
     if (st != MTLORA_OK) return st;
     if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta || !scratch) return MTLORA_ERR_NULL;
-    if (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx | (uintptr_t)scratch) & 15u) return MTLORA_ERR_ALIGN;
+    if (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx | (uintptr_t)scratch | (uintptr_t)dx_addend) & 15u) return MTLORA_ERR_ALIGN;
     if (scratch_bytes < mtlora_layernorm_bwd_scratch_bytes(M, C, x_dtype) - 256) return MTLORA_ERR_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
     if (M == 0) {
@@ -417,6 +425,7 @@ int mtlora_layernorm_bwd(const void* dy, const void* x, const float* gamma, cons
     p.mean = const_cast<float*>(mean);
     p.rstd = const_cast<float*>(rstd);
     p.dx = dx;
+    p.add = dx_addend;
     p.part = reinterpret_cast<float*>(scratch);
     p.M = M;
     p.C = (int)C;

@@ -309,45 +309,83 @@ def window_merge_and_roll_backward(grad_in, B, H, W, C, shift_size, window_size)
 # ----------------------------------------------------------------------------------------------
 # LayerNorm (block glue): reads x once, writes y directly in the dtype the next linear consumes
 # ----------------------------------------------------------------------------------------------
+def _ln_forward(ctx, x, weight, bias, eps, out_dtype):
+    L.require_gpu(x, weight, bias)
+    C = x.shape[-1]
+    x2 = x.reshape(-1, C).contiguous()
+    M = x2.shape[0]
+    w, b = weight.detach().float().contiguous(), bias.detach().float().contiguous()
+    y = torch.empty((M, C), dtype=out_dtype, device=x.device)
+    mean = torch.empty(M, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(M, dtype=torch.float32, device=x.device)
+    st = L.lib().mtlora_layernorm_fwd(L.ptr(x2), L.ptr(w), L.ptr(b), L.ptr(y), L.ptr(mean), L.ptr(rstd), M, C,
+                                      float(eps), L.dtype_code(x2), L.dtype_code(y), L.stream_ptr())
+    L.check(st, "mtlora_layernorm_fwd")
+    ctx.save_for_backward(x2, w, mean, rstd)
+    ctx.shape = x.shape
+    return y.reshape(x.shape)
+
+
+def _ln_backward(ctx, dy, addend=None):
+    """dx (+ addend), dgamma, dbeta"""
+    x2, w, mean, rstd = ctx.saved_tensors
+    M, C = x2.shape
+    dy2 = dy.reshape(M, C).contiguous()
+    if dy2.dtype not in (torch.float32, torch.bfloat16):
+        dy2 = dy2.float()
+    add2 = None
+    if addend is not None:
+        add2 = addend.reshape(M, C).to(x2.dtype).contiguous()
+    lib = L.lib()
+    sb = lib.mtlora_layernorm_bwd_scratch_bytes(M, C, L.dtype_code(x2))
+    scratch = torch.empty(sb, dtype=torch.uint8, device=x2.device)
+    dx = torch.empty_like(x2)
+    dg = torch.empty(C, dtype=torch.float32, device=x2.device)
+    db = torch.empty(C, dtype=torch.float32, device=x2.device)
+    st = lib.mtlora_layernorm_bwd(L.ptr(dy2), L.ptr(x2), L.ptr(w), L.ptr(mean), L.ptr(rstd), L.ptr(dx), L.ptr(dg),
+                                  L.ptr(db), M, C, L.dtype_code(x2), L.dtype_code(dy2), L.ptr(scratch), sb, L.ptr(add2),
+                                  L.stream_ptr())
+    L.check(st, "mtlora_layernorm_bwd")
+    return dx.reshape(ctx.shape), dg, db
+
+
 class LayerNormFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, eps: float, out_dtype: torch.dtype):
-        L.require_gpu(x, weight, bias)
-        C = x.shape[-1]
-        x2 = x.reshape(-1, C).contiguous()
-        M = x2.shape[0]
-        w, b = weight.detach().float().contiguous(), bias.detach().float().contiguous()
-        y = torch.empty((M, C), dtype=out_dtype, device=x.device)
-        mean = torch.empty(M, dtype=torch.float32, device=x.device)
-        rstd = torch.empty(M, dtype=torch.float32, device=x.device)
-        st = L.lib().mtlora_layernorm_fwd(L.ptr(x2), L.ptr(w), L.ptr(b), L.ptr(y), L.ptr(mean), L.ptr(rstd), M, C,
-                                          float(eps), L.dtype_code(x2), L.dtype_code(y), L.stream_ptr())
-        L.check(st, "mtlora_layernorm_fwd")
-        ctx.save_for_backward(x2, w, mean, rstd)
-        ctx.shape = x.shape
-        return y.reshape(x.shape)
+        return _ln_forward(ctx, x, weight, bias, eps, out_dtype)
 
     @staticmethod
     def backward(ctx, dy):
-        x2, w, mean, rstd = ctx.saved_tensors
-        M, C = x2.shape
-        dy2 = dy.reshape(M, C).contiguous()
-        if dy2.dtype not in (torch.float32, torch.bfloat16):
-            dy2 = dy2.float()
-        lib = L.lib()
-        sb = lib.mtlora_layernorm_bwd_scratch_bytes(M, C, L.dtype_code(x2))
-        scratch = torch.empty(sb, dtype=torch.uint8, device=x2.device)
-        dx = torch.empty_like(x2)
-        dg = torch.empty(C, dtype=torch.float32, device=x2.device)
-        db = torch.empty(C, dtype=torch.float32, device=x2.device)
-        st = lib.mtlora_layernorm_bwd(L.ptr(dy2), L.ptr(x2), L.ptr(w), L.ptr(mean), L.ptr(rstd), L.ptr(dx), L.ptr(dg),
-                                      L.ptr(db), M, C, L.dtype_code(x2), L.dtype_code(dy2), L.ptr(scratch), sb,
-                                      L.stream_ptr())
-        L.check(st, "mtlora_layernorm_bwd")
-        return dx.reshape(ctx.shape), dg, db, None, None
+        dx, dg, db = _ln_backward(ctx, dy)
+        return dx, dg, db, None, None
 
 
-def layer_norm(mod: torch.nn.Module, x: torch.Tensor, feeds_linear: bool = True) -> torch.Tensor:
+class LayerNormForkFn(torch.autograd.Function):
+    """(x_skip, y) = (x, LayerNorm(x)): the block input feeds the LayerNorm AND the residual connection.  Routing both
+    uses through one node lets the backward form  d x = g_skip + LN-backward(g_y)  inside the LayerNorm kernel
+    (``dx_addend``) instead of autograd's separate full-size gradient add (one per stream per half block)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps: float, out_dtype: torch.dtype):
+        y = _ln_forward(ctx, x, weight, bias, eps, out_dtype)
+        return x.view_as(x), y
+
+    @staticmethod
+    def backward(ctx, g_skip, gy):
+        if gy is None:  # the normalised output was not used
+            return g_skip, None, None, None, None
+        dx, dg, db = _ln_backward(ctx, gy, g_skip)
+        return dx, dg, db, None, None
+
+
+def layer_norm_fork(mod: torch.nn.Module, x: torch.Tensor):
+    """(x for the skip connection, LayerNorm(x) for the following linear): see LayerNormForkFn.  Same dispatch rules as
+    ``layer_norm`` (falls back to two separate uses of x when the fused kernel does not apply)."""
+    y = layer_norm(mod, x, _fork=True)
+    return y if isinstance(y, tuple) else (x, y)
+
+
+def layer_norm(mod: torch.nn.Module, x: torch.Tensor, feeds_linear: bool = True, _fork: bool = False):
     """``mod(x)`` for an ``nn.LayerNorm`` over the last dim, through the HIP kernel.  ``feeds_linear``: the output is
     only consumed by an MTLoRALinear, so it is written directly in the hot path's compute dtype (bf16 under autocast
     -- no fp32 intermediate + cast pass).  Otherwise (patch_embed.norm, whose output IS the residual stream) the
@@ -362,6 +400,8 @@ def layer_norm(mod: torch.nn.Module, x: torch.Tensor, feeds_linear: bool = True)
         out_dtype = compute_dtype(x)
     else:
         out_dtype = torch.float32 if torch.is_autocast_enabled() else x.dtype
+    if _fork and x.requires_grad:
+        return LayerNormForkFn.apply(x, mod.weight, mod.bias, mod.eps, out_dtype)  # (x_skip, y)
     return LayerNormFn.apply(x, mod.weight, mod.bias, mod.eps, out_dtype)
 
 

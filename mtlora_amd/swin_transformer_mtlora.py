@@ -261,8 +261,9 @@ class SwinTransformerBlock(nn.Module):
         H, W = self.input_resolution
         B, L, C = x.shape
         assert L == H * W, "input feature has wrong size"
-        shortcut = x
-        xn = Fn.layer_norm(self.norm1, x)
+        # x feeds norm1 AND the skip connection: one autograd node for both, so that the skip gradient is added inside the
+        # LayerNorm backward kernel instead of by a separate full-size add (functional.LayerNormForkFn)
+        shortcut, xn = Fn.layer_norm_fork(self.norm1, x)
         if self.attention_layout == "windows":
             a, a_t = self._attend_windows(xn, B, H, W, C)
         else:
@@ -277,8 +278,13 @@ class SwinTransformerBlock(nn.Module):
         else:
             x = Fn.residual_droppath(shortcut, [a], p_dp, self.training)[0]
         # MLP half
-        m, m_t = self.mlp(Fn.layer_norm(self.norm2, x),
-                          None if x_t is None else {t: Fn.layer_norm(self.norm2, x_t[t]) for t in self.tasks})
+        x, xn2 = Fn.layer_norm_fork(self.norm2, x)
+        xn2_t = None
+        if x_t is not None:
+            forks = {t: Fn.layer_norm_fork(self.norm2, x_t[t]) for t in self.tasks}
+            x_t = {t: forks[t][0] for t in self.tasks}
+            xn2_t = {t: forks[t][1] for t in self.tasks}
+        m, m_t = self.mlp(xn2, xn2_t)
         if m_t is None:
             return Fn.residual_droppath(x, [m], p_dp, self.training)[0], None
         if x_t is None:  # INTERMEDIATE_SPECIALIZATION-style: mlp specialises but attention did not (:401-403)

@@ -162,16 +162,19 @@ int mtlora_window_attn_bwd(const mtlora_attn_desc* d, const void* qkv, const flo
  * swin_transformer_mtlora.py:331-333, 395-396, 469) -- replaces aten::native_layer_norm + the autocast cast:
  * reads x (fp32 or bf16) once and writes y directly in the dtype the following linear consumes; fp32 statistics
  * (mean, rstd: (M) fp32) are saved for backward.  bwd also writes dgamma / dbeta (C) fp32 (overwritten).
+ * merge_h, merge_w (0, 0 = off): PatchMerging (swin_transformer_mtlora.py:429-481) in front of its LayerNorm: x (and dx,
+ * dx_addend) are the (B, merge_h*merge_w, C/4) token tensor and row (b, y2, x2) of the normalised (M, C) matrix is the
+ * 2x2 neighbourhood [x(2y2,2x2) | x(2y2+1,2x2) | x(2y2,2x2+1) | x(2y2+1,2x2+1)] gathered on the fly (backward scatters).
  * dx_addend (nullable, dtype and shape of x): dx = dx_addend + LN-backward(dy).  In a transformer block x feeds the
  * LayerNorm AND the skip connection; passing the skip path's gradient here replaces the framework's separate
  * full-size gradient add.
  * ------------------------------------------------------------------------------------------ */
 int mtlora_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
-                         int64_t M, int64_t C, float eps, int x_dtype, int y_dtype, void* stream);
+                         int64_t M, int64_t C, float eps, int x_dtype, int y_dtype, int merge_h, int merge_w, void* stream);
 int64_t mtlora_layernorm_bwd_scratch_bytes(int64_t M, int64_t C, int x_dtype);
 int mtlora_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
                          void* dx, float* dgamma, float* dbeta, int64_t M, int64_t C, int x_dtype, int dy_dtype,
-                         void* scratch, int64_t scratch_bytes, const void* dx_addend, void* stream);
+                         void* scratch, int64_t scratch_bytes, const void* dx_addend, int merge_h, int merge_w, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Training-mode BatchNorm + optional ReLU over a channels-last (R rows, C channels) matrix -- the decoder heads'

@@ -64,10 +64,10 @@ _SIGS = {
     "mtlora_window_attn_bwd": (c_int, [POINTER(AttnDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                        c_void_p, c_void_p, c_int64, c_void_p]),
     "mtlora_layernorm_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_float,
-                                     c_int, c_int, c_void_p]),
+                                     c_int, c_int, c_int, c_int, c_void_p]),
     "mtlora_layernorm_bwd_scratch_bytes": (c_int64, [c_int64, c_int64, c_int]),
     "mtlora_layernorm_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                     c_int64, c_int64, c_int, c_int, c_void_p, c_int64, c_void_p, c_void_p]),
+                                     c_int64, c_int64, c_int, c_int, c_void_p, c_int64, c_void_p, c_int, c_int, c_void_p]),
     "mtlora_bn_scratch_bytes": (c_int64, [c_int64, c_int64, c_int]),
     "mtlora_bn_relu_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_int, c_void_p,
                                    c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p, c_int64,

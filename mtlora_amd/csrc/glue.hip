@@ -69,7 +69,35 @@ struct LnParams {
     int64_t M;
     int C;
     float eps;
+    // patch-merging gather (PatchMerging: 2x2 neighbourhood concat before its LayerNorm): x / dx / add are (B, mg_H*mg_W, C/4)
+    // token tensors and row r = (b, y2, x2) of the normalised (M, C) matrix is [x(2y2,2x2) | x(2y2+1,2x2) | x(2y2,2x2+1) |
+    // x(2y2+1,2x2+1)]; mg_W == 0: plain rows
+    int mg_H, mg_W;
 };
+
+// element offset of column `col` (a multiple of the vector width) of row `row` in x / dx
+struct LnRow {
+    int64_t base;  // plain: row * C; merged: offset of token (2y2, 2x2)
+};
+__device__ __forceinline__ LnRow ln_row(const LnParams& p, int64_t row) {
+    LnRow r;
+    if (p.mg_W == 0) {
+        r.base = row * p.C;
+    } else {
+        const int W2 = p.mg_W >> 1, H2 = p.mg_H >> 1, Cs = p.C >> 2;
+        const int64_t b = row / ((int64_t)H2 * W2);
+        const int rem = (int)(row - b * H2 * W2);
+        const int y2 = rem / W2, x2 = rem - y2 * W2;
+        r.base = ((b * p.mg_H + 2 * y2) * p.mg_W + 2 * x2) * (int64_t)Cs;
+    }
+    return r;
+}
+// per-lane constant part: offset of column `col` relative to the row base
+__device__ __forceinline__ int64_t ln_col(const LnParams& p, int col) {
+    if (p.mg_W == 0) return col;
+    const int Cs = p.C >> 2, q = col / Cs, within = col - q * Cs;
+    return ((int64_t)(q & 1) * p.mg_W + (q >> 1)) * Cs + within;  // (dy = q & 1, dx = q >> 1)
+}
 
 // raw 16-byte vector -> floats
 template <typename T>
@@ -113,6 +141,9 @@ __global__ __launch_bounds__(256) void k_ln_fwd(const LnParams p) {
             b[i][e] = v < nvec ? p.beta[v * VE + e] : 0.f;
         }
     }
+    int64_t coff[MAXV];  // x offset of this lane's vectors relative to the row base (plain or patch-merging gather)
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) coff[i] = ln_col(p, (lr + i * LPR < nvec ? lr + i * LPR : 0) * VE);
     const float inv_c = 1.f / (float)p.C;
     const int64_t rows_per_blk = 4 * RPW * UNR;
     for (int64_t r0 = (int64_t)blockIdx.x * rows_per_blk; r0 < p.M; r0 += (int64_t)gridDim.x * rows_per_blk) {
@@ -121,10 +152,11 @@ __global__ __launch_bounds__(256) void k_ln_fwd(const LnParams p) {
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
             row[u] = r0 + (int64_t)(wave * UNR + u) * RPW + sub;
+            const int64_t xb = ln_row(p, row[u] < p.M ? row[u] : 0).base;
 #pragma unroll
             for (int i = 0; i < MAXV; ++i) {
                 const int v = lr + i * LPR;
-                raw[u][i] = (row[u] < p.M && v < nvec) ? *reinterpret_cast<const u32x4*>(x + row[u] * p.C + v * VE)
+                raw[u][i] = (row[u] < p.M && v < nvec) ? *reinterpret_cast<const u32x4*>(x + xb + coff[i])
                                                       : u32x4{0u, 0u, 0u, 0u};
             }
         }
@@ -197,10 +229,14 @@ __global__ __launch_bounds__(256) void k_ln_bwd(const LnParams p) {
             ab[i][e] = 0.f;
         }
     }
+    int64_t coff[MAXV];  // x / dx / addend offsets of this lane's vectors relative to the row base
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) coff[i] = ln_col(p, (lr + i * LPR < nvec ? lr + i * LPR : 0) * VE);
     const int64_t rows_per_blk = 4 * RPW;
     for (int64_t r0 = (int64_t)blockIdx.x * rows_per_blk; r0 < p.M; r0 += (int64_t)gridDim.x * rows_per_blk) {
         const int64_t row = r0 + wave * RPW + sub;
         const bool rv = row < p.M;
+        const int64_t xb = ln_row(p, rv ? row : 0).base;
         const float mean = rv ? p.mean[row] : 0.f, rstd = rv ? p.rstd[row] : 0.f;
         float xh[MAXV][VE], gy[MAXV][VE];
         float c1 = 0.f, c2 = 0.f;
@@ -209,7 +245,7 @@ __global__ __launch_bounds__(256) void k_ln_bwd(const LnParams p) {
             const int v = lr + i * LPR;
             if (rv && v < nvec) {
                 float fx[8], fg[8];
-                ld_vec<TX>(x + row * p.C + v * VE, fx);
+                ld_vec<TX>(x + xb + coff[i], fx);
                 if constexpr (sizeof(TG) == sizeof(TX)) {
                     ld_vec<TG>(dy + row * p.C + v * VE, fg);
                 } else if constexpr (sizeof(TG) == 2) {  // x fp32 (4 per vec), dy bf16: 4 elements = 8 bytes
@@ -256,11 +292,11 @@ __global__ __launch_bounds__(256) void k_ln_bwd(const LnParams p) {
                     for (int e = 0; e < VE; ++e) o[e] = rstd * (gy[i][e] - c1 - xh[i][e] * c2);
                     if (addp) {
                         float fa[8];
-                        ld_vec<TX>(addp + row * p.C + v * VE, fa);
+                        ld_vec<TX>(addp + xb + coff[i], fa);
 #pragma unroll
                         for (int e = 0; e < VE; ++e) o[e] += fa[e];
                     }
-                    st_vec<TX, VE>(dx + row * p.C + v * VE, o);
+                    st_vec<TX, VE>(dx + xb + coff[i], o);
                 }
             }
         }
@@ -333,6 +369,18 @@ int ln_grid(int64_t M, int lpr, int cap = 256 * 2) {
     return (int)(g < 1 ? 1 : g);
 }
 
+// patch-merging gather: rows = B * (H/2) * (W/2), C = 4 * C_token, C_token a multiple of the vector width
+int ln_merge(LnParams& p, int64_t M, int64_t C, int xdt, int mh, int mw) {
+    p.mg_H = p.mg_W = 0;
+    if (mh == 0 && mw == 0) return MTLORA_OK;
+    const int ve = xdt == MTLORA_F32 ? 4 : 8;
+    if (mh <= 0 || mw <= 0 || (mh & 1) || (mw & 1) || C % 4 || (C / 4) % ve) return MTLORA_ERR_SHAPE;
+    if (M % ((int64_t)(mh / 2) * (mw / 2))) return MTLORA_ERR_SHAPE;
+    p.mg_H = mh;
+    p.mg_W = mw;
+    return MTLORA_OK;
+}
+
 int ln_check(int64_t M, int64_t C, int xdt, int ydt) {
     if ((xdt != MTLORA_F32 && xdt != MTLORA_BF16) || (ydt != MTLORA_F32 && ydt != MTLORA_BF16)) return MTLORA_ERR_DTYPE;
     const int ve = xdt == MTLORA_F32 ? 4 : 8;
@@ -365,7 +413,7 @@ int64_t mtlora_layernorm_bwd_scratch_bytes(int64_t M, int64_t C, int x_dtype) {
     }
 
 int mtlora_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
-                         int64_t M, int64_t C, float eps, int x_dtype, int y_dtype, void* stream) {
+                         int64_t M, int64_t C, float eps, int x_dtype, int y_dtype, int merge_h, int merge_w, void* stream) {
     int st = ln_check(M, C, x_dtype, y_dtype);
     if (st != MTLORA_OK) return st;
     if (!x || !gamma || !beta || !y || !mean || !rstd) return MTLORA_ERR_NULL;
@@ -381,6 +429,8 @@ int mtlora_layernorm_fwd(const void* x, const float* gamma, const float* beta, v
     p.M = M;
     p.C = (int)C;
     p.eps = eps;
+    st = ln_merge(p, M, C, x_dtype, merge_h, merge_w);
+    if (st != MTLORA_OK) return st;
     const int nvec_h = (int)(C / (x_dtype == MTLORA_F32 ? 4 : 8));
     const int lpr = pick_lpr(nvec_h);
     const int vpl = (nvec_h + lpr - 1) / lpr;
@@ -406,7 +456,7 @@ int mtlora_layernorm_fwd(const void* x, const float* gamma, const float* beta, v
 
 int mtlora_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
                          void* dx, float* dgamma, float* dbeta, int64_t M, int64_t C, int x_dtype, int dy_dtype,
-                         void* scratch, int64_t scratch_bytes, const void* dx_addend, void* stream) {
+                         void* scratch, int64_t scratch_bytes, const void* dx_addend, int merge_h, int merge_w, void* stream) {
     int st = ln_check(M, C, x_dtype, dy_dtype);
     if (st != MTLORA_OK) return st;
     if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta || !scratch) return MTLORA_ERR_NULL;
@@ -429,6 +479,8 @@ int mtlora_layernorm_bwd(const void* dy, const void* x, const float* gamma, cons
     p.part = reinterpret_cast<float*>(scratch);
     p.M = M;
     p.C = (int)C;
+    st = ln_merge(p, M, C, x_dtype, merge_h, merge_w);
+    if (st != MTLORA_OK) return st;
     const int nvec_h = (int)(C / (x_dtype == MTLORA_F32 ? 4 : 8));
     const int lpr = pick_lpr(nvec_h);
     const int vpl = (nvec_h + lpr - 1) / lpr;

@@ -309,33 +309,44 @@ def window_merge_and_roll_backward(grad_in, B, H, W, C, shift_size, window_size)
 # ----------------------------------------------------------------------------------------------
 # LayerNorm (block glue): reads x once, writes y directly in the dtype the next linear consumes
 # ----------------------------------------------------------------------------------------------
-def _ln_forward(ctx, x, weight, bias, eps, out_dtype):
+def _ln_forward(ctx, x, weight, bias, eps, out_dtype, merge=None):
+    """merge=(H, W): x is a (B, H*W, C) token tensor and the normalised rows are its 2x2 neighbourhoods (PatchMerging):
+    output (B, H*W/4, 4C), gathered by the kernel."""
     L.require_gpu(x, weight, bias)
-    C = x.shape[-1]
-    x2 = x.reshape(-1, C).contiguous()
-    M = x2.shape[0]
+    if merge is None:
+        C = x.shape[-1]
+        x2 = x.reshape(-1, C).contiguous()
+        M, mh, mw = x2.shape[0], 0, 0
+        out_shape = x.shape
+    else:
+        mh, mw = merge
+        B, Lt, Ct = x.shape
+        C, M = 4 * Ct, B * Lt // 4
+        x2 = x.contiguous()
+        out_shape = (B, Lt // 4, C)
     w, b = weight.detach().float().contiguous(), bias.detach().float().contiguous()
     y = torch.empty((M, C), dtype=out_dtype, device=x.device)
     mean = torch.empty(M, dtype=torch.float32, device=x.device)
     rstd = torch.empty(M, dtype=torch.float32, device=x.device)
     st = L.lib().mtlora_layernorm_fwd(L.ptr(x2), L.ptr(w), L.ptr(b), L.ptr(y), L.ptr(mean), L.ptr(rstd), M, C,
-                                      float(eps), L.dtype_code(x2), L.dtype_code(y), L.stream_ptr())
+                                      float(eps), L.dtype_code(x2), L.dtype_code(y), mh, mw, L.stream_ptr())
     L.check(st, "mtlora_layernorm_fwd")
     ctx.save_for_backward(x2, w, mean, rstd)
-    ctx.shape = x.shape
-    return y.reshape(x.shape)
+    ctx.shape, ctx.merge, ctx.MC = x.shape, (mh, mw), (M, C)
+    return y.reshape(out_shape)
 
 
 def _ln_backward(ctx, dy, addend=None):
     """dx (+ addend), dgamma, dbeta"""
     x2, w, mean, rstd = ctx.saved_tensors
-    M, C = x2.shape
+    M, C = ctx.MC
+    mh, mw = ctx.merge
     dy2 = dy.reshape(M, C).contiguous()
     if dy2.dtype not in (torch.float32, torch.bfloat16):
         dy2 = dy2.float()
     add2 = None
     if addend is not None:
-        add2 = addend.reshape(M, C).to(x2.dtype).contiguous()
+        add2 = addend.reshape(x2.shape).to(x2.dtype).contiguous()
     lib = L.lib()
     sb = lib.mtlora_layernorm_bwd_scratch_bytes(M, C, L.dtype_code(x2))
     scratch = torch.empty(sb, dtype=torch.uint8, device=x2.device)
@@ -344,20 +355,20 @@ def _ln_backward(ctx, dy, addend=None):
     db = torch.empty(C, dtype=torch.float32, device=x2.device)
     st = lib.mtlora_layernorm_bwd(L.ptr(dy2), L.ptr(x2), L.ptr(w), L.ptr(mean), L.ptr(rstd), L.ptr(dx), L.ptr(dg),
                                   L.ptr(db), M, C, L.dtype_code(x2), L.dtype_code(dy2), L.ptr(scratch), sb, L.ptr(add2),
-                                  L.stream_ptr())
+                                  mh, mw, L.stream_ptr())
     L.check(st, "mtlora_layernorm_bwd")
     return dx.reshape(ctx.shape), dg, db
 
 
 class LayerNormFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, eps: float, out_dtype: torch.dtype):
-        return _ln_forward(ctx, x, weight, bias, eps, out_dtype)
+    def forward(ctx, x, weight, bias, eps: float, out_dtype: torch.dtype, merge=None):
+        return _ln_forward(ctx, x, weight, bias, eps, out_dtype, merge)
 
     @staticmethod
     def backward(ctx, dy):
         dx, dg, db = _ln_backward(ctx, dy)
-        return dx, dg, db, None, None
+        return dx, dg, db, None, None, None
 
 
 class LayerNormForkFn(torch.autograd.Function):
@@ -383,6 +394,21 @@ def layer_norm_fork(mod: torch.nn.Module, x: torch.Tensor):
     ``layer_norm`` (falls back to two separate uses of x when the fused kernel does not apply)."""
     y = layer_norm(mod, x, _fork=True)
     return y if isinstance(y, tuple) else (x, y)
+
+
+def layer_norm_merge(mod: torch.nn.Module, x: torch.Tensor, H: int, W: int) -> torch.Tensor:
+    """PatchMerging's ``norm(cat of the 2x2 neighbourhood)`` on a (B, H*W, C) token tensor -> (B, H*W/4, 4C): the gather is
+    done by the LayerNorm kernels' addressing (forward reads, backward scatters), not by a strided copy.  Falls back to
+    the explicit gather when the kernel does not apply."""
+    B, Lt, C = x.shape
+    ve = 4 if x.dtype == torch.float32 else 8
+    ok = (type(mod) is torch.nn.LayerNorm and mod.elementwise_affine and mod.bias is not None and x.is_cuda
+          and x.dtype in (torch.float32, torch.bfloat16) and C % ve == 0 and Lt == H * W and H % 2 == 0 and W % 2 == 0
+          and 4 * C <= (2048 if x.dtype == torch.float32 else 4096))
+    if not ok:
+        g = x.view(B, H // 2, 2, W // 2, 2, C).permute(0, 1, 3, 4, 2, 5).reshape(B, (H // 2) * (W // 2), 4 * C)
+        return layer_norm(mod, g)
+    return LayerNormFn.apply(x, mod.weight, mod.bias, mod.eps, compute_dtype(x), (H, W))
 
 
 def layer_norm(mod: torch.nn.Module, x: torch.Tensor, feeds_linear: bool = True, _fork: bool = False):

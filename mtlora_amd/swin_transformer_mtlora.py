@@ -320,9 +320,9 @@ class PatchMerging(nn.Module):
         B, L, C = x.shape
         assert L == H * W, "input feature has wrong size"
         assert H % 2 == 0 and W % 2 == 0, f"x size ({H}*{W}) are not even."
-        # (B, H/2, 2, W/2, 2, C) -> channel order [x(0,0), x(1,0), x(0,1), x(1,1)] as the reference's cat
-        g = x.view(B, H // 2, 2, W // 2, 2, C).permute(0, 1, 3, 4, 2, 5).reshape(B, (H // 2) * (W // 2), 4 * C)
-        y, _ = self.reduction(Fn.layer_norm(self.norm, g))
+        # rows of the normalised matrix = 2x2 neighbourhoods, channel order [x(0,0), x(1,0), x(0,1), x(1,1)] as the
+        # reference's cat; gathered by the LayerNorm kernel itself (no strided copy forward, no scatter copy backward)
+        y, _ = self.reduction(Fn.layer_norm_merge(self.norm, x, H, W))
         return y
 
     def extra_repr(self) -> str:

@@ -153,10 +153,23 @@ class WindowAttention(nn.Module):
         self.softmax = nn.Softmax(dim=-1)
 
     def dense_bias(self) -> Tensor:
-        """(nH, N, N) = table[index] (reference :202-206); autograd routes the kernel's dbias into the table."""
+        """(nH, N, N) = table[index] (reference :202-206); autograd routes the kernel's dbias into the table.
+        On the GPU the gather is a product with a constant one-hot matrix (fp32, outside autocast): same values, and the
+        backward is ONE deterministic GEMM  d table^T = dbias (nH x N^2) @ onehot^T  instead of index_put's sort +
+        segmented-reduce kernels."""
         n = self.window_size[0] * self.window_size[1]
-        b = self.relative_position_bias_table[self.relative_position_index.view(-1)]
-        return b.view(n, n, -1).permute(2, 0, 1).float()
+        table = self.relative_position_bias_table
+        if not table.is_cuda:
+            b = table[self.relative_position_index.view(-1)]
+            return b.view(n, n, -1).permute(2, 0, 1).float()
+        oh = getattr(self, "_rpi_onehot", None)
+        if oh is None or oh.device != table.device:
+            idx = self.relative_position_index.view(-1).to(table.device)
+            oh = torch.zeros(table.shape[0], n * n, dtype=torch.float32, device=table.device)
+            oh[idx, torch.arange(n * n, device=table.device)] = 1.0
+            self._rpi_onehot = oh  # plain attribute: a constant derived from relative_position_index, not module state
+        with torch.autocast("cuda", enabled=False):
+            return (table.float().t() @ oh).view(-1, n, n)
 
     def _core(self, qkv: Tensor, meta: Fn.AttnMeta, mask: Optional[Tensor], mask_ids: Optional[Tensor]) -> Tensor:
         if self.training and self.attn_drop.p > 0:

@@ -597,15 +597,20 @@ class UpsampleLossFn(torch.autograd.Function):
 class SplitKLinearFn(torch.autograd.Function):
     """y = x W^T + b on hipBLASLt, like F.linear, but with dW = dY^T X evaluated as a batched GEMM over S row chunks
     + a sum: with M = 100k..400k rows and an output of a few hundred x a few hundred elements the single GEMM runs on
-    17-34 workgroups of the 256 CUs (568 us for 1080x270 over 401k rows), the batched form fills the GPU."""
+    17-34 workgroups of the 256 CUs (568 us for 1080x270 over 401k rows), the batched form fills the GPU.
+    ``weight`` / ``bias`` are the (fp32) master parameters: they are cast to ``cdtype`` inside (no autograd cast nodes) and
+    their gradients are returned in the masters' dtype straight from the fp32 chunk sum (no bf16 round trip)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, splits: int, zero_bias_grad: bool = False):
-        ctx.save_for_backward(x, weight)
+    def forward(ctx, x, weight, bias, splits: int, zero_bias_grad: bool, cdtype):
+        w = weight.detach().to(cdtype)
+        ctx.save_for_backward(x, w)
         ctx.has_bias = bias is not None
         ctx.splits = splits
         ctx.zero_bias_grad = zero_bias_grad
-        return torch.nn.functional.linear(x, weight, bias)
+        ctx.wdtype = weight.dtype
+        ctx.bdtype = None if bias is None else bias.dtype
+        return torch.nn.functional.linear(x, w, None if bias is None else bias.detach().to(cdtype))
 
     @staticmethod
     def backward(ctx, gy):
@@ -618,17 +623,17 @@ class SplitKLinearFn(torch.autograd.Function):
         dw = None
         if ctx.needs_input_grad[1]:
             part = torch.bmm(gy.view(S, M // S, N).transpose(1, 2), x.view(S, M // S, K))  # (S, N, K)
-            dw = part.float().sum(0).to(w.dtype)
+            dw = part.sum(0, dtype=torch.float32).to(ctx.wdtype)
         db = None
         if ctx.has_bias and ctx.needs_input_grad[2]:
             # zero_bias_grad: the output feeds a training-mode BatchNorm, whose backward returns columns that sum to zero
             # EXACTLY (dx = scale (dy' - mean(dy') - xhat mean(dy' xhat)), sum(xhat) = 0): the bias gradient is 0, and
             # summing 400k x 1080 elements only to obtain rounding noise costs a full pass over the gradient
             if ctx.zero_bias_grad:
-                db = torch.zeros(N, dtype=gy.dtype, device=gy.device)
+                db = torch.zeros(N, dtype=ctx.bdtype, device=gy.device)
             else:  # two-stage column sum: a (400k x 21) sum(0) runs on 64 workgroups for 256 us in one stage
-                db = gy.view(S, M // S, N).sum(1, dtype=torch.float32).sum(0).to(gy.dtype)
-        return dx, dw, db, None, None
+                db = gy.view(S, M // S, N).sum(1, dtype=torch.float32).sum(0).to(ctx.bdtype)
+        return dx, dw, db, None, None, None
 
 
 def linear_big_m(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor],
@@ -646,8 +651,8 @@ def linear_big_m(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Ten
             if torch.is_autocast_enabled("cuda"):
                 dt = torch.get_autocast_dtype("cuda")
                 with torch.autocast("cuda", enabled=False):
-                    return SplitKLinearFn.apply(x.to(dt), weight.to(dt), None if bias is None else bias.to(dt), S, feeds_batchnorm)
-            return SplitKLinearFn.apply(x, weight, bias, S, feeds_batchnorm)
+                    return SplitKLinearFn.apply(x.to(dt), weight, bias, S, feeds_batchnorm, dt)
+            return SplitKLinearFn.apply(x, weight, bias, S, feeds_batchnorm, x.dtype)
     return torch.nn.functional.linear(x, weight, bias)
 
 

@@ -6,6 +6,7 @@ current stream to the library.  Every op raises if the library or a GPU tensor i
 from __future__ import annotations
 
 import ctypes
+import os
 from dataclasses import dataclass, field
 from typing import List, Optional, Sequence, Tuple
 
@@ -636,6 +637,81 @@ class SplitKLinearFn(torch.autograd.Function):
         return dx, dw, db, None, None, None
 
 
+class PlainLinearFn(torch.autograd.Function):
+    """y = x W^T + b through the library's fused-GEMM kernel used at rank 0 (``mtlora_linear_fwd/bwd`` with r_s = 0, T = 0):
+    for the skinny-K / huge-M GEMMs of the heads (e.g. 100k x 272 -> 1080) hipBLASLt reaches ~1.3 TB/s and ~12 % of the
+    MFMA peak, k_nt ~3 TB/s.  dX comes from the same kernel (W^T re-materialised per step: the weight is trained); dW / db
+    stay on hipBLASLt as the split-reduction batched GEMM of SplitKLinearFn."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, splits: int, zero_bias_grad: bool, cdtype):
+        L.require_gpu(x, weight)
+        M, K = x.shape
+        N = weight.shape[0]
+        w = weight.detach().to(cdtype).contiguous()
+        meta = LinearMeta(K=K, N=N, r_s=0, r_t=(), scale_s=0.0, scale_t=(), mode=0, has_x_tasks=False, dropout_p=0.0, seed=0,
+                          dtype=cdtype)
+        d = meta.desc(M)
+        lib = L.lib()
+        ctx_bytes = lib.mtlora_linear_ctx_bytes(ctypes.byref(d))
+        if ctx_bytes < 0:
+            raise RuntimeError(f"mtlora_amd: invalid plain-linear shape M={M} K={K} N={N}")
+        ctxbuf = torch.empty(max(ctx_bytes, 16), dtype=torch.uint8, device=x.device)
+        y = torch.empty((M, N), dtype=cdtype, device=x.device)
+        bf = None if bias is None else bias.detach().float().contiguous()
+        st = lib.mtlora_linear_fwd(ctypes.byref(d), L.ptr(x), L.ptr_array(None), L.ptr(w), L.ptr(bf), L.ptr(None), L.ptr(None),
+                                   L.ptr_array(None), L.ptr_array(None), L.ptr(y), L.ptr_array(None), L.ptr(ctxbuf), ctx_bytes,
+                                   L.stream_ptr())
+        L.check(st, "mtlora_linear_fwd (rank 0)")
+        ctx.save_for_backward(x, w, ctxbuf)
+        ctx.meta, ctx.splits, ctx.zero_bias_grad = meta, splits, zero_bias_grad
+        ctx.has_bias, ctx.wdtype = bias is not None, weight.dtype
+        ctx.bdtype = None if bias is None else bias.dtype
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w, ctxbuf = ctx.saved_tensors
+        gy = gy.contiguous()
+        M, K = x.shape
+        N = w.shape[0]
+        S = ctx.splits
+        dx = None
+        if ctx.needs_input_grad[0]:
+            d = ctx.meta.desc(M)
+            lib = L.lib()
+            sb = lib.mtlora_linear_bwd_scratch_bytes(ctypes.byref(d))
+            scratch = torch.empty(max(sb, 16), dtype=torch.uint8, device=x.device)
+            wt = w.t().contiguous()
+            dx = torch.empty((M, K), dtype=x.dtype, device=x.device)
+            st = lib.mtlora_linear_bwd(ctypes.byref(d), L.ptr(x), L.ptr_array(None), L.ptr(wt), L.ptr(gy), L.ptr_array(None),
+                                       L.ptr(ctxbuf), ctxbuf.numel(), L.ptr(dx), L.ptr_array(None), L.ptr(None), L.ptr(None),
+                                       L.ptr_array(None), L.ptr_array(None), L.ptr(scratch), sb, L.stream_ptr())
+            L.check(st, "mtlora_linear_bwd (rank 0)")
+        dw = None
+        if ctx.needs_input_grad[1]:
+            part = torch.bmm(gy.view(S, M // S, N).transpose(1, 2), x.view(S, M // S, K))
+            dw = part.sum(0, dtype=torch.float32).to(ctx.wdtype)
+        db = None
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            if ctx.zero_bias_grad:
+                db = torch.zeros(N, dtype=ctx.bdtype, device=gy.device)
+            else:
+                db = gy.view(S, M // S, N).sum(1, dtype=torch.float32).sum(0).to(ctx.bdtype)
+        return dx, dw, db, None, None, None
+
+
+_PLAIN_VIA_KNT = os.environ.get("MTLORA_HEAD_GEMM", "knt") != "blas"
+
+
+def _big_linear(x, weight, bias, S, feeds_batchnorm, cdtype):
+    K, N = weight.shape[1], weight.shape[0]
+    if (_PLAIN_VIA_KNT and cdtype in (torch.float32, torch.bfloat16) and K % 8 == 0 and N % 8 == 0 and K <= 1024
+            and x.dtype == cdtype):
+        return PlainLinearFn.apply(x, weight, bias, S, feeds_batchnorm, cdtype)
+    return SplitKLinearFn.apply(x, weight, bias, S, feeds_batchnorm, cdtype)
+
+
 def linear_big_m(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor],
                  feeds_batchnorm: bool = False) -> torch.Tensor:
     """F.linear for (M, K) inputs; switches to SplitKLinearFn when M is large and the weight is trained.
@@ -651,8 +727,8 @@ def linear_big_m(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Ten
             if torch.is_autocast_enabled("cuda"):
                 dt = torch.get_autocast_dtype("cuda")
                 with torch.autocast("cuda", enabled=False):
-                    return SplitKLinearFn.apply(x.to(dt), weight, bias, S, feeds_batchnorm, dt)
-            return SplitKLinearFn.apply(x, weight, bias, S, feeds_batchnorm, x.dtype)
+                    return _big_linear(x.to(dt), weight, bias, S, feeds_batchnorm, dt)
+            return _big_linear(x, weight, bias, S, feeds_batchnorm, x.dtype)
     return torch.nn.functional.linear(x, weight, bias)
 
 

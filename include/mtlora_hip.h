@@ -117,6 +117,14 @@ int mtlora_linear_bwd(const mtlora_linear_desc* d, const void* x, const void* co
                       void* const* dx_t, float* dA_s, float* dB_s, float* const* dA_t, float* const* dB_t,
                       void* scratch, int64_t scratch_bytes, void* stream);
 
+/* Weight gradient of a plain linear layer with a NARROW output (the decoder heads' final 1x1 convolutions,
+ * models/seg_hrnet.py:518-526: nn.Conv2d(1080, num_classes, 1) on B*H*W pixels; autograd's dW = dY^T X):
+ *   out (Na x Nb, fp32, row-major) = a^T b,  a = (M x Na, row stride lda), b = (M x Nb, row stride ldb).
+ * Na, Nb, lda, ldb multiples of 8 (bf16) / 4 (f32); Na <= 1024.  Deterministic (fixed-order split-M partials). */
+int64_t mtlora_gemm_tn_scratch_bytes(int64_t M, int Na, int Nb);
+int mtlora_gemm_tn(const void* a, const void* b, float* out, int64_t M, int Na, int Nb, int64_t lda, int64_t ldb,
+                   int dtype, void* scratch, int64_t scratch_bytes, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Window attention core -- replaces swin_transformer_mtlora.py:194-220 (q*scale, q@k^T, + relative
  * position bias, + shift mask, softmax, @v, head merge) and, with image_layout = 1, also the

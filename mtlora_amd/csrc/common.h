@@ -251,6 +251,7 @@ enum MtlProfKind {
     PK_COUNT = 24
 };
 int mtl_prof_start(int kind, double alg_bytes, hipStream_t s);
+void mtl_prof_tag(const char* fmt, ...);  // shape note attached to the NEXT record (MTLORA_PROF_DUMP=<file> lists records)
 void mtl_prof_stop(int idx, hipStream_t s);
 struct MtlProfScope {
     int idx;

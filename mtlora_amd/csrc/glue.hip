@@ -232,38 +232,72 @@ __global__ __launch_bounds__(256) void k_ln_bwd(const LnParams p) {
     int64_t coff[MAXV];  // x / dx / addend offsets of this lane's vectors relative to the row base
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) coff[i] = ln_col(p, (lr + i * LPR < nvec ? lr + i * LPR : 0) * VE);
-    const int64_t rows_per_blk = 4 * RPW;
+    // UNR row groups per wave iteration, loads issued back to back as raw vectors before any arithmetic (as in k_ln_fwd)
+    constexpr int UNR = MAXV <= 3 ? 2 : 1;
+    constexpr int GW = sizeof(TG) == sizeof(TX) ? 4 : (sizeof(TG) == 2 ? 2 : 8);  // dwords of dy per lane-vector
+    const int64_t rows_per_blk = 4 * RPW * UNR;
     for (int64_t r0 = (int64_t)blockIdx.x * rows_per_blk; r0 < p.M; r0 += (int64_t)gridDim.x * rows_per_blk) {
-        const int64_t row = r0 + wave * RPW + sub;
-        const bool rv = row < p.M;
-        const int64_t xb = ln_row(p, rv ? row : 0).base;
-        const float mean = rv ? p.mean[row] : 0.f, rstd = rv ? p.rstd[row] : 0.f;
-        float xh[MAXV][VE], gy[MAXV][VE];
-        float c1 = 0.f, c2 = 0.f;
+        u32x4 rx[UNR][MAXV], ra[UNR][MAXV];
+        uint32_t rg[UNR][MAXV][GW];
+        int64_t row[UNR], xb[UNR];
+        float mean[UNR], rstd[UNR];
 #pragma unroll
-        for (int i = 0; i < MAXV; ++i) {
-            const int v = lr + i * LPR;
-            if (rv && v < nvec) {
-                float fx[8], fg[8];
-                ld_vec<TX>(x + xb + coff[i], fx);
-                if constexpr (sizeof(TG) == sizeof(TX)) {
-                    ld_vec<TG>(dy + row * p.C + v * VE, fg);
-                } else if constexpr (sizeof(TG) == 2) {  // x fp32 (4 per vec), dy bf16: 4 elements = 8 bytes
-                    bf16x4 t = *reinterpret_cast<const bf16x4*>(dy + row * p.C + v * VE);
+        for (int u = 0; u < UNR; ++u) {
+            row[u] = r0 + (int64_t)(wave * UNR + u) * RPW + sub;
+            const bool rv = row[u] < p.M;
+            xb[u] = ln_row(p, rv ? row[u] : 0).base;
+            mean[u] = rv ? p.mean[row[u]] : 0.f;
+            rstd[u] = rv ? p.rstd[row[u]] : 0.f;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) fg[e] = (float)t[e];
-                } else {  // x bf16 (8 per vec), dy fp32: two 16-byte loads
-                    f32x4 t0 = *reinterpret_cast<const f32x4*>(dy + row * p.C + v * VE);
-                    f32x4 t1 = *reinterpret_cast<const f32x4*>(dy + row * p.C + v * VE + 4);
+            for (int i = 0; i < MAXV; ++i) {
+                const int v = lr + i * LPR;
+                const bool ok = rv && v < nvec;
+                rx[u][i] = ok ? *reinterpret_cast<const u32x4*>(x + xb[u] + coff[i]) : u32x4{0u, 0u, 0u, 0u};
+                const TG* gp = dy + (rv ? row[u] : 0) * p.C + (v < nvec ? v : 0) * VE;
+                if constexpr (GW == 4) {
+                    const u32x4 t = ok ? *reinterpret_cast<const u32x4*>(gp) : u32x4{0u, 0u, 0u, 0u};
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        fg[e] = t0[e];
-                        fg[4 + e] = t1[e];
+                    for (int q = 0; q < 4; ++q) rg[u][i][q] = t[q];
+                } else if constexpr (GW == 2) {
+                    const u32x2 t = ok ? *reinterpret_cast<const u32x2*>(gp) : u32x2{0u, 0u};
+                    rg[u][i][0] = t[0];
+                    rg[u][i][1] = t[1];
+                } else {
+                    const u32x4 t0 = ok ? *reinterpret_cast<const u32x4*>(gp) : u32x4{0u, 0u, 0u, 0u};
+                    const u32x4 t1 = ok ? *reinterpret_cast<const u32x4*>(gp + 4) : u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        rg[u][i][q] = t0[q];
+                        rg[u][i][4 + q] = t1[q];
                     }
                 }
+                ra[u][i] = (ok && addp) ? *reinterpret_cast<const u32x4*>(addp + xb[u] + coff[i]) : u32x4{0u, 0u, 0u, 0u};
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const bool rv = row[u] < p.M;
+            float xh[MAXV][VE], gy[MAXV][VE];
+            float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < MAXV; ++i) {
+                float fx[8], fg[8];
+                cvt_vec<TX>(rx[u][i], fx);
+                if constexpr (GW == 4) {
+                    cvt_vec<TG>(u32x4{rg[u][i][0], rg[u][i][1], rg[u][i][2], rg[u][i][3]}, fg);
+                } else if constexpr (GW == 2) {  // x fp32 (4 per vector), dy bf16
+                    fg[0] = __builtin_bit_cast(float, rg[u][i][0] << 16);
+                    fg[1] = __builtin_bit_cast(float, rg[u][i][0] & 0xFFFF0000u);
+                    fg[2] = __builtin_bit_cast(float, rg[u][i][1] << 16);
+                    fg[3] = __builtin_bit_cast(float, rg[u][i][1] & 0xFFFF0000u);
+                } else {  // x bf16 (8 per vector), dy fp32
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) fg[q] = __builtin_bit_cast(float, rg[u][i][q]);
+                }
+                // out-of-range rows / vectors were loaded as zeros with mean = rstd = 0: every term below is then 0
 #pragma unroll
                 for (int e = 0; e < VE; ++e) {
-                    const float h = (fx[e] - mean) * rstd;
+                    const float h = (fx[e] - mean[u]) * rstd[u];
                     xh[i][e] = h;
                     ag[i][e] += fg[e] * h;
                     ab[i][e] += fg[e];
@@ -272,31 +306,20 @@ __global__ __launch_bounds__(256) void k_ln_bwd(const LnParams p) {
                     c1 += t;
                     c2 += t * h;
                 }
-            } else {
-#pragma unroll
-                for (int e = 0; e < VE; ++e) {
-                    xh[i][e] = 0.f;
-                    gy[i][e] = 0.f;
-                }
             }
-        }
-        c1 = group_sum<LPR>(c1) / p.C;
-        c2 = group_sum<LPR>(c2) / p.C;
-        if (rv) {
+            c1 = group_sum<LPR>(c1) / p.C;
+            c2 = group_sum<LPR>(c2) / p.C;
+            if (rv) {
 #pragma unroll
-            for (int i = 0; i < MAXV; ++i) {
-                const int v = lr + i * LPR;
-                if (v < nvec) {
-                    float o[8];
+                for (int i = 0; i < MAXV; ++i) {
+                    const int v = lr + i * LPR;
+                    if (v < nvec) {
+                        float o[8], fa[8];
+                        cvt_vec<TX>(ra[u][i], fa);
 #pragma unroll
-                    for (int e = 0; e < VE; ++e) o[e] = rstd * (gy[i][e] - c1 - xh[i][e] * c2);
-                    if (addp) {
-                        float fa[8];
-                        ld_vec<TX>(addp + xb + coff[i], fa);
-#pragma unroll
-                        for (int e = 0; e < VE; ++e) o[e] += fa[e];
+                        for (int e = 0; e < VE; ++e) o[e] = rstd[u] * (gy[i][e] - c1 - xh[i][e] * c2) + fa[e];
+                        st_vec<TX, VE>(dx + xb[u] + coff[i], o);
                     }
-                    st_vec<TX, VE>(dx + xb + coff[i], o);
                 }
             }
         }
@@ -362,8 +385,8 @@ int pick_lpr(int nvec) {
     return lpr;
 }
 
-int ln_grid(int64_t M, int lpr, int cap = 256 * 2) {
-    const int64_t rows_per_blk = 4 * (64 / lpr);
+int ln_grid(int64_t M, int lpr, int cap = 256 * 4, int unr = 1) {
+    const int64_t rows_per_blk = 4 * (64 / lpr) * unr;
     int64_t g = mtl_ceil_div(M, rows_per_blk);
     if (g > cap) g = cap;  // also the number of dgamma/dbeta partials the second stage sums
     return (int)(g < 1 ? 1 : g);
@@ -440,6 +463,7 @@ int mtlora_layernorm_fwd(const void* x, const float* gamma, const float* beta, v
     const size_t lds = 0;
     hipStream_t s = (hipStream_t)stream;
     const int es_x = mtl_elem_size(x_dtype), es_y = mtl_elem_size(y_dtype);
+    mtl_prof_tag("M%lld C%lld x%d y%d mg%d", (long long)M, (long long)C, x_dtype, y_dtype, merge_w);
     MtlProfScope prof(PK_LN_FWD, (double)M * C * (es_x + es_y), s);
     if (x_dtype == MTLORA_F32 && y_dtype == MTLORA_F32) {
         LN_DISPATCH_LPR(k_ln_fwd, float, float)
@@ -488,6 +512,7 @@ int mtlora_layernorm_bwd(const void* dy, const void* x, const float* gamma, cons
     const size_t lds = (size_t)4 * (64 / lpr) * 2 * C * 4;
     const int es_x = mtl_elem_size(x_dtype), es_g = mtl_elem_size(dy_dtype);
     {
+        mtl_prof_tag("M%lld C%lld x%d g%d mg%d add%d", (long long)M, (long long)C, x_dtype, dy_dtype, merge_w, dx_addend ? 1 : 0);
         MtlProfScope prof(PK_LN_BWD, (double)M * C * (2 * es_x + es_g), s);
         if (x_dtype == MTLORA_F32 && dy_dtype == MTLORA_F32) {
             LN_DISPATCH_LPR(k_ln_bwd, float, float)

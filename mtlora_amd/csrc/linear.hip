@@ -1005,6 +1005,7 @@ static int nt_waves() {
 
 template <typename T>
 static void launch_nt(const NtParams& P, hipStream_t s, int kind, double alg_bytes) {
+    mtl_prof_tag("M%lld K%d N%d ldL%lld no%d na%d nz%d", (long long)P.M, P.K, P.n_rows, (long long)P.ldL, P.n_out, P.n_act, P.nz);
     MtlProfScope prof(kind, alg_bytes, s);
     int max_rows = P.n_rows;
     if (P.nz > 0) {
@@ -1567,6 +1568,84 @@ int mtlora_linear_bwd(const mtlora_linear_desc* d, const void* x, const void* co
     else
         st = bwd_impl<bf16>(d, x, x_t, Wt, dy_s, dy_t, ctx, dx, dx_t, dA_s, dB_s, dA_t, dB_t, scratch, s);
     if (st != MTLORA_OK) return st;
+    MTL_CHECK_LAUNCH();
+    return MTLORA_OK;
+}
+
+// ---- out (Na x Nb, fp32) = a^T b reduced over the M rows: the weight gradient dW = dY^T X of a plain linear layer whose
+// output is narrow (the decoder heads' last 1x1 convolutions, seg_hrnet.py:518-526: Na = classes, Nb = 1080, M = B*H*W).
+// Same split-M TN kernel as the LoRA factor gradients (k_tn + fixed-order k_tn_reduce: deterministic).
+static int tn_plan(int64_t M, int Na, int Nb, int& tiles_a, int& tiles_b, int& nsplit, int64_t& rps) {
+    tiles_a = (int)mtl_ceil_div(Na, TN_A);
+    tiles_b = (int)mtl_ceil_div(Nb, TN_B);
+    const int64_t tiles = (int64_t)tiles_a * tiles_b;
+    nsplit = (int)(TN_TARGET_CTAS / (tiles > 0 ? tiles : 1));
+    const int64_t max_by_rows = mtl_ceil_div(M, 256);
+    if (nsplit > max_by_rows) nsplit = (int)max_by_rows;
+    if (nsplit > 256) nsplit = 256;
+    if (nsplit < 1) nsplit = 1;
+    rps = mtl_round_up(mtl_ceil_div(M > 0 ? M : 1, nsplit), 64);
+    return MTLORA_OK;
+}
+
+int64_t mtlora_gemm_tn_scratch_bytes(int64_t M, int Na, int Nb) {
+    if (M < 0 || Na <= 0 || Nb <= 0) return -1;
+    int ta, tb, ns;
+    int64_t rps;
+    tn_plan(M, Na, Nb, ta, tb, ns, rps);
+    return (int64_t)ta * tb * ns * TN_TILE * 4 + 256;
+}
+
+int mtlora_gemm_tn(const void* a, const void* b, float* out, int64_t M, int Na, int Nb, int64_t lda, int64_t ldb,
+                   int dtype, void* scratch, int64_t scratch_bytes, void* stream) {
+    if (dtype != MTLORA_F32 && dtype != MTLORA_BF16) return MTLORA_ERR_DTYPE;
+    const int vec = dtype == MTLORA_F32 ? 4 : 8;
+    if (M < 0 || M >= ((int64_t)1 << 31) || Na <= 0 || Nb <= 0 || lda < Na || ldb < Nb) return MTLORA_ERR_SHAPE;
+    if (Na % vec || Nb % vec || lda % vec || ldb % vec) return MTLORA_ERR_ALIGN;
+    if (Na > 1024) return MTLORA_ERR_UNSUPPORTED;  // narrow side only (every a-tile re-reads b)
+    if (!out || !scratch || (M > 0 && (!a || !b))) return MTLORA_ERR_NULL;
+    if (misaligned(a) || misaligned(b) || misaligned(scratch) || ((uintptr_t)out & 3u)) return MTLORA_ERR_ALIGN;
+    if (scratch_bytes < mtlora_gemm_tn_scratch_bytes(M, Na, Nb) - 256) return MTLORA_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    if (M == 0) {
+        mtl_zero_async(out, (size_t)Na * Nb * 4, s);
+        return MTLORA_OK;
+    }
+    TnParams tp = {};
+    tp.M = M;
+    int ta, tb;
+    tn_plan(M, Na, Nb, ta, tb, tp.nsplit, tp.rows_per_split);
+    tp.drop = mtl_make_dropout(0.f, 0, nullptr);
+    tp.n_prob = 1;
+    TnProblem& p = tp.p[0];
+    p.A = a;
+    p.B = b;
+    p.lda = lda;
+    p.ldb = ldb;
+    p.a0 = 0;
+    p.Na = Na;
+    p.b0 = 0;
+    p.Nb = Nb;
+    p.b_mask = 0;
+    p.tiles_a = ta;
+    p.tiles_b = tb;
+    p.part = reinterpret_cast<float*>(scratch);
+    p.out = out;
+    p.out_a = Na;
+    p.out_b = Nb;
+    p.ldo = Nb;
+    p.transpose = 0;
+    const int es = mtl_elem_size(dtype);
+    {
+        mtl_prof_tag("M%lld Na%d Nb%d", (long long)M, Na, Nb);
+        MtlProfScope prof(PK_TN, (double)es * M * ((double)ta * Nb + Na), s);
+        if (dtype == MTLORA_F32)
+            hipLaunchKernelGGL(k_tn<float>, dim3((unsigned)tp.nsplit, (unsigned)(ta * tb), 1), dim3(256), 0, s, tp);
+        else
+            hipLaunchKernelGGL(k_tn<bf16>, dim3((unsigned)tp.nsplit, (unsigned)(ta * tb), 1), dim3(256), 0, s, tp);
+    }
+    MtlProfScope prof(PK_REDUCE, 0.0, s);
+    hipLaunchKernelGGL(k_tn_reduce, dim3(TN_TILE / 1024, (unsigned)(ta * tb), 1), dim3(256 * TN_RG), 0, s, tp);
     MTL_CHECK_LAUNCH();
     return MTLORA_OK;
 }

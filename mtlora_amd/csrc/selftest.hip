@@ -2,6 +2,9 @@
 // assert them (tests/test_gpu_layouts.py): MFMA 32x32 C/D layout (bf16 and f32 forms) and the
 // ds_read_b64_tr_b16 gather.
 #include "common.h"
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
 
 namespace {
 __global__ __launch_bounds__(64) void k_selftest(int32_t* out) {
@@ -73,7 +76,9 @@ struct ProfRec {
     int kind;
     double bytes;
     hipEvent_t a, b;
+    char tag[56];
 };
+thread_local char g_next_tag[56] = {0};
 std::atomic<int> g_prof_on{0};
 std::mutex g_prof_mu;
 std::vector<ProfRec> g_prof;
@@ -87,6 +92,8 @@ int mtl_prof_start(int kind, double alg_bytes, hipStream_t s) {
     ProfRec r;
     r.kind = kind;
     r.bytes = alg_bytes;
+    memcpy(r.tag, g_next_tag, sizeof(r.tag));
+    g_next_tag[0] = 0;
     if (hipEventCreate(&r.a) != hipSuccess) return -1;
     if (hipEventCreate(&r.b) != hipSuccess) {
         (void)hipEventDestroy(r.a);
@@ -95,6 +102,13 @@ int mtl_prof_start(int kind, double alg_bytes, hipStream_t s) {
     (void)hipEventRecord(r.a, s);
     g_prof.push_back(r);
     return (int)g_prof.size() - 1;
+}
+void mtl_prof_tag(const char* fmt, ...) {
+    if (!g_prof_on.load(std::memory_order_relaxed)) return;
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_next_tag, sizeof(g_next_tag), fmt, ap);
+    va_end(ap);
 }
 void mtl_prof_stop(int idx, hipStream_t s) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
@@ -125,9 +139,12 @@ extern "C" int mtlora_prof_end(mtlora_prof_summary* out) {
         }
     }
     int st = MTLORA_OK;
+    const char* dump = getenv("MTLORA_PROF_DUMP");  // developer aid: one line per record (kind, alg bytes, ms, shape note)
+    FILE* df = dump && dump[0] ? fopen(dump, "w") : nullptr;
     for (auto& r : g_prof) {
         float ms = 0.f;
         if (hipEventSynchronize(r.b) != hipSuccess || hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) st = MTLORA_ERR_HIP;
+        if (df) fprintf(df, "%s,%.0f,%.4f,%s\n", mtlora_prof_kind_name(r.kind), r.bytes, ms, r.tag);
         if (out && r.kind >= 0 && r.kind < MTLORA_PROF_KINDS) {
             out->count[r.kind] += 1;
             out->ms[r.kind] += ms;
@@ -136,6 +153,7 @@ extern "C" int mtlora_prof_end(mtlora_prof_summary* out) {
         (void)hipEventDestroy(r.a);
         (void)hipEventDestroy(r.b);
     }
+    if (df) fclose(df);
     g_prof.clear();
     return st;
 }

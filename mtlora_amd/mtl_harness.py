@@ -120,7 +120,13 @@ class HighResolutionHead(nn.Module):
         else:
             h = F.relu(F.batch_norm(h, bn.running_mean, bn.running_var, bn.weight, bn.bias,
                                     bn.training or not bn.track_running_stats, bn.momentum, bn.eps))
-        o = Fn.linear_big_m(h, c3.weight.view(c3.out_channels, c3.in_channels), c3.bias).view(B, Hh, Ww, c3.out_channels)
+        w3, b3, nc = c3.weight.view(c3.out_channels, c3.in_channels), c3.bias, c3.out_channels
+        if h.is_cuda and nc % 8:  # zero rows up to a multiple of 8 classes: the library's GEMM kernels take 16-byte rows
+            pad = 8 - nc % 8
+            w3 = torch.cat([w3, w3.new_zeros(pad, w3.shape[1])], 0)
+            b3 = None if b3 is None else torch.cat([b3, b3.new_zeros(pad)], 0)
+        o = Fn.linear_big_m(h, w3, b3)
+        o = (o if o.shape[1] == nc else o[:, :nc].contiguous()).view(B, Hh, Ww, nc)
         return o if channels_last_out else o.permute(0, 3, 1, 2)
 
 

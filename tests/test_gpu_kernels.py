@@ -4,6 +4,7 @@ the golden vectors captured from the reference.  Tolerances (BASELINE.json north
 difference is 5e-3 relative."""
 import ctypes
 
+import math
 import pytest
 import torch
 
@@ -924,12 +925,30 @@ def test_full_model_loss_and_gradients_vs_oracle():
     assert checked > 200
 
 
-@pytest.mark.parametrize("autocast", [False, True])
-def test_split_reduction_linear_vs_f_linear(autocast):
-    """functional.linear_big_m (hipBLASLt, weight gradient as a batched GEMM over row chunks, two-stage bias sum) ==
-    F.linear, values and gradients; feeds_batchnorm=True returns an exactly zero bias gradient."""
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,Na,Nb", [(20000, 24, 1080), (4099, 8, 264), (70001, 136, 40), (300, 64, 256), (0, 8, 8)])
+def test_gemm_tn_vs_torch(dtype, M, Na, Nb):
+    """mtlora_gemm_tn: out = a^T b (the narrow-output weight gradient), ragged M, several a-tiles, empty input."""
     from mtlora_amd import functional as Fn
-    M, K, N = 32768, 72, 40
+    torch.manual_seed(M + Na)
+    a = torch.randn(M, Na, device=dev()).to(dtype)
+    b = torch.randn(M, Nb, device=dev()).to(dtype)
+    out = Fn.gemm_tn(a, b)
+    ref = a.double().cpu().t() @ b.double().cpu()
+    assert out.dtype == torch.float32 and out.shape == (Na, Nb)
+    tol = 1e-3 * max(1.0, math.sqrt(M))  # fp32 accumulation of M products of unit-variance terms
+    assert (out.double().cpu() - ref).abs().max().item() <= tol
+    assert torch.equal(out, Fn.gemm_tn(a, b))  # deterministic
+
+
+@pytest.mark.parametrize("shape", [(32768, 72, 40), (32768, 72, 136), (16384, 1080, 24)])
+@pytest.mark.parametrize("autocast", [False, True])
+def test_split_reduction_linear_vs_f_linear(autocast, shape):
+    """functional.linear_big_m (forward / dX through the rank-0 k_nt path, weight gradient as the library's TN reduction
+    for narrow outputs or a batched GEMM over row chunks, two-stage bias sum) == F.linear, values and gradients;
+    feeds_batchnorm=True returns an exactly zero bias gradient."""
+    from mtlora_amd import functional as Fn
+    M, K, N = shape
     torch.manual_seed(4)
     x = torch.randn(M, K, device=dev(), requires_grad=True)
     w = (torch.randn(N, K, device=dev()) * 0.1).requires_grad_(True)

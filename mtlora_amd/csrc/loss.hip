@@ -5,8 +5,10 @@
 // re-reads (7 passes over 540 MB for the 21-class head at B = 32, 448 x 448) never exist: the kernel reads the
 // low-resolution logits (34 MB) and the labels (26 MB) and writes the low-resolution gradient.
 //
-// One thread per LOW-resolution pixel q (16 x 16 pixels per workgroup, their 18 x 18 neighbourhood staged in LDS as
-// fp32): it visits the <= 2S x 2S output pixels whose bilinear taps include q, rebuilds their C interpolated logits
+// UNS threads per LOW-resolution pixel q (8 x 8 pixels per workgroup, their 10 x 10 neighbourhood staged in LDS as
+// fp32; the threads of a pixel are adjacent lanes, take the output rows round-robin and add their shares with a
+// fixed shuffle tree -- one thread per pixel left 1.5 waves per SIMD for 2S x 2S = 256 serial output pixels each at
+// S = 8): a pixel visits the <= 2S x 2S output pixels whose bilinear taps include q, rebuilds their C interpolated logits
 // (vertical lerp of the 3 neighbour columns once per output row, then a horizontal lerp), evaluates the per-pixel
 // loss gradient and accumulates  w_y w_x d loss / d up  -- the transpose of the interpolation as a GATHER, so the
 // result is deterministic (no float atomics).  Every output pixel is evaluated by the <= 4 low-res pixels it taps
@@ -33,12 +35,14 @@ struct UpLossParams {
     float ignore;
 };
 
-constexpr int UQ = 16;  // low-res pixels per workgroup side
+constexpr int UQ = 8;   // low-res pixels per workgroup side
+constexpr int UNS = 4;  // threads per low-res pixel (power of two, <= 64)
 
 template <typename T, int KIND, int CMAX>
-__global__ __launch_bounds__(256) void k_up_loss(const UpLossParams p) {
+__global__ __launch_bounds__(UQ * UQ * UNS) void k_up_loss(const UpLossParams p) {
     extern __shared__ float sm[];  // [(UQ+2)*(UQ+2)][Cs]
-    __shared__ float red[4];
+    constexpr int NT = UQ * UQ * UNS;
+    __shared__ float red[NT / 64];
     const int tid = threadIdx.x;
     const int tiles_x = (p.w + UQ - 1) / UQ, tiles_y = (p.h + UQ - 1) / UQ;
     const int b = blockIdx.x / (tiles_x * tiles_y);
@@ -50,7 +54,7 @@ __global__ __launch_bounds__(256) void k_up_loss(const UpLossParams p) {
     const int H = p.h * p.S, W = p.w * p.S, S = p.S;
     const T* low = reinterpret_cast<const T*>(p.low);
 
-    for (int i = tid; i < (UQ + 2) * (UQ + 2) * C; i += 256) {
+    for (int i = tid; i < (UQ + 2) * (UQ + 2) * C; i += NT) {
         const int pix = i / C, c = i - pix * C;
         int gy = qy0 - 1 + pix / (UQ + 2), gx = qx0 - 1 + pix % (UQ + 2);
         gy = gy < 0 ? 0 : (gy > p.h - 1 ? p.h - 1 : gy);
@@ -59,7 +63,8 @@ __global__ __launch_bounds__(256) void k_up_loss(const UpLossParams p) {
     }
     __syncthreads();
 
-    const int ly = tid / UQ, lx = tid % UQ;
+    const int px = tid / UNS, part = tid % UNS;
+    const int ly = px / UQ, lx = px % UQ;
     const int qy = qy0 + ly, qx = qx0 + lx;
     const bool active = qy < p.h && qx < p.w;
     float g[CMAX];
@@ -79,7 +84,7 @@ __global__ __launch_bounds__(256) void k_up_loss(const UpLossParams p) {
         const float wneg = KIND == 2 ? p.stat[0] : 0.f;
         const int oy_lo = S * qy - S < 0 ? 0 : S * qy - S, oy_hi = S * qy + 2 * S > H ? H : S * qy + 2 * S;
         const int ox_lo = S * qx - S < 0 ? 0 : S * qx - S, ox_hi = S * qx + 2 * S > W ? W : S * qx + 2 * S;
-        for (int oy = oy_lo; oy < oy_hi; ++oy) {
+        for (int oy = oy_lo + part; oy < oy_hi; oy += UNS) {
             float sy = ((float)oy + 0.5f) * rs - 0.5f;
             sy = sy < 0.f ? 0.f : sy;
             const int iy0 = (int)sy, iy1 = iy0 + (iy0 < p.h - 1 ? 1 : 0);
@@ -165,25 +170,37 @@ __global__ __launch_bounds__(256) void k_up_loss(const UpLossParams p) {
                 }
             }
         }
+    }
+    // the UNS shares of a pixel (adjacent lanes; inactive pixels hold zeros) -> fixed butterfly, then lane `part == 0` writes
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c)
+#pragma unroll
+        for (int o = 1; o < UNS; o <<= 1) g[c] += __shfl_xor(g[c], o);
+    if (active && part == 0) {
         T* dl = reinterpret_cast<T*>(p.dlow) + (((int64_t)b * p.h + qy) * p.w + qx) * C;
 #pragma unroll
         for (int c = 0; c < CMAX; ++c)
             if (c < C) dl[c] = mtl_from_f32<T>(g[c]);
     }
 
-    // loss value: wave reduce, then the 4 waves in a fixed order
+    // loss value: wave reduce, then the waves in a fixed order
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) loss += __shfl_xor(loss, o);
     if ((tid & 63) == 0) red[tid >> 6] = loss;
     __syncthreads();
-    if (tid == 0) p.part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+    if (tid == 0) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < NT / 64; ++i) t += red[i];
+        p.part[blockIdx.x] = t;
+    }
 }
 
 template <typename T, int KIND, int CMAX>
 static void launch_up(const UpLossParams& p, int64_t blocks, hipStream_t s) {
     const int cs = p.C | 1, rp = (UQ + 2) * cs + ((16 - (UQ + 2) * cs) & 31);
     const size_t lds = (size_t)(UQ + 2) * rp * sizeof(float);
-    hipLaunchKernelGGL((k_up_loss<T, KIND, CMAX>), dim3((unsigned)blocks), dim3(256), lds, s, p);
+    hipLaunchKernelGGL((k_up_loss<T, KIND, CMAX>), dim3((unsigned)blocks), dim3(UQ * UQ * UNS), lds, s, p);
 }
 
 template <typename T>

@@ -184,6 +184,20 @@ int mtlora_layernorm_bwd(const void* dy, const void* x, const float* gamma, cons
                          void* dx, float* dgamma, float* dbeta, int64_t M, int64_t C, int x_dtype, int dy_dtype,
                          void* scratch, int64_t scratch_bytes, const void* dx_addend, int merge_h, int merge_w, void* stream);
 
+/* Residual + DropPath fused with the LayerNorm that follows it (swin_transformer_mtlora.py:389-396: x = shortcut +
+ * drop_path(attn(..)); then norm2(x); and :398-408 followed by the next block's norm1):
+ *   fwd: x_new = shortcut + scale[sample] * branch  (written, dtype of shortcut = x_dtype);  y = LayerNorm(x_new) (y_dtype)
+ *        branch has y_dtype; scale: (B) fp32 DropPath mask / keep, or NULL (= 1); rows M = B * tokens.
+ *   bwd: d_shortcut = dx_addend + LN-backward(dy) (x_dtype);  d_branch = scale[sample] * d_shortcut (dy_dtype)
+ * -- one pass each instead of residual kernel + LayerNorm kernel (saves re-reading the fp32 residual stream). */
+int mtlora_residual_layernorm_fwd(const void* shortcut, const void* branch, const float* scale, int64_t B, const float* gamma,
+                                  const float* beta, void* x_new, void* y, float* mean, float* rstd, int64_t M, int64_t C,
+                                  float eps, int x_dtype, int y_dtype, void* stream);
+int mtlora_residual_layernorm_bwd(const void* dy, const void* x_new, const float* gamma, const float* mean, const float* rstd,
+                                  void* d_shortcut, void* d_branch, float* dgamma, float* dbeta, const float* scale,
+                                  int64_t B, int64_t M, int64_t C, int x_dtype, int dy_dtype, void* scratch,
+                                  int64_t scratch_bytes, const void* dx_addend, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Training-mode BatchNorm + optional ReLU over a channels-last (R rows, C channels) matrix -- the decoder heads'
  * conv1x1 -> BatchNorm2d -> ReLU (seg_hrnet.py:498-526) on the (pixels, channels) matrix; replaces

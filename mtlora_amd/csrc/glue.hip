@@ -73,6 +73,14 @@ struct LnParams {
     // token tensors and row r = (b, y2, x2) of the normalised (M, C) matrix is [x(2y2,2x2) | x(2y2+1,2x2) | x(2y2,2x2+1) |
     // x(2y2+1,2x2+1)]; mg_W == 0: plain rows
     int mg_H, mg_W;
+    // fused residual (Swin block: x_new = shortcut + DropPath(branch) immediately followed by LayerNorm(x_new)):
+    //   forward : x = shortcut, rb = branch (dtype of y), xsum = x_new (dtype of x) written by the kernel, then normalised
+    //   backward: dbr = rscale[sample] * dx (dtype of dy): the branch gradient, written next to dx (= the shortcut gradient)
+    const void* rb;
+    void* xsum;
+    void* dbr;
+    const float* rscale;  // [B] per-sample DropPath scale or null (1)
+    int64_t rows_per_sample;
 };
 
 // element offset of column `col` (a multiple of the vector width) of row `row` in x / dx
@@ -121,7 +129,42 @@ __device__ __forceinline__ void cvt_vec<bf16>(const u32x4& r, float (&f)[8]) {
 
 // UNR row groups per wave iteration: their loads are issued back to back and kept as raw 16-byte vectors (a wave with a
 // single 1.5 KB row group in flight per iteration ran at 1.5-2.8 TB/s for the stage-1..3 shapes)
-template <typename TI, typename TO, int LPR, int MAXV>
+// NE elements of type T -> floats (NE = 4 or 8)
+template <typename T, int NE>
+__device__ __forceinline__ void ld_n(const T* p, float (&f)[8]) {
+    if constexpr (sizeof(T) == 4) {
+#pragma unroll
+        for (int e = 0; e < NE; e += 4) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(p + e);
+            f[e] = v[0];
+            f[e + 1] = v[1];
+            f[e + 2] = v[2];
+            f[e + 3] = v[3];
+        }
+    } else if constexpr (NE == 8) {
+        cvt_vec<bf16>(*reinterpret_cast<const u32x4*>(p), f);
+    } else {
+        const u32x2 r = *reinterpret_cast<const u32x2*>(p);
+        f[0] = __builtin_bit_cast(float, r[0] << 16);
+        f[1] = __builtin_bit_cast(float, r[0] & 0xFFFF0000u);
+        f[2] = __builtin_bit_cast(float, r[1] << 16);
+        f[3] = __builtin_bit_cast(float, r[1] & 0xFFFF0000u);
+    }
+}
+// floats -> one raw 16-byte vector of T (4 fp32 or 8 bf16)
+template <typename T>
+__device__ __forceinline__ u32x4 pack_vec(const float (&f)[8]) {
+    if constexpr (sizeof(T) == 4) {
+        return __builtin_bit_cast(u32x4, f32x4{f[0], f[1], f[2], f[3]});
+    } else {
+        Vec16<bf16> v;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v.e[e] = (bf16)f[e];
+        return v.raw;
+    }
+}
+
+template <typename TI, typename TO, int LPR, int MAXV, bool RES>
 __global__ __launch_bounds__(256) void k_ln_fwd(const LnParams p) {
     constexpr int VE = ET<TI>::VEC;
     constexpr int RPW = 64 / LPR;  // rows per wave per group
@@ -158,6 +201,28 @@ __global__ __launch_bounds__(256) void k_ln_fwd(const LnParams p) {
                 const int v = lr + i * LPR;
                 raw[u][i] = (row[u] < p.M && v < nvec) ? *reinterpret_cast<const u32x4*>(x + xb + coff[i])
                                                       : u32x4{0u, 0u, 0u, 0u};
+            }
+        }
+        if constexpr (RES) {  // x_new = shortcut + s * branch, stored (rounded to the stream dtype) and normalised
+            const TO* rb = reinterpret_cast<const TO*>(p.rb);
+            TI* xs = reinterpret_cast<TI*>(p.xsum);
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                if (row[u] >= p.M) continue;
+                const float sc = p.rscale ? p.rscale[row[u] / p.rows_per_sample] : 1.f;
+#pragma unroll
+                for (int i = 0; i < MAXV; ++i) {
+                    const int v = lr + i * LPR;
+                    if (v < nvec) {
+                        float fb[8], fx[8];
+                        ld_n<TO, VE>(rb + row[u] * p.C + v * VE, fb);
+                        cvt_vec<TI>(raw[u][i], fx);
+#pragma unroll
+                        for (int e = 0; e < VE; ++e) fx[e] += sc * fb[e];
+                        raw[u][i] = pack_vec<TI>(fx);
+                        *reinterpret_cast<u32x4*>(xs + row[u] * p.C + v * VE) = raw[u][i];
+                    }
+                }
             }
         }
 #pragma unroll
@@ -319,6 +384,12 @@ __global__ __launch_bounds__(256) void k_ln_bwd(const LnParams p) {
 #pragma unroll
                         for (int e = 0; e < VE; ++e) o[e] = rstd[u] * (gy[i][e] - c1 - xh[i][e] * c2) + fa[e];
                         st_vec<TX, VE>(dx + xb[u] + coff[i], o);
+                        if (p.dbr) {  // gradient of the residual branch (plain rows only): DropPath scale, dtype of dy
+                            const float sc = p.rscale ? p.rscale[row[u] / p.rows_per_sample] : 1.f;
+#pragma unroll
+                            for (int e = 0; e < VE; ++e) o[e] *= sc;
+                            st_vec<TG, VE>(reinterpret_cast<TG*>(p.dbr) + row[u] * p.C + v * VE, o);
+                        }
                     }
                 }
             }
@@ -424,9 +495,9 @@ int64_t mtlora_layernorm_bwd_scratch_bytes(int64_t M, int64_t C, int x_dtype) {
 
 #define LN_LAUNCH(KERNEL, L_, ...)                                                                        \
     if (vpl <= 3)                                                                                           \
-        hipLaunchKernelGGL((KERNEL<__VA_ARGS__, L_, 3>), dim3(grid), dim3(256), lds, s, p);                  \
+        hipLaunchKernelGGL((KERNEL<__VA_ARGS__, L_, 3 LN_EXTRA>), dim3(grid), dim3(256), lds, s, p);         \
     else                                                                                                    \
-        hipLaunchKernelGGL((KERNEL<__VA_ARGS__, L_, LN_MAXV>), dim3(grid), dim3(256), lds, s, p);
+        hipLaunchKernelGGL((KERNEL<__VA_ARGS__, L_, LN_MAXV LN_EXTRA>), dim3(grid), dim3(256), lds, s, p);
 #define LN_DISPATCH_LPR(KERNEL, ...)                       \
     switch (lpr) {                                         \
         case 8: LN_LAUNCH(KERNEL, 8, __VA_ARGS__) break;   \
@@ -435,14 +506,20 @@ int64_t mtlora_layernorm_bwd_scratch_bytes(int64_t M, int64_t C, int x_dtype) {
         default: LN_LAUNCH(KERNEL, 64, __VA_ARGS__) break; \
     }
 
-int mtlora_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
-                         int64_t M, int64_t C, float eps, int x_dtype, int y_dtype, int merge_h, int merge_w, void* stream) {
+static int ln_fwd_impl(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd, int64_t M,
+                       int64_t C, float eps, int x_dtype, int y_dtype, int merge_h, int merge_w, const void* branch,
+                       void* x_new, const float* scale, int64_t B, void* stream) {
     int st = ln_check(M, C, x_dtype, y_dtype);
     if (st != MTLORA_OK) return st;
     if (!x || !gamma || !beta || !y || !mean || !rstd) return MTLORA_ERR_NULL;
-    if (((uintptr_t)x | (uintptr_t)y) & 15u) return MTLORA_ERR_ALIGN;
+    if (((uintptr_t)x | (uintptr_t)y | (uintptr_t)branch | (uintptr_t)x_new) & 15u) return MTLORA_ERR_ALIGN;
+    if (branch && (!x_new || B <= 0 || M % B || merge_h || merge_w)) return MTLORA_ERR_SHAPE;
     if (M == 0) return MTLORA_OK;
     LnParams p = {};
+    p.rb = branch;
+    p.xsum = x_new;
+    p.rscale = scale;
+    p.rows_per_sample = branch ? M / B : 1;
     p.x = x;
     p.gamma = gamma;
     p.beta = beta;
@@ -464,27 +541,59 @@ int mtlora_layernorm_fwd(const void* x, const float* gamma, const float* beta, v
     hipStream_t s = (hipStream_t)stream;
     const int es_x = mtl_elem_size(x_dtype), es_y = mtl_elem_size(y_dtype);
     mtl_prof_tag("M%lld C%lld x%d y%d mg%d", (long long)M, (long long)C, x_dtype, y_dtype, merge_w);
-    MtlProfScope prof(PK_LN_FWD, (double)M * C * (es_x + es_y), s);
-    if (x_dtype == MTLORA_F32 && y_dtype == MTLORA_F32) {
-        LN_DISPATCH_LPR(k_ln_fwd, float, float)
-    } else if (x_dtype == MTLORA_F32) {
-        LN_DISPATCH_LPR(k_ln_fwd, float, bf16)
-    } else if (y_dtype == MTLORA_F32) {
-        LN_DISPATCH_LPR(k_ln_fwd, bf16, float)
+    MtlProfScope prof(PK_LN_FWD, (double)M * C * (es_x + es_y + (branch ? es_x + es_y : 0)), s);
+    if (branch) {
+#define LN_EXTRA , true
+        if (x_dtype == MTLORA_F32 && y_dtype == MTLORA_F32) {
+            LN_DISPATCH_LPR(k_ln_fwd, float, float)
+        } else if (x_dtype == MTLORA_F32) {
+            LN_DISPATCH_LPR(k_ln_fwd, float, bf16)
+        } else if (y_dtype == MTLORA_F32) {
+            LN_DISPATCH_LPR(k_ln_fwd, bf16, float)
+        } else {
+            LN_DISPATCH_LPR(k_ln_fwd, bf16, bf16)
+        }
+#undef LN_EXTRA
     } else {
-        LN_DISPATCH_LPR(k_ln_fwd, bf16, bf16)
+#define LN_EXTRA , false
+        if (x_dtype == MTLORA_F32 && y_dtype == MTLORA_F32) {
+            LN_DISPATCH_LPR(k_ln_fwd, float, float)
+        } else if (x_dtype == MTLORA_F32) {
+            LN_DISPATCH_LPR(k_ln_fwd, float, bf16)
+        } else if (y_dtype == MTLORA_F32) {
+            LN_DISPATCH_LPR(k_ln_fwd, bf16, float)
+        } else {
+            LN_DISPATCH_LPR(k_ln_fwd, bf16, bf16)
+        }
+#undef LN_EXTRA
     }
     MTL_CHECK_LAUNCH();
     return MTLORA_OK;
 }
 
-int mtlora_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
-                         void* dx, float* dgamma, float* dbeta, int64_t M, int64_t C, int x_dtype, int dy_dtype,
-                         void* scratch, int64_t scratch_bytes, const void* dx_addend, int merge_h, int merge_w, void* stream) {
+int mtlora_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
+                         int64_t M, int64_t C, float eps, int x_dtype, int y_dtype, int merge_h, int merge_w, void* stream) {
+    return ln_fwd_impl(x, gamma, beta, y, mean, rstd, M, C, eps, x_dtype, y_dtype, merge_h, merge_w, nullptr, nullptr, nullptr,
+                       1, stream);
+}
+
+int mtlora_residual_layernorm_fwd(const void* shortcut, const void* branch, const float* scale, int64_t B, const float* gamma,
+                                  const float* beta, void* x_new, void* y, float* mean, float* rstd, int64_t M, int64_t C,
+                                  float eps, int x_dtype, int y_dtype, void* stream) {
+    if (!branch || !x_new) return MTLORA_ERR_NULL;
+    return ln_fwd_impl(shortcut, gamma, beta, y, mean, rstd, M, C, eps, x_dtype, y_dtype, 0, 0, branch, x_new, scale, B, stream);
+}
+
+static int ln_bwd_impl(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd, void* dx,
+                       float* dgamma, float* dbeta, int64_t M, int64_t C, int x_dtype, int dy_dtype, void* scratch,
+                       int64_t scratch_bytes, const void* dx_addend, int merge_h, int merge_w, void* d_branch,
+                       const float* scale, int64_t B, void* stream) {
     int st = ln_check(M, C, x_dtype, dy_dtype);
     if (st != MTLORA_OK) return st;
     if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta || !scratch) return MTLORA_ERR_NULL;
-    if (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx | (uintptr_t)scratch | (uintptr_t)dx_addend) & 15u) return MTLORA_ERR_ALIGN;
+    if (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx | (uintptr_t)scratch | (uintptr_t)dx_addend | (uintptr_t)d_branch) & 15u)
+        return MTLORA_ERR_ALIGN;
+    if (d_branch && (B <= 0 || M % B || merge_h || merge_w)) return MTLORA_ERR_SHAPE;
     if (scratch_bytes < mtlora_layernorm_bwd_scratch_bytes(M, C, x_dtype) - 256) return MTLORA_ERR_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
     if (M == 0) {
@@ -500,6 +609,9 @@ int mtlora_layernorm_bwd(const void* dy, const void* x, const float* gamma, cons
     p.rstd = const_cast<float*>(rstd);
     p.dx = dx;
     p.add = dx_addend;
+    p.dbr = d_branch;
+    p.rscale = scale;
+    p.rows_per_sample = d_branch ? M / B : 1;
     p.part = reinterpret_cast<float*>(scratch);
     p.M = M;
     p.C = (int)C;
@@ -513,7 +625,8 @@ int mtlora_layernorm_bwd(const void* dy, const void* x, const float* gamma, cons
     const int es_x = mtl_elem_size(x_dtype), es_g = mtl_elem_size(dy_dtype);
     {
         mtl_prof_tag("M%lld C%lld x%d g%d mg%d add%d", (long long)M, (long long)C, x_dtype, dy_dtype, merge_w, dx_addend ? 1 : 0);
-        MtlProfScope prof(PK_LN_BWD, (double)M * C * (2 * es_x + es_g), s);
+        MtlProfScope prof(PK_LN_BWD, (double)M * C * (2 * es_x + es_g + (dx_addend ? es_x : 0) + (d_branch ? es_g : 0)), s);
+#define LN_EXTRA
         if (x_dtype == MTLORA_F32 && dy_dtype == MTLORA_F32) {
             LN_DISPATCH_LPR(k_ln_bwd, float, float)
         } else if (x_dtype == MTLORA_F32) {
@@ -523,11 +636,28 @@ int mtlora_layernorm_bwd(const void* dy, const void* x, const float* gamma, cons
         } else {
             LN_DISPATCH_LPR(k_ln_bwd, bf16, bf16)
         }
+#undef LN_EXTRA
     }
     hipLaunchKernelGGL(k_ln_reduce, dim3((unsigned)mtl_ceil_div(2 * C, 64)), dim3(64 * LN_RW), 0, s, (const float*)p.part, dgamma,
                        dbeta, grid, (int)C);
     MTL_CHECK_LAUNCH();
     return MTLORA_OK;
+}
+
+int mtlora_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
+                         void* dx, float* dgamma, float* dbeta, int64_t M, int64_t C, int x_dtype, int dy_dtype,
+                         void* scratch, int64_t scratch_bytes, const void* dx_addend, int merge_h, int merge_w, void* stream) {
+    return ln_bwd_impl(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, M, C, x_dtype, dy_dtype, scratch, scratch_bytes, dx_addend,
+                       merge_h, merge_w, nullptr, nullptr, 1, stream);
+}
+
+int mtlora_residual_layernorm_bwd(const void* dy, const void* x_new, const float* gamma, const float* mean, const float* rstd,
+                                  void* d_shortcut, void* d_branch, float* dgamma, float* dbeta, const float* scale,
+                                  int64_t B, int64_t M, int64_t C, int x_dtype, int dy_dtype, void* scratch,
+                                  int64_t scratch_bytes, const void* dx_addend, void* stream) {
+    if (!d_branch) return MTLORA_ERR_NULL;
+    return ln_bwd_impl(dy, x_new, gamma, mean, rstd, d_shortcut, dgamma, dbeta, M, C, x_dtype, dy_dtype, scratch, scratch_bytes,
+                       dx_addend, 0, 0, d_branch, scale, B, stream);
 }
 }
 

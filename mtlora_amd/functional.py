@@ -390,6 +390,84 @@ class LayerNormForkFn(torch.autograd.Function):
         return dx, dg, db, None, None
 
 
+class ResidualLayerNormFn(torch.autograd.Function):
+    """(x_new, y) = (shortcut + scale[sample] * branch, LayerNorm(x_new)) as ONE kernel; x_new is the next skip path
+    (a ``LayerNormForkFn``-style fork), y feeds the following linear.  Backward: d_shortcut = g_x_new +
+    LN-backward(g_y), d_branch = scale * d_shortcut, both written by the LayerNorm backward kernel
+    (``mtlora_residual_layernorm_fwd/bwd``).  Replaces ResidualDropPathFn + LayerNormForkFn for a single stream."""
+
+    @staticmethod
+    def forward(ctx, shortcut, branch, scale, weight, bias, eps: float, out_dtype: torch.dtype):
+        L.require_gpu(shortcut, branch, weight, bias)
+        C = shortcut.shape[-1]
+        B = shortcut.shape[0]
+        s2 = shortcut.reshape(-1, C).contiguous()
+        b2 = branch.reshape(-1, C).contiguous()
+        M = s2.shape[0]
+        w, b = weight.detach().float().contiguous(), bias.detach().float().contiguous()
+        x_new = torch.empty_like(s2)
+        y = torch.empty((M, C), dtype=out_dtype, device=s2.device)
+        mean = torch.empty(M, dtype=torch.float32, device=s2.device)
+        rstd = torch.empty(M, dtype=torch.float32, device=s2.device)
+        st = L.lib().mtlora_residual_layernorm_fwd(L.ptr(s2), L.ptr(b2), L.ptr(scale), B, L.ptr(w), L.ptr(b), L.ptr(x_new),
+                                                   L.ptr(y), L.ptr(mean), L.ptr(rstd), M, C, float(eps), L.dtype_code(s2),
+                                                   L.dtype_code(y), L.stream_ptr())
+        L.check(st, "mtlora_residual_layernorm_fwd")
+        ctx.save_for_backward(x_new, w, mean, rstd, scale)
+        ctx.shape, ctx.MC, ctx.B, ctx.bdtype = shortcut.shape, (M, C), B, branch.dtype
+        ctx.set_materialize_grads(False)
+        return x_new.view(shortcut.shape), y.view(shortcut.shape)
+
+    @staticmethod
+    def backward(ctx, g_skip, gy):
+        x_new, w, mean, rstd, scale = ctx.saved_tensors
+        M, C = ctx.MC
+        if gy is None:  # the normalised output was not used: plain residual backward
+            if g_skip is None:
+                return (None,) * 7
+            g = g_skip.reshape(ctx.B, -1, C)
+            db_ = g if scale is None else g * scale.view(-1, 1, 1).to(g.dtype)
+            return g_skip, db_.to(ctx.bdtype).reshape(ctx.shape), None, None, None, None, None
+        dy2 = gy.reshape(M, C).contiguous()
+        if dy2.dtype != ctx.bdtype:
+            dy2 = dy2.to(ctx.bdtype)
+        add2 = None if g_skip is None else g_skip.reshape(M, C).to(x_new.dtype).contiguous()
+        lib = L.lib()
+        sb = lib.mtlora_layernorm_bwd_scratch_bytes(M, C, L.dtype_code(x_new))
+        scratch = torch.empty(sb, dtype=torch.uint8, device=x_new.device)
+        dx = torch.empty_like(x_new)
+        dbr = torch.empty((M, C), dtype=ctx.bdtype, device=x_new.device)
+        dg = torch.empty(C, dtype=torch.float32, device=x_new.device)
+        db = torch.empty(C, dtype=torch.float32, device=x_new.device)
+        st = lib.mtlora_residual_layernorm_bwd(L.ptr(dy2), L.ptr(x_new), L.ptr(w), L.ptr(mean), L.ptr(rstd), L.ptr(dx),
+                                               L.ptr(dbr), L.ptr(dg), L.ptr(db), L.ptr(scale), ctx.B, M, C,
+                                               L.dtype_code(x_new), L.dtype_code(dy2), L.ptr(scratch), sb, L.ptr(add2),
+                                               L.stream_ptr())
+        L.check(st, "mtlora_residual_layernorm_bwd")
+        return dx.view(ctx.shape), dbr.view(ctx.shape), None, dg, db, None, None
+
+
+def residual_layer_norm(mod: torch.nn.Module, shortcut: torch.Tensor, branch: torch.Tensor, drop_prob: float, training: bool):
+    """(x_new, mod(x_new)) with x_new = shortcut + DropPath(branch): the fused kernel when it applies (nn.LayerNorm over
+    the last dim, branch already in the dtype the LayerNorm output takes), else residual_droppath + layer_norm_fork."""
+    C = shortcut.shape[-1]
+    ok = (type(mod) is torch.nn.LayerNorm and mod.elementwise_affine and mod.bias is not None
+          and len(mod.normalized_shape) == 1 and shortcut.is_cuda and shortcut.dtype in (torch.float32, torch.bfloat16)
+          and C % 8 == 0 and C <= (2048 if shortcut.dtype == torch.float32 else 4096) and branch.shape == shortcut.shape
+          and shortcut.dim() == 3 and torch.is_grad_enabled() and (shortcut.requires_grad or branch.requires_grad))
+    if ok:
+        out_dtype = compute_dtype(shortcut)
+        ok = branch.dtype == out_dtype
+    if not ok:
+        x = residual_droppath(shortcut, [branch], drop_prob, training)[0]
+        return layer_norm_fork(mod, x)
+    scale = None
+    if training and drop_prob > 0.0:
+        keep = 1.0 - drop_prob
+        scale = torch.empty(shortcut.shape[0], dtype=torch.float32, device=shortcut.device).bernoulli_(keep).div_(keep)
+    return ResidualLayerNormFn.apply(shortcut, branch, scale, mod.weight, mod.bias, mod.eps, out_dtype)
+
+
 def layer_norm_fork(mod: torch.nn.Module, x: torch.Tensor):
     """(x for the skip connection, LayerNorm(x) for the following linear): see LayerNormForkFn.  Same dispatch rules as
     ``layer_norm`` (falls back to two separate uses of x when the fused kernel does not apply)."""

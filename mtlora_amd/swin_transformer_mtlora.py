@@ -270,13 +270,18 @@ class SwinTransformerBlock(nn.Module):
         merge = lambda v: WindowProcessReverse.apply(v.reshape(-1, ws, ws, C).contiguous(), B, H, W, C, s, ws).view(B, H * W, C)
         return merge(a), None if a_t is None else {t: merge(a_t[t]) for t in self.tasks}
 
-    def forward(self, x):
+    def forward(self, x, normed=None, next_norm=None):
+        """normed: norm1(x) already formed by the previous block's fused residual + LayerNorm; next_norm: the following
+        block's norm1 -- when this block ends in a single-stream residual the call returns (x, None, next_norm(x))."""
         H, W = self.input_resolution
         B, L, C = x.shape
         assert L == H * W, "input feature has wrong size"
         # x feeds norm1 AND the skip connection: one autograd node for both, so that the skip gradient is added inside the
         # LayerNorm backward kernel instead of by a separate full-size add (functional.LayerNormForkFn)
-        shortcut, xn = Fn.layer_norm_fork(self.norm1, x)
+        if normed is None:
+            shortcut, xn = Fn.layer_norm_fork(self.norm1, x)
+        else:
+            shortcut, xn = x, normed
         if self.attention_layout == "windows":
             a, a_t = self._attend_windows(xn, B, H, W, C)
         else:
@@ -288,10 +293,10 @@ class SwinTransformerBlock(nn.Module):
         if a_t is not None:
             r = Fn.residual_droppath(shortcut, [a] + [a_t[t] for t in self.tasks], p_dp, self.training)
             x, x_t = r[0], {t: r[1 + i] for i, t in enumerate(self.tasks)}
-        else:
-            x = Fn.residual_droppath(shortcut, [a], p_dp, self.training)[0]
+            x, xn2 = Fn.layer_norm_fork(self.norm2, x)
+        else:  # single stream: residual + DropPath + norm2 in one kernel
+            x, xn2 = Fn.residual_layer_norm(self.norm2, shortcut, a, p_dp, self.training)
         # MLP half
-        x, xn2 = Fn.layer_norm_fork(self.norm2, x)
         xn2_t = None
         if x_t is not None:
             forks = {t: Fn.layer_norm_fork(self.norm2, x_t[t]) for t in self.tasks}
@@ -299,6 +304,9 @@ class SwinTransformerBlock(nn.Module):
             xn2_t = {t: forks[t][1] for t in self.tasks}
         m, m_t = self.mlp(xn2, xn2_t)
         if m_t is None:
+            if next_norm is not None:
+                x, nxt = Fn.residual_layer_norm(next_norm, x, m, p_dp, self.training)
+                return x, None, nxt
             return Fn.residual_droppath(x, [m], p_dp, self.training)[0], None
         if x_t is None:  # INTERMEDIATE_SPECIALIZATION-style: mlp specialises but attention did not (:401-403)
             out = Fn.residual_droppath(x, [m], p_dp, self.training)[0]
@@ -372,8 +380,13 @@ class BasicLayer(nn.Module):
 
     def forward(self, x):
         tasks_lora = None
-        for blk in self.blocks:
-            x, tasks_lora = blk(x)
+        normed = None
+        for i, blk in enumerate(self.blocks):
+            # a block that ends in a single-stream residual also applies the next block's norm1 (one fused kernel)
+            nxt = self.blocks[i + 1].norm1 if (i + 1 < len(self.blocks) and not blk.lora) else None
+            out = blk(x, normed, nxt)
+            x, tasks_lora = out[0], out[1]
+            normed = out[2] if len(out) > 2 else None
         if self.downsample is not None:
             x = self.downsample(x)
             if tasks_lora is not None:

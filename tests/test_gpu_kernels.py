@@ -545,6 +545,44 @@ def test_residual_droppath(shared, rdt, ydt):
     assert ys[1].grad is None
 
 
+@pytest.mark.parametrize("use_scale", [True, False])
+@pytest.mark.parametrize("B,Ltok,C", [(6, 49, 96), (3, 200, 384), (2, 50, 1536), (5, 7, 768)])
+@pytest.mark.parametrize("rdt,ydt", [(torch.float32, torch.bfloat16), (torch.bfloat16, torch.bfloat16), (torch.float32, torch.float32)])
+def test_residual_layer_norm_fused(rdt, ydt, B, Ltok, C, use_scale):
+    """mtlora_residual_layernorm_fwd/bwd: x_new = shortcut + DropPath-scale * branch, y = LayerNorm(x_new); backward with
+    gradients arriving on BOTH outputs (skip path + normalised path) against fp64 autograd of the composition, where the
+    reference rounds x_new to the stream dtype before normalising (as the unfused kernels do)."""
+    from mtlora_amd import functional as Fn
+    torch.manual_seed(B * C)
+    sc_ = torch.randn(B, Ltok, C, device=dev()).to(rdt).requires_grad_(True)
+    br = torch.randn(B, Ltok, C, device=dev()).to(ydt).requires_grad_(True)
+    w = (1.0 + 0.1 * torch.randn(C, device=dev())).requires_grad_(True)
+    b = (0.1 * torch.randn(C, device=dev())).requires_grad_(True)
+    scale = ((torch.rand(B, device=dev()) < 0.7).float() / 0.7) if use_scale else None
+    x_new, y = Fn.ResidualLayerNormFn.apply(sc_, br, scale, w, b, 1e-5, ydt)
+    assert x_new.dtype == rdt and y.dtype == ydt
+    g_skip, g_y = torch.randn_like(x_new), torch.randn_like(y)
+    torch.autograd.backward([x_new, y], [g_skip, g_y])
+    s64, b64, w64, bb64 = (t.detach().double().requires_grad_(True) for t in (sc_, br, w, b))
+    sc64 = torch.ones(B, device=dev(), dtype=torch.float64) if scale is None else scale.double()
+    xr = s64 + sc64.view(B, 1, 1) * b64
+    xr_q = xr + (xr.detach().to(rdt).double() - xr.detach())  # straight-through rounding to the stream dtype
+    yr = torch.nn.functional.layer_norm(xr_q, (C,), w64, bb64, 1e-5)
+    torch.autograd.backward([xr_q, yr], [g_skip.double(), g_y.double()])
+    assert_close(x_new, xr, rdt, "x_new")
+    assert_close(y, yr, ydt, "y", mult=2)
+    assert_close(sc_.grad, s64.grad, rdt, "d_shortcut", mult=3)
+    assert_close(br.grad, b64.grad, ydt, "d_branch", mult=3)
+    assert_close(w.grad, w64.grad, ydt, "dgamma", mult=4)
+    assert_close(b.grad, bb64.grad, ydt, "dbeta", mult=4)
+    # only the skip path used: plain residual backward
+    sc2, br2 = sc_.detach().clone().requires_grad_(True), br.detach().clone().requires_grad_(True)
+    x2, _ = Fn.ResidualLayerNormFn.apply(sc2, br2, scale, w, b, 1e-5, ydt)
+    x2.backward(g_skip)
+    assert_close(sc2.grad, g_skip.double(), rdt, "d_shortcut (skip only)")
+    assert_close(br2.grad, g_skip.double() * sc64.view(B, 1, 1), ydt, "d_branch (skip only)")
+
+
 def test_linear_fused_projection():
     """Row-panel form of k_nt (projection P / Q formed inside the output kernel, workgroup loops over its n-tiles):
     forward AND backward against the two-pass form, in subprocesses (the switches are read once per process).

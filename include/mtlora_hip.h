@@ -117,6 +117,16 @@ int mtlora_linear_bwd(const mtlora_linear_desc* d, const void* x, const void* co
                       void* const* dx_t, float* dA_s, float* dB_s, float* const* dA_t, float* const* dB_t,
                       void* scratch, int64_t scratch_bytes, void* stream);
 
+/* mtlora_linear_bwd for a layer whose inputs are x = gelu(h_s), x_t[t] = gelu(h_t[t]) (the Mlp's fc2,
+ * swin_transformer_mtlora.py:57-78: fc1 -> GELU -> fc2): dx and dx_t[t] are additionally multiplied by the exact-erf
+ * GELU derivative gelu'(h) = Phi(h) + h phi(h) at the pre-activations (M x K, dtype of x), i.e. they are the gradients
+ * w.r.t. h -- autograd's separate GeluBackward pass (read dX, read h, write dH) is folded into the dX epilogue.
+ * h_t[t] is required wherever dx_t[t] is written. */
+int mtlora_linear_bwd_gelu(const mtlora_linear_desc* d, const void* x, const void* const* x_t, const void* Wt,
+                           const void* dy_s, const void* const* dy_t, const void* ctx, int64_t ctx_bytes, void* dx,
+                           void* const* dx_t, float* dA_s, float* dB_s, float* const* dA_t, float* const* dB_t,
+                           void* scratch, int64_t scratch_bytes, const void* h_s, const void* const* h_t, void* stream);
+
 /* Weight gradient of a plain linear layer with a NARROW output (the decoder heads' final 1x1 convolutions,
  * models/seg_hrnet.py:518-526: nn.Conv2d(1080, num_classes, 1) on B*H*W pixels; autograd's dW = dY^T X):
  *   out (Na x Nb, fp32, row-major) = a^T b,  a = (M x Na, row stride lda), b = (M x Nb, row stride ldb).

@@ -62,6 +62,9 @@ _SIGS = {
     "mtlora_gemm_tn_scratch_bytes": (c_int64, [c_int64, c_int, c_int]),
     "mtlora_gemm_tn": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int64, c_int64, c_int, c_void_p, c_int64,
                                c_void_p]),
+    "mtlora_linear_bwd_gelu": (c_int, [POINTER(LinearDesc), c_void_p, POINTER(c_void_p), c_void_p, c_void_p, POINTER(c_void_p),
+                                       c_void_p, c_int64, c_void_p, POINTER(c_void_p), c_void_p, c_void_p, POINTER(c_void_p),
+                                       POINTER(c_void_p), c_void_p, c_int64, c_void_p, POINTER(c_void_p), c_void_p]),
     "mtlora_window_attn_bwd_scratch_bytes": (c_int64, [POINTER(AttnDesc)]),
     "mtlora_window_attn_fwd": (c_int, [POINTER(AttnDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mtlora_window_attn_bwd": (c_int, [POINTER(AttnDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

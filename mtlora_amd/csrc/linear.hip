@@ -137,6 +137,7 @@ struct NtOut {
     int use_base;    // add the shared base accumulator
     int mask_lr;     // multiply the low-rank part by the dropout keep mask of (m, n)
     int fold;        // after storing: base += low-rank part ('matrixv2': tasks see the shared update)
+    const void* gate;  // GATE kernels: out *= gelu'(gate[m][n]) (same shape / dtype / row stride as the output), nullable
 };
 
 struct NtParams {
@@ -337,6 +338,7 @@ __device__ __forceinline__ NtOut nt_out(NtPtr P, int o) {
     O.use_base = P->out[o].use_base;
     O.mask_lr = P->out[o].mask_lr;
     O.fold = P->out[o].fold;
+    O.gate = P->out[o].gate;
     return O;
 }
 
@@ -412,7 +414,25 @@ __device__ __forceinline__ NtCursor nt_seek(NtPtr P, int q, int nseq, int bn, in
 // NW = waves per workgroup.  The 128 x 128 tile is unchanged; with 8 waves a wave owns 64 n x 32 m (half the
 // accumulators, half the staging registers, half the loads / LDS traffic / MFMAs per step), fits 128 VGPRs and runs
 // 4 waves per SIMD instead of 2 -- the kernel is latency- and issue-bound, not bandwidth-bound.
-template <typename T, bool MULTI, bool MS, bool FUSE, bool MLR, int NW>
+// d/dh of the exact (erf) GELU, the factor ATen's GeluBackward applies: Phi(h) + h * phi(h)
+// erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, i.e. fp32 rounding level) sharing its exp(-h^2/2) with the density:
+// ~16 VALU operations per element -- with ocml's erff + expf (~60) the epilogue of the hidden-width dX launches became
+// VALU-bound and gave back most of the saved pass.
+__device__ __forceinline__ float gelu_grad(float h) {
+    const float z = fabsf(h) * 0.70710678118654752f;
+    const float t = __builtin_amdgcn_rcpf(1.f + 0.3275911f * z);
+    const float e = __expf(-z * z);  // exp(-h^2 / 2)
+    float p = 1.061405429f;
+    p = p * t - 1.453152027f;
+    p = p * t + 1.421413741f;
+    p = p * t - 0.284496736f;
+    p = p * t + 0.254829592f;
+    const float erf_abs = 1.f - p * t * e;  // erf(|h| / sqrt 2)
+    const float cdf = 0.5f + 0.5f * copysignf(erf_abs, h);
+    return cdf + h * e * 0.39894228040143268f;
+}
+
+template <typename T, bool MULTI, bool MS, bool FUSE, bool MLR, int NW, bool GATE = false>
 __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void k_nt(const NtParams Pv) {
     constexpr int SM = 8 / NW;       // 32-row m sub-blocks per wave
     constexpr int MW = 32 * SM;      // m rows per wave
@@ -563,8 +583,10 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void k_nt(const NtParams 
                 }
         }
     };
-    auto store = [&](const f32x16(&a)[2][SM], void* ptr) __attribute__((always_inline)) {
+    auto store = [&](const f32x16(&a)[2][SM], void* ptr, const void* gate_ptr) __attribute__((always_inline)) {
         T* outp = reinterpret_cast<T*>(ptr);
+        const T* gate = reinterpret_cast<const T*>(gate_ptr);
+        (void)gate;
         if (!outp || n0 + wn * 64 >= n_rows) return;  // (the per-wave LDS image needs no workgroup barrier)
         if constexpr (sizeof(T) == 2) {
             // bf16: transpose the wave's 64(n) x 64(m) accumulator tile through LDS so that every store instruction
@@ -590,8 +612,22 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void k_nt(const NtParams 
                 const int ml = it * 8 + (lane >> 3), c16 = lane & 7;
                 const int64_t m = m0 + wm * MW + ml;
                 const int n = n0 + wn * 64 + c16 * 8;
-                const u32x4 v = *reinterpret_cast<const u32x4*>(img + ml * ORS + c16 * 16);
-                if (m < P->M && n < n_rows) *reinterpret_cast<u32x4*>(outp + m * P->ld_out + row_off + n) = v;
+                u32x4 v = *reinterpret_cast<const u32x4*>(img + ml * ORS + c16 * 16);
+                if (m < P->M && n < n_rows) {
+                    if constexpr (GATE) {
+                        if (gate) {  // the bf16-rounded gradient times gelu'(pre-activation), rounded once (as ATen does)
+                            const u32x4 hv = *reinterpret_cast<const u32x4*>(gate + m * P->ld_out + row_off + n);
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const float g0 = __builtin_bit_cast(float, v[q] << 16) * gelu_grad(__builtin_bit_cast(float, hv[q] << 16));
+                                const float g1 = __builtin_bit_cast(float, v[q] & 0xFFFF0000u) *
+                                                 gelu_grad(__builtin_bit_cast(float, hv[q] & 0xFFFF0000u));
+                                v[q] = mtl_pack_bf16(g0, g1);
+                            }
+                        }
+                    }
+                    *reinterpret_cast<u32x4*>(outp + m * P->ld_out + row_off + n) = v;
+                }
             }
             __builtin_amdgcn_wave_barrier();
         } else {
@@ -605,8 +641,15 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void k_nt(const NtParams 
                         const int n = n0 + wn * 64 + sn * 32 + 8 * q + 4 * (lane >> 5);
                         if (m < P->M && n < n_rows) {
                             T* dst = outp + m * P->ld_out + row_off + n;
-                            *reinterpret_cast<f32x4*>(dst) =
-                                f32x4{a[sn][sm][q * 4], a[sn][sm][q * 4 + 1], a[sn][sm][q * 4 + 2], a[sn][sm][q * 4 + 3]};
+                            f32x4 o4 = {a[sn][sm][q * 4], a[sn][sm][q * 4 + 1], a[sn][sm][q * 4 + 2], a[sn][sm][q * 4 + 3]};
+                            if constexpr (GATE) {
+                                if (gate) {
+                                    const f32x4 hv = *reinterpret_cast<const f32x4*>(gate + m * P->ld_out + row_off + n);
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) o4[e] *= gelu_grad(hv[e]);
+                                }
+                            }
+                            *reinterpret_cast<f32x4*>(dst) = o4;
                         }
                     }
             }
@@ -671,7 +714,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void k_nt(const NtParams 
 #pragma unroll
                         for (int j = 0; j < SM; ++j) base[i][j] = acc[i][j];
                 }
-                store(acc, O.ptr);
+                store(acc, O.ptr, O.gate);
                 __syncthreads();  // the output image lives in the staging buffers
             }
         }
@@ -695,7 +738,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void k_nt(const NtParams 
                 }
                 run_part(np + 2 * o + 1, acc);
                 if (O.use_base) affine(acc);
-                store(acc, O.ptr);
+                store(acc, O.ptr, O.gate);
                 __syncthreads();  // the output image lives in the staging buffers
             }
         }
@@ -1041,10 +1084,28 @@ static void launch_nt(const NtParams& P, hipStream_t s, int kind, double alg_byt
         else                                                                                                   \
             MTL_NT_LAUNCH_W(MU, MSRC, FU, ML, 4);                                                              \
     } while (0)
-    bool mlr = false;
-    for (int o = 0; o < P.n_out; ++o) mlr = mlr || P.out[o].mask_lr != 0;
+    bool mlr = false, gated = false;
+    for (int o = 0; o < P.n_out; ++o) {
+        mlr = mlr || P.out[o].mask_lr != 0;
+        gated = gated || P.out[o].gate != nullptr;
+    }
     mlr = mlr && P.drop.enabled();
-    if (variant == 0) {
+    if (gated) {  // dX * gelu'(h) epilogue: the lean (single accumulator set) variants, never the row-panel form
+#define MTL_NT_LAUNCH_G(MSRC, ML)                                                               \
+    do {                                                                                        \
+        if (sizeof(T) == 2 && nt_waves() == 8)                                                  \
+            hipLaunchKernelGGL((k_nt<T, false, MSRC, false, ML, 8, true>), g, dim3(512), lds, s, P); \
+        else                                                                                    \
+            hipLaunchKernelGGL((k_nt<T, false, MSRC, false, ML, 4, true>), g, dim3(256), lds, s, P); \
+    } while (0)
+        if (variant == 1)
+            MTL_NT_LAUNCH_G(true, true);
+        else if (mlr)
+            MTL_NT_LAUNCH_G(false, true);
+        else
+            MTL_NT_LAUNCH_G(false, false);
+#undef MTL_NT_LAUNCH_G
+    } else if (variant == 0) {
         if (fuse)
             MTL_NT_LAUNCH(true, false, true, false);
         else
@@ -1277,7 +1338,8 @@ static BwdScratch bwd_scratch(const mtlora_linear_desc* d, const Segs& sg) {
 template <typename T>
 static int bwd_impl(const mtlora_linear_desc* d, const void* x, const void* const* x_t, const void* Wt,
                     const void* dy_s, const void* const* dy_t, const void* ctx, void* dx, void* const* dx_t,
-                    float* dA_s, float* dB_s, float* const* dA_t, float* const* dB_t, void* scratch, hipStream_t s) {
+                    float* dA_s, float* dB_s, float* const* dA_t, float* const* dB_t, void* scratch, hipStream_t s,
+                    const void* gate_s = nullptr, const void* const* gate_t = nullptr) {
     const Segs sg = make_segs(d);
     const CtxLayout L = ctx_layout(d, sg);
     const BwdScratch S = bwd_scratch(d, sg);
@@ -1328,7 +1390,7 @@ static int bwd_impl(const mtlora_linear_desc* d, const void* x, const void* cons
     for (int o = 0; o < sg.n; ++o) dyo[o] = (o == 0) ? dy_shared : dy[o];
 
     // Q[:, seg_o] = alpha_o * dY_o B_o   (zero where the output got no gradient)
-    const int groups = (dx && dyo[0]) ? fuse_groups(d, sg, d->K) : 0;  // row-panel form: Q is formed inside the dX kernel
+    const int groups = (dx && dyo[0] && !gate_s) ? fuse_groups(d, sg, d->K) : 0;  // row-panel form: Q is formed inside the dX kernel
     if (sg.R > 0 && groups == 0) {
         bool any_missing = false;
         for (int o = 0; o < sg.n; ++o)
@@ -1386,6 +1448,7 @@ static int bwd_impl(const mtlora_linear_desc* d, const void* x, const void* cons
         O.ptr = dx;
         O.use_base = 1;
         O.mask_lr = 1;
+        O.gate = gate_s;
         if (groups > 0) {  // T == 0: one gradient source, one rank segment
             m.np = 1;
             m.pact[0] = dyo[0];
@@ -1411,6 +1474,7 @@ static int bwd_impl(const mtlora_linear_desc* d, const void* x, const void* cons
                 Ot.use_base = 0;
                 Ot.mask_lr = 0;
                 Ot.fold = 0;
+                Ot.gate = gate_t ? gate_t[t] : nullptr;
             }
         } else {
             O.seg_lo = 0;
@@ -1482,6 +1546,8 @@ static int bwd_impl(const mtlora_linear_desc* d, const void* x, const void* cons
         }
         if (tp.n_prob > 0 && d->M > 0) {
             {
+                mtl_prof_tag("M%lld K%lld N%lld T%d np%d ns%d tiles%d", (long long)d->M, (long long)d->K, (long long)d->N, d->T, tp.n_prob,
+                             S.nsplit, max_tiles);
                 MtlProfScope prof(PK_TN, (double)sizeof(T) * d->M * (double)(1 + (d->has_x_tasks ? d->T : 0)) * d->K, s);
                 hipLaunchKernelGGL(k_tn<T>, dim3((unsigned)S.nsplit, (unsigned)max_tiles, (unsigned)tp.n_prob),
                                    dim3(256), 0, s, tp);
@@ -1541,10 +1607,11 @@ int mtlora_linear_fwd(const mtlora_linear_desc* d, const void* x, const void* co
     return MTLORA_OK;
 }
 
-int mtlora_linear_bwd(const mtlora_linear_desc* d, const void* x, const void* const* x_t, const void* Wt,
-                      const void* dy_s, const void* const* dy_t, const void* ctx, int64_t ctx_bytes, void* dx,
-                      void* const* dx_t, float* dA_s, float* dB_s, float* const* dA_t, float* const* dB_t,
-                      void* scratch, int64_t scratch_bytes, void* stream) {
+static int linear_bwd_entry(const mtlora_linear_desc* d, const void* x, const void* const* x_t, const void* Wt,
+                            const void* dy_s, const void* const* dy_t, const void* ctx, int64_t ctx_bytes, void* dx,
+                            void* const* dx_t, float* dA_s, float* dB_s, float* const* dA_t, float* const* dB_t,
+                            void* scratch, int64_t scratch_bytes, const void* gate_s, const void* const* gate_t,
+                            void* stream) {
     int st = check_desc(d);
     if (st != MTLORA_OK) return st;
     if (!x || !Wt) return MTLORA_ERR_NULL;
@@ -1564,12 +1631,34 @@ int mtlora_linear_bwd(const mtlora_linear_desc* d, const void* x, const void* co
     if (d->M == 0) return MTLORA_OK;
     hipStream_t s = (hipStream_t)stream;
     if (d->dtype == MTLORA_F32)
-        st = bwd_impl<float>(d, x, x_t, Wt, dy_s, dy_t, ctx, dx, dx_t, dA_s, dB_s, dA_t, dB_t, scratch, s);
+        st = bwd_impl<float>(d, x, x_t, Wt, dy_s, dy_t, ctx, dx, dx_t, dA_s, dB_s, dA_t, dB_t, scratch, s, gate_s, gate_t);
     else
-        st = bwd_impl<bf16>(d, x, x_t, Wt, dy_s, dy_t, ctx, dx, dx_t, dA_s, dB_s, dA_t, dB_t, scratch, s);
+        st = bwd_impl<bf16>(d, x, x_t, Wt, dy_s, dy_t, ctx, dx, dx_t, dA_s, dB_s, dA_t, dB_t, scratch, s, gate_s, gate_t);
     if (st != MTLORA_OK) return st;
     MTL_CHECK_LAUNCH();
     return MTLORA_OK;
+}
+
+int mtlora_linear_bwd(const mtlora_linear_desc* d, const void* x, const void* const* x_t, const void* Wt,
+                      const void* dy_s, const void* const* dy_t, const void* ctx, int64_t ctx_bytes, void* dx,
+                      void* const* dx_t, float* dA_s, float* dB_s, float* const* dA_t, float* const* dB_t,
+                      void* scratch, int64_t scratch_bytes, void* stream) {
+    return linear_bwd_entry(d, x, x_t, Wt, dy_s, dy_t, ctx, ctx_bytes, dx, dx_t, dA_s, dB_s, dA_t, dB_t, scratch, scratch_bytes,
+                            nullptr, nullptr, stream);
+}
+
+int mtlora_linear_bwd_gelu(const mtlora_linear_desc* d, const void* x, const void* const* x_t, const void* Wt,
+                           const void* dy_s, const void* const* dy_t, const void* ctx, int64_t ctx_bytes, void* dx,
+                           void* const* dx_t, float* dA_s, float* dB_s, float* const* dA_t, float* const* dB_t,
+                           void* scratch, int64_t scratch_bytes, const void* h_s, const void* const* h_t, void* stream) {
+    if (!h_s || !dx) return MTLORA_ERR_NULL;
+    if (misaligned(h_s)) return MTLORA_ERR_ALIGN;
+    for (int t = 0; t < d->T && d->has_x_tasks; ++t) {
+        if (dx_t && dx_t[t] && (!h_t || !h_t[t])) return MTLORA_ERR_NULL;
+        if (h_t && misaligned(h_t[t])) return MTLORA_ERR_ALIGN;
+    }
+    return linear_bwd_entry(d, x, x_t, Wt, dy_s, dy_t, ctx, ctx_bytes, dx, dx_t, dA_s, dB_s, dA_t, dB_t, scratch, scratch_bytes,
+                            h_s, h_t, stream);
 }
 
 // ---- out (Na x Nb, fp32) = a^T b reduced over the M rows: the weight gradient dW = dY^T X of a plain linear layer whose

@@ -74,6 +74,7 @@ class LinearMeta:
     dtype: torch.dtype
     weight_requires_grad: bool = False
     n_scale_t: int = 0        # >0: per-task scales are trainable Parameters passed after B_t
+    n_gate: int = 0           # >0: x (and x_t) = gelu(gate): the LAST n_gate args are the pre-activations; dx *= gelu'(gate)
 
     @property
     def T(self) -> int:
@@ -99,7 +100,7 @@ class MTLoRALinearFn(torch.autograd.Function):
     """(y_s, y_t[0..T-1]) = f(x, x_t[0..T-1], A_s, B_s, A_t[..], B_t[..]); W (and bias) frozen by default.
 
     args: meta, x, W_c, Wt_c, bias_f32, W_master, bias_master, A_s, B_s, scale_s_param,
-          *x_t(T or 0), *A_t(T), *B_t(T), *scale_t_params(T or 0)
+          *x_t(T or 0), *A_t(T), *B_t(T), *scale_t_params(T or 0), *gelu_gates(0 or 1 + len(x_t))
     W_c / Wt_c are the compute-dtype copies the module caches; W_master / bias_master are only used to
     route gradients when the pretrained weight is left trainable (MTLORA.FREEZE_PRETRAINED False);
     scale_*_param are the 1-element Parameters of TRAINABLE_SCALE_* (None otherwise): the kernels take the
@@ -134,7 +135,12 @@ class MTLoRALinearFn(torch.autograd.Function):
         L.check(st, "mtlora_linear_fwd")
         ctx.meta, ctx.lead, ctx.nx = meta, lead, nx
         ctx.in_dtypes = [x.dtype] + [t.dtype for t in x_t]
-        ctx.save_for_backward(x2, Wt_c, ctxbuf, *xt2)
+        gates = []
+        if meta.n_gate:
+            gates = [g.reshape(-1, meta.K) for g in rest[len(rest) - meta.n_gate:]]
+            if len(gates) != 1 + nx or any(g.dtype != meta.dtype or not g.is_contiguous() or g.shape != x2.shape for g in gates):
+                raise RuntimeError("mtlora_amd: gelu gates must be contiguous pre-activations of x / x_t in the compute dtype")
+        ctx.save_for_backward(x2, Wt_c, ctxbuf, *xt2, *gates)
         ctx.keep = (A_s_c, B_s_c, A_t_c, B_t_c)  # fp32 factor views (also used for the trainable-scale gradients)
         ctx.has_scale_s = scale_s_param is not None
         outs = [ys.reshape(*lead, meta.N)] + [y.reshape(*lead, meta.N) for y in yt]
@@ -145,8 +151,11 @@ class MTLoRALinearFn(torch.autograd.Function):
         meta: LinearMeta = ctx.meta
         T, nx = meta.T, ctx.nx
         if all(g is None for g in grads):
-            return (None,) * (10 + nx + 2 * T + meta.n_scale_t)
+            return (None,) * (10 + nx + 2 * T + meta.n_scale_t + meta.n_gate)
         x2, Wt_c, ctxbuf, *xt2 = ctx.saved_tensors
+        gates = []
+        if meta.n_gate:
+            xt2, gates = xt2[:nx], xt2[nx:]
         M = x2.shape[0]
         dev = x2.device
         g2 = [None if g is None else g.reshape(-1, meta.N).to(meta.dtype).contiguous() for g in grads]
@@ -169,11 +178,18 @@ class MTLoRALinearFn(torch.autograd.Function):
             for t in range(T):
                 if dy_t[t] is None:
                     dxt[t].zero_()
-        st = lib.mtlora_linear_bwd(ctypes.byref(d), L.ptr(x2), L.ptr_array(xt2), L.ptr(Wt_c), L.ptr(dy_s),
-                                   L.ptr_array(dy_t), L.ptr(ctxbuf), ctxbuf.numel(), L.ptr(dx), L.ptr_array(dxt),
-                                   L.ptr(dA_s), L.ptr(dB_s), L.ptr_array(dA_t), L.ptr_array(dB_t), L.ptr(scratch),
-                                   scratch_bytes, L.stream_ptr())
-        L.check(st, "mtlora_linear_bwd")
+        if gates:  # the inputs were gelu(gate): the dX epilogue also applies gelu'(gate) (GELU backward fused)
+            st = lib.mtlora_linear_bwd_gelu(ctypes.byref(d), L.ptr(x2), L.ptr_array(xt2), L.ptr(Wt_c), L.ptr(dy_s),
+                                            L.ptr_array(dy_t), L.ptr(ctxbuf), ctxbuf.numel(), L.ptr(dx), L.ptr_array(dxt),
+                                            L.ptr(dA_s), L.ptr(dB_s), L.ptr_array(dA_t), L.ptr_array(dB_t), L.ptr(scratch),
+                                            scratch_bytes, L.ptr(gates[0]), L.ptr_array(gates[1:]), L.stream_ptr())
+            L.check(st, "mtlora_linear_bwd_gelu")
+        else:
+            st = lib.mtlora_linear_bwd(ctypes.byref(d), L.ptr(x2), L.ptr_array(xt2), L.ptr(Wt_c), L.ptr(dy_s),
+                                       L.ptr_array(dy_t), L.ptr(ctxbuf), ctxbuf.numel(), L.ptr(dx), L.ptr_array(dxt),
+                                       L.ptr(dA_s), L.ptr(dB_s), L.ptr_array(dA_t), L.ptr_array(dB_t), L.ptr(scratch),
+                                       scratch_bytes, L.stream_ptr())
+            L.check(st, "mtlora_linear_bwd")
         dW = dbias = None
         if meta.weight_requires_grad:  # pretrained weight left trainable: dense dW outside the frozen-W hot path
             G = None
@@ -195,7 +211,21 @@ class MTLoRALinearFn(torch.autograd.Function):
         for t in range(meta.n_scale_t):
             ok = dB_t[t] is not None and meta.scale_t[t] != 0.0
             d_st.append(((dB_t[t] * B_t_c[t]).sum() / meta.scale_t[t]).reshape(1) if ok else None)
-        return (None, dxo, None, None, None, dW, dbias, dA_s, dB_s, d_ss, *dxto, *dA_t, *dB_t, *d_st)
+        return (None, dxo, None, None, None, dW, dbias, dA_s, dB_s, d_ss, *dxto, *dA_t, *dB_t, *d_st, *([None] * meta.n_gate))
+
+
+class GeluDeferredGradFn(torch.autograd.Function):
+    """a = gelu(h) (exact erf form) whose backward is the IDENTITY: the consumer is an MTLoRALinear called with
+    ``gelu_gate=h``, whose dX kernel multiplies by gelu'(h) itself (``mtlora_linear_bwd_gelu``) -- the standalone GELU
+    backward pass (read dA, read h, write dH) disappears.  Only ``Mlp.forward`` pairs the two."""
+
+    @staticmethod
+    def forward(ctx, h):
+        return torch.nn.functional.gelu(h)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
 
 
 # ----------------------------------------------------------------------------------------------

@@ -118,8 +118,10 @@ class MTLoRALinear(LoRALayer):
         self._wcache = {}
         return super()._apply(fn, *a, **k)
 
-    def forward(self, x: torch.Tensor, x_tasks: Optional[Dict[str, torch.Tensor]] = None
+    def forward(self, x: torch.Tensor, x_tasks: Optional[Dict[str, torch.Tensor]] = None, gelu_gate=None
                 ) -> Tuple[torch.Tensor, Optional[Dict[str, torch.Tensor]]]:
+        """gelu_gate = (h, {task: h_t} or None): x = gelu(h) and x_tasks[t] = gelu(h_t) were produced by
+        ``Fn.GeluDeferredGradFn`` (identity backward); this layer's backward then returns the gradients w.r.t. h."""
         Fn.L.require_gpu(x)
         dtype = Fn.compute_dtype(x)
         wc, wt, bf = self._weights(dtype)
@@ -139,6 +141,10 @@ class MTLoRALinear(LoRALayer):
             has_x_tasks=bool(tasks) and x_tasks is not None, dropout_p=p, seed=Fn.next_seed() if p > 0 else 0,
             dtype=dtype, weight_requires_grad=self.linear.weight.requires_grad,
             n_scale_t=len(tasks) if (tasks and isinstance(st[0], nn.Parameter)) else 0)
+        gates = []
+        if gelu_gate is not None:
+            gates = [gelu_gate[0]] + ([gelu_gate[1][t] for t in tasks] if meta.has_x_tasks else [])
+            meta.n_gate = len(gates)
         args = [meta, x, wc, wt, bf, self.linear.weight, self.linear.bias,
                 self.lora_shared_A if shared else None, self.lora_shared_B if shared else None, par(ss)]
         if meta.has_x_tasks:
@@ -146,6 +152,7 @@ class MTLoRALinear(LoRALayer):
         args += [self.lora_tasks_A[t] for t in tasks] + [self.lora_tasks_B[t] for t in tasks]
         if meta.n_scale_t:
             args += st
+        args += gates
         outs = Fn.MTLoRALinearFn.apply(*args)
         y = outs[0]
         if not has_lora:

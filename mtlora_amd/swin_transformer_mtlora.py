@@ -94,8 +94,22 @@ class Mlp(nn.Module):
         self.tasks = tasks
         self.drop = nn.Dropout(drop)
 
+    def _fused_gelu_backward(self, h, h_t) -> bool:
+        """fc2's dX kernel can apply the GELU derivative itself (one pass less over the 4C-wide hidden tensor per stream)."""
+        from .lora import MTLoRALinear
+        ts = [h] + ([h_t[t] for t in self.tasks] if h_t is not None else [])
+        return (isinstance(self.fc2, MTLoRALinear) and type(self.act) is nn.GELU and getattr(self.act, "approximate", "none") == "none"
+                and (self.drop.p == 0.0 or not self.training) and torch.is_grad_enabled() and h.requires_grad
+                and all(t.is_cuda and t.is_contiguous() and t.dtype == Fn.compute_dtype(t) for t in ts)
+                and self.fc2.linear.in_features % 8 == 0 and not self.fc2.linear.weight.requires_grad
+                and self.fc2.shared_mode in ("matrix", "matrixv2"))
+
     def forward(self, x, x_tasks=None):
         h, h_t = self.fc1(x, x_tasks)
+        if self._fused_gelu_backward(h, h_t):
+            a = Fn.GeluDeferredGradFn.apply(h)
+            a_t = {t: Fn.GeluDeferredGradFn.apply(h_t[t]) for t in self.tasks} if h_t is not None else None
+            return self.fc2(a, a_t, gelu_gate=(h, h_t))
         h = self.drop(self.act(h))
         if h_t is not None:
             h_t = {t: self.drop(self.act(h_t[t])) for t in self.tasks}

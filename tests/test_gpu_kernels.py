@@ -583,6 +583,56 @@ def test_residual_layer_norm_fused(rdt, ydt, B, Ltok, C, use_scale):
     assert_close(br2.grad, g_skip.double() * sc64.view(B, 1, 1), ydt, "d_branch (skip only)")
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("with_tasks", [False, True])
+def test_linear_bwd_gelu_fused(dtype, with_tasks):
+    """mtlora_linear_bwd_gelu: fc2(gelu(h)) with the GELU derivative applied inside fc2's dX kernel == the unfused
+    composition (ATen gelu + gelu_backward), same dropout seeds; shared and per-task inputs, ragged M."""
+    from mtlora_amd import functional as Fn
+    from mtlora_amd.lora import MTLoRALinear
+    torch.manual_seed(3)
+    tasks = ["a", "b"] if with_tasks else None
+    r = {"shared": 16, "a": 4, "b": 4} if with_tasks else {"shared": 16}
+    K, N, M = 192, 96, 777
+    m = MTLoRALinear(K, N, r=r, lora_shared_scale=2.0, lora_task_scale={"a": 1.0, "b": 0.5} if with_tasks else 1.0,
+                     lora_dropout=0.1, tasks=tasks).to(dev())
+    with torch.no_grad():
+        for n_, p_ in m.named_parameters():
+            if "lora_" in n_:
+                p_.normal_(0, 0.1)
+    m.train()
+    hs = [(1.5 * torch.randn(3, M // 3, K, device=dev())).to(dtype).requires_grad_(True) for _ in range(1 + (2 if with_tasks else 0))]
+    gys = None
+    res = []
+    for fused in (False, True):
+        Fn._seed_counter = 1000
+        for h in hs:
+            h.grad = None
+        m.zero_grad()
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=dtype == torch.bfloat16):
+            if fused:
+                a = [Fn.GeluDeferredGradFn.apply(h) for h in hs]
+                y, yt = m(a[0], {t: a[1 + i] for i, t in enumerate(tasks)} if tasks else None,
+                          gelu_gate=(hs[0], {t: hs[1 + i] for i, t in enumerate(tasks)} if tasks else None))
+            else:
+                a = [torch.nn.functional.gelu(h) for h in hs]
+                y, yt = m(a[0], {t: a[1 + i] for i, t in enumerate(tasks)} if tasks else None)
+        outs = [y] + ([yt[t] for t in tasks] if tasks else [])
+        if gys is None:
+            gys = [torch.randn_like(o) for o in outs]
+        torch.autograd.backward(outs, gys)
+        res.append(([o.detach().clone() for o in outs], [h.grad.clone() for h in hs],
+                    {n_: p_.grad.clone() for n_, p_ in m.named_parameters() if p_.grad is not None}))
+    (o0, g0, p0), (o1, g1, p1) = res
+    for a_, b_ in zip(o0, o1):
+        assert torch.equal(a_, b_)
+    for i, (a_, b_) in enumerate(zip(g0, g1)):
+        assert_close(b_, a_.double(), dtype, f"dh{i}", mult=2)
+    assert p0.keys() == p1.keys()
+    for k in p0:
+        assert torch.equal(p0[k], p1[k]), k
+
+
 def test_linear_fused_projection():
     """Row-panel form of k_nt (projection P / Q formed inside the output kernel, workgroup loops over its n-tiles):
     forward AND backward against the two-pass form, in subprocesses (the switches are read once per process).

@@ -849,10 +849,11 @@ def linear_big_m(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Ten
     feeds_batchnorm=True: the output goes straight into a training-mode BatchNorm -> the bias gradient is exactly 0."""
     M = x.shape[0]
     if x.dim() == 2 and x.is_cuda and weight.requires_grad and torch.is_grad_enabled() and M >= 16384:
-        # enough row chunks that chunks x output tiles (64 x 64) fills the 256 CUs twice, each chunk >= 1024 rows
+        # enough row chunks that chunks x output tiles (64 x 64) fills the 256 CUs ~8 times (measured on the heads' 1080 x 272
+        # gradient: 235 us at 8 chunks, 114 us at 32), each chunk >= 1024 rows
         tiles = ((weight.shape[0] + 63) // 64) * ((weight.shape[1] + 63) // 64)
         S = 4
-        while S < 64 and S * tiles < 512 and M % (2 * S) == 0 and M // (2 * S) >= 1024:
+        while S < 64 and S * tiles < 2048 and M % (2 * S) == 0 and M // (2 * S) >= 1024:
             S *= 2
         if M % S == 0 and x.is_contiguous():
             if torch.is_autocast_enabled("cuda"):

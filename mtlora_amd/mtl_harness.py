@@ -99,15 +99,12 @@ class HighResolutionHead(nn.Module):
             # matching zero columns
             t = Fn.ConcatUpsampleFn.apply(*xc)
             offs, ld = Fn.ConcatUpsampleFn.layout(chans)
-            cols, src, end = [], 0, 0
-            for o, c in zip(offs, chans):
-                if o > end:
-                    cols.append(w2d.new_zeros(w2d.shape[0], o - end))
-                cols.append(w2d[:, src:src + c])
-                src, end = src + c, o + c
-            if ld > end:
-                cols.append(w2d.new_zeros(w2d.shape[0], ld - end))
-            w2d = torch.cat(cols, 1)
+            if ld != w2d.shape[1]:  # one scatter of the weight columns (backward: one gather), not a cat of slices
+                key = (tuple(offs), tuple(chans), w2d.device)
+                if getattr(self, "_col_key", None) != key:
+                    self._col_idx = torch.cat([torch.arange(o, o + c) for o, c in zip(offs, chans)]).to(w2d.device)
+                    self._col_key = key
+                w2d = w2d.new_zeros(w2d.shape[0], ld).index_copy(1, self._col_idx, w2d)
         else:
             cat = torch.cat([x[0]] + [F.interpolate(m, (Hh, Ww), mode="bilinear") for m in x[1:]], 1)
             t = cat.permute(0, 2, 3, 1).reshape(B * Hh * Ww, cat.shape[1])

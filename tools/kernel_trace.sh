@@ -19,7 +19,7 @@ with open(sys.argv[3], "w") as f:
     f.write("name,dur_us,grid_x,grid_y,grid_z,wg,lds,vgpr,scratch\n")
     for r in rows:
         if sys.argv[2] in r["Kernel_Name"]:
-            f.write("%s,%.2f,%s,%s,%s,%s,%s,%s,%s\n" % (r["Kernel_Name"][:60].replace(",", ";"), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3,
+            f.write("%s,%.2f,%s,%s,%s,%s,%s,%s,%s\n" % (r["Kernel_Name"][:140].replace(",", ";"), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3,
                     r["Grid_Size_X"], r["Grid_Size_Y"], r["Grid_Size_Z"], r["Workgroup_Size_X"], r["LDS_Block_Size"], r["VGPR_Count"], r["Scratch_Size"]))
 PY
 wc -l $REPO/gpurun_out/trace_${FILT}.csv

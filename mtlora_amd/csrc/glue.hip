@@ -723,24 +723,36 @@ __global__ __launch_bounds__(512) void k_bn_colsum(const BnParams p) {
     int64_t r_hi = r_lo + rows_blk;
     if (r_hi > p.R) r_hi = p.R;
     if (active) {
-        for (int64_t r = r_lo + ro; r < r_hi; r += p.rows_per_iter) {
-            float fx[8];
-            ld_vec<T>(x + r * p.C + v * VE, fx);
-            if (!BWD) {
+        constexpr int UN = 4;  // rows in flight per thread (one 16-byte load each; a single load per iteration ran at 2 TB/s)
+        for (int64_t r = r_lo + ro; r < r_hi; r += (int64_t)UN * p.rows_per_iter) {
+            u32x4 rx[UN], rg[UN];
 #pragma unroll
-                for (int e = 0; e < VE; ++e) {
-                    a0[e] += fx[e];
-                    a1[e] += fx[e] * fx[e];
-                }
-            } else {
-                float fg[8];
-                ld_vec<T>(dy + r * p.C + v * VE, fg);
+            for (int u = 0; u < UN; ++u) {
+                const int64_t rr = r + (int64_t)u * p.rows_per_iter;
+                const bool ok = rr < r_hi;
+                rx[u] = ok ? *reinterpret_cast<const u32x4*>(x + rr * p.C + v * VE) : u32x4{0u, 0u, 0u, 0u};
+                if (BWD) rg[u] = ok ? *reinterpret_cast<const u32x4*>(dy + rr * p.C + v * VE) : u32x4{0u, 0u, 0u, 0u};
+            }
 #pragma unroll
-                for (int e = 0; e < VE; ++e) {
-                    const float yv = fx[e] * sc[e] + sh[e];
-                    const float g = (p.relu && yv <= 0.f) ? 0.f : fg[e];
-                    a0[e] += g;
-                    a1[e] += g * (fx[e] - mu[e]) * rs[e];
+            for (int u = 0; u < UN; ++u) {
+                float fx[8];
+                cvt_vec<T>(rx[u], fx);
+                if (!BWD) {  // rows past the end were loaded as zeros: they add nothing
+#pragma unroll
+                    for (int e = 0; e < VE; ++e) {
+                        a0[e] += fx[e];
+                        a1[e] += fx[e] * fx[e];
+                    }
+                } else {
+                    float fg[8];
+                    cvt_vec<T>(rg[u], fg);  // (zero gradient for rows past the end)
+#pragma unroll
+                    for (int e = 0; e < VE; ++e) {
+                        const float yv = fx[e] * sc[e] + sh[e];
+                        const float g = (p.relu && yv <= 0.f) ? 0.f : fg[e];
+                        a0[e] += g;
+                        a1[e] += g * (fx[e] - mu[e]) * rs[e];
+                    }
                 }
             }
         }
@@ -845,35 +857,68 @@ __global__ __launch_bounds__(64 * BN_FW) void k_bn_bwd_finalize(const BnParams p
     p.c2[c] = (float)(s1 / (double)p.R);
 }
 
+// a thread owns ONE channel vector (its per-channel constants stay in registers -- re-reading 2-6 per-channel arrays per
+// element through the vector cache held the backward at 3.4 TB/s) and walks the rows of its workgroup's slab, 4 in flight
+constexpr int BN_APPLY_BLOCKS = 2048;
 template <typename T, bool BWD>
-__global__ __launch_bounds__(256) void k_bn_apply(const BnParams p) {
+__global__ __launch_bounds__(512) void k_bn_apply(const BnParams p) {
     constexpr int VE = ET<T>::VEC;
+    constexpr int UN = 4;
+    const int tid = threadIdx.x;
+    const int ro = tid / p.VW, v = tid % p.VW;
+    if (ro >= p.rows_per_iter) return;
     const T* x = reinterpret_cast<const T*>(p.x);
-    const int64_t nvec = p.R * p.VW;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
-        const int v = (int)(i % p.VW);
-        float fx[8], o[8];
-        ld_vec<T>(x + i * VE, fx);
-        if (!BWD) {
+    const T* dy = reinterpret_cast<const T*>(p.dy);
+    T* out = reinterpret_cast<T*>(BWD ? p.dx : p.y);
+    // forward: y = relu(x * sc + sh);  backward: dx = sc * g + kx * x + k0 with g = dy * [x * sc + sh > 0]
+    float sc[VE], sh[VE], kx[VE], k0[VE];
 #pragma unroll
-            for (int e = 0; e < VE; ++e) {
-                const float yv = fx[e] * p.scale[v * VE + e] + p.shift[v * VE + e];
-                o[e] = (p.relu && yv < 0.f) ? 0.f : yv;
-            }
-            st_vec<T, VE>(reinterpret_cast<T*>(p.y) + i * VE, o);
-        } else {
-            float fg[8];
-            ld_vec<T>(reinterpret_cast<const T*>(p.dy) + i * VE, fg);
+    for (int e = 0; e < VE; ++e) {
+        const int c = v * VE + e;
+        sc[e] = p.scale[c];
+        sh[e] = p.shift[c];
+        if (BWD) {
+            const float t = sc[e] * p.c2[c] * p.rstd[c];
+            kx[e] = -t;
+            k0[e] = t * p.mean[c] - sc[e] * p.c1[c];
+        }
+    }
+    const int64_t rows_blk = mtl_ceil_div(p.R, (int64_t)gridDim.x);
+    const int64_t r_lo = (int64_t)blockIdx.x * rows_blk;
+    int64_t r_hi = r_lo + rows_blk;
+    if (r_hi > p.R) r_hi = p.R;
+    for (int64_t r = r_lo + ro; r < r_hi; r += (int64_t)UN * p.rows_per_iter) {
+        u32x4 rx[UN], rg[UN];
 #pragma unroll
-            for (int e = 0; e < VE; ++e) {
-                const int c = v * VE + e;
-                const float sc = p.scale[c];
-                const float yv = fx[e] * sc + p.shift[c];
-                const float g = (p.relu && yv <= 0.f) ? 0.f : fg[e];
-                const float xh = (fx[e] - p.mean[c]) * p.rstd[c];
-                o[e] = sc * (g - p.c1[c] - xh * p.c2[c]);
+        for (int u = 0; u < UN; ++u) {
+            const int64_t rr = r + (int64_t)u * p.rows_per_iter;
+            const bool ok = rr < r_hi;
+            rx[u] = ok ? *reinterpret_cast<const u32x4*>(x + rr * p.C + v * VE) : u32x4{0u, 0u, 0u, 0u};
+            if (BWD) rg[u] = ok ? *reinterpret_cast<const u32x4*>(dy + rr * p.C + v * VE) : u32x4{0u, 0u, 0u, 0u};
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int64_t rr = r + (int64_t)u * p.rows_per_iter;
+            if (rr >= r_hi) continue;
+            float fx[8], o[8];
+            cvt_vec<T>(rx[u], fx);
+            if (!BWD) {
+#pragma unroll
+                for (int e = 0; e < VE; ++e) {
+                    const float yv = fx[e] * sc[e] + sh[e];
+                    o[e] = (p.relu && yv < 0.f) ? 0.f : yv;
+                }
+            } else {
+                float fg[8];
+                cvt_vec<T>(rg[u], fg);
+#pragma unroll
+                for (int e = 0; e < VE; ++e) {
+                    const float yv = fx[e] * sc[e] + sh[e];
+                    const float g = (p.relu && yv <= 0.f) ? 0.f : fg[e];
+                    o[e] = sc[e] * g + kx[e] * fx[e] + k0[e];
+                }
             }
-            st_vec<T, VE>(reinterpret_cast<T*>(p.dx) + i * VE, o);
+            st_vec<T, VE>(out + rr * p.C + v * VE, o);
         }
     }
 }
@@ -932,6 +977,7 @@ int mtlora_bn_relu_fwd(const void* x, const float* gamma, const float* beta, flo
     p.relu = relu;
     hipStream_t s = (hipStream_t)stream;
     const int threads = (int)mtl_round_up((int64_t)p.rows_per_iter * p.VW, 64);
+    const unsigned apply_blocks = (unsigned)(mtl_ceil_div(R, 16) < BN_APPLY_BLOCKS ? mtl_ceil_div(R, 16) : BN_APPLY_BLOCKS);
     const size_t lds = (size_t)p.rows_per_iter * 2 * C * 4;
     const int es = mtl_elem_size(dtype);
     {
@@ -945,9 +991,9 @@ int mtlora_bn_relu_fwd(const void* x, const float* gamma, const float* beta, flo
     {
         MtlProfScope prof(PK_BN, (double)R * C * es * 2, s);
         if (dtype == MTLORA_F32)
-            hipLaunchKernelGGL((k_bn_apply<float, false>), dim3(2048), dim3(256), 0, s, p);
+            hipLaunchKernelGGL((k_bn_apply<float, false>), dim3(apply_blocks), dim3(threads), 0, s, p);
         else
-            hipLaunchKernelGGL((k_bn_apply<bf16, false>), dim3(2048), dim3(256), 0, s, p);
+            hipLaunchKernelGGL((k_bn_apply<bf16, false>), dim3(apply_blocks), dim3(threads), 0, s, p);
     }
     MTL_CHECK_LAUNCH();
     return MTLORA_OK;
@@ -978,6 +1024,7 @@ int mtlora_bn_relu_bwd(const void* dy, const void* x, const float* save_mean, co
     p.relu = relu;
     hipStream_t s = (hipStream_t)stream;
     const int threads = (int)mtl_round_up((int64_t)p.rows_per_iter * p.VW, 64);
+    const unsigned apply_blocks = (unsigned)(mtl_ceil_div(R, 16) < BN_APPLY_BLOCKS ? mtl_ceil_div(R, 16) : BN_APPLY_BLOCKS);
     const size_t lds = (size_t)p.rows_per_iter * 2 * C * 4;
     const int es = mtl_elem_size(dtype);
     {
@@ -991,9 +1038,9 @@ int mtlora_bn_relu_bwd(const void* dy, const void* x, const float* save_mean, co
     {
         MtlProfScope prof(PK_BN, (double)R * C * es * 3, s);
         if (dtype == MTLORA_F32)
-            hipLaunchKernelGGL((k_bn_apply<float, true>), dim3(2048), dim3(256), 0, s, p);
+            hipLaunchKernelGGL((k_bn_apply<float, true>), dim3(apply_blocks), dim3(threads), 0, s, p);
         else
-            hipLaunchKernelGGL((k_bn_apply<bf16, true>), dim3(2048), dim3(256), 0, s, p);
+            hipLaunchKernelGGL((k_bn_apply<bf16, true>), dim3(apply_blocks), dim3(threads), 0, s, p);
     }
     MTL_CHECK_LAUNCH();
     return MTLORA_OK;

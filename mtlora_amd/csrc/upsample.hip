@@ -73,7 +73,10 @@ __global__ __launch_bounds__(256) void k_up_fwd(const UpParams p) {
     }
 }
 
-// src = gradient of the fine tensor (strided), dst = gradient of the coarse tensor
+// src = gradient of the fine tensor (strided), dst = gradient of the coarse tensor.  UB adjacent lanes share one (coarse
+// pixel, 4-channel vector): they take the <= 2S tapping fine rows round-robin and add their shares with a fixed shuffle
+// tree (one thread per output left a 64-iteration serial gather of 8-byte loads per thread at S = 4).
+constexpr int UB = 4;
 template <typename T>
 __global__ __launch_bounds__(256) void k_up_bwd(const UpParams p) {
     const int H = p.h * p.S, W = p.w * p.S, CV = p.C / 4, S = p.S;
@@ -81,9 +84,15 @@ __global__ __launch_bounds__(256) void k_up_bwd(const UpParams p) {
     const T* g = reinterpret_cast<const T*>(p.src);
     T* dst = reinterpret_cast<T*>(p.dst);
     const int64_t total = (int64_t)p.B * p.h * p.w * CV;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        const int cv = (int)(i % CV);
-        int64_t r = i / CV;
+    const int part = threadIdx.x % UB;
+    // (all lanes of a shuffle group run the same number of iterations: the loop bound is rounded up per group)
+    const int64_t stride = (int64_t)gridDim.x * (256 / UB);
+    for (int64_t i0 = (int64_t)blockIdx.x * (256 / UB); i0 < total; i0 += stride) {
+        const int64_t i = i0 + threadIdx.x / UB;
+        const bool live = i < total;
+        const int64_t ii = live ? i : 0;
+        const int cv = (int)(ii % CV);
+        int64_t r = ii / CV;
         const int qx = (int)(r % p.w);
         r /= p.w;
         const int qy = (int)(r % p.h);
@@ -91,25 +100,31 @@ __global__ __launch_bounds__(256) void k_up_bwd(const UpParams p) {
         const int oy_lo = S * qy - S < 0 ? 0 : S * qy - S, oy_hi = S * qy + 2 * S > H ? H : S * qy + 2 * S;
         const int ox_lo = S * qx - S < 0 ? 0 : S * qx - S, ox_hi = S * qx + 2 * S > W ? W : S * qx + 2 * S;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        for (int oy = oy_lo; oy < oy_hi; ++oy) {
-            int iy0, iy1;
-            float fy;
-            src_index(oy, rs, p.h, iy0, iy1, fy);
-            const float wy = (iy0 == qy ? 1.f - fy : 0.f) + (iy1 == qy ? fy : 0.f);
-            if (wy == 0.f) continue;
-            const T* row = g + ((b * H + oy) * W) * p.ld_fine + cv * 4;
-            for (int ox = ox_lo; ox < ox_hi; ++ox) {
-                int ix0, ix1;
-                float fx;
-                src_index(ox, rs, p.w, ix0, ix1, fx);
-                const float wq = wy * ((ix0 == qx ? 1.f - fx : 0.f) + (ix1 == qx ? fx : 0.f));
-                if (wq == 0.f) continue;
-                const f32x4 v = V4<T>::ld(row + (int64_t)ox * p.ld_fine);
+        if (live) {
+            for (int oy = oy_lo + part; oy < oy_hi; oy += UB) {
+                int iy0, iy1;
+                float fy;
+                src_index(oy, rs, p.h, iy0, iy1, fy);
+                const float wy = (iy0 == qy ? 1.f - fy : 0.f) + (iy1 == qy ? fy : 0.f);
+                if (wy == 0.f) continue;
+                const T* row = g + ((b * H + oy) * W) * p.ld_fine + cv * 4;
+                for (int ox = ox_lo; ox < ox_hi; ++ox) {
+                    int ix0, ix1;
+                    float fx;
+                    src_index(ox, rs, p.w, ix0, ix1, fx);
+                    const float wq = wy * ((ix0 == qx ? 1.f - fx : 0.f) + (ix1 == qx ? fx : 0.f));
+                    if (wq == 0.f) continue;
+                    const f32x4 v = V4<T>::ld(row + (int64_t)ox * p.ld_fine);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) acc[e] += wq * v[e];
+                    for (int e = 0; e < 4; ++e) acc[e] += wq * v[e];
+                }
             }
         }
-        V4<T>::st(dst + ((b * p.h + qy) * p.w + qx) * p.C + cv * 4, acc);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int o = 1; o < UB; o <<= 1) acc[e] += __shfl_xor(acc[e], o);
+        if (live && part == 0) V4<T>::st(dst + ((b * p.h + qy) * p.w + qx) * p.C + cv * 4, acc);
     }
 }
 
@@ -153,7 +168,7 @@ int mtlora_upsample_cl_bwd(const void* grad_fine, void* grad_coarse, int64_t B, 
     UpParams p = {grad_fine, grad_coarse, (int)B, h, w, C, scale, ld_fine};
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int64_t total = B * (int64_t)h * w * (C / 4);
-    int64_t blocks = mtl_ceil_div(total, 256);
+    int64_t blocks = mtl_ceil_div(total, 256 / UB);
     if (blocks > 65536) blocks = 65536;
     MtlProfScope prof(PK_UPSAMPLE, (double)mtl_elem_size(dtype) * B * h * w * C * (1.0 + (double)scale * scale), s);
     if (dtype == MTLORA_F32)

@@ -746,6 +746,234 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void k_nt(const NtParams 
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_nt2 : the lean single-output case of k_nt (bf16; one rank segment + base GEMM, optional masked low-rank part and
+// GELU' gate) with a DIRECT-TO-LDS load path for the MFMA-dense launches (stages 2 / 3, decoder heads):
+//   * 256 (m) x 128 (n) workgroup tile, 8 waves of 64 x 64, k-tiles of 64 elements (128-byte rows);
+//   * tiles are fetched with global_load_lds_dwordx4 (no staging registers): a wave instruction fills 1 KB = 8 rows of
+//     LDS linearly; WHICH 16-byte chunk of its row a lane fetches is XOR-swizzled (chunk ^ ((row >> 1) & 7)) so that the
+//     ds_read_b128 fragment reads (16 lanes per LDS cycle: 16 rows, one logical chunk) touch all 64 banks once;
+//     chunks past the k range / rows past M, N come from a 16-byte zero page;
+//   * 3-stage LDS ring (3 x 48 KB), ONE barrier per k-tile: wait own loads of tile t (vmcnt), barrier, issue tile t + 2
+//     into the slot tile t - 1 just vacated, multiply tile t.
+// Same accumulator / epilogue conventions as k_nt (A operand = weights, bf16 output transposed through LDS).
+// ------------------------------------------------------------------------------------------------
+constexpr int T2_M = 256, T2_N = 128, T2_K = 64;
+constexpr int T2_ROWB = T2_K * 2;                        // 128 bytes per row per k-tile
+constexpr int T2_STAGE = (T2_M + T2_N) * T2_ROWB;        // 48 KB
+constexpr int T2_NSTAGE = 3;
+constexpr int T2_LDS = T2_NSTAGE * T2_STAGE;             // 144 KB (epilogue images 8 x 64 x 136 B reuse it)
+__device__ __attribute__((aligned(16))) const uint32_t g_zero16[4] = {0u, 0u, 0u, 0u};
+
+template <bool MLR, bool GATE>
+__global__ __launch_bounds__(512, 2) void k_nt2(const NtParams Pv) {
+    (void)Pv;
+    NtPtr P = (NtPtr)__builtin_amdgcn_kernarg_segment_ptr();
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wn = wave >> 2, wm = wave & 3;
+    const int n_rows = P->n_rows;
+    const int n_tiles = (n_rows + T2_N - 1) / T2_N;
+    const int64_t m_tiles = (P->M + T2_M - 1) / T2_M;
+    const int64_t nwg = m_tiles * n_tiles;
+    int64_t b = blockIdx.x;
+    if (b >= nwg) return;
+    {
+        const int64_t q = nwg / 8, r = nwg % 8, xcd = b % 8;
+        b = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + b / 8;
+    }
+    const int64_t m0 = (b / n_tiles) * T2_M;
+    const int n0 = (int)(b % n_tiles) * T2_N;
+    const NtOut O = nt_out(P, 0);
+    DropoutCfg drop;
+    drop.seed_lo = P->drop.seed_lo;
+    drop.seed_hi = P->drop.seed_hi;
+    drop.thr16 = P->drop.thr16;
+    drop.off = P->drop.off;
+    mtl_dropout_resolve(drop);
+
+    // tile sequence: rank segment [seg_lo, seg_hi) of (L, Rm) first, then the base GEMM [0, K) of (act, wgt)
+    const int r_tiles = (O.seg_hi - O.seg_lo + T2_K - 1) / T2_K;
+    const int b_tiles = O.use_base ? (P->K + T2_K - 1) / T2_K : 0;
+    const int n_t = r_tiles + b_tiles;
+
+    // loader: wave-instruction j of wave w fills the 8 rows [8 q, 8 q + 8), q = 6 w + j, of the stage's 384 rows
+    // (rows 0..127 = weight-side operand, 128..383 = activation-side operand)
+    const bf16* wgt = reinterpret_cast<const bf16*>(P->wgt);
+    const bf16* act = reinterpret_cast<const bf16*>(P->act[0]);
+    const bf16* Rm = reinterpret_cast<const bf16*>(P->Rm);
+    const bf16* Lm = reinterpret_cast<const bf16*>(P->L);
+    int64_t grow[6];   // global row of this lane's chunk (weight row n or activation row m), -1 when out of range
+    int kchunk[6];     // logical 16-byte chunk (0..7) this lane fetches = physical position ^ swizzle(row)
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        const int q = wave * 6 + j;
+        const int row = q * 8 + (lane >> 3);  // 0..383
+        const bool is_w = row < T2_N;
+        const int rl = is_w ? row : row - T2_N;
+        kchunk[j] = (lane & 7) ^ ((rl >> 1) & 7);
+        if (is_w)
+            grow[j] = (n0 + rl < n_rows) ? (int64_t)(n0 + rl) : -1;
+        else
+            grow[j] = (m0 + rl < P->M) ? m0 + rl : -1;
+    }
+    auto issue = [&](int t) __attribute__((always_inline)) {
+        unsigned char* stage = smem + (t % T2_NSTAGE) * T2_STAGE;
+        const bool lr = t < r_tiles;
+        const int k0 = lr ? O.seg_lo + t * T2_K : (t - r_tiles) * T2_K;
+        const int k_hi = lr ? O.seg_hi : P->K;
+        const bf16* wsrc = lr ? Rm : wgt;
+        const bf16* asrc = lr ? Lm : act;
+        const int64_t ldw = lr ? P->ldR : P->ld_wgt, lda = lr ? P->ldL : P->ld_act;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const int q = wave * 6 + j;
+            const bool is_w = q < T2_N / 8;  // wave-uniform
+            const int k = k0 + kchunk[j] * 8;
+            const bf16* src = (is_w ? wsrc + grow[j] * ldw : asrc + grow[j] * lda) + k;
+            const void* g = (grow[j] >= 0 && k < k_hi) ? (const void*)src : (const void*)g_zero16;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                             (__attribute__((address_space(3))) void*)(stage + q * 1024), 16, 0, 0);
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int h = lane >> 5, rl32 = lane & 31;
+    // byte offsets of this lane's fragment rows inside a stage (row * 128) and their swizzle
+    int wrow[2], arow[2], wsw[2], asw[2];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+        const int rw = wn * 64 + s2 * 32 + rl32, ra = wm * 64 + s2 * 32 + rl32;
+        wrow[s2] = rw * T2_ROWB;
+        arow[s2] = T2_N * T2_ROWB + ra * T2_ROWB;
+        wsw[s2] = (rw >> 1) & 7;
+        asw[s2] = (ra >> 1) & 7;
+    }
+    auto compute = [&](int t) __attribute__((always_inline)) {
+        const unsigned char* stage = smem + (t % T2_NSTAGE) * T2_STAGE;
+        Frag<bf16> fw[2][2], fa[2][2];  // [sub-tile][32-row block]
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                fw[u][s2].v[0] = *reinterpret_cast<const u32x4*>(stage + wrow[s2] + (((4 * u + h) ^ wsw[s2]) << 4));
+                fw[u][s2].v[1] = *reinterpret_cast<const u32x4*>(stage + wrow[s2] + (((4 * u + 2 + h) ^ wsw[s2]) << 4));
+                fa[u][s2].v[0] = *reinterpret_cast<const u32x4*>(stage + arow[s2] + (((4 * u + h) ^ asw[s2]) << 4));
+                fa[u][s2].v[1] = *reinterpret_cast<const u32x4*>(stage + arow[s2] + (((4 * u + 2 + h) ^ asw[s2]) << 4));
+            }
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int sn = 0; sn < 2; ++sn)
+#pragma unroll
+                for (int sm = 0; sm < 2; ++sm) mtl_mma(fw[u][sn], fa[u][sm], acc[sn][sm]);
+    };
+    auto apply_mask = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int sm = 0; sm < 2; ++sm) {
+            const int64_t m = m0 + wm * 64 + sm * 32 + (lane & 31);
+            const uint32_t rh = mtl_dropout_rowhash(drop, 0u, (uint32_t)m);
+#pragma unroll
+            for (int sn = 0; sn < 2; ++sn)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int n = n0 + wn * 64 + sn * 32 + 8 * q + 4 * (lane >> 5);
+                    const uint32_t h0 = mtl_dropout_pairbits(drop, rh, (uint32_t)n);
+                    const uint32_t h1 = mtl_dropout_pairbits(drop, rh, (uint32_t)(n + 2));
+                    if ((h0 & 0xFFFFu) < drop.thr16) acc[sn][sm][q * 4 + 0] = 0.f;
+                    if ((h0 >> 16) < drop.thr16) acc[sn][sm][q * 4 + 1] = 0.f;
+                    if ((h1 & 0xFFFFu) < drop.thr16) acc[sn][sm][q * 4 + 2] = 0.f;
+                    if ((h1 >> 16) < drop.thr16) acc[sn][sm][q * 4 + 3] = 0.f;
+                }
+        }
+    };
+
+    if (n_t > 0) issue(0);
+    if (n_t > 1) issue(1);
+    for (int t = 0; t < n_t; ++t) {
+        if (t + 1 < n_t)
+            __builtin_amdgcn_s_waitcnt(0x0F76);  // vmcnt(6): this wave's loads of tile t have landed (tile t + 1 may be in flight)
+        else
+            __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+        // (a bare s_barrier: __syncthreads() carries a workgroup fence, for which the compiler drains vmcnt to 0 -- i.e.
+        // also waits for tile t + 1 -- because LDS-DMA loads write LDS)
+        asm volatile("s_barrier" ::: "memory");  // ... and everybody else's; slot (t - 1) % 3 is free again
+        if (t + 2 < n_t) issue(t + 2);
+        compute(t);
+        if constexpr (MLR) {
+            if (t + 1 == r_tiles && O.mask_lr && drop.enabled()) apply_mask();
+        }
+    }
+
+    // acc = acc * alpha[n] + bias[n]
+    if (O.use_base && (P->alpha || P->bias)) {
+#pragma unroll
+        for (int sn = 0; sn < 2; ++sn)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n = n0 + wn * 64 + sn * 32 + 8 * q + 4 * (lane >> 5);
+                if (n < n_rows) {
+                    f32x4 al = {1.f, 1.f, 1.f, 1.f}, bi = {0.f, 0.f, 0.f, 0.f};
+                    if (P->alpha) al = *reinterpret_cast<const f32x4*>(P->alpha + n);
+                    if (P->bias) bi = *reinterpret_cast<const f32x4*>(P->bias + n);
+#pragma unroll
+                    for (int sm = 0; sm < 2; ++sm)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[sn][sm][q * 4 + e] = acc[sn][sm][q * 4 + e] * al[e] + bi[e];
+                }
+            }
+    }
+    __syncthreads();  // all fragment reads done: the ring becomes the per-wave output images
+    bf16* outp = reinterpret_cast<bf16*>(O.ptr);
+    if (!outp || n0 + wn * 64 >= n_rows) return;
+    const bf16* gate = reinterpret_cast<const bf16*>(O.gate);
+    (void)gate;
+    constexpr int ORS = EPI_ROW;
+    unsigned char* img = smem + wave * (64 * ORS);
+#pragma unroll
+    for (int sm = 0; sm < 2; ++sm)
+#pragma unroll
+        for (int sn = 0; sn < 2; ++sn)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int ml = sm * 32 + (lane & 31), nl = sn * 32 + 8 * q + 4 * (lane >> 5);
+                u32x2 pk = {mtl_pack_bf16(acc[sn][sm][q * 4], acc[sn][sm][q * 4 + 1]),
+                            mtl_pack_bf16(acc[sn][sm][q * 4 + 2], acc[sn][sm][q * 4 + 3])};
+                *reinterpret_cast<u32x2*>(img + ml * ORS + nl * 2) = pk;
+            }
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the image is private to this wave
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int ml = it * 8 + (lane >> 3), c16 = lane & 7;
+        const int64_t m = m0 + wm * 64 + ml;
+        const int n = n0 + wn * 64 + c16 * 8;
+        u32x4 v = *reinterpret_cast<const u32x4*>(img + ml * ORS + c16 * 16);
+        if (m < P->M && n < n_rows) {
+            if constexpr (GATE) {
+                if (gate) {
+                    const u32x4 hv = *reinterpret_cast<const u32x4*>(gate + m * P->ld_out + n);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float g0 = __builtin_bit_cast(float, v[q] << 16) * gelu_grad(__builtin_bit_cast(float, hv[q] << 16));
+                        const float g1 = __builtin_bit_cast(float, v[q] & 0xFFFF0000u) *
+                                         gelu_grad(__builtin_bit_cast(float, hv[q] & 0xFFFF0000u));
+                        v[q] = mtl_pack_bf16(g0, g1);
+                    }
+                }
+            }
+            *reinterpret_cast<u32x4*>(outp + m * P->ld_out + n) = v;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // k_tn : Out[a][b] = sum_m SrcA[m][a0 + a] * SrcB[m][b0 + b], split over m.
 // SrcA is always the NARROW (rank-side) operand (Q or P, <= 64 columns per tile) and SrcB the WIDE one
 // (X or dY, 256 columns per tile), so a workgroup streams 64 + 256 columns per row and the wide matrix is
@@ -1046,6 +1274,32 @@ static int nt_waves() {
     return w;
 }
 
+// k_nt2 is OPT-IN (MTLORA_NT2=1: whenever eligible; 2: eligible AND MFMA-dense).  Measured against k_nt on the C2 shapes
+// (tools/one_linear_prof.sh): within +-6 % everywhere (25088 x 384 -> 1536: 66.6 vs 67.2 us; 6272 x 3072 -> 768: 67.1 vs
+// 71.7; 100352 x 272 -> 1080: 190 vs 179) -- both kernels have the same ~650-700 TFLOP/s marginal rate and the same
+// ~20 us of per-launch fixed cost at K = 384 (4.59 residency rounds -> tail, cold start, epilogue), so the load path is
+// not what limits the MFMA-dense launches.  Kept as the base for a persistent / stream-K form.
+static int nt2_mode() {
+    static const int m = [] {
+        const char* e = getenv("MTLORA_NT2");
+        return !e ? 0 : (e[0] == '1' ? 1 : (e[0] == '2' ? 2 : 0));
+    }();
+    return m;
+}
+static bool nt2_wanted(const NtParams& P, int variant, bool fuse) {
+    const int mode = nt2_mode();
+    if (mode == 0 || variant != 2 || fuse || P.nz > 0 || P.n_out != 1 || P.n_act != 1 || P.act_mask) return false;
+    const NtOut& O = P.out[0];
+    const bool has_lr = O.seg_hi > O.seg_lo;
+    if (!O.ptr || (!O.use_base && !has_lr)) return false;
+    if (O.use_base && (P.K <= 0 || (P.ld_act % 8) || (P.ld_wgt % 8))) return false;
+    if (has_lr && ((P.ldL % 8) || (P.ldR % 8) || (O.seg_lo % 8))) return false;
+    if (P.ld_out % 8) return false;
+    if (mode == 1) return true;
+    // dense: enough reduction length and output width that the 128 x 128 kernel's tile loads, not HBM, are the limit
+    return O.use_base && P.K >= 256 && P.n_rows >= 256 && mtl_ceil_div(P.M, T2_M) * mtl_ceil_div(P.n_rows, T2_N) >= 256;
+}
+
 template <typename T>
 static void launch_nt(const NtParams& P, hipStream_t s, int kind, double alg_bytes) {
     mtl_prof_tag("M%lld K%d N%d ldL%lld no%d na%d nz%d", (long long)P.M, P.K, P.n_rows, (long long)P.ldL, P.n_out, P.n_act, P.nz);
@@ -1090,6 +1344,30 @@ static void launch_nt(const NtParams& P, hipStream_t s, int kind, double alg_byt
         gated = gated || P.out[o].gate != nullptr;
     }
     mlr = mlr && P.drop.enabled();
+    if constexpr (sizeof(T) == 2) {
+        if (nt2_wanted(P, variant, fuse)) {  // MFMA-dense lean launches: direct-to-LDS 256 x 128 kernel
+            const int64_t tiles2 = mtl_ceil_div(P.M, T2_M) * mtl_ceil_div(P.n_rows, T2_N);
+#define MTL_NT2_LAUNCH(ML, GA)                                                                                       \
+    do {                                                                                                             \
+        static bool raised2 = false;                                                                                 \
+        if (!raised2) {                                                                                              \
+            (void)hipFuncSetAttribute((const void*)k_nt2<ML, GA>, hipFuncAttributeMaxDynamicSharedMemorySize, T2_LDS); \
+            raised2 = true;                                                                                          \
+        }                                                                                                            \
+        hipLaunchKernelGGL((k_nt2<ML, GA>), dim3((unsigned)tiles2), dim3(512), T2_LDS, s, P);                        \
+    } while (0)
+            if (mlr && gated)
+                MTL_NT2_LAUNCH(true, true);
+            else if (mlr)
+                MTL_NT2_LAUNCH(true, false);
+            else if (gated)
+                MTL_NT2_LAUNCH(false, true);
+            else
+                MTL_NT2_LAUNCH(false, false);
+#undef MTL_NT2_LAUNCH
+            return;
+        }
+    }
     if (gated) {  // dX * gelu'(h) epilogue: the lean (single accumulator set) variants, never the row-panel form
 #define MTL_NT_LAUNCH_G(MSRC, ML)                                                               \
     do {                                                                                        \

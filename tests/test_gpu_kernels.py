@@ -633,6 +633,22 @@ def test_linear_bwd_gelu_fused(dtype, with_tasks):
         assert torch.equal(p0[k], p1[k]), k
 
 
+def test_linear_direct_to_lds_variant():
+    """k_nt2 (opt-in MTLORA_NT2=1: 256 x 128 tiles, global_load_lds tile loads, XOR-swizzled LDS, 3-stage ring) replaces the
+    lean single-output launches: the linear parity tests (oracle, golden shapes, GELU' gate, dropout masks) must pass
+    unchanged with it forced on.  Subprocess: the switch is read once per process."""
+    import os, subprocess, sys
+    if os.environ.get("MTLORA_NT2") == "1":
+        pytest.skip("already running under MTLORA_NT2=1")
+    env = dict(os.environ, MTLORA_NT2="1")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_kernels.py"), "-q", "-x", "-m", "gpu",
+                        "-k", "linear_random_vs_oracle or linear_bwd_gelu or split_reduction or linear_golden"],
+                       env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout
+
+
 def test_linear_fused_projection():
     """Row-panel form of k_nt (projection P / Q formed inside the output kernel, workgroup loops over its n-tiles):
     forward AND backward against the two-pass form, in subprocesses (the switches are read once per process).

@@ -73,6 +73,10 @@ class GradReducer:
                 self._where[p] = (bi, pi)
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
         self._armed = False
+        # streams other than the ambient one on which gradients may be produced (a model that runs independent branches
+        # on side streams): a bucket is packed from an autograd hook whose current stream only orders ITS OWN gradient,
+        # so the pack first waits for these
+        self.extra_streams: List["torch.cuda.Stream"] = []
 
     @property
     def nbytes(self) -> int:
@@ -83,6 +87,8 @@ class GradReducer:
         copies are captured with the backward graph); the collectives are issued afterwards by ``all_reduce_packed``
         outside any graph, and ``unpack`` (capturable) writes the means back."""
         self._defer = defer
+        self._ambient = (torch.cuda.current_stream(self.buckets[0].flat.device)
+                         if self.buckets and self.buckets[0].flat.is_cuda else None)
         for b in self.buckets:
             b.pending = len(b.params)
             b.handle = None
@@ -92,6 +98,11 @@ class GradReducer:
 
     def _pack(self, b: _Bucket) -> None:
         """gather the bucket's gradients into its flat buffer: ONE multi-tensor copy (not one kernel per parameter)."""
+        if self.extra_streams and b.flat.is_cuda:
+            cur = torch.cuda.current_stream(b.flat.device)
+            for st in list(self.extra_streams) + ([self._ambient] if getattr(self, "_ambient", None) is not None else []):
+                if st != cur:
+                    cur.wait_stream(st)
         dst, src = [], []
         for pi, p in enumerate(b.params):
             view = b.flat[b.offsets[pi]:b.offsets[pi] + p.numel()]

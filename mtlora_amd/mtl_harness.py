@@ -17,6 +17,8 @@ import contextlib
 
 from typing import Dict, List, Mapping, Optional, Sequence
 
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -50,6 +52,9 @@ def mtlora_namespace(tasks: Sequence[str], r_shared=64, r_task=4, scale=4.0, dro
 
 
 # --------------------------------------------------------------------------------------------------
+_TASK_STREAMS = os.environ.get("MTLORA_TASK_STREAMS", "1") != "0"
+
+
 class Downsampler(nn.Module):
     """tokens (B, L_i, C_i) of the four stages -> NCHW maps through four bias-free 1x1 convs (swin_mtl.py:88-135).
     A 1x1 convolution on a token tensor is a per-token linear map, so it is evaluated as ``F.linear`` on the
@@ -133,12 +138,13 @@ class DecoderGroup(nn.Module):
         self.tasks, self.out_size = tasks, out_size
         self.decoders = nn.ModuleDict({t: HighResolutionHead(channels, num_outputs[t]) for t in tasks})
 
-    def forward(self, x, upsample: bool = True):
+    def forward(self, x, upsample: bool = True, tasks=None):
         """upsample=False: the low-resolution (B, h, w, C) predictions, for ``MultiTaskLoss.forward_low`` (the final
         bilinear upsample is fused into the loss kernels and never materialised)."""
+        tasks = self.tasks if tasks is None else tasks
         if not upsample:
-            return {t: self.decoders[t](x[t], channels_last_out=True) for t in self.tasks}
-        return {t: F.interpolate(self.decoders[t](x[t]), self.out_size, mode="bilinear") for t in self.tasks}
+            return {t: self.decoders[t](x[t], channels_last_out=True) for t in tasks}
+        return {t: F.interpolate(self.decoders[t](x[t]), self.out_size, mode="bilinear") for t in tasks}
 
 
 class MultiTaskSwin(nn.Module):
@@ -158,10 +164,46 @@ class MultiTaskSwin(nn.Module):
         self.downsampler = nn.ModuleDict({t: Downsampler(self.dims, decoder_channels, self.input_res) for t in self.tasks})
         self.decoders = DecoderGroup(self.tasks, num_outputs, decoder_channels, self.img_size)
 
-    def forward(self, x, upsample: bool = True):
+    def task_streams(self, device):
+        """one side stream per task (created once per device): the per-task Downsampler + head (+ fused loss) chains are
+        independent, and half of their kernels are latency-bound (fused loss, upsample gathers, small GEMMs, reductions) --
+        running the chains concurrently lets those hide under the other heads' bandwidth-bound GEMM / BatchNorm passes."""
+        key = str(device)
+        if getattr(self, "_streams_key", None) != key:
+            self._streams = [torch.cuda.Stream(device=device) for _ in self.tasks]
+            self._streams_key = key
+        return self._streams
+
+    def forward(self, x, upsample: bool = True, per_task_fn=None, concurrent: Optional[bool] = None):
+        """per_task_fn(task, prediction) -> tensor: applied to each head's output inside that task's stream (train_step
+        passes the fused per-task loss), its results are returned instead of the predictions.
+        concurrent (default: MTLORA_TASK_STREAMS != 0, CUDA, grad mode): heads on per-task side streams; the outputs are
+        joined back into the caller's stream before returning."""
         stages = self.backbone(x, return_stages=True)
-        feats = {t: self.downsampler[t]([tl[t] for _, tl in stages]) for t in self.tasks}
-        return self.decoders(feats, upsample=upsample)
+        if concurrent is None:
+            concurrent = (x.is_cuda and _TASK_STREAMS and len(self.tasks) > 1 and torch.is_grad_enabled()
+                          and not torch.cuda.is_current_stream_capturing())
+        if not concurrent:
+            feats = {t: self.downsampler[t]([tl[t] for _, tl in stages]) for t in self.tasks}
+            out = self.decoders(feats, upsample=upsample)
+            return out if per_task_fn is None else {t: per_task_fn(t, out[t]) for t in self.tasks}
+        main = torch.cuda.current_stream(x.device)
+        streams = self.task_streams(x.device)
+        out = {}
+        for t, st in zip(self.tasks, streams):
+            ins = [tl[t] for _, tl in stages]
+            st.wait_stream(main)
+            with torch.cuda.stream(st):
+                for f in ins:
+                    f.record_stream(st)  # allocated on the caller's stream, read (and saved for backward) on the side stream
+                y = self.decoders({t: self.downsampler[t](ins)}, upsample=upsample, tasks=[t])[t]
+                if per_task_fn is not None:
+                    y = per_task_fn(t, y)
+                y.record_stream(main)
+            out[t] = y
+        for st in streams:
+            main.wait_stream(st)
+        return out
 
 
 # --------------------------------------------------------------------------------------------------
@@ -203,23 +245,26 @@ class MultiTaskLoss(nn.Module):
 
     FUSED_KIND = {"semseg": "softmax", "human_parts": "softmax", "normals": "normals", "sal": "balanced_bce"}
 
+    def task_low(self, t, lo, lab):
+        """loss of task t from its LOW-resolution (B, h, w, C) prediction (fused upsample + loss + backward where it applies)"""
+        h, w = lo.shape[1:3]
+        H, W = lab.shape[-2:]
+        kind = self.FUSED_KIND.get(t)
+        if kind is not None and lo.is_cuda and H % h == 0 and W % w == 0 and H // h == W // w:
+            return UpsampleLossFn.apply(kind, lo, lab, H // h)
+        return task_loss(t, F.interpolate(lo.permute(0, 3, 1, 2), (H, W), mode="bilinear"), lab)
+
+    def combine(self, per):
+        per = dict(per)
+        total = torch.stack([self.loss_weights[t] * per[t] for t in self.tasks]).sum()
+        per["total"] = total
+        return total, per
+
     def forward_low(self, low, gt):
         """same value and gradients as ``forward(upsampled prediction, gt)`` from the LOW-resolution (B, h, w, C)
         predictions of ``model(x, upsample=False)``: bilinear upsample + loss + backward fused (csrc/loss.hip).
         Tasks without a fused kernel (depth, edge) and non-integer scales take the plain path."""
-        per = {}
-        for t in self.tasks:
-            lo, lab = low[t], gt[t]
-            h, w = lo.shape[1:3]
-            H, W = lab.shape[-2:]
-            kind = self.FUSED_KIND.get(t)
-            if kind is not None and lo.is_cuda and H % h == 0 and W % w == 0 and H // h == W // w:
-                per[t] = UpsampleLossFn.apply(kind, lo, lab, H // h)
-            else:
-                per[t] = task_loss(t, F.interpolate(lo.permute(0, 3, 1, 2), (H, W), mode="bilinear"), lab)
-        total = torch.stack([self.loss_weights[t] * per[t] for t in self.tasks]).sum()
-        per["total"] = total
-        return total, per
+        return self.combine({t: self.task_low(t, low[t], gt[t]) for t in self.tasks})
 
 
 # --------------------------------------------------------------------------------------------------
@@ -296,7 +341,10 @@ def train_step(model, criterion, optimizer, images, targets, clip_grad: float = 
     [gradient all-reduce], clip_grad_norm_(5.0), AdamW, zero_grad.  bf16 autocast needs no GradScaler
     (the reference's scaler exists for its fp16 default)."""
     def fwd():
-        if fused_loss:  # final upsample + losses (+ their backward) as one kernel per task
+        if fused_loss:  # final upsample + losses (+ their backward) as one kernel per task, inside the task's stream
+            if isinstance(model, MultiTaskSwin):
+                return criterion.combine(model(images, upsample=False,
+                                               per_task_fn=lambda t, lo: criterion.task_low(t, lo, targets[t])))
             return criterion.forward_low(model(images, upsample=False), targets)
         return criterion(model(images), targets)
 
@@ -306,6 +354,8 @@ def train_step(model, criterion, optimizer, images, targets, clip_grad: float = 
     else:
         loss, per = fwd()
     if reducer is not None:
+        if isinstance(model, MultiTaskSwin) and getattr(model, "_streams", None):
+            reducer.extra_streams = list(model._streams)  # gradients of the heads are produced on the per-task streams
         reducer.prepare()
     loss.backward()
     if reducer is not None:

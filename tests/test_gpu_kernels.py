@@ -1029,6 +1029,35 @@ def test_full_model_loss_and_gradients_vs_oracle():
     assert checked > 200
 
 
+def test_task_streams_match_single_stream():
+    """MultiTaskSwin runs the per-task Downsampler + head + fused-loss chains on one side stream per task: loss and every
+    gradient must equal the single-stream execution bit for bit (same kernels, same order within a chain), twice in a row
+    (the second step reuses the caching allocator's blocks across streams)."""
+    from mtlora_amd import mtl_harness as H
+    tasks = ["semseg", "normals", "sal", "human_parts"]
+    img, tg = H.synthetic_batch(2, 224, tasks, seed=7, device=dev())
+    res = []
+    for conc in (False, True):
+        model = H.build_model(img_size=224, tasks=tasks, depths=(2, 2, 2, 2), r_shared=16, r_task=4, drop_path_rate=0.0, seed=3,
+                              DROPOUT=[0.0] * 4).to(dev()).train()
+        crit = H.MultiTaskLoss(tasks)
+        steps = []
+        for _ in range(2):
+            model.zero_grad(set_to_none=True)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                loss, _ = crit.combine(model(img, upsample=False, per_task_fn=lambda t, lo: crit.task_low(t, lo, tg[t]),
+                                             concurrent=conc))
+            loss.backward()
+            torch.cuda.synchronize()
+            steps.append((loss.detach().clone(), {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}))
+        res.append(steps)
+    for (l0, g0), (l1, g1) in zip(*res):
+        assert torch.equal(l0, l1)
+        assert g0.keys() == g1.keys() and len(g0) > 200
+        for n in g0:
+            assert torch.equal(g0[n], g1[n]), n
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("M,Na,Nb", [(20000, 24, 1080), (4099, 8, 264), (70001, 136, 40), (300, 64, 256), (0, 8, 8)])
 def test_gemm_tn_vs_torch(dtype, M, Na, Nb):

@@ -98,6 +98,11 @@ def roofline(step_fn, steps):
     import ctypes
     from mtlora_amd import _lib as L
     lib = L.lib()
+    # single stream while profiling: with the per-task head streams on, kernels of different heads overlap and an event
+    # bracket then measures the overlapped neighbours too (the timed region above keeps the streams on)
+    from mtlora_amd import mtl_harness as H
+    streams_on, H._TASK_STREAMS = H._TASK_STREAMS, False
+    step_fn()
     torch.cuda.synchronize()
     L.check(lib.mtlora_prof_begin(200000), "prof_begin")
     for _ in range(steps):
@@ -105,6 +110,7 @@ def roofline(step_fn, steps):
     torch.cuda.synchronize()
     s = L.ProfSummary()
     L.check(lib.mtlora_prof_end(ctypes.byref(s)), "prof_end")
+    H._TASK_STREAMS = streams_on
     kinds = {}
     for k in range(L.PROF_KINDS):
         if s.count[k]:
@@ -238,7 +244,7 @@ def main():
             # profiled EAGERLY: the library's HIP-event brackets are recorded at launch time (same kernels as the graph)
             result["roofline"] = roofline(eager_step, max(2, min(args.steps, 5)))
         elif not args.no_roofline and world > 1:
-            for _ in range(max(2, min(args.steps, 5))):  # keep ranks in lock-step with rank 0's profiled steps
+            for _ in range(1 + max(2, min(args.steps, 5))):  # keep ranks in lock-step with rank 0's profiled steps
                 eager_step()
         del model, opt
         torch.cuda.empty_cache()

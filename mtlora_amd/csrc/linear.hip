@@ -1758,9 +1758,13 @@ static int bwd_impl(const mtlora_linear_desc* d, const void* x, const void* cons
             O.seg_lo = 0;
             O.seg_hi = sg.R;
         }
-        if (dx)
+        if (dx) {
+            int n_gate = 0;  // the fused GELU backward reads the pre-activation of every gated output (algorithmic: gelu'(h) needs h)
+            for (int o = 0; o < m.n_out; ++o) n_gate += m.out[o].gate ? 1 : 0;
             launch_nt<T>(m, s, PK_NT_BWD_DX,
-                         (double)sizeof(T) * d->M * ((double)n_dy * d->N + (double)(1 + (d->has_x_tasks ? d->T : 0)) * d->K));
+                         (double)sizeof(T) * d->M *
+                             ((double)n_dy * d->N + (double)(1 + (d->has_x_tasks ? d->T : 0) + n_gate) * d->K));
+        }
     }
 
     // dA_o = Q_o^T D(X_o),  dB_o = dY_o^T P_o

@@ -4,6 +4,8 @@
 set -e
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 FILT=${1:-k_}
+# single stream: per-kernel durations / counters are attributed cleanly only when the heads' task streams do not overlap
+export MTLORA_TASK_STREAMS=${MTLORA_TASK_STREAMS:-0}
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/tr
 timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/tr -- python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > /tmp/tr.log 2>&1 || { tail -5 /tmp/tr.log; exit 1; }

@@ -199,6 +199,8 @@ def main():
     from mtlora_amd import mtl_harness as H
     from mtlora_amd.ddp import GradReducer
     L.lib()  # fail loudly if the HIP extension is missing
+    if world > 1:  # N ranks share one host: keep each rank's intra-op CPU pool small (the step has no CPU-side compute)
+        torch.set_num_threads(max(1, min(4, usable_cores() // world)))
 
     result = {}
     if True:

@@ -626,7 +626,9 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void k_nt(const NtParams 
                             }
                         }
                     }
-                    *reinterpret_cast<u32x4*>(outp + m * P->ld_out + row_off + n) = v;
+                    // non-temporal: the 77 - 308 MB outputs of a launch outlive L2 / MALL anyway (+1 % on the step; the same hint
+                    // on the glue kernels' stores costs 1.5 %: their consumers do hit in cache)
+                    __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(outp + m * P->ld_out + row_off + n));
                 }
             }
             __builtin_amdgcn_wave_barrier();

@@ -616,7 +616,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void k_nt(const NtParams 
                 if (m < P->M && n < n_rows) {
                     if constexpr (GATE) {
                         if (gate) {  // the bf16-rounded gradient times gelu'(pre-activation), rounded once (as ATen does)
-                            const u32x4 hv = *reinterpret_cast<const u32x4*>(gate + m * P->ld_out + row_off + n);
+                            const u32x4 hv = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(gate + m * P->ld_out + row_off + n));
 #pragma unroll
                             for (int q = 0; q < 4; ++q) {
                                 const float g0 = __builtin_bit_cast(float, v[q] << 16) * gelu_grad(__builtin_bit_cast(float, hv[q] << 16));
@@ -1110,7 +1110,7 @@ __global__ __launch_bounds__(256, 2) void k_tn(const TnParams P) {
 #pragma unroll
         for (int j = 0; j < NLB; ++j) {
             const int64_t m = mrow + rowB + j * RSB;
-            rb[j] = (b_in && m < m_hi) ? *reinterpret_cast<const u32x4*>(Bp + m * pr.ldb) : u32x4{0u, 0u, 0u, 0u};
+            rb[j] = (b_in && m < m_hi) ? __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(Bp + m * pr.ldb)) : u32x4{0u, 0u, 0u, 0u};
         }
     };
     auto stage = [&](u32x4* ra, u32x4* rb, int64_t mrow) __attribute__((always_inline)) {

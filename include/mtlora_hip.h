@@ -117,6 +117,14 @@ int mtlora_linear_bwd(const mtlora_linear_desc* d, const void* x, const void* co
                       void* const* dx_t, float* dA_s, float* dB_s, float* const* dA_t, float* const* dB_t,
                       void* scratch, int64_t scratch_bytes, void* stream);
 
+/* mtlora_linear_fwd that ALSO writes a_s = gelu(y_s), a_t[t] = gelu(y_t[t]) (exact erf form; same shape / dtype as the
+ * outputs) from the output epilogue -- the Mlp's fc1 followed by its activation (swin_transformer_mtlora.py:57-78):
+ * replaces the separate aten::gelu pass (read h, write a) by one extra write. */
+int mtlora_linear_fwd_gelu(const mtlora_linear_desc* d, const void* x, const void* const* x_t, const void* W,
+                           const float* bias, const float* A_s, const float* B_s, const float* const* A_t,
+                           const float* const* B_t, void* y_s, void* const* y_t, void* a_s, void* const* a_t, void* ctx,
+                           int64_t ctx_bytes, void* stream);
+
 /* mtlora_linear_bwd for a layer whose inputs are x = gelu(h_s), x_t[t] = gelu(h_t[t]) (the Mlp's fc2,
  * swin_transformer_mtlora.py:57-78: fc1 -> GELU -> fc2): dx and dx_t[t] are additionally multiplied by the exact-erf
  * GELU derivative gelu'(h) = Phi(h) + h phi(h) at the pre-activations (M x K, dtype of x), i.e. they are the gradients

@@ -62,6 +62,9 @@ _SIGS = {
     "mtlora_gemm_tn_scratch_bytes": (c_int64, [c_int64, c_int, c_int]),
     "mtlora_gemm_tn": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int64, c_int64, c_int, c_void_p, c_int64,
                                c_void_p]),
+    "mtlora_linear_fwd_gelu": (c_int, [POINTER(LinearDesc), c_void_p, POINTER(c_void_p), c_void_p, c_void_p, c_void_p, c_void_p,
+                                       POINTER(c_void_p), POINTER(c_void_p), c_void_p, POINTER(c_void_p), c_void_p,
+                                       POINTER(c_void_p), c_void_p, c_int64, c_void_p]),
     "mtlora_linear_bwd_gelu": (c_int, [POINTER(LinearDesc), c_void_p, POINTER(c_void_p), c_void_p, c_void_p, POINTER(c_void_p),
                                        c_void_p, c_int64, c_void_p, POINTER(c_void_p), c_void_p, c_void_p, POINTER(c_void_p),
                                        POINTER(c_void_p), c_void_p, c_int64, c_void_p, POINTER(c_void_p), c_void_p]),

@@ -138,6 +138,7 @@ struct NtOut {
     int mask_lr;     // multiply the low-rank part by the dropout keep mask of (m, n)
     int fold;        // after storing: base += low-rank part ('matrixv2': tasks see the shared update)
     const void* gate;  // GATE kernels: out *= gelu'(gate[m][n]) (same shape / dtype / row stride as the output), nullable
+    void* act;         // ACT kernels: second output gelu(out) (same shape / dtype / row stride), nullable
 };
 
 struct NtParams {
@@ -339,6 +340,7 @@ __device__ __forceinline__ NtOut nt_out(NtPtr P, int o) {
     O.mask_lr = P->out[o].mask_lr;
     O.fold = P->out[o].fold;
     O.gate = P->out[o].gate;
+    O.act = P->out[o].act;
     return O;
 }
 
@@ -432,7 +434,20 @@ __device__ __forceinline__ float gelu_grad(float h) {
     return cdf + h * e * 0.39894228040143268f;
 }
 
-template <typename T, bool MULTI, bool MS, bool FUSE, bool MLR, int NW, bool GATE = false>
+// exact (erf) GELU with the same erf: h * Phi(h)
+__device__ __forceinline__ float gelu_fwd(float h) {
+    const float z = fabsf(h) * 0.70710678118654752f;
+    const float t = __builtin_amdgcn_rcpf(1.f + 0.3275911f * z);
+    float p = 1.061405429f;
+    p = p * t - 1.453152027f;
+    p = p * t + 1.421413741f;
+    p = p * t - 0.284496736f;
+    p = p * t + 0.254829592f;
+    const float erf_abs = 1.f - p * t * __expf(-z * z);
+    return h * (0.5f + 0.5f * copysignf(erf_abs, h));
+}
+
+template <typename T, bool MULTI, bool MS, bool FUSE, bool MLR, int NW, bool GATE = false, bool ACT = false>
 __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void k_nt(const NtParams Pv) {
     constexpr int SM = 8 / NW;       // 32-row m sub-blocks per wave
     constexpr int MW = 32 * SM;      // m rows per wave
@@ -583,10 +598,12 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void k_nt(const NtParams 
                 }
         }
     };
-    auto store = [&](const f32x16(&a)[2][SM], void* ptr, const void* gate_ptr) __attribute__((always_inline)) {
+    auto store = [&](const f32x16(&a)[2][SM], void* ptr, const void* gate_ptr, void* act_ptr) __attribute__((always_inline)) {
         T* outp = reinterpret_cast<T*>(ptr);
         const T* gate = reinterpret_cast<const T*>(gate_ptr);
+        T* actp = reinterpret_cast<T*>(act_ptr);
         (void)gate;
+        (void)actp;
         if (!outp || n0 + wn * 64 >= n_rows) return;  // (the per-wave LDS image needs no workgroup barrier)
         if constexpr (sizeof(T) == 2) {
             // bf16: transpose the wave's 64(n) x 64(m) accumulator tile through LDS so that every store instruction
@@ -629,6 +646,16 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void k_nt(const NtParams 
                     // non-temporal: the 77 - 308 MB outputs of a launch outlive L2 / MALL anyway (+1 % on the step; the same hint
                     // on the glue kernels' stores costs 1.5 %: their consumers do hit in cache)
                     __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(outp + m * P->ld_out + row_off + n));
+                    if constexpr (ACT) {
+                        if (actp) {  // second output: GELU of the bf16-rounded value, rounded once (ATen's gelu on the bf16 tensor)
+                            u32x4 av;
+#pragma unroll
+                            for (int q = 0; q < 4; ++q)
+                                av[q] = mtl_pack_bf16(gelu_fwd(__builtin_bit_cast(float, v[q] << 16)),
+                                                      gelu_fwd(__builtin_bit_cast(float, v[q] & 0xFFFF0000u)));
+                            __builtin_nontemporal_store(av, reinterpret_cast<u32x4*>(actp + m * P->ld_out + row_off + n));
+                        }
+                    }
                 }
             }
             __builtin_amdgcn_wave_barrier();
@@ -652,6 +679,14 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void k_nt(const NtParams 
                                 }
                             }
                             *reinterpret_cast<f32x4*>(dst) = o4;
+                            if constexpr (ACT) {
+                                if (actp) {
+                                    f32x4 a4;
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) a4[e] = gelu_fwd(o4[e]);
+                                    *reinterpret_cast<f32x4*>(actp + m * P->ld_out + row_off + n) = a4;
+                                }
+                            }
                         }
                     }
             }
@@ -716,7 +751,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void k_nt(const NtParams 
 #pragma unroll
                         for (int j = 0; j < SM; ++j) base[i][j] = acc[i][j];
                 }
-                store(acc, O.ptr, O.gate);
+                store(acc, O.ptr, O.gate, O.act);
                 __syncthreads();  // the output image lives in the staging buffers
             }
         }
@@ -740,7 +775,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void k_nt(const NtParams 
                 }
                 run_part(np + 2 * o + 1, acc);
                 if (O.use_base) affine(acc);
-                store(acc, O.ptr, O.gate);
+                store(acc, O.ptr, O.gate, O.act);
                 __syncthreads();  // the output image lives in the staging buffers
             }
         }
@@ -1346,6 +1381,17 @@ static void launch_nt(const NtParams& P, hipStream_t s, int kind, double alg_byt
         gated = gated || P.out[o].gate != nullptr;
     }
     mlr = mlr && P.drop.enabled();
+    bool acted = false;
+    for (int o = 0; o < P.n_out; ++o) acted = acted || P.out[o].act != nullptr;
+    if (acted) {  // forward outputs with the GELU second output (fc1 of the Mlp): lean or MULTI, never the row-panel form
+        if (variant == 0)
+            hipLaunchKernelGGL((k_nt<T, true, false, false, false, 4, false, true>), g, dim3(256), lds, s, P);
+        else if (sizeof(T) == 2 && nt_waves() == 8)
+            hipLaunchKernelGGL((k_nt<T, false, false, false, false, 8, false, true>), g, dim3(512), lds, s, P);
+        else
+            hipLaunchKernelGGL((k_nt<T, false, false, false, false, 4, false, true>), g, dim3(256), lds, s, P);
+        return;
+    }
     if constexpr (sizeof(T) == 2) {
         if (nt2_wanted(P, variant, fuse)) {  // MFMA-dense lean launches: direct-to-LDS 256 x 128 kernel
             const int64_t tiles2 = mtl_ceil_div(P.M, T2_M) * mtl_ceil_div(P.n_rows, T2_N);
@@ -1436,7 +1482,8 @@ static int fuse_groups(const mtlora_linear_desc* d, const Segs& sg, int64_t out_
 template <typename T>
 static int fwd_impl(const mtlora_linear_desc* d, const void* x, const void* const* x_t, const void* W,
                     const float* bias, const float* A_s, const float* B_s, const float* const* A_t,
-                    const float* const* B_t, void* y_s, void* const* y_t, void* ctx, hipStream_t s) {
+                    const float* const* B_t, void* y_s, void* const* y_t, void* ctx, hipStream_t s, void* a_s = nullptr,
+                    void* const* a_t = nullptr) {
     const Segs sg = make_segs(d);
     const CtxLayout L = ctx_layout(d, sg);
     unsigned char* c = reinterpret_cast<unsigned char*>(ctx);
@@ -1478,7 +1525,7 @@ static int fwd_impl(const mtlora_linear_desc* d, const void* x, const void* cons
                                alpha);
         }
 
-        groups = fuse_groups(d, sg, d->N);
+        groups = a_s ? 0 : fuse_groups(d, sg, d->N);
         fuse = groups > 0;
         if (!fuse) {
             // P = alpha * D(X) A^T  (per source)
@@ -1542,6 +1589,7 @@ static int fwd_impl(const mtlora_linear_desc* d, const void* x, const void* cons
         O.use_base = 1;
         O.mask_lr = 0;
         O.fold = (o == 0 && d->mode == 1 && d->T > 0) ? 1 : 0;
+        O.act = (o == 0) ? a_s : (a_t ? a_t[o - 1] : nullptr);
     }
     if (fuse) {
         m.pA = a_cat;
@@ -1569,7 +1617,9 @@ static int fwd_impl(const mtlora_linear_desc* d, const void* x, const void* cons
         }
     }
     const double xt_bytes = fuse ? (double)sizeof(T) * (d->has_x_tasks ? d->T : 0) * d->M * d->K : 0.0;
-    launch_nt<T>(m, s, PK_NT_FWD_MAIN, (double)sizeof(T) * d->M * (d->K + (double)(1 + d->T) * d->N) + xt_bytes);
+    int n_actout = 0;  // GELU second outputs: one more M x N write each
+    for (int o = 0; o < m.n_out; ++o) n_actout += m.out[o].act ? 1 : 0;
+    launch_nt<T>(m, s, PK_NT_FWD_MAIN, (double)sizeof(T) * d->M * (d->K + (double)(1 + d->T + n_actout) * d->N) + xt_bytes);
     return MTLORA_OK;
 }
 
@@ -1859,10 +1909,10 @@ int64_t mtlora_linear_bwd_scratch_bytes(const mtlora_linear_desc* d) {
     return bwd_scratch(d, sg).total + 256;
 }
 
-int mtlora_linear_fwd(const mtlora_linear_desc* d, const void* x, const void* const* x_t, const void* W,
-                      const float* bias, const float* A_s, const float* B_s, const float* const* A_t,
-                      const float* const* B_t, void* y_s, void* const* y_t, void* ctx, int64_t ctx_bytes,
-                      void* stream) {
+static int linear_fwd_entry(const mtlora_linear_desc* d, const void* x, const void* const* x_t, const void* W,
+                            const float* bias, const float* A_s, const float* B_s, const float* const* A_t,
+                            const float* const* B_t, void* y_s, void* const* y_t, void* a_s, void* const* a_t, void* ctx,
+                            int64_t ctx_bytes, void* stream) {
     int st = check_desc(d);
     if (st != MTLORA_OK) return st;
     if (!x || !W || !y_s) return MTLORA_ERR_NULL;
@@ -1883,12 +1933,32 @@ int mtlora_linear_fwd(const mtlora_linear_desc* d, const void* x, const void* co
     if (d->M == 0) return MTLORA_OK;
     hipStream_t s = (hipStream_t)stream;
     if (d->dtype == MTLORA_F32)
-        st = fwd_impl<float>(d, x, x_t, W, bias, A_s, B_s, A_t, B_t, y_s, y_t, ctx, s);
+        st = fwd_impl<float>(d, x, x_t, W, bias, A_s, B_s, A_t, B_t, y_s, y_t, ctx, s, a_s, a_t);
     else
-        st = fwd_impl<bf16>(d, x, x_t, W, bias, A_s, B_s, A_t, B_t, y_s, y_t, ctx, s);
+        st = fwd_impl<bf16>(d, x, x_t, W, bias, A_s, B_s, A_t, B_t, y_s, y_t, ctx, s, a_s, a_t);
     if (st != MTLORA_OK) return st;
     MTL_CHECK_LAUNCH();
     return MTLORA_OK;
+}
+
+int mtlora_linear_fwd(const mtlora_linear_desc* d, const void* x, const void* const* x_t, const void* W,
+                      const float* bias, const float* A_s, const float* B_s, const float* const* A_t,
+                      const float* const* B_t, void* y_s, void* const* y_t, void* ctx, int64_t ctx_bytes,
+                      void* stream) {
+    return linear_fwd_entry(d, x, x_t, W, bias, A_s, B_s, A_t, B_t, y_s, y_t, nullptr, nullptr, ctx, ctx_bytes, stream);
+}
+
+int mtlora_linear_fwd_gelu(const mtlora_linear_desc* d, const void* x, const void* const* x_t, const void* W,
+                           const float* bias, const float* A_s, const float* B_s, const float* const* A_t,
+                           const float* const* B_t, void* y_s, void* const* y_t, void* a_s, void* const* a_t, void* ctx,
+                           int64_t ctx_bytes, void* stream) {
+    if (!a_s) return MTLORA_ERR_NULL;
+    if (misaligned(a_s)) return MTLORA_ERR_ALIGN;
+    for (int t = 0; t < d->T; ++t) {
+        if (!a_t || !a_t[t]) return MTLORA_ERR_NULL;
+        if (misaligned(a_t[t])) return MTLORA_ERR_ALIGN;
+    }
+    return linear_fwd_entry(d, x, x_t, W, bias, A_s, B_s, A_t, B_t, y_s, y_t, a_s, a_t, ctx, ctx_bytes, stream);
 }
 
 static int linear_bwd_entry(const mtlora_linear_desc* d, const void* x, const void* const* x_t, const void* Wt,

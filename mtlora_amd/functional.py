@@ -75,6 +75,7 @@ class LinearMeta:
     weight_requires_grad: bool = False
     n_scale_t: int = 0        # >0: per-task scales are trainable Parameters passed after B_t
     n_gate: int = 0           # >0: x (and x_t) = gelu(gate): the LAST n_gate args are the pre-activations; dx *= gelu'(gate)
+    gelu_out: bool = False    # also return gelu(y) for every output (fc1 of the Mlp): outputs = (y_s, *y_t, a_s, *a_t)
 
     @property
     def T(self) -> int:
@@ -129,10 +130,19 @@ class MTLoRALinearFn(torch.autograd.Function):
         fl = lambda p: None if p is None else p.detach().float().contiguous()
         A_s_c, B_s_c = fl(A_s), fl(B_s)
         A_t_c, B_t_c = [fl(a) for a in A_t], [fl(b) for b in B_t]
-        st = lib.mtlora_linear_fwd(ctypes.byref(d), L.ptr(x2), L.ptr_array(xt2), L.ptr(W_c), L.ptr(bias_f32),
-                                   L.ptr(A_s_c), L.ptr(B_s_c), L.ptr_array(A_t_c), L.ptr_array(B_t_c), L.ptr(ys),
-                                   L.ptr_array(yt), L.ptr(ctxbuf), ctx_bytes, L.stream_ptr())
-        L.check(st, "mtlora_linear_fwd")
+        acts = []
+        if meta.gelu_out:  # second outputs gelu(y) written by the same epilogue (mtlora_linear_fwd_gelu)
+            acts = [torch.empty((M, meta.N), dtype=meta.dtype, device=x.device) for _ in range(1 + T)]
+            st = lib.mtlora_linear_fwd_gelu(ctypes.byref(d), L.ptr(x2), L.ptr_array(xt2), L.ptr(W_c), L.ptr(bias_f32),
+                                            L.ptr(A_s_c), L.ptr(B_s_c), L.ptr_array(A_t_c), L.ptr_array(B_t_c), L.ptr(ys),
+                                            L.ptr_array(yt), L.ptr(acts[0]), L.ptr_array(acts[1:]), L.ptr(ctxbuf), ctx_bytes,
+                                            L.stream_ptr())
+            L.check(st, "mtlora_linear_fwd_gelu")
+        else:
+            st = lib.mtlora_linear_fwd(ctypes.byref(d), L.ptr(x2), L.ptr_array(xt2), L.ptr(W_c), L.ptr(bias_f32),
+                                       L.ptr(A_s_c), L.ptr(B_s_c), L.ptr_array(A_t_c), L.ptr_array(B_t_c), L.ptr(ys),
+                                       L.ptr_array(yt), L.ptr(ctxbuf), ctx_bytes, L.stream_ptr())
+            L.check(st, "mtlora_linear_fwd")
         ctx.meta, ctx.lead, ctx.nx = meta, lead, nx
         ctx.in_dtypes = [x.dtype] + [t.dtype for t in x_t]
         gates = []
@@ -143,13 +153,18 @@ class MTLoRALinearFn(torch.autograd.Function):
         ctx.save_for_backward(x2, Wt_c, ctxbuf, *xt2, *gates)
         ctx.keep = (A_s_c, B_s_c, A_t_c, B_t_c)  # fp32 factor views (also used for the trainable-scale gradients)
         ctx.has_scale_s = scale_s_param is not None
-        outs = [ys.reshape(*lead, meta.N)] + [y.reshape(*lead, meta.N) for y in yt]
+        outs = [ys.reshape(*lead, meta.N)] + [y.reshape(*lead, meta.N) for y in yt] + [a.reshape(*lead, meta.N) for a in acts]
         return tuple(outs)
 
     @staticmethod
     def backward(ctx, *grads):
         meta: LinearMeta = ctx.meta
         T, nx = meta.T, ctx.nx
+        if meta.gelu_out:
+            # a gradient arriving on a_k = gelu(y_k) comes from a consumer that already applied gelu'(y_k) (an MTLoRALinear
+            # called with gelu_gate = y_k): it IS a gradient w.r.t. y_k
+            gy, ga = grads[:1 + T], grads[1 + T:]
+            grads = tuple(a if y is None else (y if a is None else y + a) for y, a in zip(gy, ga))
         if all(g is None for g in grads):
             return (None,) * (10 + nx + 2 * T + meta.n_scale_t + meta.n_gate)
         x2, Wt_c, ctxbuf, *xt2 = ctx.saved_tensors

@@ -118,10 +118,13 @@ class MTLoRALinear(LoRALayer):
         self._wcache = {}
         return super()._apply(fn, *a, **k)
 
-    def forward(self, x: torch.Tensor, x_tasks: Optional[Dict[str, torch.Tensor]] = None, gelu_gate=None
+    def forward(self, x: torch.Tensor, x_tasks: Optional[Dict[str, torch.Tensor]] = None, gelu_gate=None, gelu_out: bool = False
                 ) -> Tuple[torch.Tensor, Optional[Dict[str, torch.Tensor]]]:
-        """gelu_gate = (h, {task: h_t} or None): x = gelu(h) and x_tasks[t] = gelu(h_t) were produced by
-        ``Fn.GeluDeferredGradFn`` (identity backward); this layer's backward then returns the gradients w.r.t. h."""
+        """gelu_gate = (h, {task: h_t} or None): x = gelu(h) and x_tasks[t] = gelu(h_t) came from a deferred-gradient GELU
+        (``gelu_out`` of the producing layer, or ``Fn.GeluDeferredGradFn``: identity backward); this layer's backward then
+        returns the gradients w.r.t. h.
+        gelu_out=True: returns ``(y, y_tasks, gelu(y), {t: gelu(y_tasks[t])})``, the activations written by the same kernel;
+        a gradient reaching them is taken as a gradient w.r.t. y (see ``gelu_gate``): only for that pairing."""
         Fn.L.require_gpu(x)
         dtype = Fn.compute_dtype(x)
         wc, wt, bf = self._weights(dtype)
@@ -141,6 +144,10 @@ class MTLoRALinear(LoRALayer):
             has_x_tasks=bool(tasks) and x_tasks is not None, dropout_p=p, seed=Fn.next_seed() if p > 0 else 0,
             dtype=dtype, weight_requires_grad=self.linear.weight.requires_grad,
             n_scale_t=len(tasks) if (tasks and isinstance(st[0], nn.Parameter)) else 0)
+        if gelu_out:
+            if self.shared_mode == "addition":
+                raise RuntimeError("mtlora_amd: gelu_out is not available with shared_mode='addition'")
+            meta.gelu_out = True
         gates = []
         if gelu_gate is not None:
             gates = [gelu_gate[0]] + ([gelu_gate[1][t] for t in tasks] if meta.has_x_tasks else [])
@@ -155,6 +162,10 @@ class MTLoRALinear(LoRALayer):
         args += gates
         outs = Fn.MTLoRALinearFn.apply(*args)
         y = outs[0]
+        if gelu_out:
+            nt = len(tasks)
+            return (y, {t: outs[1 + i] for i, t in enumerate(tasks)} if tasks else None,
+                    outs[1 + nt], {t: outs[2 + nt + i] for i, t in enumerate(tasks)} if tasks else None)
         if not has_lora:
             return y, None
         y_tasks = {t: outs[1 + i] for i, t in enumerate(tasks)} if tasks else None

@@ -104,7 +104,19 @@ class Mlp(nn.Module):
                 and self.fc2.linear.in_features % 8 == 0 and not self.fc2.linear.weight.requires_grad
                 and self.fc2.shared_mode in ("matrix", "matrixv2"))
 
+    def _fused_gelu(self, x) -> bool:
+        """fc1 writes gelu(h) next to h from its epilogue and fc2's dX kernel applies gelu'(h): no separate GELU passes."""
+        from .lora import MTLoRALinear
+        ok = lambda m: (isinstance(m, MTLoRALinear) and m.shared_mode in ("matrix", "matrixv2") and not m.linear.weight.requires_grad
+                        and m.linear.in_features % 8 == 0 and m.linear.out_features % 8 == 0)
+        return (ok(self.fc1) and ok(self.fc2) and type(self.act) is nn.GELU and getattr(self.act, "approximate", "none") == "none"
+                and (self.drop.p == 0.0 or not self.training) and torch.is_grad_enabled() and x.is_cuda and x.requires_grad
+                and self.fc1.tasks == self.fc2.tasks)
+
     def forward(self, x, x_tasks=None):
+        if self._fused_gelu(x):
+            h, h_t, a, a_t = self.fc1(x, x_tasks, gelu_out=True)
+            return self.fc2(a, a_t, gelu_gate=(h.detach(), None if h_t is None else {t: v.detach() for t, v in h_t.items()}))
         h, h_t = self.fc1(x, x_tasks)
         if self._fused_gelu_backward(h, h_t):
             a = Fn.GeluDeferredGradFn.apply(h)

@@ -633,6 +633,66 @@ def test_linear_bwd_gelu_fused(dtype, with_tasks):
         assert torch.equal(p0[k], p1[k]), k
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("with_tasks", [False, True])
+def test_mlp_gelu_fused_both_ways(dtype, with_tasks):
+    """fc1 -> GELU -> fc2 with the activation written by fc1's epilogue (mtlora_linear_fwd_gelu) and its derivative applied
+    in fc2's dX epilogue (mtlora_linear_bwd_gelu) == the plain composition with ATen's gelu / gelu_backward: pre-activations
+    bit-equal, activations / outputs / every gradient within tolerance (same dropout seeds)."""
+    from mtlora_amd import functional as Fn
+    from mtlora_amd.lora import MTLoRALinear
+    torch.manual_seed(11)
+    tasks = ["a", "b"] if with_tasks else None
+    r = {"shared": 16, "a": 4, "b": 4} if with_tasks else {"shared": 16}
+    sc = {"a": 1.0, "b": 0.5} if with_tasks else 1.0
+    C, Hd, M = 96, 384, 3 * 211
+    fc1 = MTLoRALinear(C, Hd, r=r, lora_shared_scale=2.0, lora_task_scale=sc, lora_dropout=0.1, tasks=tasks).to(dev())
+    fc2 = MTLoRALinear(Hd, C, r=r, lora_shared_scale=2.0, lora_task_scale=sc, lora_dropout=0.1, tasks=tasks).to(dev())
+    with torch.no_grad():
+        for m_ in (fc1, fc2):
+            for n_, p_ in m_.named_parameters():
+                if "lora_" in n_:
+                    p_.normal_(0, 0.1)
+            m_.linear.weight.requires_grad_(False)
+            m_.linear.bias.requires_grad_(False)
+            m_.train()
+    xs = [torch.randn(3, M // 3, C, device=dev()).to(dtype).requires_grad_(True) for _ in range(1 + (2 if with_tasks else 0))]
+    td = lambda lst: {t: lst[1 + i] for i, t in enumerate(tasks)} if tasks else None
+    res, gys = [], None
+    for fused in (False, True):
+        Fn._seed_counter = 500
+        for x in xs:
+            x.grad = None
+        fc1.zero_grad()
+        fc2.zero_grad()
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=dtype == torch.bfloat16):
+            if fused:
+                h, h_t, a, a_t = fc1(xs[0], td(xs), gelu_out=True)
+                y, y_t = fc2(a, a_t, gelu_gate=(h.detach(), None if h_t is None else {t: v.detach() for t, v in h_t.items()}))
+            else:
+                h, h_t = fc1(xs[0], td(xs))
+                a = torch.nn.functional.gelu(h)
+                a_t = {t: torch.nn.functional.gelu(h_t[t]) for t in tasks} if tasks else None
+                y, y_t = fc2(a, a_t)
+        outs = [y] + ([y_t[t] for t in tasks] if tasks else [])
+        if gys is None:
+            gys = [torch.randn_like(o) for o in outs]
+        torch.autograd.backward(outs, gys)
+        res.append((h.detach().clone(), a.detach().clone(), [o.detach().clone() for o in outs], [x.grad.clone() for x in xs],
+                    {f"fc{i_}.{n_}": p_.grad.clone() for i_, m_ in enumerate((fc1, fc2), 1) for n_, p_ in m_.named_parameters()
+                     if p_.grad is not None}))
+    (h0, a0, o0, g0, p0), (h1, a1, o1, g1, p1) = res
+    assert torch.equal(h0, h1)
+    assert_close(a1, a0.double(), dtype, "gelu(h)")
+    for i, (u, v) in enumerate(zip(o0, o1)):
+        assert_close(v, u.double(), dtype, f"y{i}", mult=2)
+    for i, (u, v) in enumerate(zip(g0, g1)):
+        assert_close(v, u.double(), dtype, f"dx{i}", mult=3)
+    assert p0.keys() == p1.keys() and len(p0) >= 4
+    for k in p0:
+        assert_close(p1[k], p0[k].double(), dtype, k, mult=3)
+
+
 def test_linear_direct_to_lds_variant():
     """k_nt2 (opt-in MTLORA_NT2=1: 256 x 128 tiles, global_load_lds tile loads, XOR-swizzled LDS, 3-stage ring) replaces the
     lean single-output launches: the linear parity tests (oracle, golden shapes, GELU' gate, dropout masks) must pass

@@ -216,6 +216,21 @@ int mtlora_residual_layernorm_bwd(const void* dy, const void* x_new, const float
                                   int64_t B, int64_t M, int64_t C, int x_dtype, int dy_dtype, void* scratch,
                                   int64_t scratch_bytes, const void* dx_addend, void* stream);
 
+/* The same for the task-enabled block (swin_transformer_mtlora.py:389-396 for the shared stream and each task stream): ONE
+ * shortcut, n branches -> x_new[k] = shortcut + scale[k][sample] * branch[k], y[k] = LayerNorm(x_new[k]) (one launch), and
+ * backward: d_branch[k] = scale[k] * (dx_addend[k] + LN-backward(dy[k])), d_shortcut = sum_k (dx_addend[k] + LN-backward(dy[k])),
+ * dgamma / dbeta summed over the streams (one launch + reduce instead of n LayerNorm backwards and a residual backward).
+ * scale: (n, B) fp32 or NULL; dx_addend[k], d_branch[k] nullable. */
+int mtlora_residual_layernorm_multi_fwd(int n, const void* shortcut, const void* const* branch, const float* scale, int64_t B,
+                                        const float* gamma, const float* beta, void* const* x_new, void* const* y,
+                                        float* const* mean, float* const* rstd, int64_t M, int64_t C, float eps, int x_dtype,
+                                        int y_dtype, void* stream);
+int mtlora_residual_layernorm_multi_bwd(int n, const void* const* dy, const void* const* x_new, const float* gamma,
+                                        const float* const* mean, const float* const* rstd, const void* const* dx_addend,
+                                        void* d_shortcut, void* const* d_branch, float* dgamma, float* dbeta, const float* scale,
+                                        int64_t B, int64_t M, int64_t C, int x_dtype, int dy_dtype, void* scratch,
+                                        int64_t scratch_bytes, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Training-mode BatchNorm + optional ReLU over a channels-last (R rows, C channels) matrix -- the decoder heads'
  * conv1x1 -> BatchNorm2d -> ReLU (seg_hrnet.py:498-526) on the (pixels, channels) matrix; replaces

@@ -81,7 +81,21 @@ struct LnParams {
     void* dbr;
     const float* rscale;  // [B] per-sample DropPath scale or null (1)
     int64_t rows_per_sample;
+    // multi-stream form (task-enabled block: ONE shortcut, 1+T branches, 1+T normalised outputs): stream k = blockIdx.y of the
+    // forward launch / an inner loop of k_resln_bwd_multi; rscale is then [nk][B]
+    int nk;
+    const void* rb_k[MTLORA_MAX_TASKS + 1];
+    void* xsum_k[MTLORA_MAX_TASKS + 1];
+    void* y_k[MTLORA_MAX_TASKS + 1];
+    float* mean_k[MTLORA_MAX_TASKS + 1];
+    float* rstd_k[MTLORA_MAX_TASKS + 1];
+    const void* dy_k[MTLORA_MAX_TASKS + 1];
+    const void* add_k[MTLORA_MAX_TASKS + 1];
+    void* dbr_k[MTLORA_MAX_TASKS + 1];
 };
+// arrays of the parameter block are indexed through the kernarg segment (constant address space): dynamic indexing of the
+// by-value copy would move the whole struct to scratch
+typedef const __attribute__((address_space(4))) LnParams* LnKargs;
 
 // element offset of column `col` (a multiple of the vector width) of row `row` in x / dx
 struct LnRow {
@@ -174,6 +188,24 @@ __global__ __launch_bounds__(256) void k_ln_fwd(const LnParams p) {
     const int nvec = p.C / VE;
     const TI* x = reinterpret_cast<const TI*>(p.x);
     TO* y = reinterpret_cast<TO*>(p.y);
+    float* mean_out = p.mean;
+    float* rstd_out = p.rstd;
+    const void* rb_ptr = p.rb;
+    void* xs_ptr = p.xsum;
+    const float* rscale = p.rscale;
+    if constexpr (RES) {
+        if (p.nk > 0) {  // multi-stream launch: blockIdx.y selects the branch / outputs; the shortcut x is shared (an in-kernel
+                         // loop over the streams that reads it once was slower: 473 vs 424 us at stage 0 -- fewer workgroups)
+            LnKargs K = (LnKargs)__builtin_amdgcn_kernarg_segment_ptr();
+            const int k = blockIdx.y;
+            y = reinterpret_cast<TO*>(K->y_k[k]);
+            mean_out = K->mean_k[k];
+            rstd_out = K->rstd_k[k];
+            rb_ptr = K->rb_k[k];
+            xs_ptr = K->xsum_k[k];
+            if (rscale) rscale += (int64_t)k * (p.M / p.rows_per_sample);
+        }
+    }
     float g[MAXV][VE], b[MAXV][VE];
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
@@ -204,12 +236,12 @@ __global__ __launch_bounds__(256) void k_ln_fwd(const LnParams p) {
             }
         }
         if constexpr (RES) {  // x_new = shortcut + s * branch, stored (rounded to the stream dtype) and normalised
-            const TO* rb = reinterpret_cast<const TO*>(p.rb);
-            TI* xs = reinterpret_cast<TI*>(p.xsum);
+            const TO* rb = reinterpret_cast<const TO*>(rb_ptr);
+            TI* xs = reinterpret_cast<TI*>(xs_ptr);
 #pragma unroll
             for (int u = 0; u < UNR; ++u) {
                 if (row[u] >= p.M) continue;
-                const float sc = p.rscale ? p.rscale[row[u] / p.rows_per_sample] : 1.f;
+                const float sc = rscale ? rscale[row[u] / p.rows_per_sample] : 1.f;
 #pragma unroll
                 for (int i = 0; i < MAXV; ++i) {
                     const int v = lr + i * LPR;
@@ -251,8 +283,8 @@ __global__ __launch_bounds__(256) void k_ln_fwd(const LnParams p) {
             const float rstd = rsqrtf(group_sum<LPR>(q) * inv_c + p.eps);
             if (row[u] < p.M) {
                 if (lr == 0) {
-                    p.mean[row[u]] = mean;
-                    p.rstd[row[u]] = rstd;
+                    mean_out[row[u]] = mean;
+                    rstd_out[row[u]] = rstd;
                 }
 #pragma unroll
                 for (int i = 0; i < MAXV; ++i) {
@@ -397,6 +429,172 @@ __global__ __launch_bounds__(256) void k_ln_bwd(const LnParams p) {
     }
     // workgroup reduction of the column accumulators: the 4 waves x RPW row groups hold the same columns; each
     // group writes its own LDS slab and the slabs are summed in a fixed order (deterministic, no float atomics)
+    float* mine = sm + (size_t)(wave * RPW + sub) * 2 * p.C;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int v = lr + i * LPR;
+        if (v < nvec) {
+#pragma unroll
+            for (int e = 0; e < VE; ++e) {
+                mine[v * VE + e] = ag[i][e];
+                mine[p.C + v * VE + e] = ab[i][e];
+            }
+        }
+    }
+    __syncthreads();
+    float* dst = p.part + (int64_t)blockIdx.x * 2 * p.C;
+    for (int i = threadIdx.x; i < 2 * p.C; i += 256) {
+        float t = 0.f;
+        for (int gi = 0; gi < 4 * RPW; ++gi) t += sm[(size_t)gi * 2 * p.C + i];
+        dst[i] = t;
+    }
+}
+
+// Backward of the multi-stream residual + LayerNorm (task-enabled block half): for its rows a wave walks the nk streams --
+// two in flight -- and forms per stream  dx_k = add_k + LN'(dy_k)  (never stored),  d_branch_k = s_k dx_k  (stored, dtype of
+// dy), while  d_shortcut = sum_k dx_k  and the dgamma / dbeta partials accumulate in registers across the streams: one pass
+// instead of nk LayerNorm backward launches + their reduces + the shared-residual backward (which re-read all nk dx_k).
+template <typename TX, typename TG, int LPR, int MAXV>
+__global__ __launch_bounds__(256) void k_resln_bwd_multi(const LnParams p) {
+    constexpr int VE = ET<TX>::VEC;
+    constexpr int RPW = 64 / LPR;
+    constexpr int GW = sizeof(TG) == sizeof(TX) ? 4 : (sizeof(TG) == 2 ? 2 : 8);
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    LnKargs K = (LnKargs)__builtin_amdgcn_kernarg_segment_ptr();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sub = lane / LPR, lr = lane % LPR;
+    const int nvec = p.C / VE;
+    TX* dsh = reinterpret_cast<TX*>(p.dx);
+    const int64_t Bn = p.M / p.rows_per_sample;
+    float g[MAXV][VE], ag[MAXV][VE], ab[MAXV][VE];
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int v = lr + i * LPR;
+#pragma unroll
+        for (int e = 0; e < VE; ++e) {
+            g[i][e] = v < nvec ? p.gamma[v * VE + e] : 0.f;
+            ag[i][e] = 0.f;
+            ab[i][e] = 0.f;
+        }
+    }
+    struct Regs {
+        u32x4 rx[MAXV], ra[MAXV];
+        uint32_t rg[MAXV][GW];
+        float mean, rstd, sc;
+    };
+    const int64_t rows_per_blk = 4 * RPW;
+    for (int64_t r0 = (int64_t)blockIdx.x * rows_per_blk; r0 < p.M; r0 += (int64_t)gridDim.x * rows_per_blk) {
+        const int64_t row = r0 + wave * RPW + sub;
+        const bool rv = row < p.M;
+        const int64_t rbase = (rv ? row : 0) * p.C;
+        float dsum[MAXV][VE];
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i)
+#pragma unroll
+            for (int e = 0; e < VE; ++e) dsum[i][e] = 0.f;
+        auto load = [&](Regs& R, int k) __attribute__((always_inline)) {
+            const TX* x = reinterpret_cast<const TX*>(K->xsum_k[k]);
+            const TG* dy = reinterpret_cast<const TG*>(K->dy_k[k]);
+            const TX* addp = reinterpret_cast<const TX*>(K->add_k[k]);
+            R.mean = rv ? K->mean_k[k][row] : 0.f;
+            R.rstd = rv ? K->rstd_k[k][row] : 0.f;
+            R.sc = (rv && p.rscale) ? p.rscale[(int64_t)k * Bn + row / p.rows_per_sample] : 1.f;
+#pragma unroll
+            for (int i = 0; i < MAXV; ++i) {
+                const int v = lr + i * LPR;
+                const bool ok = rv && v < nvec;
+                const int64_t off = rbase + (v < nvec ? v : 0) * VE;
+                R.rx[i] = ok ? *reinterpret_cast<const u32x4*>(x + off) : u32x4{0u, 0u, 0u, 0u};
+                R.ra[i] = (ok && addp) ? *reinterpret_cast<const u32x4*>(addp + off) : u32x4{0u, 0u, 0u, 0u};
+                const TG* gp = dy + off;
+                if constexpr (GW == 4) {
+                    const u32x4 t = ok ? *reinterpret_cast<const u32x4*>(gp) : u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) R.rg[i][q] = t[q];
+                } else if constexpr (GW == 2) {
+                    const u32x2 t = ok ? *reinterpret_cast<const u32x2*>(gp) : u32x2{0u, 0u};
+                    R.rg[i][0] = t[0];
+                    R.rg[i][1] = t[1];
+                } else {
+                    const u32x4 t0 = ok ? *reinterpret_cast<const u32x4*>(gp) : u32x4{0u, 0u, 0u, 0u};
+                    const u32x4 t1 = ok ? *reinterpret_cast<const u32x4*>(gp + 4) : u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        R.rg[i][q] = t0[q];
+                        R.rg[i][4 + q] = t1[q];
+                    }
+                }
+            }
+        };
+        auto compute = [&](Regs& R, int k) __attribute__((always_inline)) {
+            TG* dbr = reinterpret_cast<TG*>(K->dbr_k[k]);
+            float xh[MAXV][VE], gy[MAXV][VE];
+            float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < MAXV; ++i) {
+                float fx[8], fg[8];
+                cvt_vec<TX>(R.rx[i], fx);
+                if constexpr (GW == 4) {
+                    cvt_vec<TG>(u32x4{R.rg[i][0], R.rg[i][1], R.rg[i][2], R.rg[i][3]}, fg);
+                } else if constexpr (GW == 2) {
+                    fg[0] = __builtin_bit_cast(float, R.rg[i][0] << 16);
+                    fg[1] = __builtin_bit_cast(float, R.rg[i][0] & 0xFFFF0000u);
+                    fg[2] = __builtin_bit_cast(float, R.rg[i][1] << 16);
+                    fg[3] = __builtin_bit_cast(float, R.rg[i][1] & 0xFFFF0000u);
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) fg[q] = __builtin_bit_cast(float, R.rg[i][q]);
+                }
+#pragma unroll
+                for (int e = 0; e < VE; ++e) {
+                    const float h = (fx[e] - R.mean) * R.rstd;
+                    xh[i][e] = h;
+                    ag[i][e] += fg[e] * h;
+                    ab[i][e] += fg[e];
+                    const float t = fg[e] * g[i][e];
+                    gy[i][e] = t;
+                    c1 += t;
+                    c2 += t * h;
+                }
+            }
+            c1 = group_sum<LPR>(c1) / p.C;
+            c2 = group_sum<LPR>(c2) / p.C;
+            if (rv) {
+#pragma unroll
+                for (int i = 0; i < MAXV; ++i) {
+                    const int v = lr + i * LPR;
+                    if (v < nvec) {
+                        float o[8], fa[8];
+                        cvt_vec<TX>(R.ra[i], fa);
+#pragma unroll
+                        for (int e = 0; e < VE; ++e) {
+                            o[e] = R.rstd * (gy[i][e] - c1 - xh[i][e] * c2) + fa[e];
+                            dsum[i][e] += o[e];
+                            o[e] *= R.sc;
+                        }
+                        if (dbr) st_vec<TG, VE>(dbr + rbase + v * VE, o);
+                    }
+                }
+            }
+        };
+        Regs A, Bq;
+        load(A, 0);
+        for (int k = 0; k < p.nk; k += 2) {
+            if (k + 1 < p.nk) load(Bq, k + 1);
+            compute(A, k);
+            if (k + 1 < p.nk) {
+                if (k + 2 < p.nk) load(A, k + 2);
+                compute(Bq, k + 1);
+            }
+        }
+        if (rv) {
+#pragma unroll
+            for (int i = 0; i < MAXV; ++i) {
+                const int v = lr + i * LPR;
+                if (v < nvec) st_vec<TX, VE>(dsh + rbase + v * VE, dsum[i]);
+            }
+        }
+    }
     float* mine = sm + (size_t)(wave * RPW + sub) * 2 * p.C;
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
@@ -658,6 +856,136 @@ int mtlora_residual_layernorm_bwd(const void* dy, const void* x_new, const float
     if (!d_branch) return MTLORA_ERR_NULL;
     return ln_bwd_impl(dy, x_new, gamma, mean, rstd, d_shortcut, dgamma, dbeta, M, C, x_dtype, dy_dtype, scratch, scratch_bytes,
                        dx_addend, 0, 0, d_branch, scale, B, stream);
+}
+
+/* multi-stream forms: ONE shortcut, n branches -> n (x_new, y) pairs (task-enabled Swin block: swin_transformer_mtlora.py:389-396
+ * for the shared stream and every task stream) */
+int mtlora_residual_layernorm_multi_fwd(int n, const void* shortcut, const void* const* branch, const float* scale, int64_t B,
+                                        const float* gamma, const float* beta, void* const* x_new, void* const* y,
+                                        float* const* mean, float* const* rstd, int64_t M, int64_t C, float eps, int x_dtype,
+                                        int y_dtype, void* stream) {
+    int st = ln_check(M, C, x_dtype, y_dtype);
+    if (st != MTLORA_OK) return st;
+    if (n < 1 || n > MTLORA_MAX_TASKS + 1 || B <= 0 || M % B) return MTLORA_ERR_SHAPE;
+    if (!shortcut || !branch || !gamma || !beta || !x_new || !y || !mean || !rstd) return MTLORA_ERR_NULL;
+    if ((uintptr_t)shortcut & 15u) return MTLORA_ERR_ALIGN;
+    LnParams p = {};
+    for (int k = 0; k < n; ++k) {
+        if (!branch[k] || !x_new[k] || !y[k] || !mean[k] || !rstd[k]) return MTLORA_ERR_NULL;
+        if (((uintptr_t)branch[k] | (uintptr_t)x_new[k] | (uintptr_t)y[k]) & 15u) return MTLORA_ERR_ALIGN;
+        p.rb_k[k] = branch[k];
+        p.xsum_k[k] = x_new[k];
+        p.y_k[k] = y[k];
+        p.mean_k[k] = mean[k];
+        p.rstd_k[k] = rstd[k];
+    }
+    if (M == 0) return MTLORA_OK;
+    p.nk = n;
+    p.x = shortcut;
+    p.gamma = gamma;
+    p.beta = beta;
+    p.rb = branch[0];
+    p.xsum = x_new[0];
+    p.y = y[0];
+    p.mean = mean[0];
+    p.rstd = rstd[0];
+    p.rscale = scale;
+    p.rows_per_sample = M / B;
+    p.M = M;
+    p.C = (int)C;
+    p.eps = eps;
+    const int nvec_h = (int)(C / (x_dtype == MTLORA_F32 ? 4 : 8));
+    const int lpr = pick_lpr(nvec_h);
+    const int vpl = (nvec_h + lpr - 1) / lpr;
+    const int gx = (int)mtl_ceil_div(ln_grid(M, lpr, 1 << 30), vpl <= 3 ? 4 : 1) < 256 * 8
+                       ? (int)mtl_ceil_div(ln_grid(M, lpr, 1 << 30), vpl <= 3 ? 4 : 1)
+                       : 256 * 8;
+    const dim3 grid((unsigned)gx, (unsigned)n);
+    const size_t lds = 0;
+    hipStream_t s = (hipStream_t)stream;
+    const int es_x = mtl_elem_size(x_dtype), es_y = mtl_elem_size(y_dtype);
+    mtl_prof_tag("M%lld C%lld x%d y%d n%d", (long long)M, (long long)C, x_dtype, y_dtype, n);
+    MtlProfScope prof(PK_LN_FWD, (double)M * C * (es_x + (double)n * (es_x + 2 * es_y)), s);
+#define LN_EXTRA , true
+    if (x_dtype == MTLORA_F32 && y_dtype == MTLORA_F32) {
+        LN_DISPATCH_LPR(k_ln_fwd, float, float)
+    } else if (x_dtype == MTLORA_F32) {
+        LN_DISPATCH_LPR(k_ln_fwd, float, bf16)
+    } else if (y_dtype == MTLORA_F32) {
+        LN_DISPATCH_LPR(k_ln_fwd, bf16, float)
+    } else {
+        LN_DISPATCH_LPR(k_ln_fwd, bf16, bf16)
+    }
+#undef LN_EXTRA
+    MTL_CHECK_LAUNCH();
+    return MTLORA_OK;
+}
+
+/* d_shortcut = sum_k (dx_addend[k] + LN-backward(dy[k]));  d_branch[k] = scale[k][sample] * (dx_addend[k] + LN-backward(dy[k]));
+ * dgamma / dbeta summed over the streams.  dx_addend[k] / d_branch[k] may be NULL. */
+int mtlora_residual_layernorm_multi_bwd(int n, const void* const* dy, const void* const* x_new, const float* gamma,
+                                        const float* const* mean, const float* const* rstd, const void* const* dx_addend,
+                                        void* d_shortcut, void* const* d_branch, float* dgamma, float* dbeta, const float* scale,
+                                        int64_t B, int64_t M, int64_t C, int x_dtype, int dy_dtype, void* scratch,
+                                        int64_t scratch_bytes, void* stream) {
+    int st = ln_check(M, C, x_dtype, dy_dtype);
+    if (st != MTLORA_OK) return st;
+    if (n < 1 || n > MTLORA_MAX_TASKS + 1 || B <= 0 || M % B) return MTLORA_ERR_SHAPE;
+    if (!dy || !x_new || !gamma || !mean || !rstd || !d_shortcut || !dgamma || !dbeta || !scratch) return MTLORA_ERR_NULL;
+    if (((uintptr_t)d_shortcut | (uintptr_t)scratch) & 15u) return MTLORA_ERR_ALIGN;
+    if (scratch_bytes < mtlora_layernorm_bwd_scratch_bytes(M, C, x_dtype) - 256) return MTLORA_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    if (M == 0) {
+        mtl_zero_async(dgamma, (size_t)C * 4, s);
+        mtl_zero_async(dbeta, (size_t)C * 4, s);
+        return MTLORA_OK;
+    }
+    LnParams p = {};
+    for (int k = 0; k < n; ++k) {
+        if (!dy[k] || !x_new[k] || !mean[k] || !rstd[k]) return MTLORA_ERR_NULL;
+        const void* ad = dx_addend ? dx_addend[k] : nullptr;
+        void* db = d_branch ? d_branch[k] : nullptr;
+        if (((uintptr_t)dy[k] | (uintptr_t)x_new[k] | (uintptr_t)ad | (uintptr_t)db) & 15u) return MTLORA_ERR_ALIGN;
+        p.dy_k[k] = dy[k];
+        p.xsum_k[k] = const_cast<void*>(x_new[k]);
+        p.mean_k[k] = const_cast<float*>(mean[k]);
+        p.rstd_k[k] = const_cast<float*>(rstd[k]);
+        p.add_k[k] = ad;
+        p.dbr_k[k] = db;
+    }
+    p.nk = n;
+    p.gamma = gamma;
+    p.dx = d_shortcut;
+    p.rscale = scale;
+    p.rows_per_sample = M / B;
+    p.part = reinterpret_cast<float*>(scratch);
+    p.M = M;
+    p.C = (int)C;
+    const int nvec_h = (int)(C / (x_dtype == MTLORA_F32 ? 4 : 8));
+    const int lpr = pick_lpr(nvec_h);
+    const int vpl = (nvec_h + lpr - 1) / lpr;
+    const int grid = ln_grid(M, lpr);
+    const size_t lds = (size_t)4 * (64 / lpr) * 2 * C * 4;
+    const int es_x = mtl_elem_size(x_dtype), es_g = mtl_elem_size(dy_dtype);
+    {
+        mtl_prof_tag("M%lld C%lld x%d g%d n%d", (long long)M, (long long)C, x_dtype, dy_dtype, n);
+        MtlProfScope prof(PK_LN_BWD, (double)M * C * (es_x + (double)n * (2 * es_x + 2 * es_g)), s);
+#define LN_EXTRA
+        if (x_dtype == MTLORA_F32 && dy_dtype == MTLORA_F32) {
+            LN_DISPATCH_LPR(k_resln_bwd_multi, float, float)
+        } else if (x_dtype == MTLORA_F32) {
+            LN_DISPATCH_LPR(k_resln_bwd_multi, float, bf16)
+        } else if (dy_dtype == MTLORA_F32) {
+            LN_DISPATCH_LPR(k_resln_bwd_multi, bf16, float)
+        } else {
+            LN_DISPATCH_LPR(k_resln_bwd_multi, bf16, bf16)
+        }
+#undef LN_EXTRA
+    }
+    hipLaunchKernelGGL(k_ln_reduce, dim3((unsigned)mtl_ceil_div(2 * C, 64)), dim3(64 * LN_RW), 0, s, (const float*)p.part, dgamma,
+                       dbeta, grid, (int)C);
+    MTL_CHECK_LAUNCH();
+    return MTLORA_OK;
 }
 }
 

@@ -492,6 +492,81 @@ class ResidualLayerNormFn(torch.autograd.Function):
         return dx.view(ctx.shape), dbr.view(ctx.shape), None, dg, db, None, None
 
 
+class ResidualLayerNormMultiFn(torch.autograd.Function):
+    """Task-enabled block half: ONE shortcut, n branches -> (x_new_0..n-1, y_0..n-1) with x_new_k = shortcut + scale[k] *
+    branch_k and y_k = LayerNorm(x_new_k), one kernel; backward one kernel: d_branch_k = scale[k] * dx_k, d_shortcut = sum_k
+    dx_k, dx_k = g_x_new_k + LN'(g_y_k) (never stored), dgamma / dbeta over all streams.
+    args: scale ((n, B) fp32 or None), weight, bias, eps, out_dtype, n, shortcut, *branches"""
+
+    @staticmethod
+    def forward(ctx, scale, weight, bias, eps: float, out_dtype: torch.dtype, n: int, shortcut, *branches):
+        L.require_gpu(shortcut, weight, bias, *branches)
+        C, B = shortcut.shape[-1], shortcut.shape[0]
+        s2 = shortcut.reshape(-1, C).contiguous()
+        bs = [b.reshape(-1, C).contiguous() for b in branches]
+        M = s2.shape[0]
+        w, b = weight.detach().float().contiguous(), bias.detach().float().contiguous()
+        xs = [torch.empty_like(s2) for _ in range(n)]
+        ys = [torch.empty((M, C), dtype=out_dtype, device=s2.device) for _ in range(n)]
+        stats = torch.empty((2 * n, M), dtype=torch.float32, device=s2.device)
+        means, rstds = [stats[k] for k in range(n)], [stats[n + k] for k in range(n)]
+        st = L.lib().mtlora_residual_layernorm_multi_fwd(n, L.ptr(s2), L.ptr_array9(bs), L.ptr(scale), B, L.ptr(w), L.ptr(b),
+                                                         L.ptr_array9(xs), L.ptr_array9(ys), L.ptr_array9(means),
+                                                         L.ptr_array9(rstds), M, C, float(eps), L.dtype_code(s2),
+                                                         L.dtype_code(ys[0]), L.stream_ptr())
+        L.check(st, "mtlora_residual_layernorm_multi_fwd")
+        ctx.save_for_backward(w, stats, scale, *xs)
+        ctx.shape, ctx.MC, ctx.B, ctx.n, ctx.bdtype = shortcut.shape, (M, C), B, n, branches[0].dtype
+        return tuple(x.view(shortcut.shape) for x in xs) + tuple(y.view(shortcut.shape) for y in ys)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        w, stats, scale, *xs = ctx.saved_tensors
+        n, (M, C) = ctx.n, ctx.MC
+        g_skip, g_y = grads[:n], grads[n:]
+        dev = xs[0].device
+        dys = [g.reshape(M, C).to(ctx.bdtype).contiguous() for g in g_y]             # (materialised: zeros if unused)
+        adds = [g.reshape(M, C).to(xs[0].dtype).contiguous() for g in g_skip]
+        lib = L.lib()
+        sb = lib.mtlora_layernorm_bwd_scratch_bytes(M, C, L.dtype_code(xs[0]))
+        scratch = torch.empty(sb, dtype=torch.uint8, device=dev)
+        dsh = torch.empty_like(xs[0])
+        dbr = [torch.empty((M, C), dtype=ctx.bdtype, device=dev) for _ in range(n)]
+        dg = torch.empty(C, dtype=torch.float32, device=dev)
+        db = torch.empty(C, dtype=torch.float32, device=dev)
+        means, rstds = [stats[k] for k in range(n)], [stats[n + k] for k in range(n)]
+        st = lib.mtlora_residual_layernorm_multi_bwd(n, L.ptr_array9(dys), L.ptr_array9(xs), L.ptr(w), L.ptr_array9(means),
+                                                     L.ptr_array9(rstds), L.ptr_array9(adds), L.ptr(dsh), L.ptr_array9(dbr),
+                                                     L.ptr(dg), L.ptr(db), L.ptr(scale), ctx.B, M, C, L.dtype_code(xs[0]),
+                                                     L.dtype_code(dys[0]), L.ptr(scratch), sb, L.stream_ptr())
+        L.check(st, "mtlora_residual_layernorm_multi_bwd")
+        return (None, dg, db, None, None, None, dsh.view(ctx.shape), *[d.view(ctx.shape) for d in dbr])
+
+
+def residual_layer_norm_multi(mod: torch.nn.Module, shortcut: torch.Tensor, branches, drop_prob: float, training: bool):
+    """([x_new_k], [mod(x_new_k)]) with x_new_k = shortcut + DropPath_k(branches[k]) (an independent per-sample mask per k):
+    the fused multi-stream kernels when they apply, else residual_droppath + layer_norm_fork per stream."""
+    C, n = shortcut.shape[-1], len(branches)
+    ok = (type(mod) is torch.nn.LayerNorm and mod.elementwise_affine and mod.bias is not None
+          and len(mod.normalized_shape) == 1 and shortcut.is_cuda and shortcut.dtype in (torch.float32, torch.bfloat16)
+          and C % 8 == 0 and C <= (1024 if shortcut.dtype == torch.float32 else 1536) and shortcut.dim() == 3
+          and 1 <= n <= L.MAX_TASKS + 1 and all(b.shape == shortcut.shape for b in branches) and torch.is_grad_enabled()
+          and (shortcut.requires_grad or any(b.requires_grad for b in branches)))
+    if ok:
+        out_dtype = compute_dtype(shortcut)
+        ok = all(b.dtype == out_dtype for b in branches)
+    if not ok:
+        r = residual_droppath(shortcut, list(branches), drop_prob, training)
+        forks = [layer_norm_fork(mod, x) for x in r]
+        return [f[0] for f in forks], [f[1] for f in forks]
+    scale = None
+    if training and drop_prob > 0.0:
+        keep = 1.0 - drop_prob
+        scale = torch.empty(n, shortcut.shape[0], dtype=torch.float32, device=shortcut.device).bernoulli_(keep).div_(keep)
+    outs = ResidualLayerNormMultiFn.apply(scale, mod.weight, mod.bias, mod.eps, out_dtype, n, shortcut, *branches)
+    return list(outs[:n]), list(outs[n:])
+
+
 def residual_layer_norm(mod: torch.nn.Module, shortcut: torch.Tensor, branch: torch.Tensor, drop_prob: float, training: bool):
     """(x_new, mod(x_new)) with x_new = shortcut + DropPath(branch): the fused kernel when it applies (nn.LayerNorm over
     the last dim, branch already in the dtype the LayerNorm output takes), else residual_droppath + layer_norm_fork."""

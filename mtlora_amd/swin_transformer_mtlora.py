@@ -316,18 +316,15 @@ class SwinTransformerBlock(nn.Module):
         # fused kernel (shared shortcut -> the backward also forms d_shortcut = sum of the 1+T gradients)
         p_dp = self.drop_path.drop_prob if isinstance(self.drop_path, DropPath) else 0.0
         x_t = None
-        if a_t is not None:
-            r = Fn.residual_droppath(shortcut, [a] + [a_t[t] for t in self.tasks], p_dp, self.training)
-            x, x_t = r[0], {t: r[1 + i] for i, t in enumerate(self.tasks)}
-            x, xn2 = Fn.layer_norm_fork(self.norm2, x)
+        xn2_t = None
+        if a_t is not None:  # shared shortcut, 1+T branches: residuals + DropPath + norm2 of every stream in one kernel
+            xs, xns = Fn.residual_layer_norm_multi(self.norm2, shortcut, [a] + [a_t[t] for t in self.tasks], p_dp, self.training)
+            x, xn2 = xs[0], xns[0]
+            x_t = {t: xs[1 + i] for i, t in enumerate(self.tasks)}
+            xn2_t = {t: xns[1 + i] for i, t in enumerate(self.tasks)}
         else:  # single stream: residual + DropPath + norm2 in one kernel
             x, xn2 = Fn.residual_layer_norm(self.norm2, shortcut, a, p_dp, self.training)
         # MLP half
-        xn2_t = None
-        if x_t is not None:
-            forks = {t: Fn.layer_norm_fork(self.norm2, x_t[t]) for t in self.tasks}
-            x_t = {t: forks[t][0] for t in self.tasks}
-            xn2_t = {t: forks[t][1] for t in self.tasks}
         m, m_t = self.mlp(xn2, xn2_t)
         if m_t is None:
             if next_norm is not None:

@@ -583,6 +583,48 @@ def test_residual_layer_norm_fused(rdt, ydt, B, Ltok, C, use_scale):
     assert_close(br2.grad, g_skip.double() * sc64.view(B, 1, 1), ydt, "d_branch (skip only)")
 
 
+@pytest.mark.parametrize("use_scale", [True, False])
+@pytest.mark.parametrize("n,B,Ltok,C", [(5, 4, 49, 96), (3, 2, 100, 384), (5, 2, 9, 768), (9, 2, 30, 192)])
+@pytest.mark.parametrize("rdt,ydt", [(torch.float32, torch.bfloat16), (torch.bfloat16, torch.bfloat16), (torch.float32, torch.float32)])
+def test_residual_layer_norm_multi(rdt, ydt, n, B, Ltok, C, use_scale):
+    """mtlora_residual_layernorm_multi_fwd/bwd (one shortcut, n branches, n normalised outputs; backward sums the shortcut
+    gradient and the LayerNorm parameter gradients over the streams) against fp64 autograd of the per-stream composition;
+    one y output and one skip output are left without a gradient (zero-materialised)."""
+    from mtlora_amd import functional as Fn
+    torch.manual_seed(n * C)
+    sc_ = torch.randn(B, Ltok, C, device=dev()).to(rdt).requires_grad_(True)
+    brs = [torch.randn(B, Ltok, C, device=dev()).to(ydt).requires_grad_(True) for _ in range(n)]
+    w = (1.0 + 0.1 * torch.randn(C, device=dev())).requires_grad_(True)
+    b = (0.1 * torch.randn(C, device=dev())).requires_grad_(True)
+    scale = ((torch.rand(n, B, device=dev()) < 0.7).float() / 0.7) if use_scale else None
+    outs = Fn.ResidualLayerNormMultiFn.apply(scale, w, b, 1e-5, ydt, n, sc_, *brs)
+    xs, ys = outs[:n], outs[n:]
+    assert all(x.dtype == rdt for x in xs) and all(y.dtype == ydt for y in ys)
+    g_skip = [torch.randn_like(x) for x in xs]
+    g_y = [torch.randn_like(y) for y in ys]
+    use_x = [k for k in range(n) if k != 1]      # stream 1: no skip gradient
+    use_y = [k for k in range(n) if k != n - 1]  # last stream: normalised output unused
+    torch.autograd.backward([xs[k] for k in use_x] + [ys[k] for k in use_y], [g_skip[k] for k in use_x] + [g_y[k] for k in use_y])
+    s64, w64, b64 = (t.detach().double().requires_grad_(True) for t in (sc_, w, b))
+    br64 = [t.detach().double().requires_grad_(True) for t in brs]
+    rx, ry = [], []
+    for k in range(n):
+        f = torch.ones(B, device=dev(), dtype=torch.float64) if scale is None else scale[k].double()
+        xr = s64 + f.view(B, 1, 1) * br64[k]
+        xq = xr + (xr.detach().to(rdt).double() - xr.detach())
+        rx.append(xq)
+        ry.append(torch.nn.functional.layer_norm(xq, (C,), w64, b64, 1e-5))
+    torch.autograd.backward([rx[k] for k in use_x] + [ry[k] for k in use_y],
+                            [g_skip[k].double() for k in use_x] + [g_y[k].double() for k in use_y])
+    for k in range(n):
+        assert_close(xs[k], rx[k], rdt, f"x_new{k}")
+        assert_close(ys[k], ry[k], ydt, f"y{k}", mult=2)
+        assert_close(brs[k].grad, br64[k].grad, ydt, f"d_branch{k}", mult=3)
+    assert_close(sc_.grad, s64.grad, rdt, "d_shortcut", mult=4)
+    assert_close(w.grad, w64.grad, ydt, "dgamma", mult=6)
+    assert_close(b.grad, b64.grad, ydt, "dbeta", mult=6)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("with_tasks", [False, True])
 def test_linear_bwd_gelu_fused(dtype, with_tasks):

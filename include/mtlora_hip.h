@@ -216,6 +216,18 @@ int mtlora_residual_layernorm_bwd(const void* dy, const void* x_new, const float
                                   int64_t B, int64_t M, int64_t C, int x_dtype, int dy_dtype, void* scratch,
                                   int64_t scratch_bytes, const void* dx_addend, void* stream);
 
+/* n independent inputs through the SAME LayerNorm, one launch each way (PatchMerging.norm applied to the shared tensor and to
+ * every task tensor, swin_transformer_mtlora.py:543-551); y[k] may be slices of one stacked buffer; dgamma / dbeta are summed
+ * over the inputs; dx_addend (array, nullable entries) as in mtlora_layernorm_bwd. */
+int64_t mtlora_layernorm_multi_bwd_scratch_bytes(int n, int64_t M, int64_t C, int x_dtype);
+int mtlora_layernorm_multi_fwd(int n, const void* const* x, const float* gamma, const float* beta, void* const* y,
+                               float* const* mean, float* const* rstd, int64_t M, int64_t C, float eps, int x_dtype, int y_dtype,
+                               int merge_h, int merge_w, void* stream);
+int mtlora_layernorm_multi_bwd(int n, const void* const* dy, const void* const* x, const float* gamma, const float* const* mean,
+                               const float* const* rstd, void* const* dx, float* dgamma, float* dbeta, int64_t M, int64_t C,
+                               int x_dtype, int dy_dtype, void* scratch, int64_t scratch_bytes, const void* const* dx_addend,
+                               int merge_h, int merge_w, void* stream);
+
 /* The same for the task-enabled block (swin_transformer_mtlora.py:389-396 for the shared stream and each task stream): ONE
  * shortcut, n branches -> x_new[k] = shortcut + scale[k][sample] * branch[k], y[k] = LayerNorm(x_new[k]) (one launch), and
  * backward: d_branch[k] = scale[k] * (dx_addend[k] + LN-backward(dy[k])), d_shortcut = sum_k (dx_addend[k] + LN-backward(dy[k])),

@@ -77,6 +77,12 @@ _SIGS = {
     "mtlora_layernorm_bwd_scratch_bytes": (c_int64, [c_int64, c_int64, c_int]),
     "mtlora_residual_layernorm_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
                                               c_void_p, c_void_p, c_int64, c_int64, c_float, c_int, c_int, c_void_p]),
+    "mtlora_layernorm_multi_bwd_scratch_bytes": (c_int64, [c_int, c_int64, c_int64, c_int]),
+    "mtlora_layernorm_multi_fwd": (c_int, [c_int, POINTER(c_void_p), c_void_p, c_void_p, POINTER(c_void_p), POINTER(c_void_p),
+                                           POINTER(c_void_p), c_int64, c_int64, c_float, c_int, c_int, c_int, c_int, c_void_p]),
+    "mtlora_layernorm_multi_bwd": (c_int, [c_int, POINTER(c_void_p), POINTER(c_void_p), c_void_p, POINTER(c_void_p),
+                                           POINTER(c_void_p), POINTER(c_void_p), c_void_p, c_void_p, c_int64, c_int64, c_int,
+                                           c_int, c_void_p, c_int64, POINTER(c_void_p), c_int, c_int, c_void_p]),
     "mtlora_residual_layernorm_multi_fwd": (c_int, [c_int, c_void_p, POINTER(c_void_p), c_void_p, c_int64, c_void_p, c_void_p,
                                                     POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p),
                                                     c_int64, c_int64, c_float, c_int, c_int, c_void_p]),

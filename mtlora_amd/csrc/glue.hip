@@ -92,6 +92,11 @@ struct LnParams {
     const void* dy_k[MTLORA_MAX_TASKS + 1];
     const void* add_k[MTLORA_MAX_TASKS + 1];
     void* dbr_k[MTLORA_MAX_TASKS + 1];
+    // independent streams through the SAME LayerNorm in one launch (multi_x: blockIdx.y selects x / y / statistics, backward
+    // dy / dx / addend and a partial-sum slab; PatchMerging's norm over the shared + task tensors)
+    int multi_x;
+    const void* x_k[MTLORA_MAX_TASKS + 1];
+    void* dx_k[MTLORA_MAX_TASKS + 1];
 };
 // arrays of the parameter block are indexed through the kernarg segment (constant address space): dynamic indexing of the
 // by-value copy would move the whole struct to scratch
@@ -193,6 +198,14 @@ __global__ __launch_bounds__(256) void k_ln_fwd(const LnParams p) {
     const void* rb_ptr = p.rb;
     void* xs_ptr = p.xsum;
     const float* rscale = p.rscale;
+    if (p.multi_x) {
+        LnKargs K = (LnKargs)__builtin_amdgcn_kernarg_segment_ptr();
+        const int k = blockIdx.y;
+        x = reinterpret_cast<const TI*>(K->x_k[k]);
+        y = reinterpret_cast<TO*>(K->y_k[k]);
+        mean_out = K->mean_k[k];
+        rstd_out = K->rstd_k[k];
+    }
     if constexpr (RES) {
         if (p.nk > 0) {  // multi-stream launch: blockIdx.y selects the branch / outputs; the shortcut x is shared (an in-kernel
                          // loop over the streams that reads it once was slower: 473 vs 424 us at stage 0 -- fewer workgroups)
@@ -315,6 +328,20 @@ __global__ __launch_bounds__(256) void k_ln_bwd(const LnParams p) {
     const TG* dy = reinterpret_cast<const TG*>(p.dy);
     TX* dx = reinterpret_cast<TX*>(p.dx);
     const TX* addp = reinterpret_cast<const TX*>(p.add);
+    const float* mean_in = p.mean;
+    const float* rstd_in = p.rstd;
+    float* part_out = p.part + (int64_t)blockIdx.x * 2 * p.C;
+    if (p.multi_x) {
+        LnKargs K = (LnKargs)__builtin_amdgcn_kernarg_segment_ptr();
+        const int k = blockIdx.y;
+        x = reinterpret_cast<const TX*>(K->x_k[k]);
+        dy = reinterpret_cast<const TG*>(K->dy_k[k]);
+        dx = reinterpret_cast<TX*>(K->dx_k[k]);
+        addp = reinterpret_cast<const TX*>(K->add_k[k]);
+        mean_in = K->mean_k[k];
+        rstd_in = K->rstd_k[k];
+        part_out = p.part + ((int64_t)k * gridDim.x + blockIdx.x) * 2 * p.C;
+    }
     float g[MAXV][VE], ag[MAXV][VE], ab[MAXV][VE];
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
@@ -343,8 +370,8 @@ __global__ __launch_bounds__(256) void k_ln_bwd(const LnParams p) {
             row[u] = r0 + (int64_t)(wave * UNR + u) * RPW + sub;
             const bool rv = row[u] < p.M;
             xb[u] = ln_row(p, rv ? row[u] : 0).base;
-            mean[u] = rv ? p.mean[row[u]] : 0.f;
-            rstd[u] = rv ? p.rstd[row[u]] : 0.f;
+            mean[u] = rv ? mean_in[row[u]] : 0.f;
+            rstd[u] = rv ? rstd_in[row[u]] : 0.f;
 #pragma unroll
             for (int i = 0; i < MAXV; ++i) {
                 const int v = lr + i * LPR;
@@ -442,7 +469,7 @@ __global__ __launch_bounds__(256) void k_ln_bwd(const LnParams p) {
         }
     }
     __syncthreads();
-    float* dst = p.part + (int64_t)blockIdx.x * 2 * p.C;
+    float* dst = part_out;
     for (int i = threadIdx.x; i < 2 * p.C; i += 256) {
         float t = 0.f;
         for (int gi = 0; gi < 4 * RPW; ++gi) t += sm[(size_t)gi * 2 * p.C + i];
@@ -856,6 +883,140 @@ int mtlora_residual_layernorm_bwd(const void* dy, const void* x_new, const float
     if (!d_branch) return MTLORA_ERR_NULL;
     return ln_bwd_impl(dy, x_new, gamma, mean, rstd, d_shortcut, dgamma, dbeta, M, C, x_dtype, dy_dtype, scratch, scratch_bytes,
                        dx_addend, 0, 0, d_branch, scale, B, stream);
+}
+
+/* n independent inputs through the SAME LayerNorm in one launch each way (PatchMerging's norm applied to the shared tensor and
+ * to every task tensor, swin_transformer_mtlora.py:543-551): dgamma / dbeta come out summed over the inputs. */
+int64_t mtlora_layernorm_multi_bwd_scratch_bytes(int n, int64_t M, int64_t C, int x_dtype) {
+    const int64_t one = mtlora_layernorm_bwd_scratch_bytes(M, C, x_dtype);
+    if (one < 0 || n < 1 || n > MTLORA_MAX_TASKS + 1) return -1;
+    return (one - 256) * n + 256;
+}
+
+int mtlora_layernorm_multi_fwd(int n, const void* const* x, const float* gamma, const float* beta, void* const* y,
+                               float* const* mean, float* const* rstd, int64_t M, int64_t C, float eps, int x_dtype, int y_dtype,
+                               int merge_h, int merge_w, void* stream) {
+    int st = ln_check(M, C, x_dtype, y_dtype);
+    if (st != MTLORA_OK) return st;
+    if (n < 1 || n > MTLORA_MAX_TASKS + 1) return MTLORA_ERR_SHAPE;
+    if (!x || !gamma || !beta || !y || !mean || !rstd) return MTLORA_ERR_NULL;
+    LnParams p = {};
+    for (int k = 0; k < n; ++k) {
+        if (!x[k] || !y[k] || !mean[k] || !rstd[k]) return MTLORA_ERR_NULL;
+        if (((uintptr_t)x[k] | (uintptr_t)y[k]) & 15u) return MTLORA_ERR_ALIGN;
+        p.x_k[k] = x[k];
+        p.y_k[k] = y[k];
+        p.mean_k[k] = mean[k];
+        p.rstd_k[k] = rstd[k];
+    }
+    if (M == 0) return MTLORA_OK;
+    p.multi_x = 1;
+    p.x = x[0];
+    p.y = y[0];
+    p.mean = mean[0];
+    p.rstd = rstd[0];
+    p.gamma = gamma;
+    p.beta = beta;
+    p.M = M;
+    p.C = (int)C;
+    p.eps = eps;
+    p.rows_per_sample = 1;
+    st = ln_merge(p, M, C, x_dtype, merge_h, merge_w);
+    if (st != MTLORA_OK) return st;
+    const int nvec_h = (int)(C / (x_dtype == MTLORA_F32 ? 4 : 8));
+    const int lpr = pick_lpr(nvec_h);
+    const int vpl = (nvec_h + lpr - 1) / lpr;
+    const int gx = (int)mtl_ceil_div(ln_grid(M, lpr, 1 << 30), vpl <= 3 ? 4 : 1) < 256 * 8
+                       ? (int)mtl_ceil_div(ln_grid(M, lpr, 1 << 30), vpl <= 3 ? 4 : 1)
+                       : 256 * 8;
+    const dim3 grid((unsigned)gx, (unsigned)n);
+    const size_t lds = 0;
+    hipStream_t s = (hipStream_t)stream;
+    const int es_x = mtl_elem_size(x_dtype), es_y = mtl_elem_size(y_dtype);
+    mtl_prof_tag("M%lld C%lld x%d y%d mg%d n%d", (long long)M, (long long)C, x_dtype, y_dtype, merge_w, n);
+    MtlProfScope prof(PK_LN_FWD, (double)n * M * C * (es_x + es_y), s);
+#define LN_EXTRA , false
+    if (x_dtype == MTLORA_F32 && y_dtype == MTLORA_F32) {
+        LN_DISPATCH_LPR(k_ln_fwd, float, float)
+    } else if (x_dtype == MTLORA_F32) {
+        LN_DISPATCH_LPR(k_ln_fwd, float, bf16)
+    } else if (y_dtype == MTLORA_F32) {
+        LN_DISPATCH_LPR(k_ln_fwd, bf16, float)
+    } else {
+        LN_DISPATCH_LPR(k_ln_fwd, bf16, bf16)
+    }
+#undef LN_EXTRA
+    MTL_CHECK_LAUNCH();
+    return MTLORA_OK;
+}
+
+int mtlora_layernorm_multi_bwd(int n, const void* const* dy, const void* const* x, const float* gamma, const float* const* mean,
+                               const float* const* rstd, void* const* dx, float* dgamma, float* dbeta, int64_t M, int64_t C,
+                               int x_dtype, int dy_dtype, void* scratch, int64_t scratch_bytes, const void* const* dx_addend,
+                               int merge_h, int merge_w, void* stream) {
+    int st = ln_check(M, C, x_dtype, dy_dtype);
+    if (st != MTLORA_OK) return st;
+    if (n < 1 || n > MTLORA_MAX_TASKS + 1) return MTLORA_ERR_SHAPE;
+    if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta || !scratch) return MTLORA_ERR_NULL;
+    if ((uintptr_t)scratch & 15u) return MTLORA_ERR_ALIGN;
+    if (scratch_bytes < mtlora_layernorm_multi_bwd_scratch_bytes(n, M, C, x_dtype) - 256) return MTLORA_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    if (M == 0) {
+        mtl_zero_async(dgamma, (size_t)C * 4, s);
+        mtl_zero_async(dbeta, (size_t)C * 4, s);
+        return MTLORA_OK;
+    }
+    LnParams p = {};
+    for (int k = 0; k < n; ++k) {
+        if (!dy[k] || !x[k] || !mean[k] || !rstd[k] || !dx[k]) return MTLORA_ERR_NULL;
+        const void* ad = dx_addend ? dx_addend[k] : nullptr;
+        if (((uintptr_t)dy[k] | (uintptr_t)x[k] | (uintptr_t)dx[k] | (uintptr_t)ad) & 15u) return MTLORA_ERR_ALIGN;
+        p.dy_k[k] = dy[k];
+        p.x_k[k] = x[k];
+        p.dx_k[k] = dx[k];
+        p.add_k[k] = ad;
+        p.mean_k[k] = const_cast<float*>(mean[k]);
+        p.rstd_k[k] = const_cast<float*>(rstd[k]);
+    }
+    p.multi_x = 1;
+    p.x = x[0];
+    p.dy = dy[0];
+    p.dx = dx[0];
+    p.gamma = gamma;
+    p.mean = const_cast<float*>(mean[0]);
+    p.rstd = const_cast<float*>(rstd[0]);
+    p.part = reinterpret_cast<float*>(scratch);
+    p.M = M;
+    p.C = (int)C;
+    p.rows_per_sample = 1;
+    st = ln_merge(p, M, C, x_dtype, merge_h, merge_w);
+    if (st != MTLORA_OK) return st;
+    const int nvec_h = (int)(C / (x_dtype == MTLORA_F32 ? 4 : 8));
+    const int lpr = pick_lpr(nvec_h);
+    const int vpl = (nvec_h + lpr - 1) / lpr;
+    const int gx = ln_grid(M, lpr);
+    const dim3 grid((unsigned)gx, (unsigned)n);
+    const size_t lds = (size_t)4 * (64 / lpr) * 2 * C * 4;
+    const int es_x = mtl_elem_size(x_dtype), es_g = mtl_elem_size(dy_dtype);
+    {
+        mtl_prof_tag("M%lld C%lld x%d g%d mg%d n%d", (long long)M, (long long)C, x_dtype, dy_dtype, merge_w, n);
+        MtlProfScope prof(PK_LN_BWD, (double)n * M * C * (2 * es_x + es_g + (dx_addend ? es_x : 0)), s);
+#define LN_EXTRA
+        if (x_dtype == MTLORA_F32 && dy_dtype == MTLORA_F32) {
+            LN_DISPATCH_LPR(k_ln_bwd, float, float)
+        } else if (x_dtype == MTLORA_F32) {
+            LN_DISPATCH_LPR(k_ln_bwd, float, bf16)
+        } else if (dy_dtype == MTLORA_F32) {
+            LN_DISPATCH_LPR(k_ln_bwd, bf16, float)
+        } else {
+            LN_DISPATCH_LPR(k_ln_bwd, bf16, bf16)
+        }
+#undef LN_EXTRA
+    }
+    hipLaunchKernelGGL(k_ln_reduce, dim3((unsigned)mtl_ceil_div(2 * C, 64)), dim3(64 * LN_RW), 0, s, (const float*)p.part, dgamma,
+                       dbeta, gx * n, (int)C);
+    MTL_CHECK_LAUNCH();
+    return MTLORA_OK;
 }
 
 /* multi-stream forms: ONE shortcut, n branches -> n (x_new, y) pairs (task-enabled Swin block: swin_transformer_mtlora.py:389-396

@@ -610,6 +610,66 @@ def layer_norm_merge(mod: torch.nn.Module, x: torch.Tensor, H: int, W: int) -> t
     return LayerNormFn.apply(x, mod.weight, mod.bias, mod.eps, compute_dtype(x), (H, W))
 
 
+class LayerNormMergeMultiFn(torch.autograd.Function):
+    """PatchMerging's ``norm(2x2 neighbourhood concat)`` applied to n token tensors (B, H*W, C) at once: returns ONE stacked
+    (n*B, H*W/4, 4C) tensor (stream-major), so that the following reduction runs as a single GEMM over all streams; one launch
+    forward, one backward (+ one reduce) with dgamma / dbeta summed over the streams (``mtlora_layernorm_multi_fwd/bwd``)."""
+
+    @staticmethod
+    def forward(ctx, weight, bias, eps: float, out_dtype: torch.dtype, H: int, W: int, n: int, *xs):
+        L.require_gpu(weight, bias, *xs)
+        B, Lt, Ct = xs[0].shape
+        C, M = 4 * Ct, B * Lt // 4
+        x2 = [x.contiguous() for x in xs]
+        w, b = weight.detach().float().contiguous(), bias.detach().float().contiguous()
+        y = torch.empty((n, M, C), dtype=out_dtype, device=x2[0].device)
+        stats = torch.empty((2 * n, M), dtype=torch.float32, device=x2[0].device)
+        means, rstds = [stats[k] for k in range(n)], [stats[n + k] for k in range(n)]
+        st = L.lib().mtlora_layernorm_multi_fwd(n, L.ptr_array9(x2), L.ptr(w), L.ptr(b), L.ptr_array9([y[k] for k in range(n)]),
+                                                L.ptr_array9(means), L.ptr_array9(rstds), M, C, float(eps), L.dtype_code(x2[0]),
+                                                L.dtype_code(y), H, W, L.stream_ptr())
+        L.check(st, "mtlora_layernorm_multi_fwd")
+        ctx.save_for_backward(w, stats, *x2)
+        ctx.cfg = (n, M, C, H, W, xs[0].shape)
+        return y.view(n * B, Lt // 4, C)
+
+    @staticmethod
+    def backward(ctx, g):
+        w, stats, *x2 = ctx.saved_tensors
+        n, M, C, H, W, shape = ctx.cfg
+        g3 = g.reshape(n, M, C)
+        if g3.dtype not in (torch.float32, torch.bfloat16):
+            g3 = g3.float()
+        g3 = g3.contiguous()
+        dev = x2[0].device
+        lib = L.lib()
+        sb = lib.mtlora_layernorm_multi_bwd_scratch_bytes(n, M, C, L.dtype_code(x2[0]))
+        scratch = torch.empty(sb, dtype=torch.uint8, device=dev)
+        dxs = [torch.empty_like(x) for x in x2]
+        dg = torch.empty(C, dtype=torch.float32, device=dev)
+        db = torch.empty(C, dtype=torch.float32, device=dev)
+        means, rstds = [stats[k] for k in range(n)], [stats[n + k] for k in range(n)]
+        st = lib.mtlora_layernorm_multi_bwd(n, L.ptr_array9([g3[k] for k in range(n)]), L.ptr_array9(x2), L.ptr(w),
+                                            L.ptr_array9(means), L.ptr_array9(rstds), L.ptr_array9(dxs), L.ptr(dg), L.ptr(db), M, C,
+                                            L.dtype_code(x2[0]), L.dtype_code(g3), L.ptr(scratch), sb, L.ptr_array9(None), H, W,
+                                            L.stream_ptr())
+        L.check(st, "mtlora_layernorm_multi_bwd")
+        return (dg, db, None, None, None, None, None, *[d.view(shape) for d in dxs])
+
+
+def layer_norm_merge_multi(mod: torch.nn.Module, xs, H: int, W: int):
+    """stacked (n*B, H*W/4, 4C) = cat_k PatchMerging-norm(xs[k]) (stream-major), or None when the fused kernel does not apply."""
+    B, Lt, C = xs[0].shape
+    ve = 4 if xs[0].dtype == torch.float32 else 8
+    ok = (type(mod) is torch.nn.LayerNorm and mod.elementwise_affine and mod.bias is not None and 2 <= len(xs) <= L.MAX_TASKS + 1
+          and all(x.is_cuda and x.dtype == xs[0].dtype and x.shape == xs[0].shape for x in xs)
+          and xs[0].dtype in (torch.float32, torch.bfloat16) and C % ve == 0 and Lt == H * W and H % 2 == 0 and W % 2 == 0
+          and 4 * C <= (2048 if xs[0].dtype == torch.float32 else 4096))
+    if not ok:
+        return None
+    return LayerNormMergeMultiFn.apply(mod.weight, mod.bias, mod.eps, compute_dtype(xs[0]), H, W, len(xs), *xs)
+
+
 def layer_norm(mod: torch.nn.Module, x: torch.Tensor, feeds_linear: bool = True, _fork: bool = False):
     """``mod(x)`` for an ``nn.LayerNorm`` over the last dim, through the HIP kernel.  ``feeds_linear``: the output is
     only consumed by an MTLoRALinear, so it is written directly in the hot path's compute dtype (bf16 under autocast

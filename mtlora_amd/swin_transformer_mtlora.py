@@ -369,6 +369,16 @@ class PatchMerging(nn.Module):
         y, _ = self.reduction(Fn.layer_norm_merge(self.norm, x, H, W))
         return y
 
+    def forward_multi(self, xs):
+        """the shared tensor and the task tensors through the same merging in ONE LayerNorm launch and ONE reduction GEMM
+        (stacked along the batch); falls back to per-tensor calls when the fused kernel does not apply."""
+        H, W = self.input_resolution
+        stacked = Fn.layer_norm_merge_multi(self.norm, xs, H, W) if len(xs) > 1 else None
+        if stacked is None:
+            return [self.forward(x) for x in xs]
+        y, _ = self.reduction(stacked)
+        return list(y.view(len(xs), -1, *y.shape[1:]).unbind(0))
+
     def extra_repr(self) -> str:
         return f"input_resolution={self.input_resolution}, dim={self.dim}"
 
@@ -411,9 +421,13 @@ class BasicLayer(nn.Module):
             x, tasks_lora = out[0], out[1]
             normed = out[2] if len(out) > 2 else None
         if self.downsample is not None:
-            x = self.downsample(x)
-            if tasks_lora is not None:
-                tasks_lora = {t: self.downsample(tasks_lora[t]) for t in self.tasks}
+            if tasks_lora is not None and hasattr(self.downsample, "forward_multi"):
+                outs = self.downsample.forward_multi([x] + [tasks_lora[t] for t in self.tasks])
+                x, tasks_lora = outs[0], {t: outs[1 + i] for i, t in enumerate(self.tasks)}
+            else:
+                x = self.downsample(x)
+                if tasks_lora is not None:
+                    tasks_lora = {t: self.downsample(tasks_lora[t]) for t in self.tasks}
         return x, tasks_lora
 
     def extra_repr(self) -> str:

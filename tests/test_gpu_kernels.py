@@ -583,6 +583,40 @@ def test_residual_layer_norm_fused(rdt, ydt, B, Ltok, C, use_scale):
     assert_close(br2.grad, g_skip.double() * sc64.view(B, 1, 1), ydt, "d_branch (skip only)")
 
 
+@pytest.mark.parametrize("xdt,autocast", [(torch.float32, True), (torch.bfloat16, True), (torch.float32, False)])
+@pytest.mark.parametrize("n,B,H,W,C", [(5, 2, 8, 8, 96), (3, 2, 6, 10, 192), (2, 1, 4, 4, 384)])
+def test_layer_norm_merge_multi(xdt, autocast, n, B, H, W, C):
+    """PatchMerging's norm over n token tensors in one launch (stacked output) == n single-tensor merge-gather LayerNorms:
+    outputs bit-equal, input gradients bit-equal, dgamma / dbeta equal to the sum over the streams."""
+    from mtlora_amd import functional as Fn
+    torch.manual_seed(C + n)
+    ln = torch.nn.LayerNorm(4 * C).to(dev())
+    with torch.no_grad():
+        ln.weight.normal_(1.0, 0.1)
+        ln.bias.normal_(0.0, 0.1)
+    xs = [torch.randn(B, H * W, C, device=dev()).to(xdt).requires_grad_(True) for _ in range(n)]
+    with torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
+        ref = [Fn.layer_norm_merge(ln, x, H, W) for x in xs]
+    g = [torch.randn_like(r) for r in ref]
+    torch.autograd.backward(ref, g)
+    gx_ref = [x.grad.clone() for x in xs]
+    gw_ref, gb_ref = ln.weight.grad.clone(), ln.bias.grad.clone()
+    for x in xs:
+        x.grad = None
+    ln.zero_grad()
+    with torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
+        st = Fn.layer_norm_merge_multi(ln, xs, H, W)
+    assert st is not None and st.shape == (n * B, H * W // 4, 4 * C) and st.dtype == ref[0].dtype
+    for k in range(n):
+        assert torch.equal(st[k * B:(k + 1) * B], ref[k])
+    st.backward(torch.cat(g, 0))
+    for k in range(n):
+        assert torch.equal(xs[k].grad, gx_ref[k])
+    dt = ref[0].dtype
+    assert_close(ln.weight.grad, gw_ref.double(), dt, "dgamma", mult=2)
+    assert_close(ln.bias.grad, gb_ref.double(), dt, "dbeta", mult=2)
+
+
 @pytest.mark.parametrize("use_scale", [True, False])
 @pytest.mark.parametrize("n,B,Ltok,C", [(5, 4, 49, 96), (3, 2, 100, 384), (5, 2, 9, 768), (9, 2, 30, 192)])
 @pytest.mark.parametrize("rdt,ydt", [(torch.float32, torch.bfloat16), (torch.bfloat16, torch.bfloat16), (torch.float32, torch.float32)])

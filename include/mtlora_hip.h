@@ -228,6 +228,21 @@ int mtlora_layernorm_multi_bwd(int n, const void* const* dy, const void* const* 
                                int x_dtype, int dy_dtype, void* scratch, int64_t scratch_bytes, const void* const* dx_addend,
                                int merge_h, int merge_w, void* stream);
 
+/* n independent streams, each  x_new[k] = res[k] + scale[k][sample] * branch[k]  followed by the SAME LayerNorm (plain rows, or
+ * the PatchMerging gather with merge_h / merge_w): the MLP residual of the task-enabled block (swin_transformer_mtlora.py:398-408)
+ * fused with the stage's PatchMerging norm over the shared + task tensors (:543-551).  res / branch / x_new / d_res / d_branch are
+ * token tensors in the layout of x; y[k] may be slices of one stacked buffer.  Backward: d_res[k] = dx_addend[k] + LN-backward,
+ * d_branch[k] = scale[k] * d_res[k], dgamma / dbeta summed over the streams (scratch: mtlora_layernorm_multi_bwd_scratch_bytes). */
+int mtlora_residual_layernorm_streams_fwd(int n, const void* const* res, const void* const* branch, const float* scale,
+                                          int64_t B, const float* gamma, const float* beta, void* const* x_new, void* const* y,
+                                          float* const* mean, float* const* rstd, int64_t M, int64_t C, float eps, int x_dtype,
+                                          int y_dtype, int merge_h, int merge_w, void* stream);
+int mtlora_residual_layernorm_streams_bwd(int n, const void* const* dy, const void* const* x_new, const float* gamma,
+                                          const float* const* mean, const float* const* rstd, void* const* d_res,
+                                          void* const* d_branch, float* dgamma, float* dbeta, const float* scale, int64_t B,
+                                          int64_t M, int64_t C, int x_dtype, int dy_dtype, void* scratch, int64_t scratch_bytes,
+                                          const void* const* dx_addend, int merge_h, int merge_w, void* stream);
+
 /* The same for the task-enabled block (swin_transformer_mtlora.py:389-396 for the shared stream and each task stream): ONE
  * shortcut, n branches -> x_new[k] = shortcut + scale[k][sample] * branch[k], y[k] = LayerNorm(x_new[k]) (one launch), and
  * backward: d_branch[k] = scale[k] * (dx_addend[k] + LN-backward(dy[k])), d_shortcut = sum_k (dx_addend[k] + LN-backward(dy[k])),

@@ -83,6 +83,14 @@ _SIGS = {
     "mtlora_layernorm_multi_bwd": (c_int, [c_int, POINTER(c_void_p), POINTER(c_void_p), c_void_p, POINTER(c_void_p),
                                            POINTER(c_void_p), POINTER(c_void_p), c_void_p, c_void_p, c_int64, c_int64, c_int,
                                            c_int, c_void_p, c_int64, POINTER(c_void_p), c_int, c_int, c_void_p]),
+    "mtlora_residual_layernorm_streams_fwd": (c_int, [c_int, POINTER(c_void_p), POINTER(c_void_p), c_void_p, c_int64, c_void_p,
+                                                      c_void_p, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p),
+                                                      POINTER(c_void_p), c_int64, c_int64, c_float, c_int, c_int, c_int, c_int,
+                                                      c_void_p]),
+    "mtlora_residual_layernorm_streams_bwd": (c_int, [c_int, POINTER(c_void_p), POINTER(c_void_p), c_void_p, POINTER(c_void_p),
+                                                      POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), c_void_p, c_void_p,
+                                                      c_void_p, c_int64, c_int64, c_int64, c_int, c_int, c_void_p, c_int64,
+                                                      POINTER(c_void_p), c_int, c_int, c_void_p]),
     "mtlora_residual_layernorm_multi_fwd": (c_int, [c_int, c_void_p, POINTER(c_void_p), c_void_p, c_int64, c_void_p, c_void_p,
                                                     POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p),
                                                     c_int64, c_int64, c_float, c_int, c_int, c_void_p]),

@@ -205,6 +205,11 @@ __global__ __launch_bounds__(256) void k_ln_fwd(const LnParams p) {
         y = reinterpret_cast<TO*>(K->y_k[k]);
         mean_out = K->mean_k[k];
         rstd_out = K->rstd_k[k];
+        if constexpr (RES) {  // independent streams, each with its own residual: x_k + s_k * branch_k
+            rb_ptr = K->rb_k[k];
+            xs_ptr = K->xsum_k[k];
+            if (rscale) rscale += (int64_t)k * (p.M / p.rows_per_sample);
+        }
     }
     if constexpr (RES) {
         if (p.nk > 0) {  // multi-stream launch: blockIdx.y selects the branch / outputs; the shortcut x is shared (an in-kernel
@@ -236,11 +241,12 @@ __global__ __launch_bounds__(256) void k_ln_fwd(const LnParams p) {
     const int64_t rows_per_blk = 4 * RPW * UNR;
     for (int64_t r0 = (int64_t)blockIdx.x * rows_per_blk; r0 < p.M; r0 += (int64_t)gridDim.x * rows_per_blk) {
         u32x4 raw[UNR][MAXV];
-        int64_t row[UNR];
+        int64_t row[UNR], xbs[UNR];
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
             row[u] = r0 + (int64_t)(wave * UNR + u) * RPW + sub;
             const int64_t xb = ln_row(p, row[u] < p.M ? row[u] : 0).base;
+            xbs[u] = xb;
 #pragma unroll
             for (int i = 0; i < MAXV; ++i) {
                 const int v = lr + i * LPR;
@@ -260,12 +266,13 @@ __global__ __launch_bounds__(256) void k_ln_fwd(const LnParams p) {
                     const int v = lr + i * LPR;
                     if (v < nvec) {
                         float fb[8], fx[8];
-                        ld_n<TO, VE>(rb + row[u] * p.C + v * VE, fb);
+                        // (branch and x_new share the layout of x: plain rows, or the token tensor of the merge gather)
+                        ld_n<TO, VE>(rb + xbs[u] + coff[i], fb);
                         cvt_vec<TI>(raw[u][i], fx);
 #pragma unroll
                         for (int e = 0; e < VE; ++e) fx[e] += sc * fb[e];
                         raw[u][i] = pack_vec<TI>(fx);
-                        *reinterpret_cast<u32x4*>(xs + row[u] * p.C + v * VE) = raw[u][i];
+                        *reinterpret_cast<u32x4*>(xs + xbs[u] + coff[i]) = raw[u][i];
                     }
                 }
             }
@@ -330,6 +337,8 @@ __global__ __launch_bounds__(256) void k_ln_bwd(const LnParams p) {
     const TX* addp = reinterpret_cast<const TX*>(p.add);
     const float* mean_in = p.mean;
     const float* rstd_in = p.rstd;
+    void* dbr_ptr = p.dbr;
+    const float* rscale_in = p.rscale;
     float* part_out = p.part + (int64_t)blockIdx.x * 2 * p.C;
     if (p.multi_x) {
         LnKargs K = (LnKargs)__builtin_amdgcn_kernarg_segment_ptr();
@@ -341,6 +350,8 @@ __global__ __launch_bounds__(256) void k_ln_bwd(const LnParams p) {
         mean_in = K->mean_k[k];
         rstd_in = K->rstd_k[k];
         part_out = p.part + ((int64_t)k * gridDim.x + blockIdx.x) * 2 * p.C;
+        dbr_ptr = K->dbr_k[k];
+        if (rscale_in) rscale_in += (int64_t)k * (p.M / p.rows_per_sample);
     }
     float g[MAXV][VE], ag[MAXV][VE], ab[MAXV][VE];
 #pragma unroll
@@ -443,11 +454,11 @@ __global__ __launch_bounds__(256) void k_ln_bwd(const LnParams p) {
 #pragma unroll
                         for (int e = 0; e < VE; ++e) o[e] = rstd[u] * (gy[i][e] - c1 - xh[i][e] * c2) + fa[e];
                         st_vec<TX, VE>(dx + xb[u] + coff[i], o);
-                        if (p.dbr) {  // gradient of the residual branch (plain rows only): DropPath scale, dtype of dy
-                            const float sc = p.rscale ? p.rscale[row[u] / p.rows_per_sample] : 1.f;
+                        if (dbr_ptr) {  // gradient of the residual branch (layout of x / dx): DropPath scale, dtype of dy
+                            const float sc = rscale_in ? rscale_in[row[u] / p.rows_per_sample] : 1.f;
 #pragma unroll
                             for (int e = 0; e < VE; ++e) o[e] *= sc;
-                            st_vec<TG, VE>(reinterpret_cast<TG*>(p.dbr) + row[u] * p.C + v * VE, o);
+                            st_vec<TG, VE>(reinterpret_cast<TG*>(dbr_ptr) + xb[u] + coff[i], o);
                         }
                     }
                 }
@@ -893,13 +904,15 @@ int64_t mtlora_layernorm_multi_bwd_scratch_bytes(int n, int64_t M, int64_t C, in
     return (one - 256) * n + 256;
 }
 
-int mtlora_layernorm_multi_fwd(int n, const void* const* x, const float* gamma, const float* beta, void* const* y,
-                               float* const* mean, float* const* rstd, int64_t M, int64_t C, float eps, int x_dtype, int y_dtype,
-                               int merge_h, int merge_w, void* stream) {
+static int ln_multi_fwd_impl(int n, const void* const* x, const float* gamma, const float* beta, void* const* y,
+                             float* const* mean, float* const* rstd, int64_t M, int64_t C, float eps, int x_dtype, int y_dtype,
+                             int merge_h, int merge_w, const void* const* branch, void* const* x_new, const float* scale,
+                             int64_t B, void* stream) {
     int st = ln_check(M, C, x_dtype, y_dtype);
     if (st != MTLORA_OK) return st;
     if (n < 1 || n > MTLORA_MAX_TASKS + 1) return MTLORA_ERR_SHAPE;
     if (!x || !gamma || !beta || !y || !mean || !rstd) return MTLORA_ERR_NULL;
+    if (branch && (!x_new || B <= 0 || M % B)) return MTLORA_ERR_SHAPE;
     LnParams p = {};
     for (int k = 0; k < n; ++k) {
         if (!x[k] || !y[k] || !mean[k] || !rstd[k]) return MTLORA_ERR_NULL;
@@ -908,8 +921,19 @@ int mtlora_layernorm_multi_fwd(int n, const void* const* x, const float* gamma, 
         p.y_k[k] = y[k];
         p.mean_k[k] = mean[k];
         p.rstd_k[k] = rstd[k];
+        if (branch) {
+            if (!branch[k] || !x_new[k]) return MTLORA_ERR_NULL;
+            if (((uintptr_t)branch[k] | (uintptr_t)x_new[k]) & 15u) return MTLORA_ERR_ALIGN;
+            p.rb_k[k] = branch[k];
+            p.xsum_k[k] = x_new[k];
+        }
     }
     if (M == 0) return MTLORA_OK;
+    if (branch) {
+        p.rb = branch[0];
+        p.xsum = x_new[0];
+        p.rscale = scale;
+    }
     p.multi_x = 1;
     p.x = x[0];
     p.y = y[0];
@@ -920,7 +944,7 @@ int mtlora_layernorm_multi_fwd(int n, const void* const* x, const float* gamma, 
     p.M = M;
     p.C = (int)C;
     p.eps = eps;
-    p.rows_per_sample = 1;
+    p.rows_per_sample = branch ? M / B : 1;
     st = ln_merge(p, M, C, x_dtype, merge_h, merge_w);
     if (st != MTLORA_OK) return st;
     const int nvec_h = (int)(C / (x_dtype == MTLORA_F32 ? 4 : 8));
@@ -933,28 +957,61 @@ int mtlora_layernorm_multi_fwd(int n, const void* const* x, const float* gamma, 
     const size_t lds = 0;
     hipStream_t s = (hipStream_t)stream;
     const int es_x = mtl_elem_size(x_dtype), es_y = mtl_elem_size(y_dtype);
-    mtl_prof_tag("M%lld C%lld x%d y%d mg%d n%d", (long long)M, (long long)C, x_dtype, y_dtype, merge_w, n);
-    MtlProfScope prof(PK_LN_FWD, (double)n * M * C * (es_x + es_y), s);
-#define LN_EXTRA , false
-    if (x_dtype == MTLORA_F32 && y_dtype == MTLORA_F32) {
-        LN_DISPATCH_LPR(k_ln_fwd, float, float)
-    } else if (x_dtype == MTLORA_F32) {
-        LN_DISPATCH_LPR(k_ln_fwd, float, bf16)
-    } else if (y_dtype == MTLORA_F32) {
-        LN_DISPATCH_LPR(k_ln_fwd, bf16, float)
-    } else {
-        LN_DISPATCH_LPR(k_ln_fwd, bf16, bf16)
-    }
+    mtl_prof_tag("M%lld C%lld x%d y%d mg%d n%d res%d", (long long)M, (long long)C, x_dtype, y_dtype, merge_w, n, branch ? 1 : 0);
+    MtlProfScope prof(PK_LN_FWD, (double)n * M * C * (es_x + es_y + (branch ? es_x + es_y : 0)), s);
+    if (branch) {
+#define LN_EXTRA , true
+        if (x_dtype == MTLORA_F32 && y_dtype == MTLORA_F32) {
+            LN_DISPATCH_LPR(k_ln_fwd, float, float)
+        } else if (x_dtype == MTLORA_F32) {
+            LN_DISPATCH_LPR(k_ln_fwd, float, bf16)
+        } else if (y_dtype == MTLORA_F32) {
+            LN_DISPATCH_LPR(k_ln_fwd, bf16, float)
+        } else {
+            LN_DISPATCH_LPR(k_ln_fwd, bf16, bf16)
+        }
 #undef LN_EXTRA
+    } else {
+#define LN_EXTRA , false
+        if (x_dtype == MTLORA_F32 && y_dtype == MTLORA_F32) {
+            LN_DISPATCH_LPR(k_ln_fwd, float, float)
+        } else if (x_dtype == MTLORA_F32) {
+            LN_DISPATCH_LPR(k_ln_fwd, float, bf16)
+        } else if (y_dtype == MTLORA_F32) {
+            LN_DISPATCH_LPR(k_ln_fwd, bf16, float)
+        } else {
+            LN_DISPATCH_LPR(k_ln_fwd, bf16, bf16)
+        }
+#undef LN_EXTRA
+    }
     MTL_CHECK_LAUNCH();
     return MTLORA_OK;
 }
 
-int mtlora_layernorm_multi_bwd(int n, const void* const* dy, const void* const* x, const float* gamma, const float* const* mean,
-                               const float* const* rstd, void* const* dx, float* dgamma, float* dbeta, int64_t M, int64_t C,
-                               int x_dtype, int dy_dtype, void* scratch, int64_t scratch_bytes, const void* const* dx_addend,
+int mtlora_layernorm_multi_fwd(int n, const void* const* x, const float* gamma, const float* beta, void* const* y,
+                               float* const* mean, float* const* rstd, int64_t M, int64_t C, float eps, int x_dtype, int y_dtype,
                                int merge_h, int merge_w, void* stream) {
+    return ln_multi_fwd_impl(n, x, gamma, beta, y, mean, rstd, M, C, eps, x_dtype, y_dtype, merge_h, merge_w, nullptr, nullptr,
+                             nullptr, 1, stream);
+}
+
+/* n independent streams, each  x_new[k] = res[k] + scale[k][sample] * branch[k]  then the SAME LayerNorm (plain rows or the
+ * PatchMerging gather): the MLP residual of the task-enabled block fused with the stage's PatchMerging norm. */
+int mtlora_residual_layernorm_streams_fwd(int n, const void* const* res, const void* const* branch, const float* scale,
+                                          int64_t B, const float* gamma, const float* beta, void* const* x_new, void* const* y,
+                                          float* const* mean, float* const* rstd, int64_t M, int64_t C, float eps, int x_dtype,
+                                          int y_dtype, int merge_h, int merge_w, void* stream) {
+    if (!branch || !x_new) return MTLORA_ERR_NULL;
+    return ln_multi_fwd_impl(n, res, gamma, beta, y, mean, rstd, M, C, eps, x_dtype, y_dtype, merge_h, merge_w, branch, x_new,
+                             scale, B, stream);
+}
+
+static int ln_multi_bwd_impl(int n, const void* const* dy, const void* const* x, const float* gamma, const float* const* mean,
+                             const float* const* rstd, void* const* dx, float* dgamma, float* dbeta, int64_t M, int64_t C,
+                             int x_dtype, int dy_dtype, void* scratch, int64_t scratch_bytes, const void* const* dx_addend,
+                             int merge_h, int merge_w, void* const* d_branch, const float* scale, int64_t B, void* stream) {
     int st = ln_check(M, C, x_dtype, dy_dtype);
+    if (d_branch && (B <= 0 || M % B)) return MTLORA_ERR_SHAPE;
     if (st != MTLORA_OK) return st;
     if (n < 1 || n > MTLORA_MAX_TASKS + 1) return MTLORA_ERR_SHAPE;
     if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta || !scratch) return MTLORA_ERR_NULL;
@@ -977,6 +1034,10 @@ int mtlora_layernorm_multi_bwd(int n, const void* const* dy, const void* const* 
         p.add_k[k] = ad;
         p.mean_k[k] = const_cast<float*>(mean[k]);
         p.rstd_k[k] = const_cast<float*>(rstd[k]);
+        if (d_branch) {
+            if ((uintptr_t)d_branch[k] & 15u) return MTLORA_ERR_ALIGN;
+            p.dbr_k[k] = d_branch[k];
+        }
     }
     p.multi_x = 1;
     p.x = x[0];
@@ -988,7 +1049,8 @@ int mtlora_layernorm_multi_bwd(int n, const void* const* dy, const void* const* 
     p.part = reinterpret_cast<float*>(scratch);
     p.M = M;
     p.C = (int)C;
-    p.rows_per_sample = 1;
+    p.rscale = d_branch ? scale : nullptr;
+    p.rows_per_sample = d_branch ? M / B : 1;
     st = ln_merge(p, M, C, x_dtype, merge_h, merge_w);
     if (st != MTLORA_OK) return st;
     const int nvec_h = (int)(C / (x_dtype == MTLORA_F32 ? 4 : 8));
@@ -1017,6 +1079,26 @@ int mtlora_layernorm_multi_bwd(int n, const void* const* dy, const void* const* 
                        dbeta, gx * n, (int)C);
     MTL_CHECK_LAUNCH();
     return MTLORA_OK;
+}
+
+int mtlora_layernorm_multi_bwd(int n, const void* const* dy, const void* const* x, const float* gamma, const float* const* mean,
+                               const float* const* rstd, void* const* dx, float* dgamma, float* dbeta, int64_t M, int64_t C,
+                               int x_dtype, int dy_dtype, void* scratch, int64_t scratch_bytes, const void* const* dx_addend,
+                               int merge_h, int merge_w, void* stream) {
+    return ln_multi_bwd_impl(n, dy, x, gamma, mean, rstd, dx, dgamma, dbeta, M, C, x_dtype, dy_dtype, scratch, scratch_bytes,
+                             dx_addend, merge_h, merge_w, nullptr, nullptr, 1, stream);
+}
+
+/* backward of mtlora_residual_layernorm_streams_fwd: d_res[k] = dx_addend[k] + LN-backward(dy[k]) (layout of res),
+ * d_branch[k] = scale[k][sample] * d_res[k]; dgamma / dbeta summed over the streams. */
+int mtlora_residual_layernorm_streams_bwd(int n, const void* const* dy, const void* const* x_new, const float* gamma,
+                                          const float* const* mean, const float* const* rstd, void* const* d_res,
+                                          void* const* d_branch, float* dgamma, float* dbeta, const float* scale, int64_t B,
+                                          int64_t M, int64_t C, int x_dtype, int dy_dtype, void* scratch, int64_t scratch_bytes,
+                                          const void* const* dx_addend, int merge_h, int merge_w, void* stream) {
+    if (!d_branch) return MTLORA_ERR_NULL;
+    return ln_multi_bwd_impl(n, dy, x_new, gamma, mean, rstd, d_res, dgamma, dbeta, M, C, x_dtype, dy_dtype, scratch,
+                             scratch_bytes, dx_addend, merge_h, merge_w, d_branch, scale, B, stream);
 }
 
 /* multi-stream forms: ONE shortcut, n branches -> n (x_new, y) pairs (task-enabled Swin block: swin_transformer_mtlora.py:389-396

@@ -657,6 +657,84 @@ class LayerNormMergeMultiFn(torch.autograd.Function):
         return (dg, db, None, None, None, None, None, *[d.view(shape) for d in dxs])
 
 
+class ResidualMergeNormStreamsFn(torch.autograd.Function):
+    """n independent streams: x_new_k = res_k + scale[k] * branch_k (the MLP residual + DropPath of the task-enabled block),
+    then PatchMerging's ``norm(2x2 neighbourhood concat)`` of every x_new_k -> ONE stacked (n*B, H*W/4, 4C) tensor.  One launch
+    forward, one backward (+ reduce): d_res_k = LN'(g)_k scattered back, d_branch_k = scale[k] * d_res_k; x_new_k is only kept
+    for the backward (the block output feeds nothing but the merging).
+    args: scale ((n, B) fp32 or None), weight, bias, eps, out_dtype, H, W, n, *res(n), *branches(n)"""
+
+    @staticmethod
+    def forward(ctx, scale, weight, bias, eps: float, out_dtype: torch.dtype, H: int, W: int, n: int, *tensors):
+        res, brs = tensors[:n], tensors[n:]
+        L.require_gpu(weight, bias, *tensors)
+        B, Lt, Ct = res[0].shape
+        C, M = 4 * Ct, B * Lt // 4
+        r2 = [x.contiguous() for x in res]
+        b2 = [x.contiguous() for x in brs]
+        w, b = weight.detach().float().contiguous(), bias.detach().float().contiguous()
+        xs = [torch.empty_like(x) for x in r2]
+        y = torch.empty((n, M, C), dtype=out_dtype, device=r2[0].device)
+        stats = torch.empty((2 * n, M), dtype=torch.float32, device=r2[0].device)
+        means, rstds = [stats[k] for k in range(n)], [stats[n + k] for k in range(n)]
+        st = L.lib().mtlora_residual_layernorm_streams_fwd(n, L.ptr_array9(r2), L.ptr_array9(b2), L.ptr(scale), B, L.ptr(w), L.ptr(b),
+                                                           L.ptr_array9(xs), L.ptr_array9([y[k] for k in range(n)]),
+                                                           L.ptr_array9(means), L.ptr_array9(rstds), M, C, float(eps),
+                                                           L.dtype_code(r2[0]), L.dtype_code(y), H, W, L.stream_ptr())
+        L.check(st, "mtlora_residual_layernorm_streams_fwd")
+        ctx.save_for_backward(w, stats, scale, *xs)
+        ctx.cfg = (n, M, C, H, W, B, res[0].shape, brs[0].dtype)
+        return y.view(n * B, Lt // 4, C)
+
+    @staticmethod
+    def backward(ctx, g):
+        w, stats, scale, *xs = ctx.saved_tensors
+        n, M, C, H, W, B, shape, bdt = ctx.cfg
+        g3 = g.reshape(n, M, C)
+        if g3.dtype != bdt:
+            g3 = g3.to(bdt)
+        g3 = g3.contiguous()
+        dev = xs[0].device
+        lib = L.lib()
+        sb = lib.mtlora_layernorm_multi_bwd_scratch_bytes(n, M, C, L.dtype_code(xs[0]))
+        scratch = torch.empty(sb, dtype=torch.uint8, device=dev)
+        dres = [torch.empty_like(x) for x in xs]
+        dbr = [torch.empty(shape, dtype=bdt, device=dev) for _ in range(n)]
+        dg = torch.empty(C, dtype=torch.float32, device=dev)
+        db = torch.empty(C, dtype=torch.float32, device=dev)
+        means, rstds = [stats[k] for k in range(n)], [stats[n + k] for k in range(n)]
+        st = lib.mtlora_residual_layernorm_streams_bwd(n, L.ptr_array9([g3[k] for k in range(n)]), L.ptr_array9(xs), L.ptr(w),
+                                                       L.ptr_array9(means), L.ptr_array9(rstds), L.ptr_array9(dres),
+                                                       L.ptr_array9(dbr), L.ptr(dg), L.ptr(db), L.ptr(scale), B, M, C,
+                                                       L.dtype_code(xs[0]), L.dtype_code(g3), L.ptr(scratch), sb, L.ptr_array9(None),
+                                                       H, W, L.stream_ptr())
+        L.check(st, "mtlora_residual_layernorm_streams_bwd")
+        return (None, dg, db, None, None, None, None, None, *[d.view(shape) for d in dres], *dbr)
+
+
+def residual_merge_norm_streams(mod: torch.nn.Module, res, branches, H: int, W: int, drop_prob: float, training: bool):
+    """stacked PatchMerging-norm of (res_k + DropPath_k(branches_k)) over the streams, or None when the fused kernels do not
+    apply (the caller then forms the residuals and calls ``layer_norm_merge_multi`` / per-stream code)."""
+    n = len(res)
+    B, Lt, C = res[0].shape
+    ve = 4 if res[0].dtype == torch.float32 else 8
+    ok = (type(mod) is torch.nn.LayerNorm and mod.elementwise_affine and mod.bias is not None and 2 <= n <= L.MAX_TASKS + 1
+          and len(branches) == n and all(x.is_cuda and x.dtype == res[0].dtype and x.shape == res[0].shape for x in res)
+          and all(x.shape == res[0].shape and x.dtype == branches[0].dtype for x in branches)
+          and res[0].dtype in (torch.float32, torch.bfloat16) and C % ve == 0 and Lt == H * W and H % 2 == 0 and W % 2 == 0
+          and 4 * C <= (2048 if res[0].dtype == torch.float32 else 4096) and torch.is_grad_enabled())
+    if ok:
+        out_dtype = compute_dtype(res[0])
+        ok = branches[0].dtype == out_dtype
+    if not ok:
+        return None
+    scale = None
+    if training and drop_prob > 0.0:
+        keep = 1.0 - drop_prob
+        scale = torch.empty(n, B, dtype=torch.float32, device=res[0].device).bernoulli_(keep).div_(keep)
+    return ResidualMergeNormStreamsFn.apply(scale, mod.weight, mod.bias, mod.eps, out_dtype, H, W, n, *res, *branches)
+
+
 def layer_norm_merge_multi(mod: torch.nn.Module, xs, H: int, W: int):
     """stacked (n*B, H*W/4, 4C) = cat_k PatchMerging-norm(xs[k]) (stream-major), or None when the fused kernel does not apply."""
     B, Lt, C = xs[0].shape

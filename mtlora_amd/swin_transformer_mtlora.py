@@ -296,9 +296,11 @@ class SwinTransformerBlock(nn.Module):
         merge = lambda v: WindowProcessReverse.apply(v.reshape(-1, ws, ws, C).contiguous(), B, H, W, C, s, ws).view(B, H * W, C)
         return merge(a), None if a_t is None else {t: merge(a_t[t]) for t in self.tasks}
 
-    def forward(self, x, normed=None, next_norm=None):
+    def forward(self, x, normed=None, next_norm=None, defer_residual=False):
         """normed: norm1(x) already formed by the previous block's fused residual + LayerNorm; next_norm: the following
-        block's norm1 -- when this block ends in a single-stream residual the call returns (x, None, next_norm(x))."""
+        block's norm1 -- when this block ends in a single-stream residual the call returns (x, None, next_norm(x)).
+        defer_residual: a task-enabled block returns (None, None, None, (residuals, branches, drop_prob)) instead of applying
+        its MLP residual -- ``PatchMerging.forward_residual_multi`` fuses it into the merging norm."""
         H, W = self.input_resolution
         B, L, C = x.shape
         assert L == H * W, "input feature has wrong size"
@@ -334,6 +336,8 @@ class SwinTransformerBlock(nn.Module):
         if x_t is None:  # INTERMEDIATE_SPECIALIZATION-style: mlp specialises but attention did not (:401-403)
             out = Fn.residual_droppath(x, [m], p_dp, self.training)[0]
             return out, {t: self.drop_path(m_t[t]) for t in self.tasks}
+        if defer_residual:  # the stage's PatchMerging applies x_k + DropPath(m_k) itself, inside its LayerNorm kernel
+            return None, None, None, ([x] + [x_t[t] for t in self.tasks], [m] + [m_t[t] for t in self.tasks], p_dp)
         r = Fn.residual_droppath([x] + [x_t[t] for t in self.tasks], [m] + [m_t[t] for t in self.tasks], p_dp, self.training)
         return r[0], {t: r[1 + i] for i, t in enumerate(self.tasks)}
 
@@ -368,6 +372,16 @@ class PatchMerging(nn.Module):
         # reference's cat; gathered by the LayerNorm kernel itself (no strided copy forward, no scatter copy backward)
         y, _ = self.reduction(Fn.layer_norm_merge(self.norm, x, H, W))
         return y
+
+    def forward_residual_multi(self, res, branches, drop_prob, training):
+        """merging of (res_k + DropPath(branches_k)) for the shared + task streams: residual, 2x2 gather and LayerNorm in one
+        launch, one reduction GEMM; falls back to residual kernel + ``forward_multi``."""
+        H, W = self.input_resolution
+        stacked = Fn.residual_merge_norm_streams(self.norm, res, branches, H, W, drop_prob, training)
+        if stacked is None:
+            return self.forward_multi(Fn.residual_droppath(list(res), list(branches), drop_prob, training))
+        y, _ = self.reduction(stacked)
+        return list(y.view(len(res), -1, *y.shape[1:]).unbind(0))
 
     def forward_multi(self, xs):
         """the shared tensor and the task tensors through the same merging in ONE LayerNorm launch and ONE reduction GEMM
@@ -414,12 +428,20 @@ class BasicLayer(nn.Module):
     def forward(self, x):
         tasks_lora = None
         normed = None
+        deferred = None
         for i, blk in enumerate(self.blocks):
             # a block that ends in a single-stream residual also applies the next block's norm1 (one fused kernel)
             nxt = self.blocks[i + 1].norm1 if (i + 1 < len(self.blocks) and not blk.lora) else None
-            out = blk(x, normed, nxt)
+            last = i + 1 == len(self.blocks)
+            defer = (last and blk.lora and self.downsample is not None and hasattr(self.downsample, "forward_residual_multi")
+                     and self.training and torch.is_grad_enabled())
+            out = blk(x, normed, nxt, defer) if defer else blk(x, normed, nxt)
             x, tasks_lora = out[0], out[1]
             normed = out[2] if len(out) > 2 else None
+            deferred = out[3] if len(out) > 3 else None
+        if deferred is not None:
+            outs = self.downsample.forward_residual_multi(deferred[0], deferred[1], deferred[2], self.training)
+            return outs[0], {t: outs[1 + i] for i, t in enumerate(self.tasks)}
         if self.downsample is not None:
             if tasks_lora is not None and hasattr(self.downsample, "forward_multi"):
                 outs = self.downsample.forward_multi([x] + [tasks_lora[t] for t in self.tasks])

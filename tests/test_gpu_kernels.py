@@ -618,6 +618,50 @@ def test_layer_norm_merge_multi(xdt, autocast, n, B, H, W, C):
 
 
 @pytest.mark.parametrize("use_scale", [True, False])
+@pytest.mark.parametrize("rdt,ydt", [(torch.float32, torch.bfloat16), (torch.bfloat16, torch.bfloat16), (torch.float32, torch.float32)])
+@pytest.mark.parametrize("n,B,H,W,C", [(5, 2, 8, 8, 96), (3, 2, 6, 10, 192), (2, 3, 4, 4, 384)])
+def test_residual_merge_norm_streams(rdt, ydt, n, B, H, W, C, use_scale):
+    """mtlora_residual_layernorm_streams_fwd/bwd with the PatchMerging gather (per-stream residual + DropPath folded into the
+    merging LayerNorm, stacked output) == residual kernel + per-stream merge-gather LayerNorm: outputs and the residual /
+    branch gradients bit-equal, dgamma / dbeta equal to the sum over the streams."""
+    from mtlora_amd import functional as Fn
+    torch.manual_seed(3 * C + n)
+    ln = torch.nn.LayerNorm(4 * C).to(dev())
+    with torch.no_grad():
+        ln.weight.normal_(1.0, 0.1)
+        ln.bias.normal_(0.0, 0.1)
+    res = [torch.randn(B, H * W, C, device=dev()).to(rdt).requires_grad_(True) for _ in range(n)]
+    brs = [torch.randn(B, H * W, C, device=dev()).to(ydt).requires_grad_(True) for _ in range(n)]
+    scale = ((torch.rand(n, B, device=dev()) < 0.7).float() / 0.7) if use_scale else None
+    ac = ydt == torch.bfloat16
+    with torch.autocast("cuda", dtype=torch.bfloat16, enabled=ac):
+        xs = Fn.ResidualDropPathFn.apply(scale, False, n, *res, *brs)
+        ref = [Fn.layer_norm_merge(ln, x, H, W) for x in xs]
+    g = [torch.randn_like(r) for r in ref]
+    torch.autograd.backward(ref, g)
+    ref_g = [t.grad.clone() for t in res + brs]
+    gw, gb = ln.weight.grad.clone(), ln.bias.grad.clone()
+    for t in res + brs:
+        t.grad = None
+    ln.zero_grad()
+    with torch.autocast("cuda", dtype=torch.bfloat16, enabled=ac):
+        st = Fn.ResidualMergeNormStreamsFn.apply(scale, ln.weight, ln.bias, ln.eps, ydt, H, W, n, *res, *brs)
+    assert st.shape == (n * B, H * W // 4, 4 * C) and st.dtype == ydt
+    for k in range(n):
+        assert torch.equal(st[k * B:(k + 1) * B], ref[k]), k
+    st.backward(torch.cat(g, 0))
+    for t, r in zip(res, ref_g[:n]):
+        assert torch.equal(t.grad, r)
+    for k, (t, r) in enumerate(zip(brs, ref_g[n:])):
+        if rdt == torch.float32 or scale is None:
+            assert torch.equal(t.grad, r)
+        else:  # bf16 stream: the unfused path scales the bf16-ROUNDED d_res, the fused kernel scales before rounding
+            assert_close(t.grad, r.double(), ydt, f"d_branch{k}")
+    assert_close(ln.weight.grad, gw.double(), ydt, "dgamma", mult=2)
+    assert_close(ln.bias.grad, gb.double(), ydt, "dbeta", mult=2)
+
+
+@pytest.mark.parametrize("use_scale", [True, False])
 @pytest.mark.parametrize("n,B,Ltok,C", [(5, 4, 49, 96), (3, 2, 100, 384), (5, 2, 9, 768), (9, 2, 30, 192)])
 @pytest.mark.parametrize("rdt,ydt", [(torch.float32, torch.bfloat16), (torch.bfloat16, torch.bfloat16), (torch.float32, torch.float32)])
 def test_residual_layer_norm_multi(rdt, ydt, n, B, Ltok, C, use_scale):

@@ -368,7 +368,8 @@ __global__ __launch_bounds__(256) void k_ln_bwd(const LnParams p) {
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) coff[i] = ln_col(p, (lr + i * LPR < nvec ? lr + i * LPR : 0) * VE);
     // UNR row groups per wave iteration, loads issued back to back as raw vectors before any arithmetic (as in k_ln_fwd)
-    constexpr int UNR = MAXV <= 3 ? 2 : 1;
+    // (bf16 rows hold 8 elements per vector: two row groups in flight need > 256 VGPRs -- one wave per SIMD -- and ran slower)
+    constexpr int UNR = (MAXV <= 3 && sizeof(TX) == 4) ? 2 : 1;
     constexpr int GW = sizeof(TG) == sizeof(TX) ? 4 : (sizeof(TG) == 2 ? 2 : 8);  // dwords of dy per lane-vector
     const int64_t rows_per_blk = 4 * RPW * UNR;
     for (int64_t r0 = (int64_t)blockIdx.x * rows_per_blk; r0 < p.M; r0 += (int64_t)gridDim.x * rows_per_blk) {
@@ -615,14 +616,22 @@ __global__ __launch_bounds__(256) void k_resln_bwd_multi(const LnParams p) {
                 }
             }
         };
-        Regs A, Bq;
-        load(A, 0);
-        for (int k = 0; k < p.nk; k += 2) {
-            if (k + 1 < p.nk) load(Bq, k + 1);
-            compute(A, k);
-            if (k + 1 < p.nk) {
-                if (k + 2 < p.nk) load(A, k + 2);
-                compute(Bq, k + 1);
+        if constexpr (sizeof(TX) == 4) {  // two streams in flight (bf16 rows: 8 elements per vector, that needs > 256 VGPRs)
+            Regs A, Bq;
+            load(A, 0);
+            for (int k = 0; k < p.nk; k += 2) {
+                if (k + 1 < p.nk) load(Bq, k + 1);
+                compute(A, k);
+                if (k + 1 < p.nk) {
+                    if (k + 2 < p.nk) load(A, k + 2);
+                    compute(Bq, k + 1);
+                }
+            }
+        } else {
+            Regs A;
+            for (int k = 0; k < p.nk; ++k) {
+                load(A, k);
+                compute(A, k);
             }
         }
         if (rv) {

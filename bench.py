@@ -1,24 +1,34 @@
 #!/usr/bin/env python3
 """bench.py -- images/sec of one MTLoRA train step (BASELINE.json metric) on N MI355X.
 
-    python bench.py --gpus 1 --steps 10 --warmup 3
+    python bench.py --gpus 1 --steps 10 --warmup 3 [--config c2]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
-A "step" is one pass of the hot path over one synthetic batch: bf16-autocast forward of the Swin-T/448
-MTLoRA backbone (r_shared 64, r_task 4, 4 tasks) + HRNet heads + weighted multi-task loss, backward,
-[RCCL all-reduce of the trainable gradients], clip_grad_norm_(5.0), AdamW, zero_grad -- dropout 0.05 and
-DropPath 0.2 active (train mode).  Per-GPU batch is fixed (weak scaling); inputs are resident in HBM
-before the timed region.  Rank 0 prints ONE JSON line.
+A "step" is one pass of the hot path over one synthetic batch: bf16-autocast forward of the MTLoRA Swin backbone +
+HRNet heads + weighted multi-task loss, backward, [RCCL all-reduce of the trainable gradients], clip_grad_norm_(5.0),
+AdamW, zero_grad -- dropout 0.05 and DropPath 0.2 active (train mode).  Per-GPU batch is fixed (weak scaling); inputs
+are resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
+
+--config selects a row of mtlora_amd.mtl_harness.CONFIGS (the BASELINE.json configs):
+    c2 (default)  Swin-T/448, 4 tasks, r_shared 64 / r_task 4, B=32      <- the configuration the metric is quoted on
+    c1            Swin-T/224, 1 task, r=4, B=2 (the reference's CPU-runnable plumbing case)
+    c4            Swin-B/448, 4 tasks, r=128 shared and per task, B=16   (near machine balance)
+    c5:<r>        Swin-T/448, 8 synthetic tasks, r in {4,16,64,256}      (skinny-GEMM HBM regime)
 
 Extra objects in the line (this tier's contract):
-  roofline      the dominant HIP kernel (k_nt, the fused MTLoRALinear GEMM): algorithmic bytes of its
-                launches (SURVEY 8d formulas) / their HIP-event durations, measured over an extra K profiled
-                steps right after the timed region (events on the launch stream; see mtlora_prof_begin).
-  cpu_baseline  the oracle (a plain-PyTorch port of the reference) run on this box's host cores on a
-                bounded sample (B=2, fp32, 1 warm-up + 2 steps) -- kind "port".
-The eager PyTorch-ROCm comparator of the north star's ">= 4x" target is timed by tests/perf_eager_gpu.py
-(it runs the oracle's ATen dataflow on the GPU, and only tests/ may import the oracle for that).
+  roofline      the dominant HIP kernel (k_nt, the fused MTLoRALinear GEMM), HOT-PATH launches only (the callers' plain
+                rank-0 GEMMs have their own kinds): SURVEY 8(d) algorithmic bytes / their HIP-event durations, measured
+                over extra profiled steps right after the timed region (events on the launch stream; mtlora_prof_begin).
+                `frac` follows 8(d) exactly (no GELU traffic); `launched` is the same with the fused GELU write / gate
+                read counted as useful bytes; `mfma` prices the same launches against the dense bf16 MFMA peak;
+                `linear_path` covers every kernel of the MTLoRALinear path (k_nt + k_tn + pack / reduce / sum).
+  eager_gpu     the north star's ">= 4x" comparator, timed in the same process: the oracle's ATen-op dataflow (== the
+                reference's eager PyTorch-ROCm path: 6+4T launches per MTLoRALinear, roll / partition / materialised
+                scores per block) on the same GPU, same config, same batch, bf16 autocast, same train step; a bounded
+                sample (1 warm-up + 3 steps).
+  cpu_baseline  the oracle (a plain-PyTorch port of the reference) on this box's host cores on a bounded sample
+                (B=2, fp32) -- kind "port".  Reported baselines, not targets.
 """
 import argparse
 import json
@@ -32,8 +42,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")  # no exhaustive conv search for the (few) MIOpen ops left
 
-TASKS = ("semseg", "normals", "sal", "human_parts")
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s achievable)
+HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s achievable)
+MFMA_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak
 
 
 def parse():
@@ -41,15 +51,14 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=32, help="per-GPU batch (BASELINE configs[1]: 32)")
-    ap.add_argument("--img", type=int, default=448)
+    ap.add_argument("--config", default="c2", help="c1 | c2 (default, the BASELINE metric) | c4 | c5:<r>")
+    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the config's)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-eager-gpu", action="store_true")
     ap.add_argument("--graph", action="store_true",
-                    help="EXPERIMENTAL: replay the step as captured HIP graph(s).  Off by default: with this ROCm stack a "
-                         "captured small hipMemsetAsync (ATen uses them for reduction semaphores) stops taking effect from "
-                         "the second replay on, so a whole-step graph computes garbage (tests/test_gpu_kernels.py::"
-                         "test_library_is_hip_graph_safe documents the hazard; the library itself avoids memset nodes)")
+                    help="EXPERIMENTAL: replay the step as captured HIP graph(s); the capture is validated against the eager step "
+                         "and dropped if it does not reproduce it (ROCm small-memset replay bug, DESIGN.md section 5)")
     ap.add_argument("--force-reducer", action="store_true", help="run the gradient pack / RCCL all-reduce / unpack path even at 1 rank")
     ap.add_argument("--no-fused-loss", action="store_true", help="final upsample + losses through ATen instead of csrc/loss.hip")
     return ap.parse_args()
@@ -81,8 +90,12 @@ def time_steps(step_fn, steps, warmup, world):
         step_fn()
     barrier(world)
     t0 = time.perf_counter()
+    host = 0.0
     for _ in range(steps):
+        h0 = time.perf_counter()
         step_fn()
+        host += time.perf_counter() - h0   # time the host spends ISSUING a step (no sync inside the step)
+    t_issue = time.perf_counter() - t0
     barrier(world)
     dt = time.perf_counter() - t0
     if world > 1:
@@ -90,7 +103,7 @@ def time_steps(step_fn, steps, warmup, world):
         t = torch.tensor([dt], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
-    return dt
+    return dt, t_issue
 
 
 def roofline(step_fn, steps):
@@ -104,38 +117,62 @@ def roofline(step_fn, steps):
     streams_on, H._TASK_STREAMS = H._TASK_STREAMS, False
     step_fn()
     torch.cuda.synchronize()
-    L.check(lib.mtlora_prof_begin(200000), "prof_begin")
+    L.check(lib.mtlora_prof_begin(400000), "prof_begin")
     for _ in range(steps):
         step_fn()
     torch.cuda.synchronize()
     s = L.ProfSummary()
     L.check(lib.mtlora_prof_end(ctypes.byref(s)), "prof_end")
     H._TASK_STREAMS = streams_on
-    kinds = {}
+    kinds, idx = {}, {}
     for k in range(L.PROF_KINDS):
         if s.count[k]:
-            kinds[lib.mtlora_prof_kind_name(k).decode()] = {
-                "launches_per_step": s.count[k] / steps, "ms_per_step": s.ms[k] / steps,
-                "avg_us": 1e3 * s.ms[k] / s.count[k], "alg_GB_per_step": s.alg_bytes[k] / steps / 1e9,
-                "GBps": (s.alg_bytes[k] / 1e9) / (s.ms[k] / 1e3) if s.ms[k] > 0 else None}
-    nt = [k for k in range(4) if s.count[k]]
-    n = sum(s.count[k] for k in nt)
-    ms = sum(s.ms[k] for k in nt)
-    by = sum(s.alg_bytes[k] for k in nt)
-    achieved = (by / 1e9) / (ms / 1e3) if ms > 0 else 0.0
-    # HBM bytes per launch from the committed PMC passes of this same workload (separate `--pmc` runs cannot be
-    # collected from inside the timed process): profiles/r01_pmc_traffic.json, FETCH_SIZE corrected for gfx950.
+            name = lib.mtlora_prof_kind_name(k).decode()
+            idx[name] = k
+            kinds[name] = {
+                "launches_per_step": s.count[k] / steps, "ms_per_step": round(s.ms[k] / steps, 4),
+                "avg_us": round(1e3 * s.ms[k] / s.count[k], 2), "launched_GB_per_step": round(s.alg_bytes[k] / steps / 1e9, 4),
+                "s8d_GB_per_step": round(s.s8d_bytes[k] / steps / 1e9, 4),
+                "GBps_8d": round((s.s8d_bytes[k] / 1e9) / (s.ms[k] / 1e3), 1) if s.ms[k] > 0 else None,
+                "TFLOPs": round((s.flops[k] / 1e12) / (s.ms[k] / 1e3), 1) if s.ms[k] > 0 and s.flops[k] > 0 else None}
+
+    def agg(names):
+        ks = [idx[n] for n in names if n in idx]
+        return (sum(s.count[k] for k in ks), sum(s.ms[k] for k in ks), sum(s.alg_bytes[k] for k in ks),
+                sum(s.s8d_bytes[k] for k in ks), sum(s.flops[k] for k in ks))
+
+    nt = ["k_nt:fwd_outputs", "k_nt:fwd_lowrank_P", "k_nt:bwd_lowrank_Q", "k_nt:bwd_dX"]
+    n, ms, by, b8, fl = agg(nt)
+    ln, lms, lby, lb8, lfl = agg(nt + ["k_tn:dA_dB", "k_pack", "k_tn_reduce", "k_sum"])
+    gbs = lambda b, m: (b / 1e9) / (m / 1e3) if m > 0 else 0.0  # noqa: E731
+    ach8, achl = gbs(b8, ms), gbs(by, ms)
+    tfl = (fl / 1e12) / (ms / 1e3) if ms > 0 else 0.0
+    hbm_frac, mfma_frac = ach8 / HBM_PEAK_GBS, tfl / MFMA_PEAK_TFLOPS
+    # HBM bytes per launch from the committed PMC passes of this same workload (separate `--pmc` runs cannot be collected
+    # from inside the timed process): STATIC, and only quoted when the launch structure matches the profiled run
     traffic, traffic_src = None, None
-    try:
-        pm = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")))
-        if abs(pm["k_nt"]["launches_per_step"] - n / steps) < 0.5:  # same launch structure as the profiled run
-            traffic, traffic_src = round(pm["k_nt"]["traffic_bytes_per_launch"]), "profiles/r01_pmc_traffic.json"
-    except Exception:
-        pass
-    return {"bound": "hbm", "kernel": "k_nt<bf16> (fused MTLoRALinear GEMM: fwd outputs, low-rank P/Q, bwd dX)",
-            "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-            "traffic": traffic, "traffic_source": traffic_src, "launches_per_step": n / steps, "avg_launch_us": round(1e3 * ms / max(n, 1), 2),
-            "alg_bytes_per_launch": by / max(n, 1), "kernel_ms_per_step": round(ms / steps, 3),
+    for fn in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        try:
+            pm = json.load(open(os.path.join(ROOT, "profiles", fn)))
+            if abs(pm["k_nt"]["launches_per_step"] - agg(nt + ["k_nt:plain_fwd", "k_nt:plain_dX"])[0] / steps) < 0.5:
+                traffic, traffic_src = round(pm["k_nt"]["traffic_bytes_per_launch"]), f"static: profiles/{fn} (all k_nt launches)"
+                break
+        except Exception:
+            continue
+    return {"bound": "hbm" if hbm_frac >= mfma_frac else "mfma",
+            "kernel": "k_nt<bf16> hot-path launches (fused MTLoRALinear GEMM: fwd outputs, low-rank P/Q, bwd dX)",
+            "achieved": round(ach8, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hbm_frac, 4),
+            "definition": "SURVEY 8(d) bytes of the k_nt launches / their HIP-event time / 8 TB/s",
+            "traffic": traffic, "traffic_source": traffic_src,
+            "launches_per_step": n / steps, "avg_launch_us": round(1e3 * ms / max(n, 1), 2),
+            "alg_bytes_per_launch": round(b8 / max(n, 1)), "kernel_ms_per_step": round(ms / steps, 3),
+            "launched": {"achieved": round(achl, 1), "frac": round(achl / HBM_PEAK_GBS, 4),
+                         "what": "same launches, fused GELU write / GELU' gate read counted as useful bytes"},
+            "mfma": {"achieved": round(tfl, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(mfma_frac, 4)},
+            "linear_path": {"what": "k_nt + k_tn + k_pack + k_tn_reduce + k_sum vs the whole 8(d) MTLoRALinear bytes",
+                            "ms_per_step": round(lms / steps, 3), "s8d_GB_per_step": round(lb8 / steps / 1e9, 3),
+                            "GBps": round(gbs(lb8, lms), 1), "frac": round(gbs(lb8, lms) / HBM_PEAK_GBS, 4),
+                            "TFLOPs": round((lfl / 1e12) / (lms / 1e3), 1) if lms > 0 else None},
             "all_kernels": kinds}
 
 
@@ -151,30 +188,63 @@ def usable_cores():
     return max(1, min(n, 32))  # beyond ~32 threads the small ATen ops of this model only oversubscribe
 
 
-def cpu_baseline():
-    """oracle (port of the reference) on the host cores: C2 shapes, B=2, fp32, train mode, 1 warm-up + 2 steps."""
+def _oracle_step_factory(cfgrow, B, device, amp):
+    """the oracle's train step (plain-PyTorch port of the reference) on `device` -- BASELINE legs only."""
     from oracle import mtlora_oracle as O
-    n = usable_cores()
-    torch.set_num_threads(n)
-    cfg = O.swin_t_cfg(448, TASKS, 64, 4, drop_path_rate=0.2)
+    tasks = list(cfgrow["tasks"])
+    cfg = O.swin_t_cfg(cfgrow["img_size"], tasks, cfgrow["r_shared"], cfgrow["r_task"], embed_dim=cfgrow["embed_dim"],
+                       depths=cfgrow["depths"], num_heads=cfgrow["num_heads"], drop_path_rate=0.2)
     shapes = {("backbone." + k): v for k, v in O.backbone_param_shapes(cfg).items()}
-    shapes.update(O.head_param_shapes(cfg, O.NUM_OUTPUT))
-    P = O.make_params(shapes)
+    shapes.update(O.head_param_shapes(cfg, {t: O.num_output(t) for t in tasks}))
+    P = {k: v.to(device) for k, v in O.make_params(shapes).items()}
     train = [v.requires_grad_(True) for k, v in P.items()
              if O.trainable_filter(k) and not k.endswith(("running_mean", "running_var"))]
-    opt = torch.optim.AdamW(train, lr=5e-4, weight_decay=0.05)
-    B = 2
-    img, tg = O.synthetic_batch(B, 448, TASKS, seed=1234)
+    opt = torch.optim.AdamW(train, lr=5e-4, weight_decay=0.05, fused=(device.type == "cuda"))
+    img, tg = O.synthetic_batch(B, cfgrow["img_size"], tasks, seed=1234)
+    img, tg = img.to(device), {k: v.to(device) for k, v in tg.items()}
     rng = torch.Generator().manual_seed(0)
 
     def step():
-        out = O.full_model(P, img, cfg, train=True, rng=rng)
-        loss, _ = O.multi_task_loss(out, tg, TASKS)
+        if amp:
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                out = O.full_model(P, img, cfg, train=True, rng=rng)
+                loss, _ = O.multi_task_loss({k: v.float() for k, v in out.items()}, tg, tasks)
+        else:
+            loss, _ = O.multi_task_loss(O.full_model(P, img, cfg, train=True, rng=rng), tg, tasks)
         loss.backward()
         torch.nn.utils.clip_grad_norm_([p for p in train if p.grad is not None], 5.0)
         opt.step()
         opt.zero_grad(set_to_none=True)
+    return step
 
+
+def eager_gpu(cfgrow, B, dev, ours_ips):
+    """north star comparator: the reference's eager PyTorch-ROCm dataflow on the same GPU / config / batch."""
+    try:
+        step = _oracle_step_factory(cfgrow, B, dev, amp=True)
+        step()
+        torch.cuda.synchronize()
+        k = 3
+        t0 = time.perf_counter()
+        for _ in range(k):
+            step()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / k
+        res = {"value": round(B / dt, 2), "unit": "images/sec", "ms_per_step": round(1e3 * dt, 2), "kind": "port",
+               "sample": f"oracle ATen dataflow on cuda, bf16 autocast, B={B}, 1 warm-up + {k} timed steps",
+               "speedup": round(ours_ips / (B / dt), 2)}
+    except torch.OutOfMemoryError as e:  # the eager path materialises every score / per-task tensor
+        res = {"value": None, "error": f"OOM: {str(e)[:80]}"}
+    torch.cuda.empty_cache()
+    return res
+
+
+def cpu_baseline(cfgrow):
+    """oracle (port of the reference) on the host cores: the config's shapes, B=2, fp32, train mode, bounded sample."""
+    n = usable_cores()
+    torch.set_num_threads(n)
+    B = 2
+    step = _oracle_step_factory(cfgrow, B, torch.device("cpu"), amp=False)
     t0 = time.perf_counter()
     step()
     warm = time.perf_counter() - t0
@@ -188,7 +258,7 @@ def cpu_baseline():
     else:
         dt = warm
     return {"value": round(B / dt, 4), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"Swin-T/448 4-task r64/4 train step, B={B}, fp32, 1 warm-up + {k} timed steps ({dt:.2f} s/step)"}
+            "sample": f"{cfgrow['what']}: train step, B={B}, fp32, 1 warm-up + {k} timed steps ({dt:.2f} s/step)"}
 
 
 def main():
@@ -202,56 +272,62 @@ def main():
     if world > 1:  # N ranks share one host: keep each rank's intra-op CPU pool small (the step has no CPU-side compute)
         torch.set_num_threads(max(1, min(4, usable_cores() // world)))
 
-    result = {}
-    if True:
-        model = H.build_model(img_size=args.img, tasks=TASKS, r_shared=64, r_task=4, drop_path_rate=0.2, seed=0).to(dev)
-        model.train()
-        crit = H.MultiTaskLoss(TASKS)
-        opt = H.build_optimizer(model, lr=5e-4 * args.batch * world / 512.0,  # main.py:578-583 linear LR scaling
-                                capturable=args.graph)
-        reducer = (GradReducer(model.parameters(), bucket_mb=16.0, force=args.force_reducer)
-                   if (world > 1 or args.force_reducer) else None)
-        img, tg = H.synthetic_batch(args.batch, args.img, TASKS, seed=1234 + rank, device=dev)
-        torch.manual_seed(1234 + rank)
+    row = H.config(args.config)
+    tasks = list(row["tasks"])
+    B = args.batch or row["batch"]
+    model = H.build_config_model(args.config, seed=0, drop_path_rate=0.2).to(dev)
+    model.train()
+    crit = H.MultiTaskLoss(tasks)
+    opt = H.build_optimizer(model, lr=5e-4 * B * world / 512.0,  # main.py:578-583 linear LR scaling
+                            capturable=args.graph)
+    # replicas start from rank 0's parameters / buffers (GradReducer broadcasts them), not from "every rank seeds 0"
+    reducer = (GradReducer(model.parameters(), bucket_mb=16.0, force=args.force_reducer, buffers=model.buffers())
+               if (world > 1 or args.force_reducer) else None)
+    img, tg = H.synthetic_batch(B, row["img_size"], tasks, seed=1234 + rank, device=dev)
+    torch.manual_seed(1234 + rank)
 
-        def eager_step():
-            H.train_step(model, crit, opt, img, tg, clip_grad=5.0, reducer=reducer, amp_dtype=torch.bfloat16,
-                         fused_loss=not args.no_fused_loss)
+    def eager_step():
+        H.train_step(model, crit, opt, img, tg, clip_grad=5.0, reducer=reducer, amp_dtype=torch.bfloat16,
+                     fused_loss=not args.no_fused_loss)
 
-        graph_info = {"enabled": False, "why": "eager (default); --graph is experimental, see its help"}
-        step = eager_step
-        if args.graph:
-            # the whole step (fwd + losses + bwd + clip + AdamW) captured as HIP graph(s); RCCL stays outside the graphs
-            gstep = H.GraphedTrainStep(model, crit, opt, img, tg, clip_grad=5.0, reducer=reducer, amp_dtype=torch.bfloat16,
-                                       fused_loss=not args.no_fused_loss)
-            graph_info = {"enabled": gstep.graphed, "why": gstep.why}
-            if not gstep.graphed and rank == 0:
-                print(f"bench: HIP-graph capture failed, running eagerly: {gstep.why}", file=sys.stderr)
-            step = gstep
+    graph_info = {"enabled": False, "why": "eager (default); --graph is experimental, see its help"}
+    step = eager_step
+    if args.graph:
+        # the whole step (fwd + losses + bwd + clip + AdamW) captured as HIP graph(s); RCCL stays outside the graphs
+        gstep = H.GraphedTrainStep(model, crit, opt, img, tg, clip_grad=5.0, reducer=reducer, amp_dtype=torch.bfloat16,
+                                   fused_loss=not args.no_fused_loss)
+        graph_info = {"enabled": gstep.graphed, "why": gstep.why}
+        if not gstep.graphed and rank == 0:
+            print(f"bench: HIP-graph replay not used, running eagerly: {gstep.why}", file=sys.stderr)
+        step = gstep
 
-        dt = time_steps(step, args.steps, args.warmup, world)
-        ips = args.batch * world * args.steps / dt
-        n_train = sum(p.numel() for p in model.parameters() if p.requires_grad)
-        result = {
-            "metric": "images/sec (train step) Swin-T/448 r=64 4-task", "value": round(ips, 2), "unit": "images/sec",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: Swin-T 448, 4 tasks (semseg,normals,sal,human_parts), "
-                                   "r_shared=64 r_task=4 scale4, train step (fwd+loss+bwd+clip+AdamW), dropout .05, "
-                                   "drop_path .2", "per_gpu_batch": args.batch, "global_batch": args.batch * world,
-                       "img_size": args.img, "parallelism": f"dp{world}", "trainable_params": n_train,
-                       "allreduce_bytes": reducer.nbytes if reducer else 0, "hip_graph": graph_info},
-        }
-        if rank == 0 and not args.no_roofline:
-            # profiled EAGERLY: the library's HIP-event brackets are recorded at launch time (same kernels as the graph)
-            result["roofline"] = roofline(eager_step, max(2, min(args.steps, 5)))
-        elif not args.no_roofline and world > 1:
-            for _ in range(1 + max(2, min(args.steps, 5))):  # keep ranks in lock-step with rank 0's profiled steps
-                eager_step()
-        del model, opt
-        torch.cuda.empty_cache()
+    dt, t_issue = time_steps(step, args.steps, args.warmup, world)
+    ips = B * world * args.steps / dt
+    n_train = sum(p.numel() for p in model.parameters() if p.requires_grad)
+    default = args.config == "c2"
+    result = {
+        "metric": "images/sec (train step) Swin-T/448 r=64 4-task" if default else f"images/sec (train step) {args.config}",
+        "value": round(ips, 2), "unit": "images/sec",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": row["what"] + "; train step (fwd+loss+bwd+clip+AdamW), dropout .05, drop_path .2",
+                   "name": args.config, "per_gpu_batch": B, "global_batch": B * world,
+                   "img_size": row["img_size"], "parallelism": f"dp{world}", "trainable_params": n_train,
+                   "allreduce_bytes": reducer.nbytes if reducer else 0, "hip_graph": graph_info,
+                   "host_issue_ms_per_step": round(1e3 * t_issue / args.steps, 3)},
+    }
+    if rank == 0 and not args.no_roofline:
+        # profiled EAGERLY: the library's HIP-event brackets are recorded at launch time (same kernels as the graph)
+        result["roofline"] = roofline(eager_step, max(2, min(args.steps, 5)))
+    elif not args.no_roofline and world > 1:
+        for _ in range(1 + max(2, min(args.steps, 5))):  # keep ranks in lock-step with rank 0's profiled steps
+            eager_step()
+    del model, opt
+    torch.cuda.empty_cache()
+    if rank == 0 and world == 1 and not args.no_eager_gpu:
+        result["eager_gpu"] = eager_gpu(row, B, dev, ips)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline()
+        result["cpu_baseline"] = cpu_baseline(row)
     if world > 1:
         barrier(world)
         import torch.distributed as dist

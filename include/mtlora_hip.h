@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define MTLORA_ABI_VERSION 2
+#define MTLORA_ABI_VERSION 3
 #define MTLORA_MAX_TASKS 8
 
 typedef enum mtlora_dtype {
@@ -333,7 +333,11 @@ int mtlora_selftest_layouts(int32_t* out, void* stream);
 typedef struct mtlora_prof_summary {
     int64_t count[MTLORA_PROF_KINDS];
     double ms[MTLORA_PROF_KINDS];        /* sum of launch durations */
-    double alg_bytes[MTLORA_PROF_KINDS]; /* sum of algorithmic bytes */
+    double alg_bytes[MTLORA_PROF_KINDS]; /* sum of the useful bytes of the launches as issued (incl. the fused GELU write /
+                                            gate read riding on the MTLoRALinear kernels) */
+    double s8d_bytes[MTLORA_PROF_KINDS]; /* sum of the SURVEY 8(d) algorithmic bytes: the MTLoRALinear / attention-core formulas
+                                            only (no GELU traffic); 0 for kinds outside the hot path (ABI v3) */
+    double flops[MTLORA_PROF_KINDS];     /* sum of algorithmic FLOPs, un-padded ranks (GEMM kinds only; ABI v3) */
 } mtlora_prof_summary;
 int mtlora_prof_begin(int max_records);
 int mtlora_prof_end(mtlora_prof_summary* out);

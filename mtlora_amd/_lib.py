@@ -12,7 +12,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int6
 import torch
 
 MAX_TASKS = 8
-ABI_VERSION = 2
+ABI_VERSION = 3
 F32, BF16, F16 = 0, 1, 2
 _DT = {torch.float32: F32, torch.bfloat16: BF16, torch.float16: F16}
 
@@ -38,7 +38,8 @@ PROF_KINDS = 24
 
 class ProfSummary(Structure):
     _fields_ = [("count", c_int64 * PROF_KINDS), ("ms", ctypes.c_double * PROF_KINDS),
-                ("alg_bytes", ctypes.c_double * PROF_KINDS)]
+                ("alg_bytes", ctypes.c_double * PROF_KINDS), ("s8d_bytes", ctypes.c_double * PROF_KINDS),
+                ("flops", ctypes.c_double * PROF_KINDS)]
 
 
 PtrArr = c_void_p * MAX_TASKS
@@ -162,9 +163,20 @@ def dtype_code(t: torch.Tensor, allow_f16: bool = False) -> int:
 
 
 def require_gpu(*tensors: torch.Tensor) -> None:
+    """every tensor on a GPU, and on the CURRENT device: the library launches on ``torch.cuda.current_stream()`` of the
+    current device and never calls hipSetDevice, so a tensor living elsewhere would be touched from the wrong device /
+    stream (use ``torch.cuda.set_device`` or a ``with torch.cuda.device(x.device)`` block, as for any raw-pointer op)."""
+    cur = None
     for t in tensors:
-        if t is not None and not t.is_cuda:
+        if t is None:
+            continue
+        if not t.is_cuda:
             raise RuntimeError("mtlora_amd: tensors must live on a ROCm GPU (MI355X); the HIP path has no CPU fallback")
+        if cur is None:
+            cur = torch.cuda.current_device()
+        if t.device.index != cur:
+            raise RuntimeError(f"mtlora_amd: tensor on cuda:{t.device.index} but the current device is cuda:{cur}; the HIP "
+                               "path launches on the current device's stream -- call torch.cuda.set_device(tensor.device) first")
 
 
 def ptr(t) -> c_void_p:

@@ -747,7 +747,8 @@ int mtlora_window_attn_fwd(const mtlora_attn_desc* d, const void* qkv, const flo
     p.G = groups_for(lds, 8, p.nH, p.n_windows);  // persistent grid: exactly the resident workgroups
     const unsigned grid = (unsigned)(p.G * p.nH);
     hipStream_t s = (hipStream_t)stream;
-    MtlProfScope prof(PK_ATTN_FWD, 4.0 * mtl_elem_size(d->dtype) * (double)p.n_windows * p.N * p.C, s);
+    const double ab = 4.0 * mtl_elem_size(d->dtype) * (double)p.n_windows * p.N * p.C;
+    MtlProfScope prof(PK_ATTN_FWD, ab, s, ab, 4.0 * (double)p.n_windows * p.N * p.N * p.C);
     const bool dense = p.mask && !p.mask_ids;
     if (d->dtype == MTLORA_F32) {
         if (dense)
@@ -790,7 +791,8 @@ int mtlora_window_attn_bwd(const mtlora_attn_desc* d, const void* qkv, const flo
     const unsigned grid = (unsigned)(p.G * p.nH);
     const size_t lds = bwd_lds_bytes(d);
     {
-        MtlProfScope prof(PK_ATTN_BWD, 7.0 * mtl_elem_size(d->dtype) * (double)p.n_windows * p.N * p.C, s);
+        const double ab = 7.0 * mtl_elem_size(d->dtype) * (double)p.n_windows * p.N * p.C;
+        MtlProfScope prof(PK_ATTN_BWD, ab, s, ab, 8.0 * (double)p.n_windows * p.N * p.N * p.C);
         const bool dense = p.mask && !p.mask_ids;
         if (d->dtype == MTLORA_F32) {
             if (dense)

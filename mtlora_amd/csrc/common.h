@@ -248,15 +248,20 @@ enum MtlProfKind {
     PK_LOSS = 14,        // k_up_loss                     low-res logits in, gradient out, labels in
     PK_SUM = 15,         // k_sum: G = sum of the output gradients (matrixv2 / pre-summed dX operand)
     PK_UPSAMPLE = 16,    // k_up_fwd / k_up_bwd: head's coarse -> fine bilinear maps
+    PK_NT_PLAIN_FWD = 17,  // k_nt at rank 0: y = x W^T + b of the callers (heads, PatchMerging reduction, patch embed)
+    PK_NT_PLAIN_DX = 18,   // k_nt at rank 0: dX = dY W of the same
+    PK_TN_PLAIN = 19,      // k_tn through mtlora_gemm_tn: narrow-output weight gradients of the callers
     PK_COUNT = 24
 };
-int mtl_prof_start(int kind, double alg_bytes, hipStream_t s);
+int mtl_prof_start(int kind, double alg_bytes, hipStream_t s, double s8d_bytes = 0.0, double flops = 0.0);
 void mtl_prof_tag(const char* fmt, ...);  // shape note attached to the NEXT record (MTLORA_PROF_DUMP=<file> lists records)
 void mtl_prof_stop(int idx, hipStream_t s);
 struct MtlProfScope {
     int idx;
     hipStream_t s;
-    MtlProfScope(int kind, double bytes, hipStream_t st) : idx(mtl_prof_start(kind, bytes, st)), s(st) {}
+    // bytes: useful bytes of the launch as issued; s8d: the SURVEY 8(d) share of them (hot-path kinds only); flops: algorithmic
+    MtlProfScope(int kind, double bytes, hipStream_t st, double s8d = 0.0, double flops = 0.0)
+        : idx(mtl_prof_start(kind, bytes, st, s8d, flops)), s(st) {}
     ~MtlProfScope() {
         if (idx >= 0) mtl_prof_stop(idx, s);
     }

@@ -1338,9 +1338,9 @@ static bool nt2_wanted(const NtParams& P, int variant, bool fuse) {
 }
 
 template <typename T>
-static void launch_nt(const NtParams& P, hipStream_t s, int kind, double alg_bytes) {
+static void launch_nt(const NtParams& P, hipStream_t s, int kind, double alg_bytes, double s8d_bytes = 0.0, double flops = 0.0) {
     mtl_prof_tag("M%lld K%d N%d ldL%lld no%d na%d nz%d", (long long)P.M, P.K, P.n_rows, (long long)P.ldL, P.n_out, P.n_act, P.nz);
-    MtlProfScope prof(kind, alg_bytes, s);
+    MtlProfScope prof(kind, alg_bytes, s, s8d_bytes, flops);
     int max_rows = P.n_rows;
     if (P.nz > 0) {
         max_rows = 0;
@@ -1559,7 +1559,12 @@ static int fwd_impl(const mtlora_linear_desc* d, const void* x, const void* cons
                 q.n_rows = sg.R;
                 q.nz = 0;
             }
-            launch_nt<T>(q, s, PK_NT_FWD_P, (double)sizeof(T) * (d->has_x_tasks ? d->T : 0) * d->M * d->K);
+            {
+                const double xb = (double)sizeof(T) * (d->has_x_tasks ? d->T : 0) * d->M * d->K;
+                double rsum = 0.0;  // un-padded ranks
+                for (int o = 0; o < sg.n; ++o) rsum += sg.r[o];
+                launch_nt<T>(q, s, PK_NT_FWD_P, xb, xb, 2.0 * d->M * d->K * rsum);
+            }
         }
     }
 
@@ -1619,7 +1624,15 @@ static int fwd_impl(const mtlora_linear_desc* d, const void* x, const void* cons
     const double xt_bytes = fuse ? (double)sizeof(T) * (d->has_x_tasks ? d->T : 0) * d->M * d->K : 0.0;
     int n_actout = 0;  // GELU second outputs: one more M x N write each
     for (int o = 0; o < m.n_out; ++o) n_actout += m.out[o].act ? 1 : 0;
-    launch_nt<T>(m, s, PK_NT_FWD_MAIN, (double)sizeof(T) * d->M * (d->K + (double)(1 + d->T + n_actout) * d->N) + xt_bytes);
+    {
+        const double b8d = (double)sizeof(T) * d->M * (d->K + (double)(1 + d->T) * d->N) + xt_bytes;
+        double rsum = 0.0;
+        for (int o = 0; o < sg.n; ++o) rsum += sg.r[o];
+        const double fl = 2.0 * d->M * d->K * d->N + 2.0 * d->M * d->N * rsum + (fuse ? 2.0 * d->M * d->K * rsum : 0.0);
+        const bool plain = sg.R == 0;
+        launch_nt<T>(m, s, plain ? PK_NT_PLAIN_FWD : PK_NT_FWD_MAIN, b8d + (double)sizeof(T) * d->M * (double)n_actout * d->N,
+                     plain ? 0.0 : b8d, fl);
+    }
     return MTLORA_OK;
 }
 
@@ -1748,7 +1761,12 @@ static int bwd_impl(const mtlora_linear_desc* d, const void* x, const void* cons
             q.zmask[q.nz] = 0;
             ++q.nz;
         }
-        if (q.nz > 0) launch_nt<T>(q, s, PK_NT_BWD_Q, 0.0);
+        if (q.nz > 0) {
+            double rsum = 0.0;
+            for (int o = 0; o < sg.n; ++o)
+                if (sg.rp[o] > 0 && dyo[o]) rsum += sg.r[o];
+            launch_nt<T>(q, s, PK_NT_BWD_Q, 0.0, 0.0, 2.0 * d->M * d->N * rsum);
+        }
     }
 
     // dX = G W + keep .* (Q_s A_s [+ sum_t Q_t A_t]),  dX_t = Q_t A_t
@@ -1813,9 +1831,15 @@ static int bwd_impl(const mtlora_linear_desc* d, const void* x, const void* cons
         if (dx) {
             int n_gate = 0;  // the fused GELU backward reads the pre-activation of every gated output (algorithmic: gelu'(h) needs h)
             for (int o = 0; o < m.n_out; ++o) n_gate += m.out[o].gate ? 1 : 0;
-            launch_nt<T>(m, s, PK_NT_BWD_DX,
-                         (double)sizeof(T) * d->M *
-                             ((double)n_dy * d->N + (double)(1 + (d->has_x_tasks ? d->T : 0) + n_gate) * d->K));
+            const double b8d = (double)sizeof(T) * d->M * ((double)n_dy * d->N + (double)(1 + (d->has_x_tasks ? d->T : 0)) * d->K);
+            double rsum = 0.0;
+            for (int o = 0; o < sg.n; ++o)
+                if (sg.rp[o] > 0 && dyo[o]) rsum += sg.r[o];
+            const double fl = (n_dy > 0 ? 2.0 * d->M * d->N * d->K : 0.0) + 2.0 * d->M * d->K * rsum +
+                              (groups > 0 ? 2.0 * d->M * d->N * rsum : 0.0);
+            const bool plain = sg.R == 0;
+            launch_nt<T>(m, s, plain ? PK_NT_PLAIN_DX : PK_NT_BWD_DX, b8d + (double)sizeof(T) * d->M * (double)n_gate * d->K,
+                         plain ? 0.0 : b8d, fl);
         }
     }
 
@@ -1882,7 +1906,10 @@ static int bwd_impl(const mtlora_linear_desc* d, const void* x, const void* cons
             {
                 mtl_prof_tag("M%lld K%lld N%lld T%d np%d ns%d tiles%d", (long long)d->M, (long long)d->K, (long long)d->N, d->T, tp.n_prob,
                              S.nsplit, max_tiles);
-                MtlProfScope prof(PK_TN, (double)sizeof(T) * d->M * (double)(1 + (d->has_x_tasks ? d->T : 0)) * d->K, s);
+                const double xb = (double)sizeof(T) * d->M * (double)(1 + (d->has_x_tasks ? d->T : 0)) * d->K;
+                double fl = 0.0;
+                for (int i = 0; i < tp.n_prob; ++i) fl += 2.0 * d->M * (double)tp.p[i].out_a * tp.p[i].out_b;
+                MtlProfScope prof(PK_TN, xb, s, xb, fl);
                 hipLaunchKernelGGL(k_tn<T>, dim3((unsigned)S.nsplit, (unsigned)max_tiles, (unsigned)tp.n_prob),
                                    dim3(256), 0, s, tp);
             }
@@ -2081,7 +2108,7 @@ int mtlora_gemm_tn(const void* a, const void* b, float* out, int64_t M, int Na, 
     const int es = mtl_elem_size(dtype);
     {
         mtl_prof_tag("M%lld Na%d Nb%d", (long long)M, Na, Nb);
-        MtlProfScope prof(PK_TN, (double)es * M * ((double)ta * Nb + Na), s);
+        MtlProfScope prof(PK_TN_PLAIN, (double)es * M * ((double)ta * Nb + Na), s, 0.0, 2.0 * M * (double)Na * Nb);
         if (dtype == MTLORA_F32)
             hipLaunchKernelGGL(k_tn<float>, dim3((unsigned)tp.nsplit, (unsigned)(ta * tb), 1), dim3(256), 0, s, tp);
         else

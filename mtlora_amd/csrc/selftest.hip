@@ -74,7 +74,7 @@ extern "C" int mtlora_selftest_layouts(int32_t* out, void* stream) {
 namespace {
 struct ProfRec {
     int kind;
-    double bytes;
+    double bytes, s8d, flops;
     hipEvent_t a, b;
     char tag[56];
 };
@@ -85,13 +85,15 @@ std::vector<ProfRec> g_prof;
 size_t g_prof_cap = 0;
 }  // namespace
 
-int mtl_prof_start(int kind, double alg_bytes, hipStream_t s) {
+int mtl_prof_start(int kind, double alg_bytes, hipStream_t s, double s8d_bytes, double flops) {
     if (!g_prof_on.load(std::memory_order_relaxed)) return -1;
     std::lock_guard<std::mutex> lk(g_prof_mu);
     if (g_prof.size() >= g_prof_cap) return -1;
     ProfRec r;
     r.kind = kind;
     r.bytes = alg_bytes;
+    r.s8d = s8d_bytes;
+    r.flops = flops;
     memcpy(r.tag, g_next_tag, sizeof(r.tag));
     g_next_tag[0] = 0;
     if (hipEventCreate(&r.a) != hipSuccess) return -1;
@@ -136,6 +138,8 @@ extern "C" int mtlora_prof_end(mtlora_prof_summary* out) {
             out->count[k] = 0;
             out->ms[k] = 0.0;
             out->alg_bytes[k] = 0.0;
+            out->s8d_bytes[k] = 0.0;
+            out->flops[k] = 0.0;
         }
     }
     int st = MTLORA_OK;
@@ -144,11 +148,13 @@ extern "C" int mtlora_prof_end(mtlora_prof_summary* out) {
     for (auto& r : g_prof) {
         float ms = 0.f;
         if (hipEventSynchronize(r.b) != hipSuccess || hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) st = MTLORA_ERR_HIP;
-        if (df) fprintf(df, "%s,%.0f,%.4f,%s\n", mtlora_prof_kind_name(r.kind), r.bytes, ms, r.tag);
+        if (df) fprintf(df, "%s,%.0f,%.0f,%.0f,%.4f,%s\n", mtlora_prof_kind_name(r.kind), r.bytes, r.s8d, r.flops, ms, r.tag);
         if (out && r.kind >= 0 && r.kind < MTLORA_PROF_KINDS) {
             out->count[r.kind] += 1;
             out->ms[r.kind] += ms;
             out->alg_bytes[r.kind] += r.bytes;
+            out->s8d_bytes[r.kind] += r.s8d;
+            out->flops[r.kind] += r.flops;
         }
         (void)hipEventDestroy(r.a);
         (void)hipEventDestroy(r.b);
@@ -177,6 +183,9 @@ extern "C" const char* mtlora_prof_kind_name(int kind) {
         case PK_LOSS: return "k_up_loss";
         case PK_SUM: return "k_sum";
         case PK_UPSAMPLE: return "k_upsample";
+        case PK_NT_PLAIN_FWD: return "k_nt:plain_fwd";
+        case PK_NT_PLAIN_DX: return "k_nt:plain_dX";
+        case PK_TN_PLAIN: return "k_tn:plain_dW";
         default: return "";
     }
 }

@@ -48,12 +48,22 @@ class GradReducer:
     """
 
     def __init__(self, params: Iterable[torch.nn.Parameter], bucket_mb: float = 16.0,
-                 process_group: Optional[dist.ProcessGroup] = None, force: bool = False):
-        """force=True runs the pack / all-reduce / unpack path even on a single rank (hardware test of the RCCL path)."""
+                 process_group: Optional[dist.ProcessGroup] = None, force: bool = False,
+                 buffers: Optional[Iterable[torch.Tensor]] = None, broadcast: bool = True, static_graph: bool = True):
+        """force=True runs the pack / all-reduce / unpack path even on a single rank (hardware test of the RCCL path).
+        broadcast: every parameter handed over (frozen ones included) and every tensor of ``buffers`` is overwritten with
+        rank 0's copy, so replicas start identical whatever each rank's seed or checkpoint did (DDP's constructor
+        semantics); static_graph: the set of parameters that receive a gradient is the same every step (true for this
+        model: it is structural), so ranks agree on it once, at the first step, instead of every step."""
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.active = self.world > 1 or (force and dist.is_initialized())
-        plist = [p for p in params if p.requires_grad]
+        self.static_graph = static_graph
+        self._global_seen: Optional[List[List[bool]]] = None
+        all_params = list(params)
+        if broadcast and self.active:
+            self._broadcast_from_rank0([p.data for p in all_params] + ([] if buffers is None else list(buffers)))
+        plist = [p for p in all_params if p.requires_grad]
         plist.reverse()  # approximate backward completion order
         cap = int(bucket_mb * 1024 * 1024 / 4)
         self.buckets: List[_Bucket] = []
@@ -77,6 +87,45 @@ class GradReducer:
         # on side streams): a bucket is packed from an autograd hook whose current stream only orders ITS OWN gradient,
         # so the pack first waits for these
         self.extra_streams: List["torch.cuda.Stream"] = []
+
+    def _broadcast_from_rank0(self, tensors: List[torch.Tensor], chunk_bytes: int = 64 << 20) -> None:
+        """rank 0's values into every rank's tensors: coalesced by dtype into flat chunks (a few large broadcasts, not one
+        per tensor -- the C2 model has 431 state tensors)."""
+        src = dist.get_global_rank(self.group, 0) if self.group is not None else 0
+        by_dtype = {}
+        for t in tensors:
+            if t.numel():
+                by_dtype.setdefault((t.dtype, t.device), []).append(t)
+        for (_, _), ts in by_dtype.items():
+            cur, cur_b = [], 0
+            groups = []
+            for t in ts:
+                nb = t.numel() * t.element_size()
+                if cur and cur_b + nb > chunk_bytes:
+                    groups.append(cur)
+                    cur, cur_b = [], 0
+                cur.append(t)
+                cur_b += nb
+            if cur:
+                groups.append(cur)
+            for g in groups:
+                flat = torch.cat([t.reshape(-1) for t in g])
+                dist.broadcast(flat, src=src, group=self.group)
+                torch._foreach_copy_(g, [v.view(t.shape) for v, t in zip(flat.split([t.numel() for t in g]), g)])
+
+    def _agree_on_used(self) -> None:
+        """which parameters got a gradient on ANY rank this step (one small MAX all-reduce + one host read).  With
+        ``static_graph`` this runs once; a parameter used elsewhere but not here then receives the mean (its own
+        contribution being zero) instead of silently keeping ``grad None`` while other replicas step it."""
+        flags = torch.tensor([1.0 if s else 0.0 for b in self.buckets for s in b.seen], dtype=torch.float32,
+                             device=self.buckets[0].flat.device)
+        dist.all_reduce(flags, op=dist.ReduceOp.MAX, group=self.group)
+        f = flags.tolist()
+        out, i = [], 0
+        for b in self.buckets:
+            out.append([v > 0.0 for v in f[i:i + len(b.params)]])
+            i += len(b.params)
+        self._global_seen = out
 
     @property
     def nbytes(self) -> int:
@@ -141,17 +190,23 @@ class GradReducer:
             if b.pending > 0:  # some parameters produced no gradient on this rank this step: they count as zero
                 b.pending = 0
                 self._launch(b)
+        if self.active and self.buckets and (self._global_seen is None or not self.static_graph):
+            self._agree_on_used()
         inv = 1.0 / self.world
-        for b in self.buckets:
+        for bi, b in enumerate(self.buckets):
             if b.handle is not None:
                 b.handle.wait()
             if self.active:
                 b.flat.mul_(inv)
             dst, src = [], []
             for pi, p in enumerate(b.params):
-                if b.seen[pi]:  # parameters without a local gradient keep grad None (all ranks agree on the set)
-                    dst.append(p.grad)
-                    src.append(b.flat[b.offsets[pi]:b.offsets[pi] + p.numel()].view_as(p.grad))
+                used = b.seen[pi] or (self.active and self._global_seen is not None and self._global_seen[bi][pi])
+                if not used:  # no rank produced a gradient: grad stays None everywhere (the optimizer skips it everywhere)
+                    continue
+                if p.grad is None:  # used on another rank only: this rank's share is zero, the mean is still its gradient
+                    p.grad = torch.empty_like(p)
+                dst.append(p.grad)
+                src.append(b.flat[b.offsets[pi]:b.offsets[pi] + p.numel()].view_as(p.grad))
             if dst and self.active:
                 torch._foreach_copy_(dst, src)
 

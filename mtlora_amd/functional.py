@@ -206,7 +206,10 @@ class MTLoRALinearFn(torch.autograd.Function):
                                        scratch_bytes, L.stream_ptr())
             L.check(st, "mtlora_linear_bwd")
         dW = dbias = None
-        if meta.weight_requires_grad:  # pretrained weight left trainable: dense dW outside the frozen-W hot path
+        if need[5] or need[6]:
+            # pretrained weight and / or bias left trainable (MTLORA.FREEZE_PRETRAINED False; mark_only_lora_as_trainable
+            # bias='all' trains `linear.bias` with W frozen, reference lora.py:606-617): dense gradients outside the frozen-W
+            # hot path.  Every output adds the same base  x W^T + b, so both see G = sum of the output gradients.
             G = None
             for g in g2:
                 if g is not None:

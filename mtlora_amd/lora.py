@@ -105,6 +105,8 @@ class MTLoRALinear(LoRALayer):
         key = (dtype, w.device)
         ver = (w._version, w.data_ptr(), None if b is None else (b._version, b.data_ptr()))
         hit = self._wcache.get(key)
+        if w.requires_grad or (b is not None and b.requires_grad):
+            hit = None  # trained by an optimizer every step: never serve a cached copy
         if hit is None or hit[0] != ver:
             with torch.no_grad():
                 wc = w.detach().to(dtype).contiguous()
@@ -114,9 +116,24 @@ class MTLoRALinear(LoRALayer):
             self._wcache = {key: hit}
         return hit[1], hit[2], hit[3]
 
+    def invalidate_weight_cache(self) -> None:
+        """drop the cached compute-dtype copies of ``linear.weight`` / ``linear.bias``.  The cache keys on the tensors'
+        version counters and storage, which in-place updates through ``.data`` (EMA, hand-written loaders, older optimizers)
+        do NOT bump: call this after such an update.  ``load_state_dict``, ``.to()`` / ``.cuda()`` and ``train()`` /
+        ``eval()`` call it themselves."""
+        self._wcache = {}
+
     def _apply(self, fn, *a, **k):  # .to() / .cuda() invalidates the cached copies
         self._wcache = {}
         return super()._apply(fn, *a, **k)
+
+    def _load_from_state_dict(self, *a, **k):
+        self._wcache = {}
+        return super()._load_from_state_dict(*a, **k)
+
+    def train(self, mode: bool = True):
+        self._wcache = {}
+        return super().train(mode)
 
     def forward(self, x: torch.Tensor, x_tasks: Optional[Dict[str, torch.Tensor]] = None, gelu_gate=None, gelu_out: bool = False
                 ) -> Tuple[torch.Tensor, Optional[Dict[str, torch.Tensor]]]:
@@ -142,7 +159,8 @@ class MTLoRALinear(LoRALayer):
             scale_s=val(ss), scale_t=tuple(val(s) for s in st),
             mode=1 if (self.shared_mode == "matrixv2" and tasks) else 0,
             has_x_tasks=bool(tasks) and x_tasks is not None, dropout_p=p, seed=Fn.next_seed() if p > 0 else 0,
-            dtype=dtype, weight_requires_grad=self.linear.weight.requires_grad,
+            dtype=dtype, weight_requires_grad=self.linear.weight.requires_grad or (
+                self.linear.bias is not None and self.linear.bias.requires_grad),
             n_scale_t=len(tasks) if (tasks and isinstance(st[0], nn.Parameter)) else 0)
         if gelu_out:
             if self.shared_mode == "addition":

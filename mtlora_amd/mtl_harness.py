@@ -32,6 +32,64 @@ NUM_OUTPUT = {"semseg": 21, "normals": 3, "sal": 1, "human_parts": 7, "depth": 1
 LOSS_WEIGHTS = {"depth": 1.0, "semseg": 1.0, "human_parts": 2.0, "sal": 5.0, "edge": 50.0, "normals": 10.0}
 
 
+def is_synthetic_task(t: str) -> bool:
+    """``t0`` .. ``t7``: the builder-defined tasks of BASELINE configs[4] (the reference knows only its six named
+    tasks, mtl_loss_schemes.py:241-263) -- 3-channel regression heads trained with NormalsLoss, loss weight 1."""
+    return len(t) >= 2 and t[0] == "t" and t[1:].isdigit()
+
+
+def task_kind(t: str) -> str:
+    return "normals" if is_synthetic_task(t) else t
+
+
+def num_output(t: str) -> int:
+    return NUM_OUTPUT[task_kind(t)]
+
+
+def loss_weight(t: str) -> float:
+    return 1.0 if is_synthetic_task(t) else LOSS_WEIGHTS[t]
+
+
+# The BASELINE.json configs as ONE table (bench.py --config, the model-level parity tests and the docs all read it).
+# c4 has no yaml in the reference (SURVEY 8: "builder authors it"): Swin-B = embed 128, depths 2-2-18-2, heads 4-8-16-32
+# (the Swin paper's B variant through the reference constructor, swin_transformer_mtlora.py:643-649), r = 128 for the
+# shared and every task factor.  c5:<r> is the 8-synthetic-task rank sweep, r for the shared and every task factor.
+SWIN_T = dict(embed_dim=96, depths=(2, 2, 6, 2), num_heads=(3, 6, 12, 24))
+SWIN_B = dict(embed_dim=128, depths=(2, 2, 18, 2), num_heads=(4, 8, 16, 32))
+PASCAL4 = ("semseg", "normals", "sal", "human_parts")
+CONFIGS = {
+    "c1": dict(SWIN_T, img_size=224, tasks=("semseg",), r_shared=4, r_task=4, batch=2,
+               what="BASELINE configs[0]: Swin-T 224, 1 task (semseg), r=4"),
+    "c2": dict(SWIN_T, img_size=448, tasks=PASCAL4, r_shared=64, r_task=4, batch=32,
+               what="BASELINE configs[1]: Swin-T 448, 4 tasks (semseg,normals,sal,human_parts), r_shared=64 r_task=4 scale4"),
+    "c4": dict(SWIN_B, img_size=448, tasks=PASCAL4, r_shared=128, r_task=128, batch=16,
+               what="BASELINE configs[3]: Swin-B 448 (embed 128, depths 2-2-18-2, heads 4-8-16-32), 4 tasks, r=128 shared and per task"),
+}
+for _r in (4, 16, 64, 256):
+    CONFIGS[f"c5:{_r}"] = dict(SWIN_T, img_size=448, tasks=tuple(f"t{i}" for i in range(8)), r_shared=_r, r_task=_r, batch=32,
+                               what=f"BASELINE configs[4]: Swin-T 448, 8 synthetic tasks t0..t7 (3-channel NormalsLoss heads), "
+                                    f"r={_r} shared and per task")
+
+
+def config(name: str) -> dict:
+    """a copy of the CONFIGS row ``name`` (``c5:<r>`` accepts any positive rank)."""
+    if name not in CONFIGS and name.startswith("c5:") and name[3:].isdigit() and int(name[3:]) > 0:
+        r = int(name[3:])
+        return dict(CONFIGS["c5:4"], r_shared=r, r_task=r, what=CONFIGS["c5:4"]["what"].replace("r=4 ", f"r={r} "))
+    if name not in CONFIGS:
+        raise KeyError(f"unknown config {name!r}; one of {sorted(CONFIGS)}")
+    return dict(CONFIGS[name])
+
+
+def build_config_model(name: str, seed: int = 0, **over) -> "MultiTaskSwin":
+    c = config(name)
+    c.update(over)
+    return build_model(img_size=c["img_size"], tasks=c["tasks"], embed_dim=c["embed_dim"], depths=c["depths"],
+                       num_heads=c["num_heads"], r_shared=c["r_shared"], r_task=c["r_task"], seed=seed,
+                       **{k: v for k, v in c.items() if k not in ("img_size", "tasks", "embed_dim", "depths", "num_heads",
+                                                                    "r_shared", "r_task", "batch", "what")})
+
+
 class AttrDict(dict):
     """stand-in for the yacs CfgNode the reference constructors read attributes from."""
     __getattr__ = dict.__getitem__
@@ -211,6 +269,7 @@ class MultiTaskSwin(nn.Module):
 # --------------------------------------------------------------------------------------------------
 def task_loss(task: str, out: torch.Tensor, label: torch.Tensor) -> torch.Tensor:
     out = out.float()
+    task = task_kind(task)
     if task in ("semseg", "human_parts"):          # SoftMaxwithLoss (:22-39)
         return F.nll_loss(F.log_softmax(out, 1), label[:, 0].long(), ignore_index=255)
     if task == "normals":                           # NormalsLoss(normalize=True, L1, size_average) (:162-220)
@@ -235,7 +294,7 @@ class MultiTaskLoss(nn.Module):
     def __init__(self, tasks: Sequence[str], loss_weights: Optional[Mapping[str, float]] = None):
         super().__init__()
         self.tasks = list(tasks)
-        self.loss_weights = dict(loss_weights or {t: LOSS_WEIGHTS[t] for t in tasks})
+        self.loss_weights = dict(loss_weights or {t: loss_weight(t) for t in tasks})
 
     def forward(self, pred, gt):
         per = {t: task_loss(t, pred[t], gt[t]) for t in self.tasks}
@@ -249,7 +308,7 @@ class MultiTaskLoss(nn.Module):
         """loss of task t from its LOW-resolution (B, h, w, C) prediction (fused upsample + loss + backward where it applies)"""
         h, w = lo.shape[1:3]
         H, W = lab.shape[-2:]
-        kind = self.FUSED_KIND.get(t)
+        kind = self.FUSED_KIND.get(task_kind(t))
         if kind is not None and lo.is_cuda and H % h == 0 and W % w == 0 and H // h == W // w:
             return UpsampleLossFn.apply(kind, lo, lab, H // h)
         return task_loss(t, F.interpolate(lo.permute(0, 3, 1, 2), (H, W), mode="bilinear"), lab)
@@ -280,7 +339,7 @@ def build_model(img_size=448, tasks=("semseg", "normals", "sal", "human_parts"),
                                depths=list(depths), num_heads=list(num_heads), window_size=7, mlp_ratio=4.0,
                                qkv_bias=True, drop_rate=0.0, drop_path_rate=drop_path_rate, ape=False, patch_norm=True,
                                tasks=list(tasks), mtlora=mt)
-    model = MultiTaskSwin(bb, tasks, {t: NUM_OUTPUT[t] for t in tasks})
+    model = MultiTaskSwin(bb, tasks, {t: num_output(t) for t in tasks})
     if lora_b_std > 0:
         with torch.no_grad():
             for n, p in model.named_parameters():
@@ -318,16 +377,17 @@ def synthetic_batch(B: int, S: int, tasks: Sequence[str], seed: int, device="cpu
     img = torch.randn(B, 3, S, S, generator=g)
     tg = {}
     for t in tasks:
-        if t in ("semseg", "human_parts"):
-            lab = torch.randint(0, NUM_OUTPUT[t], (B, 1, S, S), generator=g).float()
+        k = task_kind(t)
+        if k in ("semseg", "human_parts"):
+            lab = torch.randint(0, NUM_OUTPUT[k], (B, 1, S, S), generator=g).float()
             lab[torch.rand(B, 1, S, S, generator=g) < 0.05] = 255.0
-        elif t == "sal":
+        elif k == "sal":
             lab = (torch.rand(B, 1, S, S, generator=g) < 0.3).float()
-        elif t == "normals":
+        elif k == "normals":
             lab = F.normalize(torch.randn(B, 3, S, S, generator=g), dim=1)
             ign = (torch.rand(B, 1, S, S, generator=g) < 0.05).expand(B, 3, S, S)
             lab = torch.where(ign, torch.full_like(lab, 255.0), lab)
-        elif t == "depth":
+        elif k == "depth":
             lab = torch.rand(B, 1, S, S, generator=g) * 10
         else:
             raise NotImplementedError(t)
@@ -403,11 +463,60 @@ class GraphedTrainStep:
         try:
             self._capture(warmup)
             self.graphed = True
-        except Exception as e:  # noqa: BLE001 -- any capture problem means: run eagerly, loudly
+            ok, why = self._replays_reproduce()
+            if not ok:
+                raise RuntimeError(why)
+        except Exception as e:  # noqa: BLE001 -- any capture / replay problem means: run eagerly, loudly
+            self.graphed = False
             self.why = f"{type(e).__name__}: {e}"
             torch.cuda.synchronize()
             self.g_bwd = self.g_opt = None
             optimizer.zero_grad(set_to_none=True)
+            Fn.set_seed_offset(None)  # the eager fallback draws its dropout seeds on the host again
+
+    def _replays_reproduce(self):
+        """Replay the captured step three times FROM THE SAME STATE (parameters, optimizer state, RNG, dropout seed offset
+        restored in between) and require bit-identical loss and parameters.  On this ROCm stack a captured small memset
+        stops taking effect from the second replay on, so a whole-step graph (ATen's reductions issue such memsets) computes
+        from stale memory after the first replay -- exactly what this catches.  The state is restored afterwards."""
+        params = [p for g in self.optimizer.param_groups for p in g["params"]]
+        bufs = [b for b in self.model.buffers() if b.is_floating_point()]
+
+        def snap():
+            st = {id(p): {k: (v.clone() if torch.is_tensor(v) else v) for k, v in self.optimizer.state.get(p, {}).items()}
+                  for p in params}
+            return ([p.detach().clone() for p in params], [b.clone() for b in bufs], st, torch.cuda.get_rng_state(),
+                    self.seed.clone())
+
+        def restore(s):
+            with torch.no_grad():
+                torch._foreach_copy_([p.data for p in params], s[0])
+                if bufs:
+                    torch._foreach_copy_(bufs, s[1])
+                for p in params:
+                    for k, v in s[2][id(p)].items():
+                        if torch.is_tensor(v):
+                            self.optimizer.state[p][k].copy_(v)
+                self.seed.copy_(s[4])
+            torch.cuda.set_rng_state(s[3])
+
+        torch.cuda.synchronize()
+        s0 = snap()
+        seen = []
+        for _ in range(3):
+            restore(s0)
+            self.g_bwd.replay()
+            if self.g_opt is not None:
+                self.reducer.all_reduce_packed()
+                self.g_opt.replay()
+            torch.cuda.synchronize()
+            seen.append((self.loss.clone(), torch.stack([p.detach().double().sum() for p in params]).sum()))
+        restore(s0)
+        for l, c in seen[1:]:
+            if not (torch.equal(l, seen[0][0]) and torch.equal(c, seen[0][1]) and torch.isfinite(l).all()):
+                return False, ("graph replays from identical state differ (loss %r vs %r): captured small memsets do not replay "
+                               "on this ROCm stack; running eagerly" % (seen[0][0].item(), l.item()))
+        return True, ""
 
     # -- pieces of the step (shared by the eager fallback and the capture)
     def _forward_backward(self):

@@ -474,8 +474,23 @@ def mtl_heads(P, stages, cfg, train=False):
 LOSS_WEIGHTS = {"depth": 1.0, "semseg": 1.0, "human_parts": 2.0, "sal": 5.0, "edge": 50.0, "normals": 10.0}  # main.py:192-199
 
 
+def task_kind(task: str) -> str:
+    """``t0``..``t7`` are the builder-defined synthetic tasks of BASELINE configs[4]: 3-channel regression
+    heads under NormalsLoss with loss weight 1 (the reference's get_loss knows only its six named tasks)."""
+    return "normals" if (len(task) >= 2 and task[0] == "t" and task[1:].isdigit()) else task
+
+
+def num_output(task: str) -> int:
+    return NUM_OUTPUT[task_kind(task)]
+
+
+def loss_weight(task: str) -> float:
+    return 1.0 if task_kind(task) != task else LOSS_WEIGHTS[task]
+
+
 def task_loss(task: str, out: Tensor, label: Tensor) -> Tensor:
     """mtl_loss_schemes.py:241-263 dispatch."""
+    task = task_kind(task)
     if task in ("semseg", "human_parts"):                        # SoftMaxwithLoss :22-39
         return F.nll_loss(F.log_softmax(out, 1), label[:, 0].long(), ignore_index=255)
     if task == "normals":                                        # NormalsLoss(normalize, L1) :162-220
@@ -501,7 +516,7 @@ def task_loss(task: str, out: Tensor, label: Tensor) -> Tensor:
 def multi_task_loss(outs: Mapping[str, Tensor], targets: Mapping[str, Tensor], tasks: Sequence[str]):
     """MultiTaskLoss.forward (mtl_loss_schemes.py:232-238) with main.py:192-204 weights."""
     per = {t: task_loss(t, outs[t], targets[t]) for t in tasks}
-    total = torch.sum(torch.stack([LOSS_WEIGHTS[t] * per[t] for t in tasks]))
+    total = torch.sum(torch.stack([loss_weight(t) * per[t] for t in tasks]))
     return total, per
 
 
@@ -614,16 +629,17 @@ def synthetic_batch(B: int, S: int, tasks: Sequence[str], seed: int, dtype=torch
     img = torch.randn(B, 3, S, S, generator=g)
     tg = {}
     for t in tasks:
-        if t in ("semseg", "human_parts"):
-            lab = torch.randint(0, NUM_OUTPUT[t], (B, 1, S, S), generator=g).float()
+        k = task_kind(t)
+        if k in ("semseg", "human_parts"):
+            lab = torch.randint(0, NUM_OUTPUT[k], (B, 1, S, S), generator=g).float()
             lab[torch.rand(B, 1, S, S, generator=g) < 0.05] = 255.0
-        elif t == "sal":
+        elif k == "sal":
             lab = (torch.rand(B, 1, S, S, generator=g) < 0.3).float()
-        elif t == "normals":
+        elif k == "normals":
             lab = F.normalize(torch.randn(B, 3, S, S, generator=g), dim=1)
             ign = (torch.rand(B, 1, S, S, generator=g) < 0.05).expand(B, 3, S, S)
             lab = torch.where(ign, torch.full_like(lab, 255.0), lab)
-        elif t == "depth":
+        elif k == "depth":
             lab = torch.rand(B, 1, S, S, generator=g) * 10
         else:
             raise NotImplementedError(t)

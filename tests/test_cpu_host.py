@@ -171,8 +171,9 @@ sys.path.insert(0, sys.argv[1])
 from mtlora_amd.ddp import GradReducer
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 dist.init_process_group("gloo", init_method="env://")
-torch.manual_seed(0)
+torch.manual_seed(rank)                        # replicas start DIFFERENT: the reducer must broadcast rank 0's parameters / buffers
 net = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.ReLU(), torch.nn.Linear(16, 4), torch.nn.Linear(4, 4))
+buf = torch.full((5,), float(rank))
 net[0].weight.requires_grad_(False)            # frozen parameters never enter a bucket
 unused = torch.nn.Parameter(torch.zeros(3))     # trainable but never used -> grad stays None
 class _Half(torch.autograd.Function):          # like MTLoRALinearFn for an unused output: returns an UNDEFINED gradient for
@@ -189,7 +190,11 @@ ha, hb = torch.nn.Parameter(torch.ones(4)), torch.nn.Parameter(torch.ones(4))
 _fwd = net.forward
 net.forward = lambda x: _Half.apply(_fwd(x), ha, hb)
 params = list(net.parameters()) + [unused, ha, hb]
-red = GradReducer(params, bucket_mb=0.0002)     # several buckets
+red = GradReducer(params, bucket_mb=0.0002, buffers=[buf])     # several buckets
+chk = torch.cat([p.detach().reshape(-1) for p in params] + [buf])
+both = [torch.zeros_like(chk) for _ in range(world)]
+dist.all_gather(both, chk)
+assert all(torch.equal(both[0], v) for v in both) and buf.eq(0).all()   # frozen weight, trainables and buffers == rank 0's
 assert red.nbytes == 4 * sum(p.numel() for p in params if p.requires_grad)
 g = torch.Generator().manual_seed(100)
 xs = torch.randn(world, 5, 8, generator=g)
@@ -210,6 +215,17 @@ t = torch.stack([p.grad.sum() for p in net.parameters() if p.requires_grad]).sum
 gathered = [torch.zeros(1) for _ in range(world)]
 dist.all_gather(gathered, t)
 assert all(torch.allclose(gathered[0], v) for v in gathered)   # every rank holds the same averaged gradients
+# a parameter that only rank 1 uses: rank 0 must still receive the mean (its own share is zero), not keep grad None
+lone = torch.nn.Parameter(torch.ones(4))
+w = torch.nn.Parameter(torch.ones(4))
+red2 = GradReducer([w, lone], bucket_mb=1.0)
+for step in range(2):
+    w.grad = lone.grad = None
+    red2.prepare()
+    y = (w * (rank + 1.0)).sum() + ((lone * 3.0).sum() if rank == 1 else 0.0)
+    y.backward(); red2.finish()
+    assert torch.allclose(w.grad, torch.full((4,), 1.5)), w.grad
+    assert lone.grad is not None and torch.allclose(lone.grad, torch.full((4,), 1.5)), (rank, lone.grad)
 dist.destroy_process_group()
 print("OK", rank)
 '''

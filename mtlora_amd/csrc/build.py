@@ -31,7 +31,8 @@ def _stale(target, deps):
 
 
 def build(force=False, verbose=True):
-    hdrs = [os.path.join(HERE, "common.h"), os.path.join(HERE, "..", "..", "include", "mtlora_hip.h")]
+    hdrs = [os.path.join(HERE, f) for f in sorted(os.listdir(HERE)) if f.endswith(".h")]  # common.h, panel.h, ...
+    hdrs.append(os.path.join(HERE, "..", "..", "include", "mtlora_hip.h"))
     objs, jobs = [], []
     for src in SOURCES:
         s = os.path.join(HERE, src)

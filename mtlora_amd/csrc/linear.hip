@@ -26,6 +26,7 @@
 // Backward = [k_sum], k_nt (Q = alpha dY_o B_o per output), k_nt (dX [+ dX_t]), k_tn + k_tn_reduce for dA / dB.
 // DESIGN.md section 4.1 / 4.3 has the measurements and the experiments that were tried and dropped.
 #include <stdlib.h>
+#include <type_traits>
 
 #include "common.h"
 
@@ -67,7 +68,7 @@ static Segs make_segs(const mtlora_linear_desc* d) {
 }
 
 struct CtxLayout {
-    int64_t a_cat, b_cat, at_cat, bt_cat, alpha, p, total;
+    int64_t a_cat, b_cat, at_cat, bt_cat, alpha, a_proj, bt_proj, p, total;
 };
 static CtxLayout ctx_layout(const mtlora_linear_desc* d, const Segs& s) {
     const int es = mtl_elem_size(d->dtype);
@@ -83,6 +84,8 @@ static CtxLayout ctx_layout(const mtlora_linear_desc* d, const Segs& s) {
     L.at_cat = take((int64_t)d->K * s.R * es);
     L.bt_cat = take((int64_t)s.R * d->N * es);
     L.alpha = take((int64_t)s.R * 4);
+    L.a_proj = take((int64_t)s.R * d->K * es);   // alpha * A_cat   (projection weights of the row-panel forward, k_pnl)
+    L.bt_proj = take((int64_t)s.R * d->N * es);  // alpha * Bt_cat  (projection weights of the row-panel dX)
     L.p = take(d->M * s.R * es);
     L.total = o;
     return L;
@@ -100,7 +103,8 @@ struct PackParams {
 };
 
 template <typename T>
-__global__ __launch_bounds__(256) void k_pack(PackParams p, T* a_cat, T* b_cat, T* at_cat, T* bt_cat, float* alpha) {
+__global__ __launch_bounds__(256) void k_pack(PackParams p, T* a_cat, T* b_cat, T* at_cat, T* bt_cat, float* alpha, T* a_proj,
+                                              T* bt_proj) {
     const int R = p.s.R;
     const int64_t na = (int64_t)R * p.K, nb = (int64_t)R * p.N;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < na + nb + R; i += (int64_t)gridDim.x * 256) {
@@ -118,10 +122,12 @@ __global__ __launch_bounds__(256) void k_pack(PackParams p, T* a_cat, T* b_cat, 
             float v = (valid && p.A[o]) ? p.A[o][(int64_t)lr * p.K + c] : 0.f;
             a_cat[(int64_t)rr * p.K + c] = mtl_from_f32<T>(v);
             at_cat[(int64_t)c * R + rr] = mtl_from_f32<T>(v);
+            a_proj[(int64_t)rr * p.K + c] = mtl_from_f32<T>(v * p.alpha[o]);
         } else if (i < na + nb) {  // B_o[c][lr]  (N x r)
             float v = (valid && p.B[o]) ? p.B[o][(int64_t)c * p.s.r[o] + lr] : 0.f;
             b_cat[(int64_t)c * R + rr] = mtl_from_f32<T>(v);
             bt_cat[(int64_t)rr * p.N + c] = mtl_from_f32<T>(v);
+            bt_proj[(int64_t)rr * p.N + c] = mtl_from_f32<T>(v * p.alpha[o]);
         } else {
             alpha[rr] = p.alpha[o];
         }
@@ -1010,6 +1016,8 @@ __global__ __launch_bounds__(512, 2) void k_nt2(const NtParams Pv) {
     }
 }
 
+#include "panel.h"
+
 // ------------------------------------------------------------------------------------------------
 // k_tn : Out[a][b] = sum_m SrcA[m][a0 + a] * SrcB[m][b0 + b], split over m.
 // SrcA is always the NARROW (rank-side) operand (Q or P, <= 64 columns per tile) and SrcB the WIDE one
@@ -1479,6 +1487,107 @@ static int fuse_groups(const mtlora_linear_desc* d, const Segs& sg, int64_t out_
     return g;
 }
 
+// ---- row-panel engine (k_pnl, panel.h).  OPT-IN (MTLORA_PNL=1): parity-tested forward and dX (every bf16 MTLoRALinear GPU
+// test also runs through it), but on the C2 shapes it is not faster than the pack + P / Q + main launches it replaces
+// (tools/bench_linear.py: 0.95-1.05x on stage 0, 0.75x on stage 1): with loads AND stores disabled it still takes 70 % of
+// its time -- it is instruction-issue bound (PMC, profiles/r02_pnl_pmc.csv: ~190 VALU + SALU instructions per wave per
+// 64-wide k-step, half of them the transposing epilogue / accumulator set-up that a K = 96 layer pays every 3.7 steps),
+// DESIGN.md 4.1b.  MTLORA_PNL_MIN_M sets the row threshold (default 32768: enough 128-row panels for every CU); both are
+// read per call, so the tests switch it in-process.
+static int64_t pnl_min_m() {
+    const char* on = getenv("MTLORA_PNL");
+    if (!(on && on[0] == '1')) return (int64_t)1 << 62;
+    const char* e = getenv("MTLORA_PNL_MIN_M");
+    return e ? (int64_t)atoll(e) : (int64_t)32768;
+}
+static int pnl_stages(int R) {  // ring depth that fits the 160 KB of LDS next to the epilogue images, the P image and the step table
+    const int64_t img = (R > 0 ? (int64_t)PN_BM * (R * 2 + PN_PPAD) : 0) + PN_TABLE;
+    if (3 * PN_STAGE + PN_EPI + img <= PN_LDS_MAX) return 3;
+    if (2 * PN_STAGE + PN_EPI + img <= PN_LDS_MAX) return 2;
+    return 0;
+}
+static int64_t pnl_steps(int64_t k) { return mtl_ceil_div(k, PN_BK); }
+// worst-case k-steps per panel of the forward / dX programs (the step table holds PN_MAXSTEPS)
+static bool pnl_eligible(const mtlora_linear_desc* d, const Segs& sg) {
+    if (!(d->dtype == MTLORA_BF16 && d->M >= pnl_min_m() && d->mode == 0 && sg.R <= 128 && pnl_stages(sg.R) > 0)) return false;
+    const int64_t src = 1 + d->T;
+    const int64_t fwd = src * pnl_steps(d->K) + mtl_ceil_div(d->N, PN_TN) * (pnl_steps(d->K) + src * 2);
+    const int64_t bwd = src * pnl_steps(d->N) + mtl_ceil_div(d->K, PN_TN) * (src * pnl_steps(d->N) + src * 2);
+    return fwd <= PN_MAXSTEPS && bwd <= PN_MAXSTEPS;
+}
+static void launch_pnl(PnParams& P, hipStream_t s, int kind, double alg_bytes, double s8d_bytes, double flops) {
+    P.nstage = pnl_stages(P.R);
+    {
+        const char* e = getenv("MTLORA_PNL_DBG");
+        P.dbg = e ? atoi(e) : 0;
+        const char* ns = getenv("MTLORA_PNL_STAGES");
+        if (ns && ns[0] == '2') P.nstage = 2;
+    }
+    mtl_prof_tag("pnl M%lld N%d R%d np%d nt%d ns%d", (long long)P.M, P.n_rows, P.R, P.n_proj, P.n_parts, P.nstage);
+    MtlProfScope prof(kind, alg_bytes, s, s8d_bytes, flops);
+    const int64_t n_panels = mtl_ceil_div(P.M, PN_BM);
+    if (n_panels == 0 || P.n_parts == 0) return;
+    P.n_proj_steps = P.n_tile_steps = 0;
+    for (int j = 0; j < P.n_proj; ++j) {
+        P.proj[j].step0 = P.n_proj_steps;
+        P.n_proj_steps += (int)pnl_steps(P.proj[j].k_hi - P.proj[j].k_lo);
+    }
+    for (int j = 0; j < P.n_parts; ++j) {
+        P.part[j].step0 = P.n_tile_steps;
+        P.n_tile_steps += (int)pnl_steps(P.part[j].k_hi - P.part[j].k_lo);
+    }
+    static const int n_cu = [] {
+        int dev = 0, cu = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev);
+        return cu > 0 ? cu : 256;
+    }();
+    const unsigned grid = (unsigned)(n_panels < n_cu ? n_panels : n_cu);  // one persistent workgroup per CU
+    const size_t lds = (size_t)P.nstage * PN_STAGE + PN_EPI + (P.R > 0 ? (size_t)PN_BM * (P.R * 2 + PN_PPAD) : 0) + PN_TABLE;
+    bool multi = false, mlr = false, gate = false, act = false;
+    for (int j = 0; j < P.n_parts; ++j) {
+        multi = multi || (P.part[j].flags & (PF_LOADBASE | PF_SAVEBASE)) != 0;
+        mlr = mlr || (P.part[j].flags & PF_MASK) != 0;
+    }
+    mlr = mlr && P.drop.enabled();
+    for (int o = 0; o < MAXO; ++o) {
+        gate = gate || P.out[o].gate != nullptr;
+        act = act || P.out[o].act != nullptr;
+    }
+#define MTL_PNL_LAUNCH_NS(MU, ML, GA, AC, NSTG)                                                                          \
+    do {                                                                                                                 \
+        static bool raised = false;                                                                                      \
+        if (!raised) {                                                                                                   \
+            (void)hipFuncSetAttribute((const void*)k_pnl<MU, ML, GA, AC, NSTG>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                      PN_LDS_MAX);                                                                       \
+            raised = true;                                                                                               \
+        }                                                                                                                \
+        hipLaunchKernelGGL((k_pnl<MU, ML, GA, AC, NSTG>), dim3(grid), dim3(512), lds, s, P);                             \
+    } while (0)
+#define MTL_PNL_LAUNCH(MU, ML, GA, AC)                       \
+    do {                                                     \
+        if (P.nstage == 3)                                   \
+            MTL_PNL_LAUNCH_NS(MU, ML, GA, AC, 3);            \
+        else                                                 \
+            MTL_PNL_LAUNCH_NS(MU, ML, GA, AC, 2);            \
+    } while (0)
+    // forward: [MULTI] x [ACT];  dX: MLR x [GATE]  (the combinations the two programs can produce)
+    if (act) {
+        if (multi) MTL_PNL_LAUNCH(true, false, false, true);
+        else MTL_PNL_LAUNCH(false, false, false, true);
+    } else if (gate) {
+        if (mlr) MTL_PNL_LAUNCH(false, true, true, false);
+        else MTL_PNL_LAUNCH(false, false, true, false);
+    } else if (mlr) {
+        MTL_PNL_LAUNCH(false, true, false, false);
+    } else if (multi) {
+        MTL_PNL_LAUNCH(true, false, false, false);
+    } else {
+        MTL_PNL_LAUNCH(false, false, false, false);
+    }
+#undef MTL_PNL_LAUNCH
+#undef MTL_PNL_LAUNCH_NS
+}
+
 template <typename T>
 static int fwd_impl(const mtlora_linear_desc* d, const void* x, const void* const* x_t, const void* W,
                     const float* bias, const float* A_s, const float* B_s, const float* const* A_t,
@@ -1497,6 +1606,7 @@ static int fwd_impl(const mtlora_linear_desc* d, const void* x, const void* cons
     const float keep_scale = dc.enabled() ? 1.f / (1.f - d->dropout_p) : 1.f;
     bool fuse = false;
     int groups = 0;
+    const bool pnl = std::is_same<T, bf16>::value && pnl_eligible(d, sg);
 
     if (sg.R > 0) {
         PackParams pp;
@@ -1522,12 +1632,12 @@ static int fwd_impl(const mtlora_linear_desc* d, const void* x, const void* cons
         {
             MtlProfScope prof(PK_PACK, 0.0, s);
             hipLaunchKernelGGL(k_pack<T>, dim3((unsigned)blocks), dim3(256), 0, s, pp, a_cat, b_cat, at_cat, bt_cat,
-                               alpha);
+                               alpha, reinterpret_cast<T*>(c + L.a_proj), reinterpret_cast<T*>(c + L.bt_proj));
         }
 
-        groups = a_s ? 0 : fuse_groups(d, sg, d->N);
+        groups = (a_s || pnl) ? 0 : fuse_groups(d, sg, d->N);
         fuse = groups > 0;
-        if (!fuse) {
+        if (!fuse && !pnl) {
             // P = alpha * D(X) A^T  (per source)
             NtParams q = {};
             q.n_act = 1;
@@ -1566,6 +1676,72 @@ static int fwd_impl(const mtlora_linear_desc* d, const void* x, const void* cons
                 launch_nt<T>(q, s, PK_NT_FWD_P, xb, xb, 2.0 * d->M * d->K * rsum);
             }
         }
+    }
+
+    if (pnl) {  // row-panel engine: projection + all outputs in ONE persistent launch
+        PnParams q = {};
+        q.M = d->M;
+        q.n_rows = (int)d->N;
+        q.ld_out = d->N;
+        q.bias = bias;
+        q.R = sg.R;
+        q.pout = sg.R > 0 ? (void*)Pm : nullptr;
+        q.drop = dc;
+        const T* a_proj = reinterpret_cast<const T*>(c + L.a_proj);
+        const bool own_x = d->T > 0 && d->has_x_tasks;
+        for (int o = 0; o < sg.n && sg.R > 0; ++o) {
+            if (!own_x && o > 0) break;
+            if (own_x && sg.rp[o] == 0) continue;
+            PnPart& pt = q.proj[q.n_proj++];
+            pt.act = (o == 0) ? x : x_t[o - 1];
+            pt.wgt = a_proj;
+            pt.ld_act = pt.ld_wgt = d->K;
+            pt.w_lo = own_x ? sg.off[o] : 0;
+            pt.w_hi = own_x ? sg.off[o] + sg.rp[o] : sg.R;
+            pt.k_lo = 0;
+            pt.k_hi = (int)d->K;
+            pt.flags = (o == 0 && dc.enabled()) ? PF_DROPACT : 0;  // tasks without their own input see the same D(x)
+        }
+        int n_actout = 0;
+        for (int o = 0; o < sg.n; ++o) {
+            q.out[o].ptr = (o == 0) ? y_s : y_t[o - 1];
+            q.out[o].act = (o == 0) ? a_s : (a_t ? a_t[o - 1] : nullptr);
+            n_actout += q.out[o].act ? 1 : 0;
+        }
+        const bool multi = sg.n > 1;
+        {
+            PnPart& pt = q.part[q.n_parts++];
+            pt.act = x;
+            pt.wgt = W;
+            pt.ld_act = pt.ld_wgt = d->K;
+            pt.w_lo = 0;
+            pt.w_hi = (int)d->N;
+            pt.k_lo = 0;
+            pt.k_hi = (int)d->K;
+            pt.flags = PF_ZERO | (bias ? PF_BIAS : 0) | (multi ? PF_SAVEBASE : 0) | (sg.rp[0] == 0 ? PF_EPI : 0);
+            pt.out = 0;
+        }
+        for (int o = 0; o < sg.n; ++o) {
+            if (sg.rp[o] == 0) continue;
+            PnPart& pt = q.part[q.n_parts++];
+            pt.act = nullptr;
+            pt.wgt = b_cat;
+            pt.ld_wgt = sg.R;
+            pt.w_lo = 0;
+            pt.w_hi = (int)d->N;
+            pt.k_lo = sg.off[o];
+            pt.k_hi = sg.off[o] + sg.rp[o];
+            pt.flags = PF_RANK | PF_EPI | ((multi && o > 0) ? PF_LOADBASE : 0);
+            pt.out = o;
+        }
+        double rsum = 0.0;
+        for (int o = 0; o < sg.n; ++o) rsum += sg.r[o];
+        const double b8d = (double)sizeof(T) * d->M * ((double)(1 + (own_x ? d->T : 0)) * d->K + (double)(1 + d->T) * d->N);
+        const double fl = 2.0 * d->M * d->K * d->N + 2.0 * d->M * d->N * rsum + 2.0 * d->M * d->K * rsum;
+        const bool plain = sg.R == 0;
+        launch_pnl(q, s, plain ? PK_NT_PLAIN_FWD : PK_NT_FWD_MAIN, b8d + (double)sizeof(T) * d->M * (double)n_actout * d->N,
+                   plain ? 0.0 : b8d, fl);
+        return MTLORA_OK;
     }
 
     // all outputs
@@ -1713,7 +1889,10 @@ static int bwd_impl(const mtlora_linear_desc* d, const void* x, const void* cons
     //    each of the ceil(K/128) n-tiles: 3..24x for fc2): one k_sum pass + the single-source kernel moves
     //    (n_dy + 1 + n_tiles) MN bytes instead of n_dy * n_tiles * MN.
     const void* dy_shared = dy[0];
-    const bool presum = n_dy > 1 && dx && mtl_ceil_div(d->K, TILE) >= 3;
+    // row-panel engine (k_pnl): Q = alpha dY B and every dX / dX_t in ONE persistent launch; no k_sum either -- the base GEMM
+    // runs once per gradient source into the same accumulators
+    const bool pnl = std::is_same<T, bf16>::value && pnl_eligible(d, sg) && dx != nullptr && n_dy > 0;
+    const bool presum = !pnl && n_dy > 1 && dx && mtl_ceil_div(d->K, TILE) >= 3;
     bool have_g = false;
     if ((v2 || presum) && n_dy > 1) {
         SumParams sp;
@@ -1732,9 +1911,95 @@ static int bwd_impl(const mtlora_linear_desc* d, const void* x, const void* cons
     const void* dyo[MAXO];  // gradient feeding factor o
     for (int o = 0; o < sg.n; ++o) dyo[o] = (o == 0) ? dy_shared : dy[o];
 
+    if (pnl) {
+        PnParams q = {};
+        q.M = d->M;
+        q.n_rows = (int)d->K;
+        q.ld_out = d->K;
+        q.R = sg.R;
+        q.pout = sg.R > 0 ? (void*)Qm : nullptr;
+        q.drop = dc;
+        const T* bt_proj = reinterpret_cast<const T*>(c + L.bt_proj);
+        double rsum = 0.0;
+        for (int o = 0; o < sg.n && sg.R > 0; ++o) {
+            if (sg.rp[o] == 0 || !dyo[o]) continue;  // a segment without a gradient stays zero in the image
+            PnPart& pt = q.proj[q.n_proj++];
+            pt.act = dyo[o];
+            pt.wgt = bt_proj;
+            pt.ld_act = pt.ld_wgt = d->N;
+            pt.w_lo = sg.off[o];
+            pt.w_hi = sg.off[o] + sg.rp[o];
+            pt.k_lo = 0;
+            pt.k_hi = (int)d->N;
+            pt.flags = 0;
+            rsum += sg.r[o];
+        }
+        const bool own_x = d->T > 0 && d->has_x_tasks;
+        int n_gate = 0;
+        q.out[0].ptr = dx;
+        q.out[0].gate = gate_s;
+        n_gate += gate_s ? 1 : 0;
+        // dX = keep .* (Q A) + sum_o dY_o W : the masked rank part first, then one base part per gradient source
+        const int lr_lo = own_x ? sg.off[0] : 0, lr_hi = own_x ? sg.off[0] + sg.rp[0] : sg.R;
+        bool zeroed = false;
+        if (q.n_proj > 0 && lr_hi > lr_lo) {
+            PnPart& pt = q.part[q.n_parts++];
+            pt.act = nullptr;
+            pt.wgt = at_cat;
+            pt.ld_wgt = sg.R;
+            pt.w_lo = 0;
+            pt.w_hi = (int)d->K;
+            pt.k_lo = lr_lo;
+            pt.k_hi = lr_hi;
+            pt.flags = PF_RANK | PF_ZERO | (dc.enabled() ? PF_MASK : 0);
+            pt.out = 0;
+            zeroed = true;
+        }
+        for (int i = 0; i < n_dy; ++i) {
+            PnPart& pt = q.part[q.n_parts++];
+            pt.act = dy_all[i];
+            pt.wgt = Wt;
+            pt.ld_act = pt.ld_wgt = d->N;
+            pt.w_lo = 0;
+            pt.w_hi = (int)d->K;
+            pt.k_lo = 0;
+            pt.k_hi = (int)d->N;
+            pt.flags = (!zeroed && i == 0 ? PF_ZERO : 0) | (i == n_dy - 1 ? PF_EPI : 0);
+            pt.out = 0;
+        }
+        int n_dxt = 0;
+        for (int t = 0; own_x && t < d->T; ++t) {
+            if (!dx_t || !dx_t[t]) continue;
+            ++n_dxt;
+            if (sg.rp[t + 1] == 0 || q.n_proj == 0 || !dyo[t + 1]) {  // no gradient reaches this input
+                mtl_zero_async(dx_t[t], (size_t)(d->M * d->K * sizeof(T)), s);
+                continue;
+            }
+            q.out[t + 1].ptr = dx_t[t];
+            q.out[t + 1].gate = gate_t ? gate_t[t] : nullptr;
+            n_gate += q.out[t + 1].gate ? 1 : 0;
+            PnPart& pt = q.part[q.n_parts++];
+            pt.act = nullptr;
+            pt.wgt = at_cat;
+            pt.ld_wgt = sg.R;
+            pt.w_lo = 0;
+            pt.w_hi = (int)d->K;
+            pt.k_lo = sg.off[t + 1];
+            pt.k_hi = sg.off[t + 1] + sg.rp[t + 1];
+            pt.flags = PF_RANK | PF_ZERO | PF_EPI;
+            pt.out = t + 1;
+        }
+        const double b8d = (double)sizeof(T) * d->M * ((double)n_dy * d->N + (double)(1 + n_dxt) * d->K);
+        const double fl = 2.0 * d->M * d->N * d->K * n_dy + 2.0 * d->M * d->K * rsum + 2.0 * d->M * d->N * rsum;
+        const bool plain = sg.R == 0;
+        launch_pnl(q, s, plain ? PK_NT_PLAIN_DX : PK_NT_BWD_DX, b8d + (double)sizeof(T) * d->M * (double)n_gate * d->K,
+                   plain ? 0.0 : b8d, fl);
+        // segments whose output got no gradient: the image holds zeros there and so does the HBM copy (written whole)
+    }
+
     // Q[:, seg_o] = alpha_o * dY_o B_o   (zero where the output got no gradient)
-    const int groups = (dx && dyo[0] && !gate_s) ? fuse_groups(d, sg, d->K) : 0;  // row-panel form: Q is formed inside the dX kernel
-    if (sg.R > 0 && groups == 0) {
+    const int groups = (!pnl && dx && dyo[0] && !gate_s) ? fuse_groups(d, sg, d->K) : 0;  // row-panel form: Q is formed inside the dX kernel
+    if (sg.R > 0 && groups == 0 && !pnl) {
         bool any_missing = false;
         for (int o = 0; o < sg.n; ++o)
             if (sg.rp[o] > 0 && !dyo[o]) any_missing = true;
@@ -1770,7 +2035,7 @@ static int bwd_impl(const mtlora_linear_desc* d, const void* x, const void* cons
     }
 
     // dX = G W + keep .* (Q_s A_s [+ sum_t Q_t A_t]),  dX_t = Q_t A_t
-    {
+    if (!pnl) {
         NtParams m = {};
         if (presum && have_g) {
             m.n_act = 1;

@@ -899,7 +899,10 @@ def _loss_case(task, B, h, w, S, seed):
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("task,B,h,w,S", [("semseg", 2, 20, 20, 4), ("human_parts", 3, 18, 33, 4), ("normals", 2, 37, 16, 4),
                                           ("sal", 2, 16, 16, 4), ("semseg", 1, 7, 9, 2), ("sal", 2, 5, 40, 3),
-                                          ("normals", 1, 16, 16, 1)])
+                                          ("normals", 1, 16, 16, 1),
+                                          # the scale the models actually run at (stage-1 maps 56 -> 448 / 28 -> 224: S = 8)
+                                          ("normals", 2, 28, 28, 8), ("semseg", 2, 28, 28, 8), ("sal", 1, 28, 28, 8),
+                                          ("human_parts", 1, 14, 21, 8)])
 def test_upsample_loss_vs_oracle(task, B, h, w, S, dtype):
     """value and gradient of loss(interpolate(low)) against the oracle's task_loss on torch's own bilinear upsample
     (fp64 on the CPU), incl. partial 16x16 tiles, h != w, borders, ignore_index pixels and scales 1..4."""

@@ -96,8 +96,38 @@ class MTLoRALinear(LoRALayer):
                 nn.init.kaiming_uniform_(self.lora_tasks_A[t], a=math.sqrt(5))
                 nn.init.zeros_(self.lora_tasks_B[t])
 
-    def merge(self):
-        raise NotImplementedError  # as the reference (lora.py:249-251)
+    # -- inference-time merging.  The reference's ``merge`` is a stub that raises (lora.py:249-251); SURVEY 8f row 4 asks for
+    # the real thing: W' = W + s_s B_s A_s.  One weight can only stand for the layer when every output sees the shared update:
+    # layers without tasks (36 of the 48 calls of a Swin-T forward) and ``matrixv2`` layers.  With ``shared_mode='matrix'`` and
+    # tasks, y_t = x W^T + s_t (x_t A_t^T) B_t^T must NOT contain the shared update, so such a layer stays unmerged.
+    def _mergeable(self) -> bool:
+        return (self.r > 0 and hasattr(self, "lora_shared_A")
+                and (self.tasks is None or self.shared_mode == "matrixv2"))
+
+    def _shared_delta(self) -> torch.Tensor:
+        s = self.lora_shared_scale
+        s = float(s.detach().item()) if isinstance(s, torch.Tensor) else float(s)
+        return (self.lora_shared_B.detach().float() @ self.lora_shared_A.detach().float()) * s
+
+    def merge(self) -> bool:
+        """fold the shared low-rank update into ``linear.weight`` (eval only: the train-time dropout in front of A cannot be
+        merged).  Returns True when the layer was merged; ``unmerge`` / ``train()`` undo it."""
+        if self.merged or not self._mergeable():
+            return False
+        with torch.no_grad():
+            self.linear.weight.data.add_(self._shared_delta().to(self.linear.weight.dtype))
+        self.merged = True
+        self.invalidate_weight_cache()
+        return True
+
+    def unmerge(self) -> bool:
+        if not self.merged:
+            return False
+        with torch.no_grad():
+            self.linear.weight.data.sub_(self._shared_delta().to(self.linear.weight.dtype))
+        self.merged = False
+        self.invalidate_weight_cache()
+        return True
 
     # -- frozen-weight copies in the compute dtype (W, W^T) and an fp32 bias, refreshed when W changes
     def _weights(self, dtype: torch.dtype):
@@ -132,6 +162,8 @@ class MTLoRALinear(LoRALayer):
         return super()._load_from_state_dict(*a, **k)
 
     def train(self, mode: bool = True):
+        if mode and self.merged:  # a merged weight cannot be trained through (loralib convention: train() un-merges)
+            self.unmerge()
         self._wcache = {}
         return super().train(mode)
 
@@ -147,7 +179,7 @@ class MTLoRALinear(LoRALayer):
         wc, wt, bf = self._weights(dtype)
         has_lora = self.r > 0
         tasks = list(self.tasks) if (has_lora and self.tasks is not None) else []
-        shared = has_lora and self.shared_mode in ("matrix", "matrixv2")
+        shared = has_lora and self.shared_mode in ("matrix", "matrixv2") and not self.merged
         p = self.dropout_p if (self.training and has_lora) else 0.0
         val = lambda s: float(s.detach().item()) if isinstance(s, torch.Tensor) else float(s)
         par = lambda s: s if isinstance(s, nn.Parameter) else None
@@ -157,7 +189,7 @@ class MTLoRALinear(LoRALayer):
             K=self.linear.in_features, N=self.linear.out_features,
             r_s=self.r if shared else 0, r_t=tuple(self._ranks[t] for t in tasks),
             scale_s=val(ss), scale_t=tuple(val(s) for s in st),
-            mode=1 if (self.shared_mode == "matrixv2" and tasks) else 0,
+            mode=1 if (self.shared_mode == "matrixv2" and tasks and not self.merged) else 0,
             has_x_tasks=bool(tasks) and x_tasks is not None, dropout_p=p, seed=Fn.next_seed() if p > 0 else 0,
             dtype=dtype, weight_requires_grad=self.linear.weight.requires_grad or (
                 self.linear.bias is not None and self.linear.bias.requires_grad),

@@ -298,6 +298,8 @@ def det_fill_(named_tensors, skip_int=True) -> None:
                 p.copy_(det_tensor(n, p.shape, 0.05, 1.0))
             elif last in ("bias", "running_mean"):
                 p.copy_(det_tensor(n, p.shape, 0.02))
+            elif "lora_shared_scale" in n or "lora_task_scale" in n:   # TRAINABLE_SCALE_*: a scale of the usual magnitude
+                p.copy_(det_tensor(n, p.shape, 0.5, 3.0))
             elif "lora_" in n and ("_A" in n):
                 p.copy_(det_tensor(n, p.shape, 0.05))
             elif "lora_" in n:
@@ -559,6 +561,8 @@ def backbone_param_shapes(cfg, prefix="") -> Dict[str, Tuple[int, ...]]:
             else:
                 S[pre + ".lora_norm.weight"] = (N,)
                 S[pre + ".lora_norm.bias"] = (N,)
+            if mt.TRAINABLE_SCALE_SHARED:                       # lora.py:205-209: a 1-element Parameter
+                S[pre + ".lora_shared_scale"] = (1,)
             if with_tasks:
                 for t in tasks:
                     S[pre + ".lora_tasks_A." + t] = (r[t], K)

@@ -261,6 +261,45 @@ def gen_backbone_small(swin):
     })
 
 
+def gen_backbone_options(swin, lora):
+    """the MTLoRA options the shipped yamls switch on beyond the defaults, each on a 2-stage backbone (56 px, T=2, r 8/4,
+    eval mode, fp64): DOWNSAMPLER_ENABLED (the six mtlora_plus_* yamls: PatchMerging.reduction becomes an MTLoRALinear,
+    swin_transformer_mtlora.py:442-447), INTERMEDIATE_SPECIALIZATION (every block specialises, :60-64 / :131-137) and
+    TRAINABLE_SCALE_SHARED (lora.py:205-209: the shared scale is a 1-element Parameter with its own gradient).
+    (TRAINABLE_SCALE_PER_TASK crashes in the reference itself with the dict the backbone passes, lora.py:212 -- SURVEY a2.)"""
+    tasks = ["semseg", "normals"]
+    out = {}
+    for name, over in (("downsampler", dict(DOWNSAMPLER_ENABLED=True)),
+                       ("intermediate", dict(INTERMEDIATE_SPECIALIZATION=True)),
+                       ("trainable_scale", dict(TRAINABLE_SCALE_SHARED=True))):
+        cfg = O.swin_t_cfg(img_size=56, tasks=tasks, r_shared=8, r_task=4, depths=(2, 2), num_heads=(3, 6),
+                           drop_path_rate=0.1, dropout=0.05, **over)
+        bb = swin.SwinTransformerMTLoRA(img_size=56, patch_size=4, in_chans=3, num_classes=0, embed_dim=96,
+                                        depths=[2, 2], num_heads=[3, 6], window_size=7, drop_path_rate=0.1,
+                                        tasks=tasks, mtlora=cfg["mtlora"])
+        O.det_fill_(bb.named_parameters())
+        lora.mark_only_lora_as_trainable(bb, bias="none")
+        bb = bb.double().eval()
+        x = O.det_tensor("bbo.x", (1, 3, 56, 56), 1.0).double()
+        stages = bb(x, return_stages=True)
+        loss = 0
+        for i, (s, tl) in enumerate(stages):
+            loss = loss + (s * O.det_tensor(f"bbo.g.{i}", s.shape, 1.0).double()).sum()
+            for t in tasks:
+                loss = loss + (tl[t] * O.det_tensor(f"bbo.g.{i}.{t}", s.shape, 1.0).double()).sum()
+        loss.backward()
+        named = dict(bb.named_parameters())
+        out[name] = {
+            "over": over, "tasks": tasks, "names": list(bb.state_dict().keys()),
+            "trainable": [n for n, p in named.items() if p.requires_grad],
+            "stages": [(s.detach().clone(), {t: v.detach().clone() for t, v in tl.items()}) for s, tl in stages],
+            "grads": {n: (p.grad.clone() if p.numel() <= 1024 else checksum(p.grad)) for n, p in named.items()
+                      if p.requires_grad and p.grad is not None},
+            "grad_is_none": sorted(n for n, p in named.items() if p.requires_grad and p.grad is None),
+        }
+    save("backbone_options.pt", out)
+
+
 def gen_c1(lora, swin, mtl, losses):
     """BASELINE config C1: Swin-T/224, 1 task (semseg), r=4, bs=2, CPU fwd+bwd; eval-mode dropout
     (main.py:329-354 step without the optimizer).  Stores loss, checksums and grad slices."""
@@ -324,6 +363,57 @@ def gen_losses(losses):
     save("losses.pt", out)
 
 
+def gen_checkpoint(lora, swin):
+    """reference utils.load_checkpoint (utils.py:41-176) on a synthetic VANILLA Swin checkpoint -> MTLoRA backbone: key
+    mapping (.weight -> .linear.weight), attn_mask strip, relative-position table re-interpolation (window 7 -> 4).
+    Stores only names / shapes of the synthetic checkpoint (values = det_tensor(name)) and checksums of the loaded model."""
+    import importlib
+    import tempfile
+    for name in ("cv2", "imageio"):  # imported by utils.py for its image helpers; absent here, unused on this path
+        sys.modules.setdefault(name, types.ModuleType(name))
+    utils = importlib.import_module("utils")
+    vanilla_mod = importlib.import_module("models.swin_transformer")
+    van = vanilla_mod.SwinTransformer(img_size=112, patch_size=4, in_chans=3, num_classes=0, embed_dim=48, depths=[2, 2],
+                                      num_heads=[2, 4], window_size=7, drop_path_rate=0.0)
+    sd = {k: v.clone() for k, v in van.state_dict().items()}
+    for k, v in sd.items():
+        if torch.is_floating_point(v) and "attn_mask" not in k:
+            v.copy_(O.det_tensor("ckpt." + k, v.shape, 0.05))
+    tasks = ["semseg", "normals"]
+    mt = O.mtlora_config(tasks, r_shared=8, r_task=4, n_stages=2, SPLIT_QKV=False)
+    tgt = swin.SwinTransformerMTLoRA(img_size=64, patch_size=4, in_chans=3, num_classes=0, embed_dim=48, depths=[2, 2],
+                                     num_heads=[2, 4], window_size=4, drop_path_rate=0.0, tasks=tasks, mtlora=mt)
+    O.det_fill_(tgt.named_parameters())
+    before = {k: v.clone() for k, v in tgt.state_dict().items()}
+
+    class Log:
+        def __init__(self):
+            self.w = []
+
+        def info(self, m):
+            pass
+
+        def warning(self, m):
+            self.w.append(str(m))
+
+    log = Log()
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "vanilla.pth")
+        torch.save({"model": sd}, path)
+        cfg = O.Cfg(MODEL=O.Cfg(RESUME="", RESUME_BACKBONE=path, MTLORA=mt, UPDATE_RELATIVE_POSITION=True),
+                    TRAIN=O.Cfg(SKIP_DECODER_CKPT=False), EVAL_MODE=True)
+        utils.load_checkpoint(cfg, tgt, None, None, None, log, backbone=True)
+    after = tgt.state_dict()
+    changed = sorted(k for k in after if not torch.equal(after[k], before[k]))
+    save("checkpoint_map.pt", {
+        "ckpt": {k: (tuple(v.shape), str(v.dtype)) for k, v in sd.items()},
+        "warnings": log.w,
+        "changed": changed,
+        "loaded": {k: checksum(after[k]) for k in changed},
+        "tables": {k: after[k].clone() for k in changed if "relative_position_bias_table" in k},
+    })
+
+
 if __name__ == "__main__":
     assert os.path.isdir(REF), "reference not mounted; golden vectors can only be regenerated in the build container"
     torch.set_num_threads(8)
@@ -340,3 +430,5 @@ if __name__ == "__main__":
     gen_backbone_small(swin)
     gen_c2_names(lora, swin, mtl)
     gen_c1(lora, swin, mtl, losses)
+    gen_checkpoint(lora, swin)
+    gen_backbone_options(swin, lora)

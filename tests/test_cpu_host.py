@@ -115,8 +115,19 @@ def test_module_api_parity(golden):
     assert m.tasks is None and m.shared_mode == "matrix"
     m = MTLoRALinear(96, 96, r=0)
     assert not hasattr(m, "lora_shared_A")
-    with pytest.raises(NotImplementedError):
-        m.merge()
+    assert m.merge() is False and not m.merged          # nothing to merge at rank 0 (the reference's merge() is a stub)
+    # merge(): W' = W + s B A for layers whose every output sees the shared update; 'matrix' + tasks stays unmerged
+    m = MTLoRALinear(16, 24, r=4, lora_shared_scale=2.0)
+    torch.nn.init.normal_(m.lora_shared_B, std=0.1)
+    w0 = m.linear.weight.detach().clone()
+    assert m.merge() and m.merged and not m.merge()
+    assert torch.allclose(m.linear.weight, w0 + 2.0 * m.lora_shared_B @ m.lora_shared_A, atol=1e-6)
+    m.train()                                            # train() un-merges
+    assert not m.merged and torch.allclose(m.linear.weight, w0, atol=1e-6)
+    mt = MTLoRALinear(16, 24, r={"shared": 4, "a": 2}, lora_task_scale={"a": 2.0}, tasks=["a"])
+    assert mt.merge() is False
+    mv2 = MTLoRALinear(16, 24, r={"shared": 4, "a": 2}, lora_task_scale={"a": 2.0}, tasks=["a"], shared_mode="matrixv2")
+    assert mv2.merge() is True and mv2.unmerge() is True
     c = golden("c2_structure.pt")
     model = H.build_model(img_size=448, freeze=True)
     mine = {k: tuple(v.shape) for k, v in model.state_dict().items()}
@@ -152,6 +163,60 @@ def test_harness_losses_match_golden(golden):
         assert abs(l.item() - d["loss"]) < 1e-5 * max(1.0, abs(d["loss"])), t
         l.backward()
         assert torch.allclose(pred.grad, d["dpred"], rtol=1e-4, atol=1e-7), t
+
+
+def test_load_checkpoint_matches_reference(golden, tmp_path):
+    """mtlora_amd.checkpoint.load_checkpoint == reference utils.load_checkpoint (utils.py:41-176) on a synthetic vanilla
+    Swin checkpoint loaded into an MTLoRA backbone (fixture captured from the real reference, make_golden.gen_checkpoint):
+    .weight -> .linear.weight mapping, attn_mask strip, relative-position table bicubic 13x13 -> 7x7, the set of tensors
+    that change, the loaded values and the missing / unexpected key report."""
+    import logging
+    from mtlora_amd import checkpoint as C
+    from mtlora_amd import mtl_harness as H
+    from mtlora_amd.swin_transformer_mtlora import SwinTransformerMTLoRA
+    from oracle import mtlora_oracle as O
+    c = golden("checkpoint_map.pt")
+    sd = {}
+    for k, (shape, dt) in c["ckpt"].items():
+        if dt.startswith("torch.float") and "attn_mask" not in k:
+            sd[k] = O.det_tensor("ckpt." + k, shape, 0.05)
+        else:
+            sd[k] = torch.zeros(shape, dtype=getattr(torch, dt.split(".")[1]))
+    tasks = ["semseg", "normals"]
+    mt = H.mtlora_namespace(tasks, r_shared=8, r_task=4, n_stages=2, SPLIT_QKV=False)
+    tgt = SwinTransformerMTLoRA(img_size=64, patch_size=4, in_chans=3, num_classes=0, embed_dim=48, depths=[2, 2],
+                                num_heads=[2, 4], window_size=4, drop_path_rate=0.0, tasks=tasks, mtlora=mt)
+    O.det_fill_(tgt.named_parameters())
+    before = {k: v.clone() for k, v in tgt.state_dict().items()}
+    path = tmp_path / "vanilla.pth"
+    torch.save({"model": sd}, path)
+
+    class Log(logging.Logger):
+        def __init__(self):
+            super().__init__("t")
+            self.w = []
+
+        def info(self, m, *a, **k):
+            pass
+
+        def warning(self, m, *a, **k):
+            self.w.append(str(m))
+
+    log = Log()
+    cfg = H.AttrDict(MODEL=H.AttrDict(RESUME="", RESUME_BACKBONE=str(path), MTLORA=mt, UPDATE_RELATIVE_POSITION=True),
+                     TRAIN=H.AttrDict(SKIP_DECODER_CKPT=False), EVAL_MODE=True)
+    assert C.load_checkpoint(cfg, tgt, None, None, None, log, backbone=True) == 0.0
+    after = tgt.state_dict()
+    changed = sorted(k for k in after if not torch.equal(after[k], before[k]))
+    assert changed == c["changed"]
+    assert log.w == c["warnings"]
+    for k, cs in c["loaded"].items():
+        f = after[k].double().flatten()
+        assert tuple(after[k].shape) == tuple(cs["shape"]), k
+        assert abs(f.sum().item() - cs["sum"]) <= 1e-6 * max(1.0, cs["abssum"]), k
+        assert torch.allclose(f[cs["idx"]], cs["samples"], rtol=1e-6, atol=1e-8), k
+    for k, t in c["tables"].items():
+        assert torch.allclose(after[k], t, rtol=1e-6, atol=1e-7), k
 
 
 def test_dropout_mask_statistics():

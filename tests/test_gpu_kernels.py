@@ -293,8 +293,34 @@ def test_linear_errors():
     m = MTLoRALinear(96, 98, r=4).to(dev())  # N % 4 != 0
     with pytest.raises(RuntimeError):
         m(torch.randn(4, 96, device=dev()))
-    with pytest.raises(NotImplementedError):
-        m.merge()
+
+
+def test_merge_matches_unmerged_eval():
+    """MTLoRALinear.merge() / checkpoint.merge_lora_weights: a 2-stage backbone in eval mode gives the same stage outputs
+    before and after folding W' = W + s B A into every mergeable layer (all layers without tasks), and unmerge restores
+    the weights bit for bit... up to the fp32 rounding of the add/sub pair."""
+    from mtlora_amd.checkpoint import merge_lora_weights, unmerge_lora_weights
+    from mtlora_amd.swin_transformer_mtlora import SwinTransformerMTLoRA
+    tasks = ["semseg", "normals"]
+    cfg = O.swin_t_cfg(img_size=56, tasks=tasks, r_shared=8, r_task=4, depths=(2, 2), num_heads=(3, 6), drop_path_rate=0.1, dropout=0.05)
+    bb = SwinTransformerMTLoRA(img_size=56, patch_size=4, in_chans=3, num_classes=0, embed_dim=96, depths=[2, 2], num_heads=[3, 6],
+                               window_size=7, drop_path_rate=0.1, tasks=tasks, mtlora=cfg["mtlora"])
+    O.det_fill_(bb.named_parameters())
+    bb = bb.to(dev()).eval()
+    x = O.det_tensor("merge.x", (2, 3, 56, 56), 1.0).to(dev())
+    w_before = {n: p.detach().clone() for n, p in bb.named_parameters() if n.endswith("linear.weight")}
+    with torch.no_grad():
+        ref = bb(x, return_stages=True)
+        n = merge_lora_weights(bb)
+        assert n == 2 * 2 * 4 - 2 * 3   # 16 linears, the 3 task-enabled ones of each stage's last block stay unmerged
+        got = bb(x, return_stages=True)
+        for (s, tl), (rs, rtl) in zip(got, ref):
+            assert_close(s, rs, torch.float32, "merged stage output")
+            for t in tasks:
+                assert_close(tl[t], rtl[t], torch.float32, f"merged task output {t}")
+        assert unmerge_lora_weights(bb) == n
+    for k, w in w_before.items():
+        assert torch.allclose(dict(bb.named_parameters())[k], w, atol=1e-6), k
 
 
 # ------------------------------------------------------------------------------------------------
@@ -466,6 +492,50 @@ def test_backbone_small_golden(golden, dtype):
 # ------------------------------------------------------------------------------------------------
 # LayerNorm glue kernel
 # ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", ["downsampler", "intermediate", "trainable_scale"])
+def test_backbone_options_golden(golden, case, dtype):
+    """the non-default MTLoRA switches of the shipped yamls through the HIP path vs fixtures from the real reference:
+    DOWNSAMPLER_ENABLED (mtlora_plus_*: the PatchMerging reduction is an MTLoRALinear over the stacked streams),
+    INTERMEDIATE_SPECIALIZATION (every block emits task outputs; only the last one's survive), TRAINABLE_SCALE_SHARED (the
+    scale is a Parameter: its gradient <dB, B> / s and the same trainable set)."""
+    from mtlora_amd.lora import mark_only_lora_as_trainable
+    from mtlora_amd.swin_transformer_mtlora import SwinTransformerMTLoRA
+    c = golden("backbone_options.pt")[case]
+    tasks = c["tasks"]
+    cfg = O.swin_t_cfg(img_size=56, tasks=tasks, r_shared=8, r_task=4, depths=(2, 2), num_heads=(3, 6), drop_path_rate=0.1,
+                       dropout=0.05, **c["over"])
+    bb = SwinTransformerMTLoRA(img_size=56, patch_size=4, in_chans=3, num_classes=0, embed_dim=96, depths=[2, 2], num_heads=[3, 6],
+                               window_size=7, drop_path_rate=0.1, tasks=tasks, mtlora=cfg["mtlora"])
+    assert [n for n in bb.state_dict().keys()] == c["names"]
+    O.det_fill_(bb.named_parameters())
+    mark_only_lora_as_trainable(bb, bias="none")
+    assert [n for n, p in bb.named_parameters() if p.requires_grad] == c["trainable"]
+    bb = bb.to(dev()).eval()
+    x = O.det_tensor("bbo.x", (1, 3, 56, 56), 1.0).to(dev())
+    with torch.autocast("cuda", dtype=torch.bfloat16, enabled=dtype == torch.bfloat16):
+        stages = bb(x, return_stages=True)
+    loss = 0
+    for i, (s, tl) in enumerate(stages):
+        assert_close(s, c["stages"][i][0], dtype, f"stage {i}", mult=2)
+        loss = loss + (s.float() * O.det_tensor(f"bbo.g.{i}", s.shape, 1.0).to(dev())).sum()
+        for t in tasks:
+            assert_close(tl[t], c["stages"][i][1][t], dtype, f"stage {i} {t}", mult=2)
+            loss = loss + (tl[t].float() * O.det_tensor(f"bbo.g.{i}.{t}", s.shape, 1.0).to(dev())).sum()
+    loss.backward()
+    named = dict(bb.named_parameters())
+    for n, g in c["grads"].items():
+        got = named[n].grad
+        assert got is not None, n
+        if isinstance(g, dict):
+            f = got.double().flatten().cpu()
+            scale = max(g["samples"].abs().max().item(), g["abssum"] / f.numel())
+            assert (f[g["idx"]] - g["samples"]).abs().max().item() <= TOL[dtype] * 3 * scale, n
+        else:
+            assert_close(got, g, dtype, n, mult=3)
+    assert sorted(n for n in c["trainable"] if named[n].grad is None or named[n].grad.abs().max() == 0) == c["grad_is_none"]
+
+
 @pytest.mark.parametrize("xdt,ydt", [(torch.float32, torch.float32), (torch.float32, torch.bfloat16),
                                      (torch.bfloat16, torch.bfloat16)])
 @pytest.mark.parametrize("M,C", [(1000, 96), (333, 192), (257, 384), (100, 768), (65, 1536), (3, 2048), (50, 40)])

@@ -203,6 +203,37 @@ def test_backbone_small(golden):
             close(P[n].grad, g, rtol=1e-7, atol=1e-8)
 
 
+@pytest.mark.parametrize("case", ["downsampler", "intermediate", "trainable_scale"])
+def test_backbone_options(golden, case):
+    """DOWNSAMPLER_ENABLED / INTERMEDIATE_SPECIALIZATION / TRAINABLE_SCALE_SHARED backbones vs the reference fixture."""
+    c = golden("backbone_options.pt")[case]
+    tasks = c["tasks"]
+    cfg = O.swin_t_cfg(img_size=56, tasks=tasks, r_shared=8, r_task=4, depths=(2, 2), num_heads=(3, 6),
+                       drop_path_rate=0.1, dropout=0.05, **c["over"])
+    shapes = O.backbone_param_shapes(cfg)
+    assert sorted(shapes) == sorted(n for n in c["names"] if not n.endswith(("attn_mask", "relative_position_index")))
+    P = {k: v.double() for k, v in O.make_params(shapes).items()}
+    for n in c["trainable"]:
+        P[n].requires_grad_(True)
+    assert sorted(n for n in P if O.trainable_filter("backbone." + n)) == sorted(c["trainable"])
+    x = O.det_tensor("bbo.x", (1, 3, 56, 56), 1.0).double()
+    stages = O.backbone_stages(P, x, cfg)
+    loss = 0
+    for i, (s, tl) in enumerate(stages):
+        close(s, c["stages"][i][0], rtol=1e-8, atol=1e-9)
+        loss = loss + (s * O.det_tensor(f"bbo.g.{i}", s.shape, 1.0).double()).sum()
+        for t in tasks:
+            close(tl[t], c["stages"][i][1][t], rtol=1e-8, atol=1e-9)
+            loss = loss + (tl[t] * O.det_tensor(f"bbo.g.{i}.{t}", s.shape, 1.0).double()).sum()
+    loss.backward()
+    for n, g in c["grads"].items():
+        if isinstance(g, dict):
+            check_sum(P[n].grad, g, rtol=1e-7)
+        else:
+            close(P[n].grad, g, rtol=1e-7, atol=1e-8)
+    assert sorted(n for n in c["trainable"] if P[n].grad is None or P[n].grad.abs().max() == 0) == c["grad_is_none"]
+
+
 def test_c2_structure(golden):
     """state-dict names/shapes and the trainable set of the C2 model."""
     c = golden("c2_structure.pt")

@@ -48,7 +48,8 @@ constexpr int MAXO = MTLORA_MAX_TASKS + 1;
 struct Segs {
     int n;  // 1 + T
     int r[MAXO], rp[MAXO], off[MAXO];
-    int R;  // total padded rank
+    int R;     // row stride of P / Q / the packed factors (columns), a multiple of 16
+    int used;  // columns that belong to a segment: [used, R) is padding nobody writes
 };
 
 static Segs make_segs(const mtlora_linear_desc* d) {
@@ -58,12 +59,18 @@ static Segs make_segs(const mtlora_linear_desc* d) {
     for (int o = 0; o < s.n; ++o) {
         int r = (o == 0) ? d->r_s : d->r_t[o - 1];
         s.r[o] = r;
-        s.rp[o] = (int)mtl_round_up(r, 16);
+        // a segment is padded to ONE 16-byte vector of bf16 (8 columns), not to the 16-wide MFMA k granule: every consumer masks
+        // per 16-byte vector (k_nt zero-fills the vectors past a part's k range on both operands, k_tn windows start on vector
+        // boundaries), so r_t = 4 costs 8 columns of P / Q / factors instead of 16 -- R = 96 instead of 128 at C2's task layers,
+        // 80 instead of 144 with 8 tasks of rank 4.  (Packing two 4-wide segments into one vector would need the P pass to merge
+        // two different activation sources into one store: DESIGN.md 7.)
+        s.rp[o] = (int)mtl_round_up(r, 8);
         s.off[o] = off;
         off += s.rp[o];
     }
     for (int o = s.n; o < MAXO; ++o) s.r[o] = s.rp[o] = s.off[o] = 0;
-    s.R = off;
+    s.used = off;
+    s.R = (int)mtl_round_up(off, 16);  // row stride of P / Q: whole 32-byte pairs (the trailing pad columns are never read)
     return s;
 }
 
@@ -190,10 +197,38 @@ struct NtParams {
 typedef const __attribute__((address_space(4))) NtParams* NtPtr;
 
 // RI = tile rows per thread per operand: 2 with 256 threads (4 waves), 1 with 512 threads (8 waves)
+// A thread stages 3 * RI 16-byte vectors per operand per k-tile.  Which (row, vector) a thread owns is chosen for the LDS
+// STORE: ds_write_b128 is served 8 lanes (128 bytes = all 32 banks) at a time, so 8 consecutive lanes must write 8 pieces that
+// are distinct mod 128 bytes.  With the 208-byte row stride (13 pieces: odd, which is what keeps the ds_read_b128 fragment
+// reads conflict-free) the earlier 4-lanes-per-row map put (row r, piece 0) and (row r+1, piece 3) on the same banks in
+// every group -- a 2-way conflict on every staging store (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.25,
+// profiles/r01_pmc_sq.csv).  Now: slots 0 .. 2 RI - 1: 8 lanes x 16 B = the first 128 bytes of ONE row (also a 128-byte
+// global-load segment instead of two 64-byte ones); the last RI slots: the remaining 64 bytes of rows r and r + 4 (52 pieces
+// apart = 4 mod 8: the two halves interleave).
+// The 4-wave variants (RI = 2: MULTI / row-panel / f32, already at 256 VGPRs) keep the 4-lanes-per-row map: six distinct row
+// addresses per thread pushed their hot loop into scratch (8 -> 104 bytes per lane for the multi-output forward).
+template <int RI>
+__device__ __forceinline__ void nt_map(int tid, int slot, int& row, int& vec) {
+    constexpr int NT = 512 / RI;
+    if constexpr (RI == 2) {
+        row = (tid >> 2) + (slot & 1) * 64;
+        vec = (tid & 3) + 4 * (slot >> 1);
+    } else if (slot < 2 * RI) {
+        const int idx = tid + NT * slot;  // 0 .. 1023
+        row = idx >> 3;
+        vec = idx & 7;
+    } else {
+        const int idx = tid + NT * (slot - 2 * RI);  // 0 .. 511
+        const int g = idx >> 3, l = idx & 7;
+        row = (g >> 2) * 8 + (g & 3) + 4 * (l >> 2);
+        vec = 8 + (l & 3);
+    }
+}
+
 template <typename T, int RI>
 struct TileRegs {
-    u32x4 w[RI][VPT], a[RI][VPT];
-    int mask;  // dropout keep-mask still to be applied to a[][] (done at LDS-store time: applying it at load time
+    u32x4 w[3 * RI], a[3 * RI];
+    int mask;  // dropout keep-mask still to be applied to a[] (done at LDS-store time: applying it at load time
     int k0;    // would put an s_waitcnt vmcnt(0) behind every single load and serialise the tile's loads)
 };
 
@@ -205,60 +240,47 @@ __device__ __forceinline__ void nt_load(TileRegs<T, RI>& rg, int tid, const T* w
     constexpr int VEC = ET<T>::VEC;
     rg.mask = mask ? 1 : 0;
     rg.k0 = k0;
-    // row bases once per tile (two rows per thread), the k offset is added per vector
-    const T* wp[RI];
-    int64_t aoff[RI];
-    bool wok[RI], aok[RI];
 #pragma unroll
-    for (int i = 0; i < RI; ++i) {
-        const int r = (tid >> 2) + i * 64;
-        const int wr = w_row0 + r;
-        wok[i] = wr < w_rows && wr >= w_lo;
-        wp[i] = wgt + (int64_t)wr * ld_w;
-        const int64_t ar = a_row0 + r;
-        aok[i] = ar < a_rows && act0 != nullptr;
-        aoff[i] = ar * ld_a;
-    }
-#pragma unroll
-    for (int j = 0; j < VPT; ++j) {
-        const int v = (tid & 3) + 4 * j;
+    for (int sl = 0; sl < 3 * RI; ++sl) {
+        int r, v;
+        nt_map<RI>(tid, sl, r, v);
         const int k = k0 + v * VEC;
         const bool kin = k < k_hi;
+        const int wr = w_row0 + r;
+        const bool wok = wr < w_rows && wr >= w_lo;
+        rg.w[sl] = (kin && wok) ? *reinterpret_cast<const u32x4*>(wgt + (int64_t)wr * ld_w + k) : u32x4{0u, 0u, 0u, 0u};
+        const int64_t ar = a_row0 + r;
+        const bool aok = ar < a_rows && act0 != nullptr;
+        const int64_t aoff = ar * ld_a;
+        if (kin && aok) {
+            u32x4 x = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(act0) + aoff + k);
+            if (MS && n_act > 1) {
+                if constexpr (sizeof(T) == 4) {
+                    f32x4 fx = __builtin_bit_cast(f32x4, x);
 #pragma unroll
-        for (int i = 0; i < RI; ++i) {
-            rg.w[i][j] = (kin && wok[i]) ? *reinterpret_cast<const u32x4*>(wp[i] + k) : u32x4{0u, 0u, 0u, 0u};
-            if (kin && aok[i]) {
-                u32x4 x = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(act0) + aoff[i] + k);
-                if (MS && n_act > 1) {
-                    if constexpr (sizeof(T) == 4) {
-                        f32x4 fx = __builtin_bit_cast(f32x4, x);
-#pragma unroll
-                        for (int s = 1; s < MAXO; ++s) {
-                            if (s < n_act)
-                                fx += *reinterpret_cast<const f32x4*>(reinterpret_cast<const T*>(P->act[s]) + aoff[i] + k);
-                        }
-                        x = __builtin_bit_cast(u32x4, fx);
-                    } else {
-                        float f[8];
-                        VOps<T>::unpack(x, f);
-#pragma unroll
-                        for (int s = 1; s < MAXO; ++s) {
-                            if (s < n_act) {
-                                const u32x4 y =
-                                    *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(P->act[s]) + aoff[i] + k);
-                                float g[8];
-                                VOps<T>::unpack(y, g);
-#pragma unroll
-                                for (int e = 0; e < 8; ++e) f[e] += g[e];
-                            }
-                        }
-                        x = VOps<T>::pack(f);
+                    for (int s = 1; s < MAXO; ++s) {
+                        if (s < n_act) fx += *reinterpret_cast<const f32x4*>(reinterpret_cast<const T*>(P->act[s]) + aoff + k);
                     }
+                    x = __builtin_bit_cast(u32x4, fx);
+                } else {
+                    float f[8];
+                    VOps<T>::unpack(x, f);
+#pragma unroll
+                    for (int s = 1; s < MAXO; ++s) {
+                        if (s < n_act) {
+                            const u32x4 y = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(P->act[s]) + aoff + k);
+                            float g[8];
+                            VOps<T>::unpack(y, g);
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) f[e] += g[e];
+                        }
+                    }
+                    x = VOps<T>::pack(f);
                 }
-                rg.a[i][j] = x;
-            } else {
-                rg.a[i][j] = u32x4{0u, 0u, 0u, 0u};
             }
+            rg.a[sl] = x;
+        } else {
+            rg.a[sl] = u32x4{0u, 0u, 0u, 0u};
         }
     }
 }
@@ -267,23 +289,16 @@ template <typename T, int RI>
 __device__ __forceinline__ void nt_store_lds(TileRegs<T, RI>& rg, int tid, unsigned char* sW, unsigned char* sA,
                                              const DropoutCfg& dc, int64_t a_row0, bool with_act = true) {
     constexpr int VEC = ET<T>::VEC;
-    if (rg.mask) {  // wave-uniform
 #pragma unroll
-        for (int i = 0; i < RI; ++i) {
-            const uint32_t rh = mtl_dropout_rowhash(dc, 0u, (uint32_t)(a_row0 + (tid >> 2) + i * 64));
-#pragma unroll
-            for (int j = 0; j < VPT; ++j) VOps<T>::drop(rg.a[i][j], dc, rh, (uint32_t)(rg.k0 + ((tid & 3) + 4 * j) * VEC));
+    for (int sl = 0; sl < 3 * RI; ++sl) {
+        int r, v;
+        nt_map<RI>(tid, sl, r, v);
+        if (rg.mask) {  // wave-uniform
+            const uint32_t rh = mtl_dropout_rowhash(dc, 0u, (uint32_t)(a_row0 + r));
+            VOps<T>::drop(rg.a[sl], dc, rh, (uint32_t)(rg.k0 + v * VEC));
         }
-    }
-#pragma unroll
-    for (int j = 0; j < VPT; ++j) {
-        const int v = (tid & 3) + 4 * j;
-#pragma unroll
-        for (int i = 0; i < RI; ++i) {
-            const int r = (tid >> 2) + i * 64;
-            *reinterpret_cast<u32x4*>(sW + r * LDSB + v * 16) = rg.w[i][j];
-            if (with_act) *reinterpret_cast<u32x4*>(sA + r * LDSB + v * 16) = rg.a[i][j];
-        }
+        *reinterpret_cast<u32x4*>(sW + r * LDSB + v * 16) = rg.w[sl];
+        if (with_act) *reinterpret_cast<u32x4*>(sA + r * LDSB + v * 16) = rg.a[sl];
     }
 }
 
@@ -1940,7 +1955,7 @@ static int bwd_impl(const mtlora_linear_desc* d, const void* x, const void* cons
         q.out[0].gate = gate_s;
         n_gate += gate_s ? 1 : 0;
         // dX = keep .* (Q A) + sum_o dY_o W : the masked rank part first, then one base part per gradient source
-        const int lr_lo = own_x ? sg.off[0] : 0, lr_hi = own_x ? sg.off[0] + sg.rp[0] : sg.R;
+        const int lr_lo = own_x ? sg.off[0] : 0, lr_hi = own_x ? sg.off[0] + sg.rp[0] : sg.used;
         bool zeroed = false;
         if (q.n_proj > 0 && lr_hi > lr_lo) {
             PnPart& pt = q.part[q.n_parts++];
@@ -2091,7 +2106,7 @@ static int bwd_impl(const mtlora_linear_desc* d, const void* x, const void* cons
             }
         } else {
             O.seg_lo = 0;
-            O.seg_hi = sg.R;
+            O.seg_hi = sg.used;  // (not R: the Q pass writes segments only, the pad columns of Q hold whatever the scratch held)
         }
         if (dx) {
             int n_gate = 0;  // the fused GELU backward reads the pre-activation of every gated output (algorithmic: gelu'(h) needs h)

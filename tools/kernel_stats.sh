@@ -8,7 +8,7 @@ TAG=${1:-run}
 export MTLORA_TASK_STREAMS=${MTLORA_TASK_STREAMS:-0}
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/ks
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks -- python $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline > /tmp/ks.log 2>&1 || { tail -5 /tmp/ks.log; exit 1; }
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks -- python $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-eager-gpu --no-roofline > /tmp/ks.log 2>&1 || { tail -5 /tmp/ks.log; exit 1; }
 mkdir -p $REPO/gpurun_out
 cp $(find /tmp/ks -name '*kernel_stats.csv' | head -1) $REPO/gpurun_out/kernel_stats_${TAG}.csv
 tail -1 /tmp/ks.log | cut -c1-200

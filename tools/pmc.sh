@@ -8,7 +8,7 @@ CTRS="$1"; TAG=${2:-pmc}
 export MTLORA_TASK_STREAMS=${MTLORA_TASK_STREAMS:-0}
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/pm
-timeout 900 rocprofv3 --pmc $CTRS --kernel-trace --output-format csv -d /tmp/pm -- ${PMC_CMD:-python $REPO/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline} > /tmp/pm.log 2>&1 || { tail -5 /tmp/pm.log; exit 1; }
+timeout 900 rocprofv3 --pmc $CTRS --kernel-trace --output-format csv -d /tmp/pm -- ${PMC_CMD:-python $REPO/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-eager-gpu --no-roofline} > /tmp/pm.log 2>&1 || { tail -5 /tmp/pm.log; exit 1; }
 F=$(find /tmp/pm -name '*counter_collection.csv' | head -1)
 mkdir -p $REPO/gpurun_out
 python - "$F" "$REPO/gpurun_out/pmc_${TAG}.csv" <<'PY'

@@ -115,6 +115,7 @@ def roofline(step_fn, steps):
     # bracket then measures the overlapped neighbours too (the timed region above keeps the streams on)
     from mtlora_amd import mtl_harness as H
     streams_on, H._TASK_STREAMS = H._TASK_STREAMS, False
+    fstream_on, H._FACTOR_STREAM = H._FACTOR_STREAM, False
     step_fn()
     torch.cuda.synchronize()
     L.check(lib.mtlora_prof_begin(400000), "prof_begin")
@@ -123,7 +124,7 @@ def roofline(step_fn, steps):
     torch.cuda.synchronize()
     s = L.ProfSummary()
     L.check(lib.mtlora_prof_end(ctypes.byref(s)), "prof_end")
-    H._TASK_STREAMS = streams_on
+    H._TASK_STREAMS, H._FACTOR_STREAM = streams_on, fstream_on
     kinds, idx = {}, {}
     for k in range(L.PROF_KINDS):
         if s.count[k]:

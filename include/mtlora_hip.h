@@ -98,6 +98,12 @@ typedef struct mtlora_linear_desc {
     const uint64_t* seed_offset; /* optional DEVICE pointer (null = none): the kernels use seed + *seed_offset (mod 2^64),
                                     read when they run -- a captured HIP graph draws fresh masks on every replay by
                                     bumping that one device word between replays (ABI v2) */
+    int32_t bwd_phase;   /* backward only (ABI v3).  0: everything on `stream`.  1: dX / dX_t only (and the Q = alpha dY B
+                            scratch the factor gradients need); 2: the factor gradients dA_* / dB_* only -- lets the caller
+                            put them on a second stream next to the rest of the backward chain: call phase 1 on stream s1,
+                            order s2 after it (event), call phase 2 with the SAME arguments on s2, and join s2 before the
+                            gradients are read.  Nothing but dA / dB depends on phase 2. */
+    int32_t pad_;
 } mtlora_linear_desc;
 
 /* bytes of the context buffer written by fwd and read by bwd (packed low-rank factors + P). */

@@ -24,7 +24,7 @@ class LinearDesc(Structure):
     _fields_ = [("M", c_int64), ("K", c_int64), ("N", c_int64), ("dtype", c_int32), ("mode", c_int32),
                 ("T", c_int32), ("r_s", c_int32), ("r_t", c_int32 * MAX_TASKS), ("scale_s", c_float),
                 ("scale_t", c_float * MAX_TASKS), ("has_x_tasks", c_int32), ("dropout_p", c_float),
-                ("seed", c_uint64), ("seed_offset", c_void_p)]
+                ("seed", c_uint64), ("seed_offset", c_void_p), ("bwd_phase", c_int32), ("pad_", c_int32)]
 
 
 class AttnDesc(Structure):

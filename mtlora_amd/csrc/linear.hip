@@ -1320,6 +1320,7 @@ static int check_desc(const mtlora_linear_desc* d) {
     for (int t = 0; t < d->T; ++t)
         if (d->r_t[t] <= 0) return MTLORA_ERR_SHAPE;
     if (d->mode != 0 && d->mode != 1) return MTLORA_ERR_UNSUPPORTED;
+    if (d->bwd_phase < 0 || d->bwd_phase > 2) return MTLORA_ERR_UNSUPPORTED;
     if (d->dropout_p < 0.f || d->dropout_p >= 1.f) return MTLORA_ERR_SHAPE;
     return MTLORA_OK;
 }
@@ -1906,10 +1907,14 @@ static int bwd_impl(const mtlora_linear_desc* d, const void* x, const void* cons
     const void* dy_shared = dy[0];
     // row-panel engine (k_pnl): Q = alpha dY B and every dX / dX_t in ONE persistent launch; no k_sum either -- the base GEMM
     // runs once per gradient source into the same accumulators
+    const bool do_dx = d->bwd_phase != 2, do_factors = d->bwd_phase != 1;  // (phase 2 re-derives the same operand table)
     const bool pnl = std::is_same<T, bf16>::value && pnl_eligible(d, sg) && dx != nullptr && n_dy > 0;
     const bool presum = !pnl && n_dy > 1 && dx && mtl_ceil_div(d->K, TILE) >= 3;
     bool have_g = false;
     if ((v2 || presum) && n_dy > 1) {
+        have_g = true;
+    }
+    if (have_g && do_dx) {
         SumParams sp;
         sp.n = n_dy;
         for (int i = 0; i < n_dy; ++i) sp.src[i] = dy_all[i];
@@ -1920,13 +1925,12 @@ static int bwd_impl(const mtlora_linear_desc* d, const void* x, const void* cons
             MtlProfScope prof(PK_SUM, (double)sizeof(T) * d->M * d->N * (n_dy + 1), s);
             hipLaunchKernelGGL(k_sum<T>, dim3((unsigned)blocks), dim3(256), 0, s, sp, Gm);
         }
-        have_g = true;
     }
     if (v2 && n_dy > 0) dy_shared = have_g ? (const void*)Gm : dy_all[0];
     const void* dyo[MAXO];  // gradient feeding factor o
     for (int o = 0; o < sg.n; ++o) dyo[o] = (o == 0) ? dy_shared : dy[o];
 
-    if (pnl) {
+    if (pnl && do_dx) {
         PnParams q = {};
         q.M = d->M;
         q.n_rows = (int)d->K;
@@ -2014,7 +2018,7 @@ static int bwd_impl(const mtlora_linear_desc* d, const void* x, const void* cons
 
     // Q[:, seg_o] = alpha_o * dY_o B_o   (zero where the output got no gradient)
     const int groups = (!pnl && dx && dyo[0] && !gate_s) ? fuse_groups(d, sg, d->K) : 0;  // row-panel form: Q is formed inside the dX kernel
-    if (sg.R > 0 && groups == 0 && !pnl) {
+    if (sg.R > 0 && groups == 0 && !pnl && do_dx) {
         bool any_missing = false;
         for (int o = 0; o < sg.n; ++o)
             if (sg.rp[o] > 0 && !dyo[o]) any_missing = true;
@@ -2050,7 +2054,7 @@ static int bwd_impl(const mtlora_linear_desc* d, const void* x, const void* cons
     }
 
     // dX = G W + keep .* (Q_s A_s [+ sum_t Q_t A_t]),  dX_t = Q_t A_t
-    if (!pnl) {
+    if (!pnl && do_dx) {
         NtParams m = {};
         if (presum && have_g) {
             m.n_act = 1;
@@ -2124,7 +2128,7 @@ static int bwd_impl(const mtlora_linear_desc* d, const void* x, const void* cons
     }
 
     // dA_o = Q_o^T D(X_o),  dB_o = dY_o^T P_o
-    if (sg.R > 0) {
+    if (sg.R > 0 && do_factors) {
         TnParams tp = {};
         tp.M = d->M;
         tp.nsplit = S.nsplit;

@@ -34,6 +34,23 @@ def set_seed_offset(t: Optional[torch.Tensor]) -> None:
     _seed_offset = t
 
 
+# optional second stream for the factor gradients (dA_*, dB_*: the split-M k_tn reductions) of MTLoRALinear.backward:
+# nothing in the backward chain depends on them (only the optimizer / the gradient reducer does), and they are a fifth of
+# the linear path's kernel time, mostly as latency-bound launches -- on their own stream they fill the gaps of the main
+# chain.  The caller that installs a stream must JOIN it before the gradients are read (train_step does; a GradReducer gets
+# it through ``extra_streams``).  Off (None) by default: a plain ``loss.backward()`` stays single-stream.
+_factor_stream: Optional["torch.cuda.Stream"] = None
+
+
+def set_factor_stream(stream: Optional["torch.cuda.Stream"]) -> None:
+    global _factor_stream
+    _factor_stream = stream
+
+
+def factor_stream() -> Optional["torch.cuda.Stream"]:
+    return _factor_stream
+
+
 def next_seed() -> int:
     global _seed_counter
     _seed_counter += 1
@@ -152,6 +169,7 @@ class MTLoRALinearFn(torch.autograd.Function):
                 raise RuntimeError("mtlora_amd: gelu gates must be contiguous pre-activations of x / x_t in the compute dtype")
         ctx.save_for_backward(x2, Wt_c, ctxbuf, *xt2, *gates)
         ctx.keep = (A_s_c, B_s_c, A_t_c, B_t_c)  # fp32 factor views (also used for the trainable-scale gradients)
+        ctx.factor_params = (A_s, B_s, *A_t, *B_t)  # the Parameters themselves: backward looks at their .grad (side stream)
         ctx.has_scale_s = scale_s_param is not None
         outs = [ys.reshape(*lead, meta.N)] + [y.reshape(*lead, meta.N) for y in yt] + [a.reshape(*lead, meta.N) for a in acts]
         return tuple(outs)
@@ -193,18 +211,39 @@ class MTLoRALinearFn(torch.autograd.Function):
             for t in range(T):
                 if dy_t[t] is None:
                     dxt[t].zero_()
-        if gates:  # the inputs were gelu(gate): the dX epilogue also applies gelu'(gate) (GELU backward fused)
-            st = lib.mtlora_linear_bwd_gelu(ctypes.byref(d), L.ptr(x2), L.ptr_array(xt2), L.ptr(Wt_c), L.ptr(dy_s),
-                                            L.ptr_array(dy_t), L.ptr(ctxbuf), ctxbuf.numel(), L.ptr(dx), L.ptr_array(dxt),
-                                            L.ptr(dA_s), L.ptr(dB_s), L.ptr_array(dA_t), L.ptr_array(dB_t), L.ptr(scratch),
-                                            scratch_bytes, L.ptr(gates[0]), L.ptr_array(gates[1:]), L.stream_ptr())
-            L.check(st, "mtlora_linear_bwd_gelu")
+        def launch(stream_ptr):
+            if gates:  # the inputs were gelu(gate): the dX epilogue also applies gelu'(gate) (GELU backward fused)
+                st = lib.mtlora_linear_bwd_gelu(ctypes.byref(d), L.ptr(x2), L.ptr_array(xt2), L.ptr(Wt_c), L.ptr(dy_s),
+                                                L.ptr_array(dy_t), L.ptr(ctxbuf), ctxbuf.numel(), L.ptr(dx), L.ptr_array(dxt),
+                                                L.ptr(dA_s), L.ptr(dB_s), L.ptr_array(dA_t), L.ptr_array(dB_t), L.ptr(scratch),
+                                                scratch_bytes, L.ptr(gates[0]), L.ptr_array(gates[1:]), stream_ptr)
+                L.check(st, "mtlora_linear_bwd_gelu")
+            else:
+                st = lib.mtlora_linear_bwd(ctypes.byref(d), L.ptr(x2), L.ptr_array(xt2), L.ptr(Wt_c), L.ptr(dy_s),
+                                           L.ptr_array(dy_t), L.ptr(ctxbuf), ctxbuf.numel(), L.ptr(dx), L.ptr_array(dxt),
+                                           L.ptr(dA_s), L.ptr(dB_s), L.ptr_array(dA_t), L.ptr_array(dB_t), L.ptr(scratch),
+                                           scratch_bytes, stream_ptr)
+                L.check(st, "mtlora_linear_bwd")
+
+        side = _factor_stream
+        fgrads = [t for t in [dA_s, dB_s, *dA_t, *dB_t] if t is not None]
+        # the factor gradients go to the side stream only when nothing on this stream reads them inside backward: no
+        # trainable-scale gradient (formed from dB below) and no gradient accumulation into an existing .grad
+        use_side = (side is not None and fgrads and not ctx.has_scale_s and meta.n_scale_t == 0
+                    and side.device == dev and not torch.cuda.is_current_stream_capturing()
+                    and all(p is None or p.grad is None for p in ctx.factor_params))
+        if use_side:
+            d.bwd_phase = 1
+            launch(L.stream_ptr())
+            ev = torch.cuda.Event()
+            ev.record()
+            side.wait_event(ev)
+            d.bwd_phase = 2
+            launch(ctypes.c_void_p(side.cuda_stream))
+            for t in [x2, ctxbuf, scratch, *xt2, *fgrads] + [g for g in g2 if g is not None]:
+                t.record_stream(side)  # allocated on this stream, still in use on the side stream when freed here
         else:
-            st = lib.mtlora_linear_bwd(ctypes.byref(d), L.ptr(x2), L.ptr_array(xt2), L.ptr(Wt_c), L.ptr(dy_s),
-                                       L.ptr_array(dy_t), L.ptr(ctxbuf), ctxbuf.numel(), L.ptr(dx), L.ptr_array(dxt),
-                                       L.ptr(dA_s), L.ptr(dB_s), L.ptr_array(dA_t), L.ptr_array(dB_t), L.ptr(scratch),
-                                       scratch_bytes, L.stream_ptr())
-            L.check(st, "mtlora_linear_bwd")
+            launch(L.stream_ptr())
         dW = dbias = None
         if need[5] or need[6]:
             # pretrained weight and / or bias left trainable (MTLORA.FREEZE_PRETRAINED False; mark_only_lora_as_trainable

@@ -395,6 +395,21 @@ def synthetic_batch(B: int, S: int, tasks: Sequence[str], seed: int, device="cpu
     return img.to(device), tg
 
 
+_FACTOR_STREAM = os.environ.get("MTLORA_FACTOR_STREAM", "1") != "0"
+_factor_streams: Dict[str, "torch.cuda.Stream"] = {}
+
+
+def _factor_side_stream(device):
+    """the stream the MTLoRALinear factor gradients (k_tn reductions) run on during ``train_step``'s backward
+    (functional.set_factor_stream); MTLORA_FACTOR_STREAM=0 keeps the backward on one stream."""
+    if not _FACTOR_STREAM or torch.cuda.is_current_stream_capturing():
+        return None
+    key = str(device)
+    if key not in _factor_streams:
+        _factor_streams[key] = torch.cuda.Stream(device=device)
+    return _factor_streams[key]
+
+
 def train_step(model, criterion, optimizer, images, targets, clip_grad: float = 5.0, reducer=None,
                amp_dtype: Optional[torch.dtype] = torch.bfloat16, fused_loss: bool = True):
     """one reference train step (main.py:329-354): autocast fwd + weighted multi-task loss, backward,
@@ -413,11 +428,18 @@ def train_step(model, criterion, optimizer, images, targets, clip_grad: float = 
             loss, per = fwd()
     else:
         loss, per = fwd()
+    side = _factor_side_stream(images.device) if images.is_cuda else None
     if reducer is not None:
-        if isinstance(model, MultiTaskSwin) and getattr(model, "_streams", None):
-            reducer.extra_streams = list(model._streams)  # gradients of the heads are produced on the per-task streams
+        extra = list(model._streams) if (isinstance(model, MultiTaskSwin) and getattr(model, "_streams", None)) else []
+        reducer.extra_streams = extra + ([side] if side is not None else [])  # gradients produced off the main stream
         reducer.prepare()
-    loss.backward()
+    Fn.set_factor_stream(side)
+    try:
+        loss.backward()
+    finally:
+        Fn.set_factor_stream(None)
+    if side is not None:
+        torch.cuda.current_stream(images.device).wait_stream(side)  # dA / dB of every MTLoRALinear are complete from here on
     if reducer is not None:
         reducer.finish()
     params = [p for g in optimizer.param_groups for p in g["params"] if p.grad is not None]

@@ -306,3 +306,31 @@ def test_reducer_on_the_real_model_matches_plain_backward():
     finally:
         if own_pg:
             dist.destroy_process_group()
+
+
+def test_factor_gradient_stream_is_bit_identical():
+    """train_step runs the MTLoRALinear factor gradients (k_tn) on a second stream next to the backward chain
+    (functional.set_factor_stream; joined before clip / AdamW): three steps must leave loss and every parameter bit-identical
+    to the single-stream run (same kernels, only their placement changes), with dropout / DropPath on."""
+    from mtlora_amd import functional as Fn
+    from mtlora_amd import mtl_harness as H
+    tasks = ["semseg", "normals", "sal", "human_parts"]
+    img, tg = H.synthetic_batch(2, 224, tasks, seed=13, device=dev())
+    runs = []
+    keep = H._FACTOR_STREAM
+    try:
+        for on in (False, True):
+            H._FACTOR_STREAM = on
+            torch.manual_seed(5)
+            Fn._seed_counter = 0
+            model = H.build_model(img_size=224, tasks=tasks, depths=(2, 2, 2, 2), r_shared=16, r_task=4, seed=3).to(dev()).train()
+            crit, opt = H.MultiTaskLoss(tasks), H.build_optimizer(model, lr=1e-3)
+            losses = [H.train_step(model, crit, opt, img, tg)[0].clone() for _ in range(3)]
+            torch.cuda.synchronize()
+            runs.append((losses, {n: p.detach().clone() for n, p in model.named_parameters()}))
+    finally:
+        H._FACTOR_STREAM = keep
+    for a, b in zip(runs[0][0], runs[1][0]):
+        assert torch.equal(a, b), (a.item(), b.item())
+    for n in runs[0][1]:
+        assert torch.equal(runs[0][1][n], runs[1][1][n]), n

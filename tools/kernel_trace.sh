@@ -6,9 +6,10 @@ REPO=${GRAFT_REPO_ROOT:-/root/repo}
 FILT=${1:-k_}
 # single stream: per-kernel durations / counters are attributed cleanly only when the heads' task streams do not overlap
 export MTLORA_TASK_STREAMS=${MTLORA_TASK_STREAMS:-0}
+export MTLORA_FACTOR_STREAM=${MTLORA_FACTOR_STREAM:-0}
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/tr
-timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/tr -- python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > /tmp/tr.log 2>&1 || { tail -5 /tmp/tr.log; exit 1; }
+timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/tr -- python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-eager-gpu --no-roofline > /tmp/tr.log 2>&1 || { tail -5 /tmp/tr.log; exit 1; }
 F=$(find /tmp/tr -name '*kernel_trace.csv' | head -1)
 mkdir -p $REPO/gpurun_out
 python - "$F" "$FILT" "$REPO/gpurun_out/trace_${FILT}.csv" <<'PY'

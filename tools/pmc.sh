@@ -6,6 +6,7 @@ REPO=${GRAFT_REPO_ROOT:-/root/repo}
 CTRS="$1"; TAG=${2:-pmc}
 # single stream: per-kernel durations / counters are attributed cleanly only when the heads' task streams do not overlap
 export MTLORA_TASK_STREAMS=${MTLORA_TASK_STREAMS:-0}
+export MTLORA_FACTOR_STREAM=${MTLORA_FACTOR_STREAM:-0}
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/pm
 timeout 900 rocprofv3 --pmc $CTRS --kernel-trace --output-format csv -d /tmp/pm -- ${PMC_CMD:-python $REPO/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-eager-gpu --no-roofline} > /tmp/pm.log 2>&1 || { tail -5 /tmp/pm.log; exit 1; }

@@ -60,7 +60,8 @@ struct PnParams {
     int n_proj, n_parts;
     int R;             // columns of the projected image (multiple of 16; 0: none)
     int nstage;        // ring depth (2 or 3)
-    int dbg;           // developer toggles (MTLORA_PNL_DBG): 1 no output stores, 2 no loads, 4 no MFMA, 8 no vmcnt waits
+    int dbg;           // developer toggles (MTLORA_PNL_DBG): 1 no output stores, 2 no loads, 4 no MFMA, 8 no vmcnt waits,
+                       // 16 no epilogue at all, 32 no dropout mask, 64 no accumulator zero / bias
     int n_proj_steps, n_tile_steps;  // k-steps of the projection parts / of one tile's parts (launch_pnl)
     int64_t ld_out;
     const float* bias;
@@ -288,7 +289,7 @@ __global__ __launch_bounds__(512, 2) void k_pnl(const PnParams Pv) {
         bf16* actp = reinterpret_cast<bf16*>(P->out[o].act);
         (void)gate;
         (void)actp;
-        if (!outp || n0 + wn * 64 >= n_rows) return;
+        if (!outp || n0 + wn * 64 >= n_rows || (dbg & 16)) return;
 #pragma unroll
         for (int sn = 0; sn < 2; ++sn)
 #pragma unroll
@@ -360,7 +361,7 @@ __global__ __launch_bounds__(512, 2) void k_pnl(const PnParams Pv) {
         // ---- before the step
         if (ctl & (PF_ZERO | PF_LOADBASE)) {
             n0 = ((ctl >> 20) & 0xFFF) * PN_TN;
-            if (ctl & PF_ZERO) {
+            if ((ctl & PF_ZERO) && !(dbg & 64)) {
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -419,7 +420,7 @@ __global__ __launch_bounds__(512, 2) void k_pnl(const PnParams Pv) {
         if (active && !(dbg & 4)) {
             const unsigned char* stage = smem + SLOT * PN_STAGE;
             const bool from_p = (ctl & PF_RANK) != 0;
-            const bool dropact = (ctl & PF_DROPACT) && drop.enabled();
+            const bool dropact = (ctl & PF_DROPACT) && drop.enabled() && !(dbg & 32);
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 if (u * 4 >= nch) break;

@@ -447,9 +447,9 @@ def test_swin_block_golden(golden, case, dtype, layout):
         if isinstance(g, dict):
             s = named[n].grad.double().flatten().cpu()
             ref = g["samples"]
-            assert ((s[g["idx"]] - ref).abs().max() / ref.abs().max().clamp_min(1e-12)).item() <= TOL[dtype] * 5, n
+            assert ((s[g["idx"]] - ref).abs().max() / ref.abs().max().clamp_min(1e-12)).item() <= TOL[dtype] * 3, n
         else:
-            assert_close(named[n].grad, g, dtype, f"grad {n}", mult=5)
+            assert_close(named[n].grad, g, dtype, f"grad {n}", mult=3)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
@@ -483,9 +483,9 @@ def test_backbone_small_golden(golden, dtype):
         elif isinstance(g, dict):
             s = named[n].grad.double().flatten().cpu()
             ref = g["samples"]
-            assert ((s[g["idx"]] - ref).abs().max() / ref.abs().max().clamp_min(1e-12)).item() <= TOL[dtype] * 10, n
+            assert ((s[g["idx"]] - ref).abs().max() / ref.abs().max().clamp_min(1e-12)).item() <= TOL[dtype] * 3, n
         else:
-            assert_close(named[n].grad, g, dtype, f"grad {n}", mult=10)
+            assert_close(named[n].grad, g, dtype, f"grad {n}", mult=3)
     assert sorted(n for n, p in bb.named_parameters() if p.grad is None) == c["grad_is_none"]
 
 

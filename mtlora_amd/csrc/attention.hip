@@ -103,6 +103,25 @@ __device__ __forceinline__ int64_t token_at(const AttnParams& p, const WinPos& q
 __device__ __forceinline__ int img_rows(int N) { return N < AN ? N + 1 : AN; }
 __host__ __device__ __forceinline__ int img_rows_h(int N) { return N < AN ? N + 1 : AN; }
 
+// which (row, 16-byte vector) of an image lane `lane` copies in iteration `it`.  ds_write_b128 is served 8 lanes (128 bytes =
+// all 32 banks) per LDS cycle, so 8 consecutive lanes must hit 8 distinct 16-byte pieces mod 128 B.  bf16 rows hold 4 vectors
+// at an 80-byte stride (5 pieces: odd, which keeps the ds_read_b128 fragment reads conflict-free): rows r and r + 1 collide
+// on one piece (2-way conflict on every staging store: SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE 0.32 in k_attn_bwd, round 1),
+// rows r and r + 4 (20 pieces apart = 4 mod 8) interleave exactly.  f32 rows are 8 vectors: one row per 8 lanes already.
+template <typename T>
+__device__ __forceinline__ void av_map(int it, int lane, int& row, int& vec) {
+    constexpr int VPR = AC<T>::VPR;
+    if constexpr (VPR == 4) {
+        const int g = lane >> 3, l = lane & 7;
+        row = it * 16 + (g >> 2) * 8 + (g & 3) + 4 * (l >> 2);
+        vec = l & 3;
+    } else {
+        const int idx = it * 64 + lane;
+        row = idx / VPR;
+        vec = idx % VPR;
+    }
+}
+
 // copy N rows of 32 elements (row r at base + tok[r]*stride) into the image, row N zeroed
 template <typename T>
 __device__ __forceinline__ void stage_rows(unsigned char* s, const T* base, int64_t stride, const int* tok, int n,
@@ -111,8 +130,8 @@ __device__ __forceinline__ void stage_rows(unsigned char* s, const T* base, int6
     const int rows = img_rows(n);
 #pragma unroll
     for (int it = 0; it < VPR; ++it) {
-        const int idx = it * 64 + lane;
-        const int row = idx / VPR, vec = idx % VPR;
+        int row, vec;
+        av_map<T>(it, lane, row, vec);
         if (row < rows) {
             u32x4 v = u32x4{0u, 0u, 0u, 0u};
             if (row < n) v = *reinterpret_cast<const u32x4*>(base + (int64_t)tok[row] * stride + vec * VEC);
@@ -136,7 +155,9 @@ __device__ __forceinline__ RowIds<T> row_ids(const AttnParams& p, int lane) {
     RowIds<T> r;
 #pragma unroll
     for (int it = 0; it < AC<T>::VPR; ++it) {
-        const int row = (it * 64 + lane) / AC<T>::VPR;
+        int row, vec;
+        av_map<T>(it, lane, row, vec);
+        (void)vec;
         r.t[it] = row < p.N ? row : -1;
         r.tyx[it] = row < p.N ? pack_tyx(p, row) : 0;
     }
@@ -154,7 +175,9 @@ __device__ __forceinline__ void load_rows(RowRegs<T>& r, const T* base, int64_t 
     constexpr int VPR = AC<T>::VPR, VEC = ET<T>::VEC;
 #pragma unroll
     for (int it = 0; it < VPR; ++it) {
-        const int vec = (it * 64 + lane) % VPR;
+        int row, vec;
+        av_map<T>(it, lane, row, vec);
+        (void)row;
         r.v[it] = off[it] >= 0 ? *reinterpret_cast<const u32x4*>(base + off[it] * stride + vec * VEC) : u32x4{0u, 0u, 0u, 0u};
     }
 }
@@ -164,8 +187,8 @@ __device__ __forceinline__ void store_rows(unsigned char* s, const RowRegs<T>& r
     const int rows = img_rows(n);
 #pragma unroll
     for (int it = 0; it < VPR; ++it) {
-        const int idx = it * 64 + lane;
-        const int row = idx / VPR, vec = idx % VPR;
+        int row, vec;
+        av_map<T>(it, lane, row, vec);
         if (row < rows) *reinterpret_cast<u32x4*>(s + row * RS + vec * 16) = r.v[it];
     }
 }

@@ -14,6 +14,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SOURCES = ["window_process.hip", "linear.hip", "attention.hip", "glue.hip", "loss.hip", "upsample.hip", "selftest.hip"]
 LIB = os.path.join(HERE, "libmtlora_hip.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-Wno-unused-result"]
+if os.environ.get("MTLORA_ABLATE") == "1":  # developer build: MTLORA_NT_DBG ablation toggles in the NT kernels (use --force)
+    FLAGS.append("-DMTL_NT_ABLATE=1")
 
 
 def _hipcc():

@@ -41,6 +41,12 @@ constexpr int EPI_ROW = 64 * 2 + 8;                      // row stride of a wave
 constexpr int EPI_BYTES = 4 * 64 * EPI_ROW;               // 4 waves x 64 rows = 8 waves x 32 rows
 constexpr int STAGE_BYTES = 2 * TILE * LDSB > EPI_BYTES ? 2 * TILE * LDSB : EPI_BYTES;  // staging / epilogue region
 constexpr int MAXO = MTLORA_MAX_TASKS + 1;
+// MTLORA_NT_DBG ablation toggles (tools/nt_ablate.sh) are compiled in only with -DMTL_NT_ABLATE=1 (MTLORA_ABLATE=1 for
+// csrc/build.py): the runtime tests cost the generic kernels ~10 SGPR spills each
+#ifndef MTL_NT_ABLATE
+#define MTL_NT_ABLATE 0
+#endif
+constexpr int NT_DBG_MASK = MTL_NT_ABLATE ? ~0 : 0;
 
 // ------------------------------------------------------------------------------------------------
 // segment table: output o (0 = shared, 1..T = tasks) owns columns [off, off + rp) of the rank axis
@@ -189,6 +195,7 @@ struct NtParams {
     const float* palpha;   // (pR)
     void* pout;            // global P (M x pR), written by the n-group-0 workgroups for the backward
     int n_groups;          // fused form: a workgroup owns a 128-row panel and 1/n_groups of its n-tiles (it loops over them)
+    int dbg;               // MTLORA_NT_DBG ablation bits (tools only): 1 no global stores, 2 no global loads, 4 no MFMA, 8 no epilogue
     DropoutCfg drop;
 };
 
@@ -495,6 +502,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void k_nt(const NtParams 
         act_mask = P->zmask[z] != 0;
     }
     if (n_rows <= 0) return;
+    if (P->dbg & NT_DBG_MASK & 16) return;
     act_mask = act_mask && P->drop.thr16 != 0;
 
     // XCD-aware tile order: hardware places block b on XCD b % 8; give every XCD a contiguous run of
@@ -547,23 +555,24 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void k_nt(const NtParams 
         else
             nt_load<T, MS, SM>(rg, tid, wgt, P->ld_wgt, c.bn * TILE, n_rows, act0, P, P->n_act, P->ld_act, m0, P->M, c.k0, c.k_hi, act_mask);
     };
-    if (ld.valid) issue(ld);
+    const int dbg = P->dbg & NT_DBG_MASK;
+    if (ld.valid && !(dbg & 2)) issue(ld);
     // consume one tile: registers -> LDS, prefetch the next tile of the stream, multiply
     auto step = [&](f32x16(&acc)[2][SM], int k_left, int from_p, int k0) __attribute__((always_inline)) {
-        nt_store_lds<T, SM>(rg, tid, sW, sA, drop, m0, !from_p);
-        __syncthreads();
+        if (!(dbg & 64)) nt_store_lds<T, SM>(rg, tid, sW, sA, drop, m0, !from_p);
+        if (!(dbg & 128)) __syncthreads();
         ld.k0 += KE;
         if (ld.k0 >= ld.k_hi) ld = nt_seek<MULTI, FUSE>(P, ld.q + 1, nseq, ld.bn, bn_hi);
-        if (ld.valid) issue(ld);
+        if (ld.valid && !(dbg & 2)) issue(ld);
         // a wave whose 64 output columns lie entirely past n_rows (P / Q passes: <= 64 of the tile's 128 columns exist)
         // only helps staging: no LDS fragment reads, no MFMAs (wave-uniform test)
-        if (n0 + wn * 64 < n_rows) {
+        if (n0 + wn * 64 < n_rows && !(dbg & 4)) {
             if (from_p)
                 nt_compute<T, SM>(acc, sW, sP + k0 * (int)sizeof(T), lane, wn, wm, k_left, PRS);
             else
                 nt_compute<T, SM>(acc, sW, sA, lane, wn, wm, k_left);
         }
-        __syncthreads();
+        if (!(dbg & 128)) __syncthreads();
     };
     auto run_part = [&](int q, f32x16(&acc)[2][SM]) __attribute__((always_inline)) {
         int lr, lo, hi;
@@ -582,7 +591,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void k_nt(const NtParams 
     };
     // acc = acc * alpha[n] + bias[n]
     auto affine = [&](f32x16(&a)[2][SM]) __attribute__((always_inline)) {
-        if (!(P->alpha || P->bias)) return;
+        if (!(P->alpha || P->bias) || (P->dbg & NT_DBG_MASK & 32)) return;
 #pragma unroll
         for (int sn = 0; sn < 2; ++sn)
 #pragma unroll
@@ -625,7 +634,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void k_nt(const NtParams 
         T* actp = reinterpret_cast<T*>(act_ptr);
         (void)gate;
         (void)actp;
-        if (!outp || n0 + wn * 64 >= n_rows) return;  // (the per-wave LDS image needs no workgroup barrier)
+        if (!outp || n0 + wn * 64 >= n_rows || (dbg & 8)) return;  // (the per-wave LDS image needs no workgroup barrier)
         if constexpr (sizeof(T) == 2) {
             // bf16: transpose the wave's 64(n) x 64(m) accumulator tile through LDS so that every store instruction
             // writes whole 128-byte row segments (8 lanes x 16 B) instead of 16-byte pieces of 32 different rows.
@@ -651,7 +660,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void k_nt(const NtParams 
                 const int64_t m = m0 + wm * MW + ml;
                 const int n = n0 + wn * 64 + c16 * 8;
                 u32x4 v = *reinterpret_cast<const u32x4*>(img + ml * ORS + c16 * 16);
-                if (m < P->M && n < n_rows) {
+                if (m < P->M && n < n_rows && !(dbg & 1)) {
                     if constexpr (GATE) {
                         if (gate) {  // the bf16-rounded gradient times gelu'(pre-activation), rounded once (as ATen does)
                             const u32x4 hv = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(gate + m * P->ld_out + row_off + n));
@@ -804,6 +813,199 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void k_nt(const NtParams 
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_ntl : the lean bf16 launches of k_nt (ONE output, one activation source, no batched / row-panel form: every P / Q pass,
+// every T = 0 forward and dX) as straight-line code.
+// Why a second kernel: an ablation of k_nt (MTLORA_NT_DBG, tools/nt_ablate.sh; profiles/r02_nt_ablate.txt) showed that with
+// loads, MFMAs, stores and the epilogue all switched OFF the s0.qkv forward still took 100 of its 164 us -- the generic
+// kernel's bookkeeping.  Its prologue is a chain of ~15 DEPENDENT scalar loads from the 1 KB parameter block (each followed by
+// s_waitcnt lgkmcnt(0)), three software 64-bit divisions (~130 SALU instructions each) for the XCD map, a part-sequence cursor
+// that re-reads the output table per step, and every global load sits in its own exec-masked branch.  With only 2 - 4 k-steps
+// per workgroup nothing amortises that.  Here:
+//   * a compact parameter block (~200 B) read once; the XCD map and tile decomposition use 32-bit arithmetic and a host-side
+//     magic multiplier instead of divisions;
+//   * the step sequence is [rank-segment k-tiles | base k-tiles], both counts known up front: no cursor;
+//   * loads are unconditional: out-of-range rows are CLAMPED (their products land in rows / columns that are never stored)
+//     and out-of-range k vectors read a 16-byte zero page -- address selects, no branches;
+//   * the bias is the accumulator's initial value (its loads overlap the first tile's) instead of a dependent load + FMA pass
+//     after the last MFMA.
+// Tile geometry, LDS layout, fragment reads and the transposing epilogue are k_nt's 8-wave variant (128 x 128 x 96, wave tile
+// 64 n x 32 m), so results are bit-identical to k_nt's.
+// ------------------------------------------------------------------------------------------------
+__device__ __attribute__((aligned(16))) const uint32_t g_zero16[4] = {0u, 0u, 0u, 0u};
+
+struct NlParams {
+    const bf16* act;    // (M x K) activation-like operand of the base part
+    const bf16* wgt;    // (n_rows x K)
+    const bf16* L;      // (M x ldL) activation-like operand of the rank part
+    const bf16* Rm;     // (n_rows x ldR)
+    bf16* out;          // (M x ld_out)
+    bf16* act2;         // ACT: second output gelu(out)
+    const float* bias;  // per output column, nullable
+    const float* alpha; // per output column multiplier, nullable
+    int64_t ld_act, ld_wgt, ldL, ldR, ld_out;
+    int M, n_rows, K, seg_lo, seg_hi;
+    int n_tiles;
+    uint32_t nt_magic;  // floor(2^32 / n_tiles) + 1: b / n_tiles == umulhi(b, nt_magic) for b * n_tiles < 2^32 (n_tiles > 1)
+    uint32_t q8, r8;    // workgroups / 8, workgroups % 8 (XCD map)
+    int act_mask, use_base;
+    int dbg, pad_;
+    DropoutCfg drop;
+};
+
+template <bool ACT>
+__global__ __launch_bounds__(512, 4) void k_ntl(const NlParams P) {
+    constexpr int KE = ROWB / 2;  // 96 elements per staged k-tile
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* sW = smem;
+    unsigned char* sA = smem + TILE * LDSB;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wn = wave >> 2, wm = wave & 3;
+
+    // XCD-aware tile order (as k_nt): block b runs on XCD b % 8; every XCD gets a contiguous run of logical tiles
+    uint32_t b = blockIdx.x;
+    {
+        const uint32_t xcd = b & 7u, q = P.q8, r = P.r8;
+        b = (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + (b >> 3);
+    }
+    const uint32_t bm = P.n_tiles == 1 ? b : __umulhi(b, P.nt_magic);
+    const int bn = (int)(b - bm * (uint32_t)P.n_tiles);
+    const int m0 = (int)bm * TILE, n0 = bn * TILE;
+    const int M = P.M, n_rows = P.n_rows;
+
+    DropoutCfg drop = P.drop;
+    mtl_dropout_resolve(drop);
+    const bool act_mask = P.act_mask != 0 && drop.thr16 != 0;
+    const int dbg = P.dbg & NT_DBG_MASK;
+
+    const int n1 = P.seg_hi > P.seg_lo ? (P.seg_hi - P.seg_lo + KE - 1) / KE : 0;
+    const int n2 = (P.use_base && P.K > 0) ? (P.K + KE - 1) / KE : 0;
+    const int total = n1 + n2;
+
+    f32x16 acc[2][1];
+    // accumulator start: the bias (when nothing multiplies the sum afterwards)
+    const bool bias_first = P.bias != nullptr && P.alpha == nullptr && P.use_base != 0;
+#pragma unroll
+    for (int sn = 0; sn < 2; ++sn)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f32x4 bi = {0.f, 0.f, 0.f, 0.f};
+            if (bias_first) {
+                int n = n0 + wn * 64 + sn * 32 + 8 * q + 4 * (lane >> 5);
+                n = n < n_rows - 4 ? n : n_rows - 4;  // (columns >= n_rows are never stored)
+                bi = *reinterpret_cast<const f32x4*>(P.bias + n);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[sn][0][q * 4 + e] = bi[e];
+        }
+
+    TileRegs<bf16, 1> rg;
+    int cur_mask = 0, cur_k0 = 0;  // of the tile sitting in rg
+    auto issue = [&](int i) __attribute__((always_inline)) {
+        const bool lr = i < n1;
+        const bf16* wp = lr ? P.Rm : P.wgt;
+        const bf16* ap = lr ? P.L : P.act;
+        const int64_t ldw = lr ? P.ldR : P.ld_wgt, lda = lr ? P.ldL : P.ld_act;
+        const int k0 = lr ? P.seg_lo + i * KE : (i - n1) * KE;
+        const int khi = lr ? P.seg_hi : P.K;
+        cur_mask = (!lr && act_mask) ? 1 : 0;
+        cur_k0 = k0;
+        const bf16* zp = reinterpret_cast<const bf16*>(g_zero16);
+#pragma unroll
+        for (int sl = 0; sl < 3; ++sl) {
+            int r, v;
+            nt_map<1>(tid, sl, r, v);
+            const int k = k0 + v * 8;
+            const bool kin = k < khi;
+            int wr = n0 + r, ar = m0 + r;
+            wr = wr < n_rows ? wr : n_rows - 1;
+            ar = ar < M ? ar : M - 1;
+            const bf16* pw = kin ? wp + (int64_t)wr * ldw + k : zp;
+            const bf16* pa = kin ? ap + (int64_t)ar * lda + k : zp;
+            rg.w[sl] = *reinterpret_cast<const u32x4*>(pw);
+            rg.a[sl] = *reinterpret_cast<const u32x4*>(pa);
+        }
+    };
+    auto stage = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int sl = 0; sl < 3; ++sl) {
+            int r, v;
+            nt_map<1>(tid, sl, r, v);
+            if (cur_mask) {  // uniform
+                const uint32_t rh = mtl_dropout_rowhash(drop, 0u, (uint32_t)(m0 + r));
+                VOps<bf16>::drop(rg.a[sl], drop, rh, (uint32_t)(cur_k0 + v * 8));
+            }
+            *reinterpret_cast<u32x4*>(sW + r * LDSB + v * 16) = rg.w[sl];
+            *reinterpret_cast<u32x4*>(sA + r * LDSB + v * 16) = rg.a[sl];
+        }
+    };
+    const bool wave_live = n0 + wn * 64 < n_rows;  // P / Q passes: a wave whose 64 columns do not exist only helps staging
+    if (total > 0 && !(dbg & 2)) issue(0);
+    for (int i = 0; i < total; ++i) {
+        const bool lr = i < n1;
+        const int k_left = lr ? P.seg_hi - (P.seg_lo + i * KE) : P.K - (i - n1) * KE;
+        if (!(dbg & 64)) stage();
+        __syncthreads();
+        if (i + 1 < total && !(dbg & 2)) issue(i + 1);
+        if (wave_live && !(dbg & 4)) nt_compute<bf16, 1>(acc, sW, sA, lane, wn, wm, k_left);
+        __syncthreads();
+    }
+    if (!wave_live || (dbg & 8)) return;
+
+    if (!bias_first && (P.alpha || P.bias) && P.use_base) {  // acc = acc * alpha[n] + bias[n]
+#pragma unroll
+        for (int sn = 0; sn < 2; ++sn)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                int n = n0 + wn * 64 + sn * 32 + 8 * q + 4 * (lane >> 5);
+                n = n < n_rows - 4 ? n : n_rows - 4;
+                f32x4 al = {1.f, 1.f, 1.f, 1.f}, bi = {0.f, 0.f, 0.f, 0.f};
+                if (P.alpha) al = *reinterpret_cast<const f32x4*>(P.alpha + n);
+                if (P.bias) bi = *reinterpret_cast<const f32x4*>(P.bias + n);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[sn][0][q * 4 + e] = acc[sn][0][q * 4 + e] * al[e] + bi[e];
+            }
+    }
+
+    // epilogue (k_nt's): transpose the wave's 64 (n) x 32 (m) tile through a private LDS image -> 128-byte row-segment stores
+    {
+        constexpr int ORS = EPI_ROW;
+        unsigned char* img = smem + wave * (32 * ORS);
+#pragma unroll
+        for (int sn = 0; sn < 2; ++sn)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int ml = lane & 31, nl = sn * 32 + 8 * q + 4 * (lane >> 5);
+                u32x2 pk = {mtl_pack_bf16(acc[sn][0][q * 4], acc[sn][0][q * 4 + 1]),
+                            mtl_pack_bf16(acc[sn][0][q * 4 + 2], acc[sn][0][q * 4 + 3])};
+                *reinterpret_cast<u32x2*>(img + ml * ORS + nl * 2) = pk;
+            }
+        __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the image is private to this wave
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int ml = it * 8 + (lane >> 3), c16 = lane & 7;
+            const int m = m0 + wm * 32 + ml;
+            const int n = n0 + wn * 64 + c16 * 8;
+            u32x4 v = *reinterpret_cast<const u32x4*>(img + ml * ORS + c16 * 16);
+            if (m < M && n < n_rows && !(dbg & 1)) {
+                const int64_t o = (int64_t)m * P.ld_out + n;
+                __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(P.out + o));
+                if constexpr (ACT) {
+                    if (P.act2) {
+                        u32x4 av;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            av[q] = mtl_pack_bf16(gelu_fwd(__builtin_bit_cast(float, v[q] << 16)),
+                                                  gelu_fwd(__builtin_bit_cast(float, v[q] & 0xFFFF0000u)));
+                        __builtin_nontemporal_store(av, reinterpret_cast<u32x4*>(P.act2 + o));
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // k_nt2 : the lean single-output case of k_nt (bf16; one rank segment + base GEMM, optional masked low-rank part and
 // GELU' gate) with a DIRECT-TO-LDS load path for the MFMA-dense launches (stages 2 / 3, decoder heads):
 //   * 256 (m) x 128 (n) workgroup tile, 8 waves of 64 x 64, k-tiles of 64 elements (128-byte rows);
@@ -820,8 +1022,6 @@ constexpr int T2_ROWB = T2_K * 2;                        // 128 bytes per row pe
 constexpr int T2_STAGE = (T2_M + T2_N) * T2_ROWB;        // 48 KB
 constexpr int T2_NSTAGE = 3;
 constexpr int T2_LDS = T2_NSTAGE * T2_STAGE;             // 144 KB (epilogue images 8 x 64 x 136 B reuse it)
-__device__ __attribute__((aligned(16))) const uint32_t g_zero16[4] = {0u, 0u, 0u, 0u};
-
 template <bool MLR, bool GATE>
 __global__ __launch_bounds__(512, 2) void k_nt2(const NtParams Pv) {
     (void)Pv;
@@ -1362,7 +1562,12 @@ static bool nt2_wanted(const NtParams& P, int variant, bool fuse) {
 }
 
 template <typename T>
-static void launch_nt(const NtParams& P, hipStream_t s, int kind, double alg_bytes, double s8d_bytes = 0.0, double flops = 0.0) {
+static void launch_nt(const NtParams& P_in, hipStream_t s, int kind, double alg_bytes, double s8d_bytes = 0.0, double flops = 0.0) {
+    NtParams P = P_in;
+    {
+        const char* e = getenv("MTLORA_NT_DBG");  // ablation timing only (tools/bench_linear.py); results are wrong with any bit set
+        P.dbg = e ? atoi(e) : 0;
+    }
     mtl_prof_tag("M%lld K%d N%d ldL%lld no%d na%d nz%d", (long long)P.M, P.K, P.n_rows, (long long)P.ldL, P.n_out, P.n_act, P.nz);
     MtlProfScope prof(kind, alg_bytes, s, s8d_bytes, flops);
     int max_rows = P.n_rows;
@@ -1407,6 +1612,50 @@ static void launch_nt(const NtParams& P, hipStream_t s, int kind, double alg_byt
     mlr = mlr && P.drop.enabled();
     bool acted = false;
     for (int o = 0; o < P.n_out; ++o) acted = acted || P.out[o].act != nullptr;
+    if constexpr (sizeof(T) == 2) {
+        // lean single-output launches: the straight-line kernel (MTLORA_NTL=0 keeps them on k_nt, for A/B timing)
+        static const bool ntl_on = [] { const char* e = getenv("MTLORA_NTL"); return !(e && e[0] == '0'); }();
+        const bool ml0 = P.n_out == 1 && P.out[0].mask_lr != 0 && P.drop.enabled();
+        if (ntl_on && variant == 2 && P.n_out == 1 && !ml0 && P.out[0].gate == nullptr && P.nz == 0 && !fuse && nt_waves() == 8 &&
+            P.M < (int64_t)0x7FFFFF00 && m_tiles * n_tiles < ((int64_t)1 << 28) && P.n_rows >= 8 && P.n_rows % 8 == 0 &&
+            !nt2_wanted(P, variant, fuse)) {
+            NlParams q;
+            q.act = reinterpret_cast<const bf16*>(P.act[0]);
+            q.wgt = reinterpret_cast<const bf16*>(P.wgt);
+            q.L = reinterpret_cast<const bf16*>(P.L);
+            q.Rm = reinterpret_cast<const bf16*>(P.Rm);
+            q.out = reinterpret_cast<bf16*>(P.out[0].ptr);
+            q.act2 = reinterpret_cast<bf16*>(P.out[0].act);
+            q.bias = P.bias;
+            q.alpha = P.alpha;
+            q.ld_act = P.ld_act;
+            q.ld_wgt = P.ld_wgt;
+            q.ldL = P.ldL;
+            q.ldR = P.ldR;
+            q.ld_out = P.ld_out;
+            q.M = (int)P.M;
+            q.n_rows = P.n_rows;
+            q.K = P.act[0] ? P.K : 0;
+            q.seg_lo = P.L ? P.out[0].seg_lo : 0;
+            q.seg_hi = P.L ? P.out[0].seg_hi : 0;
+            q.n_tiles = (int)n_tiles;
+            q.nt_magic = (uint32_t)(((uint64_t)1 << 32) / (uint64_t)n_tiles) + 1u;
+            const uint32_t nwg = (uint32_t)(m_tiles * n_tiles);
+            q.q8 = nwg / 8u;
+            q.r8 = nwg % 8u;
+            q.act_mask = P.act_mask;
+            q.use_base = P.out[0].use_base;
+            q.dbg = P.dbg;
+            q.pad_ = 0;
+            q.drop = P.drop;
+            if (q.out == nullptr) return;
+            if (q.act2)
+                hipLaunchKernelGGL((k_ntl<true>), dim3(nwg), dim3(512), (size_t)STAGE_BYTES, s, q);
+            else
+                hipLaunchKernelGGL((k_ntl<false>), dim3(nwg), dim3(512), (size_t)STAGE_BYTES, s, q);
+            return;
+        }
+    }
     if (acted) {  // forward outputs with the GELU second output (fc1 of the Mlp): lean or MULTI, never the row-panel form
         if (variant == 0)
             hipLaunchKernelGGL((k_nt<T, true, false, false, false, 4, false, true>), g, dim3(256), lds, s, P);

@@ -17,6 +17,9 @@ SHAPES = {  # name: (M, K, N, with_tasks, x_tasks)
     "head0": (100352, 272, 1080, None, False),
 }
 
+KINDS = KNT_ONLY = False
+
+
 def run(name, iters, r_s=64, r_t=4):
     M, K, N, wt, xt = SHAPES[name]
     dev = torch.device("cuda", 0)
@@ -38,7 +41,7 @@ def run(name, iters, r_s=64, r_t=4):
     x = torch.randn(M, K, device=dev, dtype=torch.bfloat16, requires_grad=True)
     xts = {t: torch.randn(M, K, device=dev, dtype=torch.bfloat16, requires_grad=True) for t in TASKS} if xt else None
     res = {}
-    for mode, env in ((("k_nt", "0"),) if os.environ.get("MTLORA_PNL_DBG") is None else ()) + (("panel", None),):
+    for mode, env in ((("k_nt", "0"),) if os.environ.get("MTLORA_PNL_DBG") is None else ()) + ((("panel", None),) if not KNT_ONLY else ()):
         os.environ["MTLORA_PNL"] = "1" if env is None else env
         with torch.autocast("cuda", dtype=torch.bfloat16):
             y, yt = m(x, xts)
@@ -63,6 +66,9 @@ def run(name, iters, r_s=64, r_t=4):
             torch.cuda.synchronize()
             sm = L.ProfSummary()
             L.check(lib.mtlora_prof_end(ctypes.byref(sm)), "prof_end")
+            if KINDS:
+                print("      " + "  ".join(f"{lib.mtlora_prof_kind_name(k).decode()} {1e3 * sm.ms[k] / iters:.1f}us/{sm.count[k] // iters}"
+                                           for k in range(L.PROF_KINDS) if sm.count[k]), flush=True)
             return 1e3 * sum(sm.ms[k] for k in range(L.PROF_KINDS)) / iters
         outs_keep = []
         def many_fwd():
@@ -80,6 +86,7 @@ def run(name, iters, r_s=64, r_t=4):
     fb = es * M * ((1 + (T if xt else 0)) * K + (1 + T) * N)
     bb = es * M * ((1 + T) * N + 2 * (1 + (T if xt else 0)) * K)
     res.setdefault("k_nt", (0.0, 0.0))
+    res.setdefault("panel", res["k_nt"])
     print(f"{name:9s} M{M} K{K} N{N} T{T}: fwd {res['k_nt'][0]:7.1f} -> {res['panel'][0]:7.1f} us ({fb / res['panel'][0] / 1e6:5.2f} TB/s) | "
           f"bwd {res['k_nt'][1]:7.1f} -> {res['panel'][1]:7.1f} us ({bb / res['panel'][1] / 1e6:5.2f} TB/s)", flush=True)
 
@@ -87,6 +94,9 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--shapes", nargs="*", default=list(SHAPES))
     ap.add_argument("--iters", type=int, default=5)
+    ap.add_argument("--kinds", action="store_true", help="per-kind kernel time of every leg")
+    ap.add_argument("--knt-only", action="store_true")
     a = ap.parse_args()
+    KINDS, KNT_ONLY = a.kinds, a.knt_only
     for s in a.shapes:
         run(s, a.iters)

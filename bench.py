@@ -59,6 +59,7 @@ def parse():
     ap.add_argument("--graph", action="store_true",
                     help="EXPERIMENTAL: replay the step as captured HIP graph(s); the capture is validated against the eager step "
                          "and dropped if it does not reproduce it (ROCm small-memset replay bug, DESIGN.md section 5)")
+    ap.add_argument("--capturable", action="store_true", help="AdamW(capturable=True) in the eager step too (step counters on the device)")
     ap.add_argument("--force-reducer", action="store_true", help="run the gradient pack / RCCL all-reduce / unpack path even at 1 rank")
     ap.add_argument("--no-fused-loss", action="store_true", help="final upsample + losses through ATen instead of csrc/loss.hip")
     return ap.parse_args()
@@ -280,7 +281,7 @@ def main():
     model.train()
     crit = H.MultiTaskLoss(tasks)
     opt = H.build_optimizer(model, lr=5e-4 * B * world / 512.0,  # main.py:578-583 linear LR scaling
-                            capturable=args.graph)
+                            capturable=args.graph or args.capturable)
     # replicas start from rank 0's parameters / buffers (GradReducer broadcasts them), not from "every rank seeds 0"
     reducer = (GradReducer(model.parameters(), bucket_mb=16.0, force=args.force_reducer, buffers=model.buffers())
                if (world > 1 or args.force_reducer) else None)

@@ -311,6 +311,22 @@ int mtlora_upsample_loss(int kind, const void* low, const float* label, const fl
                          int64_t B, int h, int w, int C, int scale, int dtype, float ignore_index, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Small deterministic reductions of the callers (two launches each: per-block partials, fixed-order combine; no atomics and
+ * no hipMemsetAsync, unlike ATen's multi-block reduce_kernel -- see csrc/reduce.hip and tools/find_memsets.py).
+ *   mtlora_colsum      out[n] = sum_m x[m][n]  (fp32 out; x (M x N) row-major fp32 / bf16, N a multiple of the 16-byte vector):
+ *                      replaces `grad.sum(0)` for the bias gradient of the heads' 1x1 convolutions
+ *                      (reference models/seg_hrnet.py:498-526 layers under torch autograd)
+ *   mtlora_label_stat  label-only statistics of the fused losses (`stat` of mtlora_upsample_loss), n fp32 labels:
+ *                      kind 0: number of elements != ignore_index   (mtl_loss_schemes.py:22-39, :162-220)
+ *                      kind 1: mean(1 - (label >= 0.5))             (mtl_loss_schemes.py:42-89)
+ * ------------------------------------------------------------------------------------------ */
+int64_t mtlora_colsum_scratch_bytes(int64_t M, int64_t N);
+int mtlora_colsum(const void* x, int64_t M, int64_t N, int dtype, float* out, void* scratch, int64_t scratch_bytes, void* stream);
+int64_t mtlora_label_stat_scratch_bytes(int64_t n);
+int mtlora_label_stat(const float* label, int64_t n, int kind, float ignore_index, float* out, void* scratch,
+                      int64_t scratch_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Channels-last bilinear upsampling by an integer factor (align_corners=False) for the HRNet head of the callers
  * (models/seg_hrnet.py:498-526: F.interpolate of the coarse maps + torch.cat).  coarse (B,h,w,C) contiguous; the fine
  * tensor (B, scale*h, scale*w, .) is addressed with `ld_fine` elements per pixel, its pointer already offset to the

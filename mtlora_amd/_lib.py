@@ -115,6 +115,10 @@ _SIGS = {
     "mtlora_residual_droppath_bwd": (c_int, [c_int, POINTER(c_void_p), POINTER(c_void_p), c_void_p, c_void_p, c_int64,
                                              c_int64, c_int64, c_int, c_int, c_void_p]),
     "mtlora_upsample_loss_partials": (c_int64, [c_int64, c_int, c_int]),
+    "mtlora_colsum_scratch_bytes": (c_int64, [c_int64, c_int64]),
+    "mtlora_colsum": (c_int, [c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p, c_int64, c_void_p]),
+    "mtlora_label_stat_scratch_bytes": (c_int64, [c_int64]),
+    "mtlora_label_stat": (c_int, [c_void_p, c_int64, c_int, c_float, c_void_p, c_void_p, c_int64, c_void_p]),
     "mtlora_upsample_loss": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int,
                                      c_int, c_int, ctypes.c_float, c_void_p]),
     "mtlora_upsample_cl_fwd": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int64, c_int, c_void_p]),
@@ -173,7 +177,7 @@ def require_gpu(*tensors: torch.Tensor) -> None:
         if not t.is_cuda:
             raise RuntimeError("mtlora_amd: tensors must live on a ROCm GPU (MI355X); the HIP path has no CPU fallback")
         if cur is None:
-            cur = torch.cuda.current_device()
+            cur = torch._C._cuda_getDevice()
         if t.device.index != cur:
             raise RuntimeError(f"mtlora_amd: tensor on cuda:{t.device.index} but the current device is cuda:{cur}; the HIP "
                                "path launches on the current device's stream -- call torch.cuda.set_device(tensor.device) first")
@@ -198,4 +202,5 @@ def ptr_array9(ts) -> "PtrArr9":
 
 
 def stream_ptr() -> c_void_p:
-    return c_void_p(torch.cuda.current_stream().cuda_stream)
+    # (torch.cuda.current_stream() builds a Stream object through four Python layers: ~10 us, once per library call)
+    return c_void_p(torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice()))

@@ -102,6 +102,14 @@ struct LnParams {
 // by-value copy would move the whole struct to scratch
 typedef const __attribute__((address_space(4))) LnParams* LnKargs;
 
+// row / d for 0 <= row < rows, 0 < d <= rows.  The int64 quotient costs ~100 VALU instructions per lane (software division),
+// once per row group -- more than the arithmetic of a 96-wide row; every shape in use has rows < 2^31, where one 32-bit unsigned
+// division (~20 instructions) gives the same result.  `rows` is wave-uniform.
+__device__ __forceinline__ int64_t row_div(int64_t row, int64_t d, int64_t rows) {
+    if (rows <= (int64_t)0x7FFFFFFF) return (int64_t)((uint32_t)row / (uint32_t)d);
+    return row / d;
+}
+
 // element offset of column `col` (a multiple of the vector width) of row `row` in x / dx
 struct LnRow {
     int64_t base;  // plain: row * C; merged: offset of token (2y2, 2x2)
@@ -112,7 +120,7 @@ __device__ __forceinline__ LnRow ln_row(const LnParams& p, int64_t row) {
         r.base = row * p.C;
     } else {
         const int W2 = p.mg_W >> 1, H2 = p.mg_H >> 1, Cs = p.C >> 2;
-        const int64_t b = row / ((int64_t)H2 * W2);
+        const int64_t b = row_div(row, (int64_t)H2 * W2, p.M);
         const int rem = (int)(row - b * H2 * W2);
         const int y2 = rem / W2, x2 = rem - y2 * W2;
         r.base = ((b * p.mg_H + 2 * y2) * p.mg_W + 2 * x2) * (int64_t)Cs;
@@ -260,7 +268,7 @@ __global__ __launch_bounds__(256) void k_ln_fwd(const LnParams p) {
 #pragma unroll
             for (int u = 0; u < UNR; ++u) {
                 if (row[u] >= p.M) continue;
-                const float sc = rscale ? rscale[row[u] / p.rows_per_sample] : 1.f;
+                const float sc = rscale ? rscale[row_div(row[u], p.rows_per_sample, p.M)] : 1.f;
 #pragma unroll
                 for (int i = 0; i < MAXV; ++i) {
                     const int v = lr + i * LPR;
@@ -456,7 +464,7 @@ __global__ __launch_bounds__(256) void k_ln_bwd(const LnParams p) {
                         for (int e = 0; e < VE; ++e) o[e] = rstd[u] * (gy[i][e] - c1 - xh[i][e] * c2) + fa[e];
                         st_vec<TX, VE>(dx + xb[u] + coff[i], o);
                         if (dbr_ptr) {  // gradient of the residual branch (layout of x / dx): DropPath scale, dtype of dy
-                            const float sc = rscale_in ? rscale_in[row[u] / p.rows_per_sample] : 1.f;
+                            const float sc = rscale_in ? rscale_in[row_div(row[u], p.rows_per_sample, p.M)] : 1.f;
 #pragma unroll
                             for (int e = 0; e < VE; ++e) o[e] *= sc;
                             st_vec<TG, VE>(reinterpret_cast<TG*>(dbr_ptr) + xb[u] + coff[i], o);
@@ -537,7 +545,7 @@ __global__ __launch_bounds__(256) void k_resln_bwd_multi(const LnParams p) {
             const TX* addp = reinterpret_cast<const TX*>(K->add_k[k]);
             R.mean = rv ? K->mean_k[k][row] : 0.f;
             R.rstd = rv ? K->rstd_k[k][row] : 0.f;
-            R.sc = (rv && p.rscale) ? p.rscale[(int64_t)k * Bn + row / p.rows_per_sample] : 1.f;
+            R.sc = (rv && p.rscale) ? p.rscale[(int64_t)k * Bn + row_div(row, p.rows_per_sample, p.M)] : 1.f;
 #pragma unroll
             for (int i = 0; i < MAXV; ++i) {
                 const int v = lr + i * LPR;

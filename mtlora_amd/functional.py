@@ -40,6 +40,10 @@ def set_seed_offset(t: Optional[torch.Tensor]) -> None:
 # chain.  The caller that installs a stream must JOIN it before the gradients are read (train_step does; a GradReducer gets
 # it through ``extra_streams``).  Off (None) by default: a plain ``loss.backward()`` stays single-stream.
 _factor_stream: Optional["torch.cuda.Stream"] = None
+# layers with fewer rows than this keep their factor gradients on the main stream: the fork / join costs ~30 us of host time per
+# layer and only pays while the kernels are long enough for the GPU to be the bottleneck (C1 at batch 2, M <= 6272 everywhere,
+# ran 35 % SLOWER with the side stream: 18.7 vs 13.8 ms / step)
+_FACTOR_MIN_M = int(os.environ.get("MTLORA_FACTOR_MIN_M", "16384"))
 
 
 def set_factor_stream(stream: Optional["torch.cuda.Stream"]) -> None:
@@ -230,7 +234,7 @@ class MTLoRALinearFn(torch.autograd.Function):
         # the factor gradients go to the side stream only when nothing on this stream reads them inside backward: no
         # trainable-scale gradient (formed from dB below) and no gradient accumulation into an existing .grad
         use_side = (side is not None and fgrads and not ctx.has_scale_s and meta.n_scale_t == 0
-                    and side.device == dev and not torch.cuda.is_current_stream_capturing()
+                    and side.device == dev and M >= _FACTOR_MIN_M
                     and all(p is None or p.grad is None for p in ctx.factor_params))
         if use_side:
             d.bwd_phase = 1
@@ -921,6 +925,35 @@ def residual_droppath(res, ys, drop_prob: float, training: bool):
     return list(ResidualDropPathFn.apply(scale, shared, n, *rl, *ys))
 
 
+def column_sum(g2: torch.Tensor) -> torch.Tensor:
+    """fp32 ``g2.sum(0)`` of a contiguous (M, N) fp32 / bf16 matrix through ``mtlora_colsum`` (deterministic, two launches, no
+    device memset: ATen's multi-block reduce zeroes a semaphore buffer first, which a HIP-graph capture of the step cannot
+    replay on this stack); shapes the kernel does not take fall back to ATen."""
+    M, N = g2.shape
+    ve = 4 if g2.dtype == torch.float32 else 8
+    if g2.dtype not in (torch.float32, torch.bfloat16) or N % ve or not g2.is_contiguous() or M == 0:
+        return g2.sum(0, dtype=torch.float32)
+    lib = L.lib()
+    sb = lib.mtlora_colsum_scratch_bytes(M, N)
+    scratch = torch.empty(sb, dtype=torch.uint8, device=g2.device)
+    out = torch.empty(N, dtype=torch.float32, device=g2.device)
+    L.check(lib.mtlora_colsum(L.ptr(g2), M, N, L.dtype_code(g2), L.ptr(out), L.ptr(scratch), sb, L.stream_ptr()), "mtlora_colsum")
+    return out
+
+
+def label_stat(lab: torch.Tensor, kind: int, ignore_index: float) -> torch.Tensor:
+    """label-only statistic of the fused losses as a 1-element fp32 tensor (kind 0: #{lab != ignore_index}; kind 1:
+    mean(1 - (lab >= 0.5))) through ``mtlora_label_stat`` (see ``column_sum`` for why not ATen)."""
+    n = lab.numel()
+    lib = L.lib()
+    sb = lib.mtlora_label_stat_scratch_bytes(n)
+    scratch = torch.empty(sb, dtype=torch.uint8, device=lab.device)
+    out = torch.empty(1, dtype=torch.float32, device=lab.device)
+    L.check(lib.mtlora_label_stat(L.ptr(lab), n, kind, float(ignore_index), L.ptr(out), L.ptr(scratch), sb, L.stream_ptr()),
+            "mtlora_label_stat")
+    return out
+
+
 # ----------------------------------------------------------------------------------------------
 # loss end of the train step: bilinear upsample (integer scale, align_corners=False) + per-task loss, fused
 # ----------------------------------------------------------------------------------------------
@@ -946,11 +979,11 @@ class UpsampleLossFn(torch.autograd.Function):
             lo = lo.float()
         # label-only statistics (independent of the prediction)
         if kind == "softmax":
-            stat = (lab != ignore_index).sum().float().reshape(1)
+            stat = label_stat(lab, 0, ignore_index)
         elif kind == "normals":
-            stat = (lab != ignore_index).sum().float().reshape(1)
+            stat = label_stat(lab, 0, ignore_index)
         elif kind == "balanced_bce":
-            stat = (1.0 - (lab >= 0.5).float()).mean().reshape(1)
+            stat = label_stat(lab, 1, ignore_index)
         else:
             raise RuntimeError(f"mtlora_amd: unknown fused loss kind {kind!r}")
         lib = L.lib()
@@ -1011,7 +1044,7 @@ class SplitKLinearFn(torch.autograd.Function):
             if ctx.zero_bias_grad:
                 db = torch.zeros(N, dtype=ctx.bdtype, device=gy.device)
             else:  # two-stage column sum: a (400k x 21) sum(0) runs on 64 workgroups for 256 us in one stage
-                db = gy.view(S, M // S, N).sum(1, dtype=torch.float32).sum(0).to(ctx.bdtype)
+                db = column_sum(gy).to(ctx.bdtype)
         return dx, dw, db, None, None, None
 
 
@@ -1078,7 +1111,7 @@ class PlainLinearFn(torch.autograd.Function):
             if ctx.zero_bias_grad:
                 db = torch.zeros(N, dtype=ctx.bdtype, device=gy.device)
             else:
-                db = gy.view(S, M // S, N).sum(1, dtype=torch.float32).sum(0).to(ctx.bdtype)
+                db = column_sum(gy).to(ctx.bdtype)
         return dx, dw, db, None, None, None
 
 
@@ -1118,19 +1151,23 @@ def linear_big_m(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Ten
     """F.linear for (M, K) inputs; switches to SplitKLinearFn when M is large and the weight is trained.
     feeds_batchnorm=True: the output goes straight into a training-mode BatchNorm -> the bias gradient is exactly 0."""
     M = x.shape[0]
-    if x.dim() == 2 and x.is_cuda and weight.requires_grad and torch.is_grad_enabled() and M >= 16384:
-        # enough row chunks that chunks x output tiles (64 x 64) fills the 256 CUs ~8 times (measured on the heads' 1080 x 272
-        # gradient: 235 us at 8 chunks, 114 us at 32), each chunk >= 1024 rows
-        tiles = ((weight.shape[0] + 63) // 64) * ((weight.shape[1] + 63) // 64)
-        S = 4
-        while S < 64 and S * tiles < 2048 and M % (2 * S) == 0 and M // (2 * S) >= 1024:
-            S *= 2
-        if M % S == 0 and x.is_contiguous():
-            if torch.is_autocast_enabled("cuda"):
-                dt = torch.get_autocast_dtype("cuda")
-                with torch.autocast("cuda", enabled=False):
-                    return _big_linear(x.to(dt), weight, bias, S, feeds_batchnorm, dt)
-            return _big_linear(x, weight, bias, S, feeds_batchnorm, x.dtype)
+    if x.dim() == 2 and x.is_cuda and weight.requires_grad and torch.is_grad_enabled() and M >= 1 and x.is_contiguous():
+        S = 1  # small M: one chunk -- still this Function, so that the bias gradient is ``column_sum`` (ATen's sum(0) of a mid-size
+               # gradient is a multi-block reduce with a device memset, which a HIP-graph capture of the step cannot replay)
+        if M >= 16384:
+            # enough row chunks that chunks x output tiles (64 x 64) fills the 256 CUs ~8 times (measured on the heads' 1080 x 272
+            # gradient: 235 us at 8 chunks, 114 us at 32), each chunk >= 1024 rows
+            tiles = ((weight.shape[0] + 63) // 64) * ((weight.shape[1] + 63) // 64)
+            S = 4
+            while S < 64 and S * tiles < 2048 and M % (2 * S) == 0 and M // (2 * S) >= 1024:
+                S *= 2
+            if M % S:
+                S = 1
+        if torch.is_autocast_enabled("cuda"):
+            dt = torch.get_autocast_dtype("cuda")
+            with torch.autocast("cuda", enabled=False):
+                return _big_linear(x.to(dt), weight, bias, S, feeds_batchnorm, dt)
+        return _big_linear(x, weight, bias, S, feeds_batchnorm, x.dtype)
     return torch.nn.functional.linear(x, weight, bias)
 
 

@@ -111,6 +111,13 @@ def mtlora_namespace(tasks: Sequence[str], r_shared=64, r_task=4, scale=4.0, dro
 
 # --------------------------------------------------------------------------------------------------
 _TASK_STREAMS = os.environ.get("MTLORA_TASK_STREAMS", "1") != "0"
+# side streams (per-task heads, factor gradients) also while a HIP graph is being captured: the fork / join events become graph
+# dependencies and the replay runs the branches concurrently.  MTLORA_GRAPH_STREAMS=0 captures a single-stream graph.
+_GRAPH_STREAMS = os.environ.get("MTLORA_GRAPH_STREAMS", "1") != "0"
+
+
+def _streams_allowed() -> bool:
+    return _GRAPH_STREAMS or not torch.cuda.is_current_stream_capturing()
 
 
 class Downsampler(nn.Module):
@@ -240,7 +247,7 @@ class MultiTaskSwin(nn.Module):
         stages = self.backbone(x, return_stages=True)
         if concurrent is None:
             concurrent = (x.is_cuda and _TASK_STREAMS and len(self.tasks) > 1 and torch.is_grad_enabled()
-                          and not torch.cuda.is_current_stream_capturing())
+                          and _streams_allowed())
         if not concurrent:
             feats = {t: self.downsampler[t]([tl[t] for _, tl in stages]) for t in self.tasks}
             out = self.decoders(feats, upsample=upsample)
@@ -402,7 +409,7 @@ _factor_streams: Dict[str, "torch.cuda.Stream"] = {}
 def _factor_side_stream(device):
     """the stream the MTLoRALinear factor gradients (k_tn reductions) run on during ``train_step``'s backward
     (functional.set_factor_stream); MTLORA_FACTOR_STREAM=0 keeps the backward on one stream."""
-    if not _FACTOR_STREAM or torch.cuda.is_current_stream_capturing():
+    if not _FACTOR_STREAM or not _streams_allowed():
         return None
     key = str(device)
     if key not in _factor_streams:
@@ -546,13 +553,25 @@ class GraphedTrainStep:
         ctx = (torch.autocast("cuda", dtype=self.amp_dtype, cache_enabled=False) if self.amp_dtype is not None
                else contextlib.nullcontext())
         with ctx:
-            if self.fused_loss:
+            if self.fused_loss and isinstance(self.model, MultiTaskSwin):  # as train_step: each loss inside its task's stream
+                loss, _ = self.criterion.combine(self.model(
+                    self.images, upsample=False, per_task_fn=lambda t, lo: self.criterion.task_low(t, lo, self.targets[t])))
+            elif self.fused_loss:
                 loss, _ = self.criterion.forward_low(self.model(self.images, upsample=False), self.targets)
             else:
                 loss, _ = self.criterion(self.model(self.images), self.targets)
+        side = _factor_side_stream(self.images.device) if self.images.is_cuda else None
         if self.reducer is not None:
+            extra = list(self.model._streams) if (isinstance(self.model, MultiTaskSwin) and getattr(self.model, "_streams", None)) else []
+            self.reducer.extra_streams = extra + ([side] if side is not None else [])
             self.reducer.prepare(defer=True)
-        loss.backward()
+        Fn.set_factor_stream(side)
+        try:
+            loss.backward()
+        finally:
+            Fn.set_factor_stream(None)
+        if side is not None:  # joins the side stream back (inside a capture: closes the graph's second branch)
+            torch.cuda.current_stream(self.images.device).wait_stream(side)
         if self.reducer is not None:
             self.reducer.flush_packs()
         return loss.detach()

@@ -41,3 +41,17 @@ for e in ev:
     cnt[(e.name, fr.split("/")[-1][:70])] += 1
 for (n, fr), c in cnt.most_common(40):
     print(f"  {c:5d}  {n:28s} {fr}")
+print("--- device memsets / fills (what a HIP-graph capture of the step would bake in): op | stack")
+ms = collections.Counter()
+for e in ev:
+    if e.device_type != torch.autograd.DeviceType.CPU or not e.kernels:
+        continue
+    ks = [k.name for k in e.kernels if "Memset" in k.name or "fillBuffer" in k.name]
+    if not ks:
+        continue
+    st = [s.split("/")[-1][:60] for s in (e.stack or []) if "mtlora_amd" in s or "bench.py" in s or "torch/optim" in s or "clip_grad" in s or "nn/functional" in s or "autograd/function" in s or "tools/" in s][:4]
+    if not st:
+        st = [s.split("/")[-1][:50] for s in (e.stack or [])][:4] or ["(autograd engine thread: no Python stack)"]
+    ms[(e.name, " < ".join(st))] += len(ks)
+for (n, st), c in ms.most_common(30):
+    print(f"  {c:4d}  {n:30s} {st}")

@@ -7,14 +7,23 @@ from mtlora_amd import mtl_harness as H
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=2)
+ap.add_argument("--config", default="c2")
+ap.add_argument("--capturable", action="store_true")
+ap.add_argument("--forward", action="store_true", help="profile the forward + loss only (no backward / optimizer)")
+ap.add_argument("--top", type=int, default=28)
+ap.add_argument("--sort", default="tottime")
 a = ap.parse_args()
-TASKS = ("semseg", "normals", "sal", "human_parts")
+row = H.config(a.config)
+TASKS = tuple(row["tasks"])
 dev = torch.device("cuda", 0)
-model = H.build_model(img_size=448, tasks=TASKS, r_shared=64, r_task=4, drop_path_rate=0.2, seed=0).to(dev).train()
+model = H.build_config_model(a.config, seed=0, drop_path_rate=0.2).to(dev).train()
 crit = H.MultiTaskLoss(TASKS)
-opt = H.build_optimizer(model, lr=1e-4)
-img, tg = H.synthetic_batch(a.batch, 448, TASKS, seed=1234, device=dev)
-step = lambda: H.train_step(model, crit, opt, img, tg, clip_grad=5.0, amp_dtype=torch.bfloat16)
+opt = H.build_optimizer(model, lr=1e-4, capturable=a.capturable)
+img, tg = H.synthetic_batch(a.batch, row["img_size"], TASKS, seed=1234, device=dev)
+def fwd_only():
+    with torch.autocast("cuda", dtype=torch.bfloat16):  # train_step's forward: fused per-task upsample + loss
+        return crit.combine(model(img, upsample=False, per_task_fn=lambda t, lo: crit.task_low(t, lo, tg[t])))
+step = fwd_only if a.forward else (lambda: H.train_step(model, crit, opt, img, tg, clip_grad=5.0, amp_dtype=torch.bfloat16))
 for _ in range(5):
     step()
 torch.cuda.synchronize()
@@ -30,4 +39,4 @@ for _ in range(5):
 torch.cuda.synchronize()
 pr.disable()
 st = pstats.Stats(pr)
-st.sort_stats("tottime").print_stats(28)
+st.sort_stats(a.sort).print_stats(a.top)

@@ -57,8 +57,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-eager-gpu", action="store_true")
     ap.add_argument("--graph", action="store_true",
-                    help="EXPERIMENTAL: replay the step as captured HIP graph(s); the capture is validated against the eager step "
-                         "and dropped if it does not reproduce it (ROCm small-memset replay bug, DESIGN.md section 5)")
+                    help="replay the step as captured HIP graph(s) (validated: replays from identical state must agree, else the eager "
+                         "step runs and the reason is reported); faster when the host is the limit (c1: 2x), not at c2 -- DESIGN.md 5")
     ap.add_argument("--capturable", action="store_true", help="AdamW(capturable=True) in the eager step too (step counters on the device)")
     ap.add_argument("--force-reducer", action="store_true", help="run the gradient pack / RCCL all-reduce / unpack path even at 1 rank")
     ap.add_argument("--no-fused-loss", action="store_true", help="final upsample + losses through ATen instead of csrc/loss.hip")
@@ -292,7 +292,7 @@ def main():
         H.train_step(model, crit, opt, img, tg, clip_grad=5.0, reducer=reducer, amp_dtype=torch.bfloat16,
                      fused_loss=not args.no_fused_loss)
 
-    graph_info = {"enabled": False, "why": "eager (default); --graph is experimental, see its help"}
+    graph_info = {"enabled": False, "why": "eager multi-stream step (default; --graph replays a captured HIP graph)"}
     step = eager_step
     if args.graph:
         # the whole step (fwd + losses + bwd + clip + AdamW) captured as HIP graph(s); RCCL stays outside the graphs

@@ -471,11 +471,12 @@ class GraphedTrainStep:
     * optimizer: must be ``capturable`` (``build_optimizer(..., capturable=True)``).
     Falls back to the eager step (``self.graphed = False``, reason in ``self.why``) if capture fails.
 
-    EXPERIMENTAL -- NOT used by bench.py by default.  On the ROCm 7.0 / PyTorch 2.10 stack of this image a captured SMALL
-    ``hipMemsetAsync`` stops taking effect from the second replay on (4 KB: stale data shows through; 4 MB is fine).
-    This library no longer issues memsets (common.h:mtl_zero_async), but ATen does (reduction semaphores, ...), so a graph
-    of the WHOLE step, which mixes both, returns garbage after the first replay.  Kept because capture itself works
-    (~1500 launches, same speed as eager while the step is GPU-bound) and only the upstream memset nodes are in the way."""
+    Not bench.py's default (``--graph``): at C2 the eager step with its side streams is faster (34.8 ms vs 36.5 ms for the
+    single-stream replay; the host is not the limit there), at C1 / small batches the replay is 2x the eager step.
+    History: on the ROCm 7.0 / PyTorch 2.10 stack of this image a captured SMALL ``hipMemsetAsync`` stops taking effect from
+    the second replay on (4 KB: stale data shows through; 4 MB is fine).  This library never issued memsets
+    (common.h:mtl_zero_async) but ATen's multi-block reductions do; the nine per step (tools/find_memsets.py) now go through
+    csrc/reduce.hip, the step issues none, and ``_replays_reproduce`` passes on every config -- it stays in place as the guard."""
 
     SEED_STEP = 0x1E3779B97F4A7C15  # odd: a full-period walk of the 64-bit seed offset
 

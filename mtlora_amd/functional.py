@@ -55,6 +55,78 @@ def factor_stream() -> Optional["torch.cuda.Stream"]:
     return _factor_stream
 
 
+# ----------------------------------------------------------------------------------------------
+# DropPath keep / scale vectors, drawn in bulk.  Every residual of the backbone needs n x B per-sample factors
+# bernoulli(keep) / keep (timm DropPath, swin_transformer_mtlora.py:388-426): 22 draws per Swin-T step = 44 tiny launches
+# (bernoulli_, div_) strung along the forward's critical path.  A train step can announce itself (``droppath_begin_step`` /
+# ``droppath_end_step``, mtl_harness.train_step): the sequence of requests (n, B, keep) seen in one step is replayed as the PLAN of
+# the next one, whose factors then come from ONE rand + compare + scale over all of them; a request that deviates from the plan
+# (other model, other batch, eval) simply draws on its own and the plan is re-recorded.  Same distribution, same global CUDA
+# generator; the individual values differ from per-call draws.
+# ----------------------------------------------------------------------------------------------
+class _DropPathPool:
+    def __init__(self):
+        self.plan, self.rec, self.rows, self.at, self.active, self.in_step = [], [], None, 0, False, False
+        self.cache_key, self.keep_col = None, None
+
+    def begin(self, device):
+        self.rec, self.at, self.in_step = [], 0, True
+        self.active = bool(self.plan) and not torch.cuda.is_current_stream_capturing()
+        if not self.active:
+            return
+        key = (tuple(self.plan), str(device))
+        if key != self.cache_key:  # per-row keep probabilities of the plan (built once)
+            B = self.plan[0][1]
+            if any(b != B for _, b, _ in self.plan):
+                self.active = False
+                return
+            keeps = [k for n, _, k in self.plan for _ in range(n)]
+            self.keep_col = torch.tensor(keeps, dtype=torch.float32, device=device).unsqueeze(1)
+            self.cache_key = key
+        B = self.plan[0][1]
+        u = torch.rand(self.keep_col.shape[0], B, dtype=torch.float32, device=device)
+        self.rows = (u < self.keep_col) / self.keep_col  # bernoulli(keep) / keep, all requests of the step at once
+        self.off = 0
+
+    def end(self):
+        if self.in_step:
+            self.plan, self.in_step, self.active, self.rows = self.rec, False, False, None
+
+    def scale(self, n: int, B: int, keep: float, device) -> torch.Tensor:
+        if self.in_step:
+            self.rec.append((n, B, keep))
+            if self.active and self.at < len(self.plan) and self.plan[self.at] == (n, B, keep) and self.rows.device == device:
+                out = self.rows[self.off:self.off + n]
+                self.off += n
+                self.at += 1
+                return out
+            self.active = False
+        return torch.empty(n, B, dtype=torch.float32, device=device).bernoulli_(keep).div_(keep)
+
+
+_droppath_pool = _DropPathPool()
+
+
+def droppath_begin_step(device) -> None:
+    _droppath_pool.begin(device)
+
+
+def droppath_end_step() -> None:
+    _droppath_pool.end()
+
+
+def droppath_reset() -> None:
+    """forget the recorded plan: the next announced step draws per request again (two runs that must see the same random
+    stream have to start from the same pool state)."""
+    global _droppath_pool
+    _droppath_pool = _DropPathPool()
+
+
+def droppath_scale(n: int, B: int, keep: float, device) -> torch.Tensor:
+    """(n, B) fp32 factors bernoulli(keep) / keep -- from the step's bulk draw when one is active (see _DropPathPool)."""
+    return _droppath_pool.scale(n, B, keep, device)
+
+
 def next_seed() -> int:
     global _seed_counter
     _seed_counter += 1
@@ -608,7 +680,7 @@ def residual_layer_norm_multi(mod: torch.nn.Module, shortcut: torch.Tensor, bran
     scale = None
     if training and drop_prob > 0.0:
         keep = 1.0 - drop_prob
-        scale = torch.empty(n, shortcut.shape[0], dtype=torch.float32, device=shortcut.device).bernoulli_(keep).div_(keep)
+        scale = droppath_scale(n, shortcut.shape[0], keep, shortcut.device)
     outs = ResidualLayerNormMultiFn.apply(scale, mod.weight, mod.bias, mod.eps, out_dtype, n, shortcut, *branches)
     return list(outs[:n]), list(outs[n:])
 
@@ -630,7 +702,7 @@ def residual_layer_norm(mod: torch.nn.Module, shortcut: torch.Tensor, branch: to
     scale = None
     if training and drop_prob > 0.0:
         keep = 1.0 - drop_prob
-        scale = torch.empty(shortcut.shape[0], dtype=torch.float32, device=shortcut.device).bernoulli_(keep).div_(keep)
+        scale = droppath_scale(1, shortcut.shape[0], keep, shortcut.device)[0]
     return ResidualLayerNormFn.apply(shortcut, branch, scale, mod.weight, mod.bias, mod.eps, out_dtype)
 
 
@@ -777,7 +849,7 @@ def residual_merge_norm_streams(mod: torch.nn.Module, res, branches, H: int, W: 
     scale = None
     if training and drop_prob > 0.0:
         keep = 1.0 - drop_prob
-        scale = torch.empty(n, B, dtype=torch.float32, device=res[0].device).bernoulli_(keep).div_(keep)
+        scale = droppath_scale(n, B, keep, res[0].device)
     return ResidualMergeNormStreamsFn.apply(scale, mod.weight, mod.bias, mod.eps, out_dtype, H, W, n, *res, *branches)
 
 
@@ -915,7 +987,7 @@ def residual_droppath(res, ys, drop_prob: float, training: bool):
     scale = None
     if training and drop_prob > 0.0:
         keep = 1.0 - drop_prob
-        scale = torch.empty(n, rl[0].shape[0], dtype=torch.float32, device=rl[0].device).bernoulli_(keep).div_(keep)
+        scale = droppath_scale(n, rl[0].shape[0], keep, rl[0].device)
     if not ok:
         out = []
         for k in range(n):

@@ -430,11 +430,16 @@ def train_step(model, criterion, optimizer, images, targets, clip_grad: float = 
             return criterion.forward_low(model(images, upsample=False), targets)
         return criterion(model(images), targets)
 
-    if amp_dtype is not None:
-        with torch.autocast("cuda", dtype=amp_dtype):
+    if images.is_cuda:
+        Fn.droppath_begin_step(images.device)  # DropPath factors of the whole step from one draw (functional._DropPathPool)
+    try:
+        if amp_dtype is not None:
+            with torch.autocast("cuda", dtype=amp_dtype):
+                loss, per = fwd()
+        else:
             loss, per = fwd()
-    else:
-        loss, per = fwd()
+    finally:
+        Fn.droppath_end_step()
     side = _factor_side_stream(images.device) if images.is_cuda else None
     if reducer is not None:
         extra = list(model._streams) if (isinstance(model, MultiTaskSwin) and getattr(model, "_streams", None)) else []

@@ -1404,3 +1404,42 @@ def test_label_stat_vs_torch(n):
     w = Fn.label_stat(sal, 1, 255.0)
     ref = (1.0 - (sal >= 0.5).double()).mean().item()
     assert abs(w.item() - ref) <= 1e-6
+
+
+@pytest.mark.gpu
+def test_droppath_bulk_draw():
+    """functional._DropPathPool: the requests of one announced step become the plan of the next, whose factors come from ONE
+    draw (views of one tensor), each in {0, 1/keep} with the right keep rate; a deviating request falls back to its own draw."""
+    from mtlora_amd import functional as Fn
+    d = dev()
+    reqs = [(1, 64, 0.9), (5, 64, 0.8), (1, 64, 0.75), (5, 64, 0.5)]
+    Fn.droppath_begin_step(d)
+    first = [Fn.droppath_scale(n, B, k, d) for n, B, k in reqs]  # recorded, drawn one by one
+    Fn.droppath_end_step()
+    assert len({t.untyped_storage().data_ptr() for t in first}) == len(first)
+    torch.manual_seed(3)
+    Fn.droppath_begin_step(d)
+    second = [Fn.droppath_scale(n, B, k, d) for n, B, k in reqs]
+    Fn.droppath_end_step()
+    assert len({t.untyped_storage().data_ptr() for t in second}) == 1  # one bulk tensor
+    for (n, B, k), t in zip(reqs, second):
+        assert t.shape == (n, B) and t.dtype == torch.float32
+        assert bool(((t == 0) | ((t - 1.0 / k).abs() < 1e-6)).all())
+    torch.manual_seed(3)
+    Fn.droppath_begin_step(d)
+    again = [Fn.droppath_scale(n, B, k, d) for n, B, k in reqs]
+    Fn.droppath_end_step()
+    assert all(torch.equal(a, b) for a, b in zip(second, again))  # reproducible under the global generator
+    # keep rate over many draws
+    Fn.droppath_begin_step(d)
+    rate = torch.stack([Fn.droppath_scale(5, 64, 0.8, d) if i == 1 else Fn.droppath_scale(*reqs[i][:2], reqs[i][2], d)
+                        for i in range(4)][1:2]).ne(0).float().mean().item()
+    Fn.droppath_end_step()
+    assert 0.6 < rate < 0.95
+    # a deviating request (other batch) gets its own draw and the plan is re-recorded
+    Fn.droppath_begin_step(d)
+    odd = Fn.droppath_scale(2, 32, 0.9, d)
+    Fn.droppath_end_step()
+    assert odd.shape == (2, 32)
+    Fn.droppath_begin_step(d)
+    Fn.droppath_end_step()  # leave an empty plan behind for the other tests

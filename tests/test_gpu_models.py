@@ -286,6 +286,7 @@ def test_reducer_on_the_real_model_matches_plain_backward():
             torch.manual_seed(7)
             from mtlora_amd import functional as Fn
             Fn._seed_counter = 0  # same dropout seeds in both runs
+            Fn.droppath_reset()   # ... and the same DropPath draw history
             model = H.build_model(img_size=224, tasks=tasks, depths=(2, 2, 2, 2), r_shared=16, r_task=4, seed=3).to(dev()).train()
             crit, opt = H.MultiTaskLoss(tasks), H.build_optimizer(model, lr=1e-3)
             red = GradReducer(model.parameters(), bucket_mb=1.0, force=True, buffers=model.buffers()) if use else None
@@ -324,6 +325,7 @@ def test_factor_gradient_stream_is_bit_identical():
             H._FACTOR_STREAM = on
             torch.manual_seed(5)
             Fn._seed_counter = 0
+            Fn.droppath_reset()
             model = H.build_model(img_size=224, tasks=tasks, depths=(2, 2, 2, 2), r_shared=16, r_task=4, seed=3).to(dev()).train()
             crit, opt = H.MultiTaskLoss(tasks), H.build_optimizer(model, lr=1e-3)
             losses = [H.train_step(model, crit, opt, img, tg)[0].clone() for _ in range(3)]

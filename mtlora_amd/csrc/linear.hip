@@ -1521,6 +1521,7 @@ static int check_desc(const mtlora_linear_desc* d) {
         if (d->r_t[t] <= 0) return MTLORA_ERR_SHAPE;
     if (d->mode != 0 && d->mode != 1) return MTLORA_ERR_UNSUPPORTED;
     if (d->bwd_phase < 0 || d->bwd_phase > 2) return MTLORA_ERR_UNSUPPORTED;
+    if (d->pack && ((uintptr_t)d->pack & 15u)) return MTLORA_ERR_ALIGN;
     if (d->dropout_p < 0.f || d->dropout_p >= 1.f) return MTLORA_ERR_SHAPE;
     return MTLORA_OK;
 }
@@ -1853,6 +1854,39 @@ static void launch_pnl(PnParams& P, hipStream_t s, int kind, double alg_bytes, d
 #undef MTL_PNL_LAUNCH_NS
 }
 
+// k_pack of one layer into the packed-factor region at `pk` (the head of a forward's ctx buffer, or the caller's persistent
+// buffer of mtlora_linear_pack)
+template <typename T>
+static void launch_pack(const mtlora_linear_desc* d, const Segs& sg, const CtxLayout& L, unsigned char* pk, const float* A_s,
+                        const float* B_s, const float* const* A_t, const float* const* B_t, hipStream_t s) {
+    const float keep_scale = mtl_make_dropout(d->dropout_p, 0).enabled() ? 1.f / (1.f - d->dropout_p) : 1.f;
+    PackParams pp;
+    pp.s = sg;
+    pp.K = (int)d->K;
+    pp.N = (int)d->N;
+    for (int o = 0; o < MAXO; ++o) {
+        pp.A[o] = nullptr;
+        pp.B[o] = nullptr;
+        pp.alpha[o] = 0.f;
+    }
+    pp.A[0] = A_s;
+    pp.B[0] = B_s;
+    pp.alpha[0] = d->scale_s * keep_scale;
+    for (int t = 0; t < d->T; ++t) {
+        pp.A[t + 1] = A_t[t];
+        pp.B[t + 1] = B_t[t];
+        pp.alpha[t + 1] = d->scale_t[t] * (d->has_x_tasks ? 1.f : keep_scale);
+    }
+    const int64_t work = (int64_t)sg.R * (d->K + d->N + 1);
+    int64_t blocks = mtl_ceil_div(work, 256);
+    if (blocks > 2048) blocks = 2048;
+    MtlProfScope prof(PK_PACK, 0.0, s);
+    hipLaunchKernelGGL(k_pack<T>, dim3((unsigned)blocks), dim3(256), 0, s, pp, reinterpret_cast<T*>(pk + L.a_cat),
+                       reinterpret_cast<T*>(pk + L.b_cat), reinterpret_cast<T*>(pk + L.at_cat), reinterpret_cast<T*>(pk + L.bt_cat),
+                       reinterpret_cast<float*>(pk + L.alpha), reinterpret_cast<T*>(pk + L.a_proj),
+                       reinterpret_cast<T*>(pk + L.bt_proj));
+}
+
 template <typename T>
 static int fwd_impl(const mtlora_linear_desc* d, const void* x, const void* const* x_t, const void* W,
                     const float* bias, const float* A_s, const float* B_s, const float* const* A_t,
@@ -1861,44 +1895,23 @@ static int fwd_impl(const mtlora_linear_desc* d, const void* x, const void* cons
     const Segs sg = make_segs(d);
     const CtxLayout L = ctx_layout(d, sg);
     unsigned char* c = reinterpret_cast<unsigned char*>(ctx);
-    T* a_cat = reinterpret_cast<T*>(c + L.a_cat);
-    T* b_cat = reinterpret_cast<T*>(c + L.b_cat);
-    T* at_cat = reinterpret_cast<T*>(c + L.at_cat);
-    T* bt_cat = reinterpret_cast<T*>(c + L.bt_cat);
-    float* alpha = reinterpret_cast<float*>(c + L.alpha);
+    // packed factors: inside ctx, or in the caller's persistent buffer (desc.pack, ABI v4)
+    unsigned char* pk = d->pack ? reinterpret_cast<unsigned char*>(const_cast<void*>(d->pack)) : c;
+    T* a_cat = reinterpret_cast<T*>(pk + L.a_cat);
+    T* b_cat = reinterpret_cast<T*>(pk + L.b_cat);
+    T* at_cat = reinterpret_cast<T*>(pk + L.at_cat);
+    T* bt_cat = reinterpret_cast<T*>(pk + L.bt_cat);
+    float* alpha = reinterpret_cast<float*>(pk + L.alpha);
+    (void)at_cat;
+    (void)bt_cat;
     T* Pm = reinterpret_cast<T*>(c + L.p);
     const DropoutCfg dc = mtl_make_dropout(d->dropout_p, d->seed, d->seed_offset);
-    const float keep_scale = dc.enabled() ? 1.f / (1.f - d->dropout_p) : 1.f;
     bool fuse = false;
     int groups = 0;
     const bool pnl = std::is_same<T, bf16>::value && pnl_eligible(d, sg);
 
     if (sg.R > 0) {
-        PackParams pp;
-        pp.s = sg;
-        pp.K = (int)d->K;
-        pp.N = (int)d->N;
-        for (int o = 0; o < MAXO; ++o) {
-            pp.A[o] = nullptr;
-            pp.B[o] = nullptr;
-            pp.alpha[o] = 0.f;
-        }
-        pp.A[0] = A_s;
-        pp.B[0] = B_s;
-        pp.alpha[0] = d->scale_s * keep_scale;
-        for (int t = 0; t < d->T; ++t) {
-            pp.A[t + 1] = A_t[t];
-            pp.B[t + 1] = B_t[t];
-            pp.alpha[t + 1] = d->scale_t[t] * (d->has_x_tasks ? 1.f : keep_scale);
-        }
-        const int64_t work = (int64_t)sg.R * (d->K + d->N + 1);
-        int64_t blocks = mtl_ceil_div(work, 256);
-        if (blocks > 2048) blocks = 2048;
-        {
-            MtlProfScope prof(PK_PACK, 0.0, s);
-            hipLaunchKernelGGL(k_pack<T>, dim3((unsigned)blocks), dim3(256), 0, s, pp, a_cat, b_cat, at_cat, bt_cat,
-                               alpha, reinterpret_cast<T*>(c + L.a_proj), reinterpret_cast<T*>(c + L.bt_proj));
-        }
+        if (!(d->pack && d->prepacked)) launch_pack<T>(d, sg, L, pk, A_s, B_s, A_t, B_t, s);
 
         groups = (a_s || pnl) ? 0 : fuse_groups(d, sg, d->N);
         fuse = groups > 0;
@@ -1952,7 +1965,7 @@ static int fwd_impl(const mtlora_linear_desc* d, const void* x, const void* cons
         q.R = sg.R;
         q.pout = sg.R > 0 ? (void*)Pm : nullptr;
         q.drop = dc;
-        const T* a_proj = reinterpret_cast<const T*>(c + L.a_proj);
+        const T* a_proj = reinterpret_cast<const T*>(pk + L.a_proj);
         const bool own_x = d->T > 0 && d->has_x_tasks;
         for (int o = 0; o < sg.n && sg.R > 0; ++o) {
             if (!own_x && o > 0) break;
@@ -2128,9 +2141,10 @@ static int bwd_impl(const mtlora_linear_desc* d, const void* x, const void* cons
     const CtxLayout L = ctx_layout(d, sg);
     const BwdScratch S = bwd_scratch(d, sg);
     const unsigned char* c = reinterpret_cast<const unsigned char*>(ctx);
-    const T* at_cat = reinterpret_cast<const T*>(c + L.at_cat);
-    const T* bt_cat = reinterpret_cast<const T*>(c + L.bt_cat);
-    const float* alpha = reinterpret_cast<const float*>(c + L.alpha);
+    const unsigned char* pk = d->pack ? reinterpret_cast<const unsigned char*>(d->pack) : c;
+    const T* at_cat = reinterpret_cast<const T*>(pk + L.at_cat);
+    const T* bt_cat = reinterpret_cast<const T*>(pk + L.bt_cat);
+    const float* alpha = reinterpret_cast<const float*>(pk + L.alpha);
     const T* Pm = reinterpret_cast<const T*>(c + L.p);
     unsigned char* sc = reinterpret_cast<unsigned char*>(scratch);
     T* Qm = reinterpret_cast<T*>(sc + S.q);
@@ -2187,7 +2201,7 @@ static int bwd_impl(const mtlora_linear_desc* d, const void* x, const void* cons
         q.R = sg.R;
         q.pout = sg.R > 0 ? (void*)Qm : nullptr;
         q.drop = dc;
-        const T* bt_proj = reinterpret_cast<const T*>(c + L.bt_proj);
+        const T* bt_proj = reinterpret_cast<const T*>(pk + L.bt_proj);
         double rsum = 0.0;
         for (int o = 0; o < sg.n && sg.R > 0; ++o) {
             if (sg.rp[o] == 0 || !dyo[o]) continue;  // a segment without a gradient stays zero in the image
@@ -2461,6 +2475,34 @@ int64_t mtlora_linear_ctx_bytes(const mtlora_linear_desc* d) {
     if (check_desc(d) != MTLORA_OK) return -1;
     const Segs sg = make_segs(d);
     return ctx_layout(d, sg).total + 256;
+}
+
+int64_t mtlora_linear_pack_bytes(const mtlora_linear_desc* d) {
+    if (check_desc(d) != MTLORA_OK) return -1;
+    const Segs sg = make_segs(d);
+    return ctx_layout(d, sg).p + 256;  // the packed-factor region precedes P in the ctx layout and does not depend on M
+}
+
+int mtlora_linear_pack(const mtlora_linear_desc* d, const float* A_s, const float* B_s, const float* const* A_t,
+                       const float* const* B_t, void* pack, int64_t pack_bytes, void* stream) {
+    int st = check_desc(d);
+    if (st != MTLORA_OK) return st;
+    const Segs sg = make_segs(d);
+    if (sg.R <= 0) return MTLORA_OK;
+    if (!pack) return MTLORA_ERR_NULL;
+    if (misaligned(pack)) return MTLORA_ERR_ALIGN;
+    if (d->r_s > 0 && (!A_s || !B_s)) return MTLORA_ERR_NULL;
+    for (int t = 0; t < d->T; ++t)
+        if (!A_t || !B_t || !A_t[t] || !B_t[t]) return MTLORA_ERR_NULL;
+    const CtxLayout L = ctx_layout(d, sg);
+    if (pack_bytes < L.p) return MTLORA_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    if (d->dtype == MTLORA_F32)
+        launch_pack<float>(d, sg, L, reinterpret_cast<unsigned char*>(pack), A_s, B_s, A_t, B_t, s);
+    else
+        launch_pack<bf16>(d, sg, L, reinterpret_cast<unsigned char*>(pack), A_s, B_s, A_t, B_t, s);
+    MTL_CHECK_LAUNCH();
+    return MTLORA_OK;
 }
 
 int64_t mtlora_linear_bwd_scratch_bytes(const mtlora_linear_desc* d) {

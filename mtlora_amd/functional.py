@@ -55,6 +55,23 @@ def factor_stream() -> Optional["torch.cuda.Stream"]:
     return _factor_stream
 
 
+# the event after which the packed factors written by ``MTLoRALinear.prepack`` calls (on a side stream) are complete; the first
+# forward that uses one makes its stream wait for it
+_prepack_event: Optional["torch.cuda.Event"] = None
+
+
+def set_prepack_event(ev: Optional["torch.cuda.Event"]) -> None:
+    global _prepack_event
+    _prepack_event = ev
+
+
+def wait_prepack() -> None:
+    global _prepack_event
+    if _prepack_event is not None:
+        torch.cuda.current_stream().wait_event(_prepack_event)
+        _prepack_event = None
+
+
 # ----------------------------------------------------------------------------------------------
 # DropPath keep / scale vectors, drawn in bulk.  Every residual of the backbone needs n x B per-sample factors
 # bernoulli(keep) / keep (timm DropPath, swin_transformer_mtlora.py:388-426): 22 draws per Swin-T step = 44 tiny launches
@@ -169,6 +186,7 @@ class LinearMeta:
     n_scale_t: int = 0        # >0: per-task scales are trainable Parameters passed after B_t
     n_gate: int = 0           # >0: x (and x_t) = gelu(gate): the LAST n_gate args are the pre-activations; dx *= gelu'(gate)
     gelu_out: bool = False    # also return gelu(y) for every output (fc1 of the Mlp): outputs = (y_s, *y_t, a_s, *a_t)
+    pack_buf: Optional[torch.Tensor] = None  # packed factors filled ahead of the call (MTLoRALinear.prepack; desc.pack, ABI v4)
 
     @property
     def T(self) -> int:
@@ -187,6 +205,8 @@ class LinearMeta:
         d.dropout_p = self.dropout_p
         d.seed = self.seed
         d.seed_offset = 0 if _seed_offset is None else _seed_offset.data_ptr()
+        if self.pack_buf is not None:
+            d.pack, d.prepacked = self.pack_buf.data_ptr(), 1
         return d
 
 

@@ -14,10 +14,9 @@ main.py:192-204 (loss weights), main.py:329-354 + utils.py:348-375 (train step).
 from __future__ import annotations
 
 import contextlib
-
-from typing import Dict, List, Mapping, Optional, Sequence
-
+import ctypes
 import os
+from typing import Dict, List, Mapping, Optional, Sequence
 
 import torch
 import torch.nn as nn
@@ -25,7 +24,7 @@ import torch.nn.functional as F
 
 from . import functional as Fn
 from .functional import BatchNormReluFn, UpsampleLossFn
-from .lora import mark_only_lora_as_trainable
+from .lora import MTLoRALinear, mark_only_lora_as_trainable
 from .swin_transformer_mtlora import SwinTransformerMTLoRA
 
 NUM_OUTPUT = {"semseg": 21, "normals": 3, "sal": 1, "human_parts": 7, "depth": 1, "edge": 1}  # data/mtl_ds.py:749-780
@@ -417,6 +416,38 @@ def _factor_side_stream(device):
     return _factor_streams[key]
 
 
+_PREPACK = os.environ.get("MTLORA_PREPACK", "0") == "1"
+
+
+def _prepack_linears(model, device) -> None:
+    """pack the low-rank factors of every MTLoRALinear for the coming forward on the side stream (``MTLoRALinear.prepack``):
+    48 small k_pack launches leave the forward's critical path (they depend on parameters only, i.e. can run as soon as the
+    previous optimizer step is done).  OPT-IN (MTLORA_PREPACK=1): measured neutral at C2 (925 vs 928 img/s) -- the step boundary
+    has nothing on the main stream for the packs to overlap with except the patch embedding, and the host issues the 48 launches
+    before it can start issuing the forward; bit-identical to the in-line packing (test_prepacked_factors_are_bit_identical)."""
+    if not _PREPACK or torch.cuda.is_current_stream_capturing():
+        return
+    side = _factor_side_stream(device)
+    if side is None:
+        return
+    mods = getattr(model, "_mtl_linears", None)
+    if mods is None:
+        mods = [m for m in model.modules() if isinstance(m, MTLoRALinear) and m.r > 0]
+        try:
+            model._mtl_linears = mods
+        except Exception:  # noqa: BLE001
+            pass
+    if not mods:
+        return
+    side.wait_stream(torch.cuda.current_stream(device))  # after the optimizer step and the previous backward's reads
+    sp = ctypes.c_void_p(side.cuda_stream)
+    n = sum(1 for m in mods if m.prepack(sp))
+    if n:
+        ev = torch.cuda.Event()
+        ev.record(side)
+        Fn.set_prepack_event(ev)
+
+
 def train_step(model, criterion, optimizer, images, targets, clip_grad: float = 5.0, reducer=None,
                amp_dtype: Optional[torch.dtype] = torch.bfloat16, fused_loss: bool = True):
     """one reference train step (main.py:329-354): autocast fwd + weighted multi-task loss, backward,
@@ -432,6 +463,7 @@ def train_step(model, criterion, optimizer, images, targets, clip_grad: float = 
 
     if images.is_cuda:
         Fn.droppath_begin_step(images.device)  # DropPath factors of the whole step from one draw (functional._DropPathPool)
+        _prepack_linears(model, images.device)  # (opt-in) every layer's k_pack on the side stream
     try:
         if amp_dtype is not None:
             with torch.autocast("cuda", dtype=amp_dtype):

@@ -375,3 +375,38 @@ def test_graphed_train_step_replays_the_eager_step():
     num = sum((out[0][1][n] * out[1][1][n]).sum().item() for n in out[0][1])
     den = (sum((out[0][1][n] ** 2).sum().item() for n in out[0][1]) * sum((out[1][1][n] ** 2).sum().item() for n in out[1][1])) ** 0.5
     assert num / den >= 0.98, num / den
+
+
+@pytest.mark.gpu
+def test_prepacked_factors_are_bit_identical():
+    """train_step packs every MTLoRALinear's low-rank factors on the side stream at the start of the step
+    (MTLoRALinear.prepack -> mtlora_linear_pack, desc.pack of ABI v4) instead of a k_pack launch inside each layer's forward:
+    three steps must leave loss and every parameter bit-identical to the in-line packing, and the layers must really have
+    consumed their persistent buffers."""
+    from mtlora_amd import functional as Fn
+    from mtlora_amd import mtl_harness as H
+    from mtlora_amd.lora import MTLoRALinear
+    tasks = ["semseg", "normals", "sal", "human_parts"]
+    img, tg = H.synthetic_batch(2, 224, tasks, seed=19, device=dev())
+    runs = []
+    keep = H._PREPACK
+    try:
+        for on in (False, True):
+            H._PREPACK = on
+            torch.manual_seed(5)
+            Fn._seed_counter = 0
+            Fn.droppath_reset()
+            model = H.build_model(img_size=224, tasks=tasks, depths=(2, 2, 2, 2), r_shared=16, r_task=4, seed=3).to(dev()).train()
+            crit, opt = H.MultiTaskLoss(tasks), H.build_optimizer(model, lr=1e-3)
+            losses = [H.train_step(model, crit, opt, img, tg)[0].clone() for _ in range(3)]
+            torch.cuda.synchronize()
+            lin = [m for m in model.modules() if isinstance(m, MTLoRALinear) and m.r > 0]
+            used = sum(1 for m in lin if m._pack_state is not None and not m._pack_state["ready"])
+            assert used == (len(lin) if on else 0), (used, len(lin))
+            runs.append((losses, {n: p.detach().clone() for n, p in model.named_parameters()}))
+    finally:
+        H._PREPACK = keep
+    for a, b in zip(runs[0][0], runs[1][0]):
+        assert torch.equal(a, b), (a.item(), b.item())
+    for n in runs[0][1]:
+        assert torch.equal(runs[0][1][n], runs[1][1][n]), n

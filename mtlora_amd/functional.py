@@ -210,6 +210,32 @@ class LinearMeta:
         return d
 
 
+def _as2d(t: torch.Tensor, cols: int, dtype: torch.dtype) -> torch.Tensor:
+    """t viewed as a contiguous (-1, cols) matrix of ``dtype`` (no op at all in the common case)."""
+    if t.dtype == dtype and t.is_contiguous():
+        return t.view(-1, cols)
+    return t.reshape(-1, cols).to(dtype).contiguous()
+
+
+def _f32c(p):
+    """fp32 contiguous view of a factor (Parameters already are: used as they come, autograd is off inside Function.forward)."""
+    if p is None or (p.dtype == torch.float32 and p.is_contiguous()):
+        return p
+    return p.detach().float().contiguous()
+
+
+_bytes_cache: dict = {}  # (kind, M, K, N, r_s, r_t, T-independent fields ...) -> ctx / scratch bytes (one ctypes call per new shape)
+
+
+def _desc_bytes(kind: str, fn, meta: "LinearMeta", M: int, d) -> int:
+    key = (kind, M, meta.K, meta.N, meta.r_s, meta.r_t, meta.has_x_tasks, meta.dtype, meta.mode)
+    v = _bytes_cache.get(key)
+    if v is None:
+        v = fn(ctypes.byref(d))
+        _bytes_cache[key] = v
+    return v
+
+
 class MTLoRALinearFn(torch.autograd.Function):
     """(y_s, y_t[0..T-1]) = f(x, x_t[0..T-1], A_s, B_s, A_t[..], B_t[..]); W (and bias) frozen by default.
 
@@ -228,21 +254,20 @@ class MTLoRALinearFn(torch.autograd.Function):
         x_t, A_t, B_t = list(rest[:nx]), list(rest[nx:nx + T]), list(rest[nx + T:nx + 2 * T])
         L.require_gpu(x, W_c, *x_t)
         lead = x.shape[:-1]
-        x2 = x.reshape(-1, meta.K).to(meta.dtype).contiguous()
-        xt2 = [t.reshape(-1, meta.K).to(meta.dtype).contiguous() for t in x_t]
+        x2 = _as2d(x, meta.K, meta.dtype)
+        xt2 = [_as2d(t, meta.K, meta.dtype) for t in x_t]
         M = x2.shape[0]
         d = meta.desc(M)
         lib = L.lib()
-        ctx_bytes = lib.mtlora_linear_ctx_bytes(ctypes.byref(d))
+        ctx_bytes = _desc_bytes("ctx", lib.mtlora_linear_ctx_bytes, meta, M, d)
         if ctx_bytes < 0:
             raise RuntimeError(f"mtlora_amd: invalid MTLoRALinear shape M={M} K={meta.K} N={meta.N} (K, N must be "
                                "multiples of 8)")
         ctxbuf = torch.empty(ctx_bytes, dtype=torch.uint8, device=x.device)
         ys = torch.empty((M, meta.N), dtype=meta.dtype, device=x.device)
         yt = [torch.empty((M, meta.N), dtype=meta.dtype, device=x.device) for _ in range(T)]
-        fl = lambda p: None if p is None else p.detach().float().contiguous()
-        A_s_c, B_s_c = fl(A_s), fl(B_s)
-        A_t_c, B_t_c = [fl(a) for a in A_t], [fl(b) for b in B_t]
+        A_s_c, B_s_c = _f32c(A_s), _f32c(B_s)
+        A_t_c, B_t_c = [_f32c(a) for a in A_t], [_f32c(b) for b in B_t]
         acts = []
         if meta.gelu_out:  # second outputs gelu(y) written by the same epilogue (mtlora_linear_fwd_gelu)
             acts = [torch.empty((M, meta.N), dtype=meta.dtype, device=x.device) for _ in range(1 + T)]
@@ -287,11 +312,11 @@ class MTLoRALinearFn(torch.autograd.Function):
             xt2, gates = xt2[:nx], xt2[nx:]
         M = x2.shape[0]
         dev = x2.device
-        g2 = [None if g is None else g.reshape(-1, meta.N).to(meta.dtype).contiguous() for g in grads]
+        g2 = [None if g is None else _as2d(g, meta.N, meta.dtype) for g in grads]
         dy_s, dy_t = g2[0], g2[1:1 + T]
         d = meta.desc(M)
         lib = L.lib()
-        scratch_bytes = lib.mtlora_linear_bwd_scratch_bytes(ctypes.byref(d))
+        scratch_bytes = _desc_bytes("bwd", lib.mtlora_linear_bwd_scratch_bytes, meta, M, d)
         scratch = torch.empty(scratch_bytes, dtype=torch.uint8, device=dev)
         need = ctx.needs_input_grad  # (meta, x, W_c, Wt_c, bias_f32, W_master, bias_master, A_s, B_s, scale_s, *rest)
         dx = torch.empty((M, meta.K), dtype=meta.dtype, device=dev)

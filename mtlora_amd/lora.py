@@ -218,8 +218,7 @@ class MTLoRALinear(LoRALayer):
         returns the gradients w.r.t. h.
         gelu_out=True: returns ``(y, y_tasks, gelu(y), {t: gelu(y_tasks[t])})``, the activations written by the same kernel;
         a gradient reaching them is taken as a gradient w.r.t. y (see ``gelu_gate``): only for that pairing."""
-        Fn.L.require_gpu(x)
-        dtype = Fn.compute_dtype(x)
+        dtype = Fn.compute_dtype(x)  # (device checks: MTLoRALinearFn.forward)
         wc, wt, bf = self._weights(dtype)
         has_lora = self.r > 0
         tasks = list(self.tasks) if (has_lora and self.tasks is not None) else []

@@ -265,17 +265,60 @@ __global__ __launch_bounds__(256) void k_ln_fwd(const LnParams p) {
         if constexpr (RES) {  // x_new = shortcut + s * branch, stored (rounded to the stream dtype) and normalised
             const TO* rb = reinterpret_cast<const TO*>(rb_ptr);
             TI* xs = reinterpret_cast<TI*>(xs_ptr);
+            // the branch vectors and the per-sample scales are fetched for ALL row groups before the first x_new store: the
+            // compiler cannot move a load above a store that may alias it, so loading inside the store loop left one branch
+            // vector in flight at a time (the shortcut loads above are already issued back to back)
+            constexpr bool PRE = sizeof(TO) * VE <= 16;  // a branch vector fits one 16-byte register (all but fp32 branch / bf16 x)
+            u32x4 braw[PRE ? UNR : 1][PRE ? MAXV : 1];
+            float scv[UNR];
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const bool rok = row[u] < p.M;
+                scv[u] = (rok && rscale) ? rscale[row_div(row[u], p.rows_per_sample, p.M)] : 1.f;
+                if constexpr (PRE) {
+#pragma unroll
+                    for (int i = 0; i < MAXV; ++i) {
+                        const int v = lr + i * LPR;
+                        u32x4 b = {0u, 0u, 0u, 0u};
+                        if (rok && v < nvec) {
+                            if constexpr (sizeof(TO) * VE == 16) {
+                                b = *reinterpret_cast<const u32x4*>(rb + xbs[u] + coff[i]);
+                            } else {
+                                const u32x2 h2 = *reinterpret_cast<const u32x2*>(rb + xbs[u] + coff[i]);
+                                b[0] = h2[0];
+                                b[1] = h2[1];
+                            }
+                        }
+                        braw[u][i] = b;
+                    }
+                }
+            }
 #pragma unroll
             for (int u = 0; u < UNR; ++u) {
                 if (row[u] >= p.M) continue;
-                const float sc = rscale ? rscale[row_div(row[u], p.rows_per_sample, p.M)] : 1.f;
+                const float sc = scv[u];
 #pragma unroll
                 for (int i = 0; i < MAXV; ++i) {
                     const int v = lr + i * LPR;
                     if (v < nvec) {
                         float fb[8], fx[8];
                         // (branch and x_new share the layout of x: plain rows, or the token tensor of the merge gather)
-                        ld_n<TO, VE>(rb + xbs[u] + coff[i], fb);
+                        if constexpr (!PRE) {
+                            ld_n<TO, VE>(rb + xbs[u] + coff[i], fb);
+                        } else if constexpr (sizeof(TO) == 4) {
+                            const f32x4 q4 = __builtin_bit_cast(f32x4, braw[u][i]);
+                            fb[0] = q4[0];
+                            fb[1] = q4[1];
+                            fb[2] = q4[2];
+                            fb[3] = q4[3];
+                        } else if constexpr (VE == 8) {
+                            cvt_vec<bf16>(braw[u][i], fb);
+                        } else {
+                            fb[0] = __builtin_bit_cast(float, braw[u][i][0] << 16);
+                            fb[1] = __builtin_bit_cast(float, braw[u][i][0] & 0xFFFF0000u);
+                            fb[2] = __builtin_bit_cast(float, braw[u][i][1] << 16);
+                            fb[3] = __builtin_bit_cast(float, braw[u][i][1] & 0xFFFF0000u);
+                        }
                         cvt_vec<TI>(raw[u][i], fx);
 #pragma unroll
                         for (int e = 0; e < VE; ++e) fx[e] += sc * fb[e];
@@ -384,7 +427,7 @@ __global__ __launch_bounds__(256) void k_ln_bwd(const LnParams p) {
         u32x4 rx[UNR][MAXV], ra[UNR][MAXV];
         uint32_t rg[UNR][MAXV][GW];
         int64_t row[UNR], xb[UNR];
-        float mean[UNR], rstd[UNR];
+        float mean[UNR], rstd[UNR], scv[UNR];
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
             row[u] = r0 + (int64_t)(wave * UNR + u) * RPW + sub;
@@ -392,6 +435,8 @@ __global__ __launch_bounds__(256) void k_ln_bwd(const LnParams p) {
             xb[u] = ln_row(p, rv ? row[u] : 0).base;
             mean[u] = rv ? mean_in[row[u]] : 0.f;
             rstd[u] = rv ? rstd_in[row[u]] : 0.f;
+            // (fetched with the other operands: a load placed after the dx stores cannot be hoisted above them)
+            scv[u] = (rv && dbr_ptr && rscale_in) ? rscale_in[row_div(row[u], p.rows_per_sample, p.M)] : 1.f;
 #pragma unroll
             for (int i = 0; i < MAXV; ++i) {
                 const int v = lr + i * LPR;
@@ -464,7 +509,7 @@ __global__ __launch_bounds__(256) void k_ln_bwd(const LnParams p) {
                         for (int e = 0; e < VE; ++e) o[e] = rstd[u] * (gy[i][e] - c1 - xh[i][e] * c2) + fa[e];
                         st_vec<TX, VE>(dx + xb[u] + coff[i], o);
                         if (dbr_ptr) {  // gradient of the residual branch (layout of x / dx): DropPath scale, dtype of dy
-                            const float sc = rscale_in ? rscale_in[row_div(row[u], p.rows_per_sample, p.M)] : 1.f;
+                            const float sc = scv[u];
 #pragma unroll
                             for (int e = 0; e < VE; ++e) o[e] *= sc;
                             st_vec<TG, VE>(reinterpret_cast<TG*>(dbr_ptr) + xb[u] + coff[i], o);

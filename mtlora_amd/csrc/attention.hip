@@ -460,12 +460,15 @@ __global__ __launch_bounds__(64, 2) void k_attn_fwd(const AttnParams p) {
     const RowIds<T> ids = row_ids<T>(p, lane);
     const int lane_tyx = pack_tyx(p, lane < p.N ? lane : 0);
     RowRegs<T> rq, rk, rv;
+    int rid_next = 0;  // region id of this lane's token in the prefetched window (a load at the top of the iteration, right
+                       // in front of its LDS store, exposed one L2 round trip per window of every shifted block)
     auto prefetch = [&](int64_t w) __attribute__((always_inline)) {
         int64_t off[AC<T>::VPR];
         row_offsets<T>(off, p, win_pos(p, w), ids);
         load_rows<T>(rq, qkv + head * HD, C3, off, lane);
         load_rows<T>(rk, qkv + p.C + head * HD, C3, off, lane);
         load_rows<T>(rv, qkv + 2 * p.C + head * HD, C3, off, lane);
+        rid_next = (p.mask_ids && lane < p.N) ? p.mask_ids[(int)(w % nWimg) * p.N + lane] : 0;
     };
     if (g < p.n_windows) prefetch(g);
 
@@ -473,7 +476,7 @@ __global__ __launch_bounds__(64, 2) void k_attn_fwd(const AttnParams p) {
         const int wm = (int)(w % nWimg);
         __syncthreads();  // previous item's LDS reads are done
         tok[lane] = lane < p.N ? (int)token_at(p, win_pos(p, w), lane, lane_tyx) : 0;
-        srid[lane] = (p.mask_ids && lane < p.N) ? p.mask_ids[wm * p.N + lane] : 0;
+        srid[lane] = rid_next;
         store_rows<T>(sQ, rq, p.N, lane);
         store_rows<T>(sK, rk, p.N, lane);
         store_rows<T>(sV, rv, p.N, lane);
@@ -544,6 +547,7 @@ __global__ __launch_bounds__(64, 1) void k_attn_bwd(const AttnParams p) {
     const RowIds<T> ids = row_ids<T>(p, lane);
     const int lane_tyx = pack_tyx(p, lane < p.N ? lane : 0);
     RowRegs<T> rq, rk, rv, ro;
+    int rid_next = 0;  // (as in k_attn_fwd)
     auto prefetch = [&](int64_t w) __attribute__((always_inline)) {
         int64_t off[AC<T>::VPR];
         row_offsets<T>(off, p, win_pos(p, w), ids);
@@ -551,13 +555,14 @@ __global__ __launch_bounds__(64, 1) void k_attn_bwd(const AttnParams p) {
         load_rows<T>(rk, qkv + p.C + head * HD, C3, off, lane);
         load_rows<T>(rv, qkv + 2 * p.C + head * HD, C3, off, lane);
         load_rows<T>(ro, dout + head * HD, (int64_t)p.C, off, lane);
+        rid_next = (p.mask_ids && lane < p.N) ? p.mask_ids[(int)(w % nWimg) * p.N + lane] : 0;
     };
     if (g < p.n_windows) prefetch(g);
     for (int64_t w = g; w < p.n_windows; w += p.G) {
         const int wm = (int)(w % nWimg);
         __syncthreads();
         tok[lane] = lane < p.N ? (int)token_at(p, win_pos(p, w), lane, lane_tyx) : 0;
-        srid[lane] = (p.mask_ids && lane < p.N) ? p.mask_ids[wm * p.N + lane] : 0;
+        srid[lane] = rid_next;
         store_rows<T>(sQ, rq, p.N, lane);
         store_rows<T>(sK, rk, p.N, lane);
         store_rows<T>(sV, rv, p.N, lane);

@@ -88,7 +88,8 @@ class _DropPathPool:
 
     def begin(self, device):
         self.rec, self.at, self.in_step = [], 0, True
-        self.active = bool(self.plan) and not torch.cuda.is_current_stream_capturing()
+        capturing = torch.device(device).type == "cuda" and torch.cuda.is_current_stream_capturing()
+        self.active = bool(self.plan) and not capturing
         if not self.active:
             return
         key = (tuple(self.plan), str(device))

@@ -308,3 +308,42 @@ def test_grad_reducer_two_ranks_gloo(tmp_path):
     outs = [p.communicate(timeout=240)[0] for p in procs]
     for p, o in zip(procs, outs):
         assert p.returncode == 0 and "OK" in o, o
+
+
+def test_droppath_pool_plan_and_fallback():
+    """functional._DropPathPool (host logic, device-agnostic): the requests of one announced step are the plan of the next; a
+    planned step serves views of ONE bulk tensor with values in {0, 1/keep}; a deviating request falls back to its own draw and
+    re-records the plan; outside an announced step every request draws on its own."""
+    from mtlora_amd import functional as Fn
+    Fn.droppath_reset()
+    d = torch.device("cpu")
+    reqs = [(1, 16, 0.9), (5, 16, 0.8), (1, 16, 0.5)]
+    lone = Fn.droppath_scale(2, 16, 0.7, d)  # no step announced
+    assert lone.shape == (2, 16)
+    Fn.droppath_begin_step(d)
+    a = [Fn.droppath_scale(n, B, k, d) for n, B, k in reqs]
+    Fn.droppath_end_step()
+    assert len({t.untyped_storage().data_ptr() for t in a}) == 3  # recorded, drawn one by one
+    torch.manual_seed(1)
+    Fn.droppath_begin_step(d)
+    b = [Fn.droppath_scale(n, B, k, d) for n, B, k in reqs]
+    Fn.droppath_end_step()
+    assert len({t.untyped_storage().data_ptr() for t in b}) == 1  # one bulk draw
+    for (n, B, k), t in zip(reqs, b):
+        assert t.shape == (n, B) and bool(((t == 0) | ((t - 1.0 / k).abs() < 1e-6)).all())
+    torch.manual_seed(1)
+    Fn.droppath_begin_step(d)
+    c = [Fn.droppath_scale(n, B, k, d) for n, B, k in reqs]
+    Fn.droppath_end_step()
+    assert all(torch.equal(x, y) for x, y in zip(b, c))  # reproducible under the global generator
+    Fn.droppath_begin_step(d)
+    first = Fn.droppath_scale(1, 16, 0.9, d)          # as planned
+    odd = Fn.droppath_scale(3, 16, 0.8, d)            # deviates: own draw, pool off for the rest of the step
+    rest = Fn.droppath_scale(1, 16, 0.5, d)
+    Fn.droppath_end_step()
+    assert odd.shape == (3, 16) and rest.untyped_storage().data_ptr() != first.untyped_storage().data_ptr()
+    Fn.droppath_begin_step(d)                          # the deviating sequence is the new plan
+    again = [Fn.droppath_scale(1, 16, 0.9, d), Fn.droppath_scale(3, 16, 0.8, d), Fn.droppath_scale(1, 16, 0.5, d)]
+    Fn.droppath_end_step()
+    assert len({t.untyped_storage().data_ptr() for t in again}) == 1
+    Fn.droppath_reset()

@@ -249,7 +249,11 @@ template <typename T>
 struct IMG;
 template <>
 struct IMG<bf16> {
-    static constexpr int RS = 64 * 2 + 16;
+    // 152 B = 38 dwords: the 32 query rows of an img_store (8 bytes per lane) start at 38 i mod 64 = every even bank exactly once
+    // -> the 64 banks are hit once per wave-instruction.  With 144 B (36 dwords) rows i and i + 16 shared their banks: a 2-way
+    // conflict on every P / dS hand-over store (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE 0.25 for k_attn_bwd,
+    // profiles/r02_pmc_sq_after_attn_staging_map.csv).  The transposing reads (4 rows x 32 B per 16-lane group) stay disjoint.
+    static constexpr int RS = 64 * 2 + 24;
 };
 template <>
 struct IMG<float> {

@@ -29,7 +29,9 @@ extern "C" {
 typedef enum mtlora_dtype {
     MTLORA_F32 = 0,  /* exact-f32 MFMA path (v_mfma_f32_32x32x2_f32) */
     MTLORA_BF16 = 1, /* bf16 in/out, fp32 accumulate (v_mfma_f32_32x32x16_bf16) */
-    MTLORA_F16 = 2   /* window_process copies only */
+    MTLORA_F16 = 2   /* fp16 in/out, fp32 accumulate (v_mfma_f32_32x32x16_f16): MTLoRALinear, window attention, gemm_tn and the
+                        window_process copies -- the reference's default autocast dtype (main.py:341); the block-glue entries
+                        (LayerNorm, residuals, BatchNorm, upsample, loss) take fp32 / bf16 only */
 } mtlora_dtype;
 
 typedef enum mtlora_status {
@@ -85,7 +87,7 @@ int mtlora_window_merge_and_roll_backward(const void* grad_image, void* grad_win
  * ------------------------------------------------------------------------------------------ */
 typedef struct mtlora_linear_desc {
     int64_t M, K, N;
-    int32_t dtype;      /* MTLORA_F32 | MTLORA_BF16 */
+    int32_t dtype;      /* MTLORA_F32 | MTLORA_BF16 | MTLORA_F16 */
     int32_t mode;       /* 0 = 'matrix', 1 = 'matrixv2' (lora.py:259-274) */
     int32_t T;          /* number of task outputs, 0..MTLORA_MAX_TASKS (0 <=> tasks is None) */
     int32_t r_s;        /* shared rank, 0 = no shared update */

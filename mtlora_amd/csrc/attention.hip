@@ -38,6 +38,8 @@ struct AC<bf16> {
     static constexpr int VPR = 4;   // 16-byte vectors per row
 };
 template <>
+struct AC<f16> : AC<bf16> {};  // same 16-bit geometry
+template <>
 struct AC<float> {
     static constexpr int KT_D = 2;
     static constexpr int KT_N = 4;
@@ -208,7 +210,8 @@ __device__ __forceinline__ Frag<T> rowfrag(const unsigned char* s, int sub, int 
 
 // operand whose MFMA rows are the 32 COLUMNS (d) of the image, k = image rows of k-tile kt, slot order =
 // accumulator order: slot (h, r) <-> row kt*KE + (r&3) + 8(r>>2) + 4h
-__device__ __forceinline__ Frag<bf16> colfrag(const unsigned char* s, int kt, int lane, int n, bf16*) {
+template <typename H>  // 16-bit element types: the transposing read moves bits
+__device__ __forceinline__ Frag<H> colfrag16(const unsigned char* s, int kt, int lane, int n) {
     const int g = lane >> 4, i = lane & 15, h = g >> 1;
     const int col = 16 * (g & 1) + 4 * (i & 3);
     uint32_t w[8];
@@ -222,10 +225,16 @@ __device__ __forceinline__ Frag<bf16> colfrag(const unsigned char* s, int kt, in
         w[2 * q] = u[0];
         w[2 * q + 1] = u[1];
     }
-    Frag<bf16> f;
+    Frag<H> f;
     f.v[0] = u32x4{w[0], w[1], w[2], w[3]};
     f.v[1] = u32x4{w[4], w[5], w[6], w[7]};
     return f;
+}
+__device__ __forceinline__ Frag<bf16> colfrag(const unsigned char* s, int kt, int lane, int n, bf16*) {
+    return colfrag16<bf16>(s, kt, lane, n);
+}
+__device__ __forceinline__ Frag<f16> colfrag(const unsigned char* s, int kt, int lane, int n, f16*) {
+    return colfrag16<f16>(s, kt, lane, n);
 }
 __device__ __forceinline__ Frag<float> colfrag(const unsigned char* s, int kt, int lane, int n, float*) {
     const int h = lane >> 5, d = lane & 31;
@@ -256,6 +265,8 @@ struct IMG<bf16> {
     static constexpr int RS = 64 * 2 + 24;
 };
 template <>
+struct IMG<f16> : IMG<bf16> {};
+template <>
 struct IMG<float> {
     static constexpr int RS = 64 * 4 + 16;
 };
@@ -272,13 +283,14 @@ __device__ __forceinline__ void img_store(unsigned char* img, const f32x16 (&a)[
                 *reinterpret_cast<f32x4*>(img + il * IMG<float>::RS + j0 * 4) =
                     f32x4{a[sj][4 * q], a[sj][4 * q + 1], a[sj][4 * q + 2], a[sj][4 * q + 3]};
             } else {
-                *reinterpret_cast<bf16x4*>(img + il * IMG<bf16>::RS + j0 * 2) =
-                    bf16x4{(bf16)a[sj][4 * q], (bf16)a[sj][4 * q + 1], (bf16)a[sj][4 * q + 2], (bf16)a[sj][4 * q + 3]};
+                *reinterpret_cast<u32x2*>(img + il * IMG<bf16>::RS + j0 * 2) =
+                    u32x2{mtl_pack2<T>(a[sj][4 * q], a[sj][4 * q + 1]), mtl_pack2<T>(a[sj][4 * q + 2], a[sj][4 * q + 3])};
             }
         }
 }
 // MFMA rows = image columns [col0, col0 + 32), k = image rows of k-tile kt
-__device__ __forceinline__ Frag<bf16> imgfrag(const unsigned char* s, int col0, int kt, int lane, bf16*) {
+template <typename H>
+__device__ __forceinline__ Frag<H> imgfrag16(const unsigned char* s, int col0, int kt, int lane) {
     const int g = lane >> 4, i = lane & 15, h = g >> 1;
     const int col = col0 + 16 * (g & 1) + 4 * (i & 3);
     uint32_t w[8];
@@ -291,10 +303,16 @@ __device__ __forceinline__ Frag<bf16> imgfrag(const unsigned char* s, int col0, 
         w[2 * q] = u[0];
         w[2 * q + 1] = u[1];
     }
-    Frag<bf16> f;
+    Frag<H> f;
     f.v[0] = u32x4{w[0], w[1], w[2], w[3]};
     f.v[1] = u32x4{w[4], w[5], w[6], w[7]};
     return f;
+}
+__device__ __forceinline__ Frag<bf16> imgfrag(const unsigned char* s, int col0, int kt, int lane, bf16*) {
+    return imgfrag16<bf16>(s, col0, kt, lane);
+}
+__device__ __forceinline__ Frag<f16> imgfrag(const unsigned char* s, int col0, int kt, int lane, f16*) {
+    return imgfrag16<f16>(s, col0, kt, lane);
 }
 __device__ __forceinline__ Frag<float> imgfrag(const unsigned char* s, int col0, int kt, int lane, float*) {
     const int h = lane >> 5, d = lane & 31;
@@ -322,6 +340,13 @@ __device__ __forceinline__ Frag<bf16> regfrag(const f32x16 (&acc)[2], int kt, bf
     f.v[1] = u32x4{pack_bf16(a[8], a[9]), pack_bf16(a[10], a[11]), pack_bf16(a[12], a[13]), pack_bf16(a[14], a[15])};
     return f;
 }
+__device__ __forceinline__ Frag<f16> regfrag(const f32x16 (&acc)[2], int kt, f16*) {
+    Frag<f16> f;
+    const f32x16& a = acc[kt];
+    f.v[0] = u32x4{mtl_pack_f16(a[0], a[1]), mtl_pack_f16(a[2], a[3]), mtl_pack_f16(a[4], a[5]), mtl_pack_f16(a[6], a[7])};
+    f.v[1] = u32x4{mtl_pack_f16(a[8], a[9]), mtl_pack_f16(a[10], a[11]), mtl_pack_f16(a[12], a[13]), mtl_pack_f16(a[14], a[15])};
+    return f;
+}
 __device__ __forceinline__ Frag<float> regfrag(const f32x16 (&acc)[2], int kt, float*) {
     Frag<float> f;
     const f32x16& a = acc[kt >> 1];
@@ -347,9 +372,8 @@ __device__ __forceinline__ void store_dt(T* base, int64_t tok_off, const f32x16&
         if constexpr (sizeof(T) == 4) {
             *reinterpret_cast<f32x4*>(dst) = f32x4{a[4 * q] * mul, a[4 * q + 1] * mul, a[4 * q + 2] * mul, a[4 * q + 3] * mul};
         } else {
-            bf16x4 pk = {(bf16)(a[4 * q] * mul), (bf16)(a[4 * q + 1] * mul), (bf16)(a[4 * q + 2] * mul),
-                         (bf16)(a[4 * q + 3] * mul)};
-            *reinterpret_cast<bf16x4*>(dst) = pk;
+            const u32x2 pk = {mtl_pack2<T>(a[4 * q] * mul, a[4 * q + 1] * mul), mtl_pack2<T>(a[4 * q + 2] * mul, a[4 * q + 3] * mul)};
+            *reinterpret_cast<u32x2*>(dst) = pk;
         }
     }
 }
@@ -694,7 +718,7 @@ __global__ __launch_bounds__(256) void k_dbias_reduce(const float* part, float* 
 
 int check(const mtlora_attn_desc* d) {
     if (!d) return MTLORA_ERR_NULL;
-    if (d->dtype != MTLORA_F32 && d->dtype != MTLORA_BF16) return MTLORA_ERR_DTYPE;
+    if (d->dtype != MTLORA_F32 && d->dtype != MTLORA_BF16 && d->dtype != MTLORA_F16) return MTLORA_ERR_DTYPE;
     if (d->head_dim != HD) return MTLORA_ERR_UNSUPPORTED;
     if (d->window_size <= 0 || d->window_size * d->window_size > AN) return MTLORA_ERR_UNSUPPORTED;
     if (d->B < 0 || d->H <= 0 || d->W <= 0 || d->num_heads <= 0) return MTLORA_ERR_SHAPE;
@@ -787,6 +811,11 @@ int mtlora_window_attn_fwd(const mtlora_attn_desc* d, const void* qkv, const flo
             hipLaunchKernelGGL((k_attn_fwd<float, true>), dim3(grid), dim3(64), lds, s, p);
         else
             hipLaunchKernelGGL((k_attn_fwd<float, false>), dim3(grid), dim3(64), lds, s, p);
+    } else if (d->dtype == MTLORA_F16) {
+        if (dense)
+            hipLaunchKernelGGL((k_attn_fwd<f16, true>), dim3(grid), dim3(64), lds, s, p);
+        else
+            hipLaunchKernelGGL((k_attn_fwd<f16, false>), dim3(grid), dim3(64), lds, s, p);
     } else {
         if (dense)
             hipLaunchKernelGGL((k_attn_fwd<bf16, true>), dim3(grid), dim3(64), lds, s, p);
@@ -831,6 +860,11 @@ int mtlora_window_attn_bwd(const mtlora_attn_desc* d, const void* qkv, const flo
                 hipLaunchKernelGGL((k_attn_bwd<float, true>), dim3(grid), dim3(64), lds, s, p);
             else
                 hipLaunchKernelGGL((k_attn_bwd<float, false>), dim3(grid), dim3(64), lds, s, p);
+        } else if (d->dtype == MTLORA_F16) {
+            if (dense)
+                hipLaunchKernelGGL((k_attn_bwd<f16, true>), dim3(grid), dim3(64), lds, s, p);
+            else
+                hipLaunchKernelGGL((k_attn_bwd<f16, false>), dim3(grid), dim3(64), lds, s, p);
         } else {
             if (dense)
                 hipLaunchKernelGGL((k_attn_bwd<bf16, true>), dim3(grid), dim3(64), lds, s, p);

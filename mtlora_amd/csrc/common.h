@@ -8,6 +8,9 @@
 typedef __bf16 bf16;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef _Float16 f16;  // IEEE half: the reference's default autocast dtype (main.py:341); same MFMA rate as bf16 on gfx950
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
@@ -38,7 +41,7 @@ static inline void mtl_zero_async(void* p, size_t bytes, hipStream_t s) {
 
 __host__ __device__ static inline int64_t mtl_ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline int64_t mtl_round_up(int64_t a, int64_t b) { return mtl_ceil_div(a, b) * b; }
-static inline int mtl_elem_size(int dtype) { return dtype == MTLORA_F32 ? 4 : 2; }
+static inline int mtl_elem_size(int dtype) { return dtype == MTLORA_F32 ? 4 : 2; }  // bf16 and f16: 2
 
 // ---------------------------------------------------------------------------------------------
 // counter-based dropout (restated in oracle/mtlora_oracle.py:dropout_keep_mask)
@@ -108,15 +111,23 @@ struct ET<bf16> {
     static constexpr int VEC = 8;
     static constexpr int DT = MTLORA_BF16;
 };
+template <>
+struct ET<f16> {
+    static constexpr int VEC = 8;
+    static constexpr int DT = MTLORA_F16;
+};
 
 __device__ __forceinline__ float mtl_to_f32(float v) { return v; }
 __device__ __forceinline__ float mtl_to_f32(bf16 v) { return (float)v; }
+__device__ __forceinline__ float mtl_to_f32(f16 v) { return (float)v; }
 template <typename T>
 __device__ __forceinline__ T mtl_from_f32(float v);
 template <>
 __device__ __forceinline__ float mtl_from_f32<float>(float v) { return v; }
 template <>
 __device__ __forceinline__ bf16 mtl_from_f32<bf16>(float v) { return (bf16)v; }
+template <>
+__device__ __forceinline__ f16 mtl_from_f32<f16>(float v) { return (f16)v; }
 
 // 16-byte vector view of VEC elements of T
 template <typename T>
@@ -144,6 +155,32 @@ __device__ __forceinline__ uint32_t mtl_pack_bf16(float a, float b) {
     bf16 x = (bf16)a, y = (bf16)b;
     return (uint32_t)__builtin_bit_cast(uint16_t, x) | ((uint32_t)__builtin_bit_cast(uint16_t, y) << 16);
 }
+__device__ __forceinline__ uint32_t mtl_pack_f16(float a, float b) {
+    f16 x = (f16)a, y = (f16)b;  // v_cvt_f16_f32: round to nearest even
+    return (uint32_t)__builtin_bit_cast(uint16_t, x) | ((uint32_t)__builtin_bit_cast(uint16_t, y) << 16);
+}
+// two 16-bit elements of T in one dword <-> two floats (lo = element 0).  bf16: shifts; f16: conversions
+template <typename T>
+__device__ __forceinline__ uint32_t mtl_pack2(float a, float b) {
+    if constexpr (__is_same(T, f16))
+        return mtl_pack_f16(a, b);
+    else
+        return mtl_pack_bf16(a, b);
+}
+template <typename T>
+__device__ __forceinline__ float mtl_lo2(uint32_t w) {
+    if constexpr (__is_same(T, f16))
+        return (float)__builtin_bit_cast(f16, (uint16_t)(w & 0xFFFFu));
+    else
+        return __builtin_bit_cast(float, w << 16);
+}
+template <typename T>
+__device__ __forceinline__ float mtl_hi2(uint32_t w) {
+    if constexpr (__is_same(T, f16))
+        return (float)__builtin_bit_cast(f16, (uint16_t)(w >> 16));
+    else
+        return __builtin_bit_cast(float, w & 0xFFFF0000u);
+}
 template <typename T>
 struct VOps;
 template <>
@@ -170,6 +207,23 @@ struct VOps<bf16> {
             if ((h >> 16) >= c.thr16) keep |= 0xFFFF0000u;
             v[w] &= keep;
         }
+    }
+};
+template <>
+struct VOps<f16> {
+    static constexpr int N = 8;
+    static __device__ __forceinline__ void unpack(const u32x4& v, float (&f)[8]) {
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            f[2 * w] = mtl_lo2<f16>(v[w]);
+            f[2 * w + 1] = mtl_hi2<f16>(v[w]);
+        }
+    }
+    static __device__ __forceinline__ u32x4 pack(const float (&f)[8]) {
+        return u32x4{mtl_pack_f16(f[0], f[1]), mtl_pack_f16(f[2], f[3]), mtl_pack_f16(f[4], f[5]), mtl_pack_f16(f[6], f[7])};
+    }
+    static __device__ __forceinline__ void drop(u32x4& v, const DropoutCfg& c, uint32_t rowhash, uint32_t k) {
+        VOps<bf16>::drop(v, c, rowhash, k);  // zeroing 16-bit lanes: the same bit masks
     }
 };
 template <>
@@ -210,6 +264,10 @@ __device__ __forceinline__ void mtl_mma(const Frag<bf16>& a, const Frag<bf16>& b
                                                 c, 0, 0, 0);
     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a.v[1]), __builtin_bit_cast(bf16x8, b.v[1]),
                                                 c, 0, 0, 0);
+}
+__device__ __forceinline__ void mtl_mma(const Frag<f16>& a, const Frag<f16>& b, f32x16& c) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a.v[0]), __builtin_bit_cast(f16x8, b.v[0]), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a.v[1]), __builtin_bit_cast(f16x8, b.v[1]), c, 0, 0, 0);
 }
 __device__ __forceinline__ void mtl_mma(const Frag<float>& a, const Frag<float>& b, f32x16& c) {
 #pragma unroll

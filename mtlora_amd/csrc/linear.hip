@@ -648,8 +648,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void k_nt(const NtParams 
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const int ml = sm * 32 + (lane & 31), nl = sn * 32 + 8 * q + 4 * (lane >> 5);
-                        u32x2 pk = {mtl_pack_bf16(a[sn][sm][q * 4], a[sn][sm][q * 4 + 1]),
-                                    mtl_pack_bf16(a[sn][sm][q * 4 + 2], a[sn][sm][q * 4 + 3])};
+                        u32x2 pk = {mtl_pack2<T>(a[sn][sm][q * 4], a[sn][sm][q * 4 + 1]),
+                                    mtl_pack2<T>(a[sn][sm][q * 4 + 2], a[sn][sm][q * 4 + 3])};
                         *reinterpret_cast<u32x2*>(img + ml * ORS + nl * 2) = pk;
                     }
             __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the image is private to this wave, no barrier needed
@@ -666,10 +666,9 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void k_nt(const NtParams 
                             const u32x4 hv = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(gate + m * P->ld_out + row_off + n));
 #pragma unroll
                             for (int q = 0; q < 4; ++q) {
-                                const float g0 = __builtin_bit_cast(float, v[q] << 16) * gelu_grad(__builtin_bit_cast(float, hv[q] << 16));
-                                const float g1 = __builtin_bit_cast(float, v[q] & 0xFFFF0000u) *
-                                                 gelu_grad(__builtin_bit_cast(float, hv[q] & 0xFFFF0000u));
-                                v[q] = mtl_pack_bf16(g0, g1);
+                                const float g0 = mtl_lo2<T>(v[q]) * gelu_grad(mtl_lo2<T>(hv[q]));
+                                const float g1 = mtl_hi2<T>(v[q]) * gelu_grad(mtl_hi2<T>(hv[q]));
+                                v[q] = mtl_pack2<T>(g0, g1);
                             }
                         }
                     }
@@ -681,8 +680,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void k_nt(const NtParams 
                             u32x4 av;
 #pragma unroll
                             for (int q = 0; q < 4; ++q)
-                                av[q] = mtl_pack_bf16(gelu_fwd(__builtin_bit_cast(float, v[q] << 16)),
-                                                      gelu_fwd(__builtin_bit_cast(float, v[q] & 0xFFFF0000u)));
+                                av[q] = mtl_pack2<T>(gelu_fwd(mtl_lo2<T>(v[q])), gelu_fwd(mtl_hi2<T>(v[q])));
                             __builtin_nontemporal_store(av, reinterpret_cast<u32x4*>(actp + m * P->ld_out + row_off + n));
                         }
                     }
@@ -746,7 +744,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void k_nt(const NtParams 
                             *reinterpret_cast<f32x4*>(sP + ml * PRS + r * 4) = f32x4{v0, v1, v2, v3};
                             if (pg && grp == 0 && m < P->M) *reinterpret_cast<f32x4*>(pg + m * P->pR + r) = f32x4{v0, v1, v2, v3};
                         } else {
-                            const u32x2 pk = {mtl_pack_bf16(v0, v1), mtl_pack_bf16(v2, v3)};
+                            const u32x2 pk = {mtl_pack2<T>(v0, v1), mtl_pack2<T>(v2, v3)};
                             *reinterpret_cast<u32x2*>(sP + ml * PRS + r * 2) = pk;
                             if (pg && grp == 0 && m < P->M) *reinterpret_cast<u32x2*>(pg + m * P->pR + r) = pk;
                         }
@@ -1270,17 +1268,22 @@ struct TnCfg<bf16> {
     static constexpr int SUB = 32;  // rows (m) per MFMA k-tile
 };
 template <>
+struct TnCfg<f16> {
+    static constexpr int SUB = 32;
+};
+template <>
 struct TnCfg<float> {
     static constexpr int SUB = 16;
 };
 
 // transposed fragment: lane (i = l & 31, h = l >> 5) gets Src[m = slot(h, e)][col0 + i]; ``lr`` = LDS row bytes
-__device__ __forceinline__ Frag<bf16> tn_frag(const unsigned char* s, int col0, int lane, int lr, bf16*) {
+template <typename H>  // any 16-bit element type (the transposing read moves bits)
+__device__ __forceinline__ Frag<H> tn_frag16(const unsigned char* s, int col0, int lane, int lr) {
     // ds_read_b64_tr_b16: within each 16-lane group, lane i supplies the 8-byte address of row (i>>2),
     // columns 4*(i&3)..+3 of a [4][16] block and receives column i of that block (4 rows).
     const int g = lane >> 4, i = lane & 15, h = g >> 1;
     const int col = col0 + 16 * (g & 1) + 4 * (i & 3);
-    Frag<bf16> f;
+    Frag<H> f;
     uint32_t w[8];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {  // rows: {8h+0..3}, {8h+4..7}, {16+8h+0..3}, {16+8h+4..7}
@@ -1295,6 +1298,12 @@ __device__ __forceinline__ Frag<bf16> tn_frag(const unsigned char* s, int col0, 
     f.v[0] = u32x4{w[0], w[1], w[2], w[3]};
     f.v[1] = u32x4{w[4], w[5], w[6], w[7]};
     return f;
+}
+__device__ __forceinline__ Frag<bf16> tn_frag(const unsigned char* s, int col0, int lane, int lr, bf16*) {
+    return tn_frag16<bf16>(s, col0, lane, lr);
+}
+__device__ __forceinline__ Frag<f16> tn_frag(const unsigned char* s, int col0, int lane, int lr, f16*) {
+    return tn_frag16<f16>(s, col0, lane, lr);
 }
 __device__ __forceinline__ Frag<float> tn_frag(const unsigned char* s, int col0, int lane, int lr, float*) {
     const int h = lane >> 5, i = lane & 31;
@@ -1511,7 +1520,7 @@ __global__ __launch_bounds__(256) void k_sum(SumParams P, T* out) {
 // ------------------------------------------------------------------------------------------------
 static int check_desc(const mtlora_linear_desc* d) {
     if (!d) return MTLORA_ERR_NULL;
-    if (d->dtype != MTLORA_F32 && d->dtype != MTLORA_BF16) return MTLORA_ERR_DTYPE;
+    if (d->dtype != MTLORA_F32 && d->dtype != MTLORA_BF16 && d->dtype != MTLORA_F16) return MTLORA_ERR_DTYPE;
     if (d->M < 0 || d->K <= 0 || d->N <= 0 || d->T < 0 || d->T > MTLORA_MAX_TASKS || d->r_s < 0)
         return MTLORA_ERR_SHAPE;
     if (d->M >= ((int64_t)1 << 31)) return MTLORA_ERR_SHAPE;
@@ -1613,7 +1622,7 @@ static void launch_nt(const NtParams& P_in, hipStream_t s, int kind, double alg_
     mlr = mlr && P.drop.enabled();
     bool acted = false;
     for (int o = 0; o < P.n_out; ++o) acted = acted || P.out[o].act != nullptr;
-    if constexpr (sizeof(T) == 2) {
+    if constexpr (std::is_same<T, bf16>::value) {  // bf16-only kernels
         // lean single-output launches: the straight-line kernel (MTLORA_NTL=0 keeps them on k_nt, for A/B timing)
         static const bool ntl_on = [] { const char* e = getenv("MTLORA_NTL"); return !(e && e[0] == '0'); }();
         const bool ml0 = P.n_out == 1 && P.out[0].mask_lr != 0 && P.drop.enabled();
@@ -1666,7 +1675,7 @@ static void launch_nt(const NtParams& P_in, hipStream_t s, int kind, double alg_
             hipLaunchKernelGGL((k_nt<T, false, false, false, false, 4, false, true>), g, dim3(256), lds, s, P);
         return;
     }
-    if constexpr (sizeof(T) == 2) {
+    if constexpr (std::is_same<T, bf16>::value) {  // bf16-only kernels
         if (nt2_wanted(P, variant, fuse)) {  // MFMA-dense lean launches: direct-to-LDS 256 x 128 kernel
             const int64_t tiles2 = mtl_ceil_div(P.M, T2_M) * mtl_ceil_div(P.n_rows, T2_N);
 #define MTL_NT2_LAUNCH(ML, GA)                                                                                       \
@@ -2499,6 +2508,8 @@ int mtlora_linear_pack(const mtlora_linear_desc* d, const float* A_s, const floa
     hipStream_t s = (hipStream_t)stream;
     if (d->dtype == MTLORA_F32)
         launch_pack<float>(d, sg, L, reinterpret_cast<unsigned char*>(pack), A_s, B_s, A_t, B_t, s);
+    else if (d->dtype == MTLORA_F16)
+        launch_pack<f16>(d, sg, L, reinterpret_cast<unsigned char*>(pack), A_s, B_s, A_t, B_t, s);
     else
         launch_pack<bf16>(d, sg, L, reinterpret_cast<unsigned char*>(pack), A_s, B_s, A_t, B_t, s);
     MTL_CHECK_LAUNCH();
@@ -2536,6 +2547,8 @@ static int linear_fwd_entry(const mtlora_linear_desc* d, const void* x, const vo
     hipStream_t s = (hipStream_t)stream;
     if (d->dtype == MTLORA_F32)
         st = fwd_impl<float>(d, x, x_t, W, bias, A_s, B_s, A_t, B_t, y_s, y_t, ctx, s, a_s, a_t);
+    else if (d->dtype == MTLORA_F16)
+        st = fwd_impl<f16>(d, x, x_t, W, bias, A_s, B_s, A_t, B_t, y_s, y_t, ctx, s, a_s, a_t);
     else
         st = fwd_impl<bf16>(d, x, x_t, W, bias, A_s, B_s, A_t, B_t, y_s, y_t, ctx, s, a_s, a_t);
     if (st != MTLORA_OK) return st;
@@ -2588,6 +2601,8 @@ static int linear_bwd_entry(const mtlora_linear_desc* d, const void* x, const vo
     hipStream_t s = (hipStream_t)stream;
     if (d->dtype == MTLORA_F32)
         st = bwd_impl<float>(d, x, x_t, Wt, dy_s, dy_t, ctx, dx, dx_t, dA_s, dB_s, dA_t, dB_t, scratch, s, gate_s, gate_t);
+    else if (d->dtype == MTLORA_F16)
+        st = bwd_impl<f16>(d, x, x_t, Wt, dy_s, dy_t, ctx, dx, dx_t, dA_s, dB_s, dA_t, dB_t, scratch, s, gate_s, gate_t);
     else
         st = bwd_impl<bf16>(d, x, x_t, Wt, dy_s, dy_t, ctx, dx, dx_t, dA_s, dB_s, dA_t, dB_t, scratch, s, gate_s, gate_t);
     if (st != MTLORA_OK) return st;
@@ -2643,7 +2658,7 @@ int64_t mtlora_gemm_tn_scratch_bytes(int64_t M, int Na, int Nb) {
 
 int mtlora_gemm_tn(const void* a, const void* b, float* out, int64_t M, int Na, int Nb, int64_t lda, int64_t ldb,
                    int dtype, void* scratch, int64_t scratch_bytes, void* stream) {
-    if (dtype != MTLORA_F32 && dtype != MTLORA_BF16) return MTLORA_ERR_DTYPE;
+    if (dtype != MTLORA_F32 && dtype != MTLORA_BF16 && dtype != MTLORA_F16) return MTLORA_ERR_DTYPE;
     const int vec = dtype == MTLORA_F32 ? 4 : 8;
     if (M < 0 || M >= ((int64_t)1 << 31) || Na <= 0 || Nb <= 0 || lda < Na || ldb < Nb) return MTLORA_ERR_SHAPE;
     if (Na % vec || Nb % vec || lda % vec || ldb % vec) return MTLORA_ERR_ALIGN;
@@ -2686,6 +2701,8 @@ int mtlora_gemm_tn(const void* a, const void* b, float* out, int64_t M, int Na, 
         MtlProfScope prof(PK_TN_PLAIN, (double)es * M * ((double)ta * Nb + Na), s, 0.0, 2.0 * M * (double)Na * Nb);
         if (dtype == MTLORA_F32)
             hipLaunchKernelGGL(k_tn<float>, dim3((unsigned)tp.nsplit, (unsigned)(ta * tb), 1), dim3(256), 0, s, tp);
+        else if (dtype == MTLORA_F16)
+            hipLaunchKernelGGL(k_tn<f16>, dim3((unsigned)tp.nsplit, (unsigned)(ta * tb), 1), dim3(256), 0, s, tp);
         else
             hipLaunchKernelGGL(k_tn<bf16>, dim3((unsigned)tp.nsplit, (unsigned)(ta * tb), 1), dim3(256), 0, s, tp);
     }

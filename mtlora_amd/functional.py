@@ -153,17 +153,30 @@ def next_seed() -> int:
     return x & 0xFFFFFFFFFFFFFFFF
 
 
+_HOT_DTYPES = (torch.float32, torch.bfloat16, torch.float16)
+_DT_CODE = {torch.float32: L.F32, torch.bfloat16: L.BF16, torch.float16: L.F16}
+
+
 def compute_dtype(x: torch.Tensor) -> torch.dtype:
-    """dtype the hot path runs in: the autocast dtype when autocast is on (like F.linear), else x's."""
+    """dtype the hot path (MTLoRALinear, window attention) runs in: the autocast dtype when autocast is on (like F.linear),
+    else x's.  bf16 is the dtype to use on MI355X (same MFMA rate as fp16, no loss scaling); fp16 -- the reference's
+    ``torch.cuda.amp.autocast()`` default, main.py:341 -- is supported by the linear / attention kernels, with the block glue
+    (LayerNorm, residuals, heads) falling back to fp32 outputs / ATen for it."""
     if torch.is_autocast_enabled():
         dt = torch.get_autocast_dtype("cuda")
-        if dt == torch.float16:
-            raise RuntimeError("mtlora_amd: fp16 autocast is not supported on the MI355X path; use "
-                               "torch.autocast('cuda', dtype=torch.bfloat16)")
+        if dt not in _HOT_DTYPES:
+            raise RuntimeError(f"mtlora_amd: unsupported autocast dtype {dt}")
         return dt
-    if x.dtype not in (torch.float32, torch.bfloat16):
+    if x.dtype not in _HOT_DTYPES:
         raise RuntimeError(f"mtlora_amd: unsupported activation dtype {x.dtype}")
     return x.dtype
+
+
+def glue_dtype(x: torch.Tensor) -> torch.dtype:
+    """output dtype of the fused glue kernels in front of an MTLoRALinear: the compute dtype, except fp16, which they do not
+    write -- the normalised activations then leave in fp32 (what ATen's autocast layer_norm returns) and the linear casts."""
+    dt = compute_dtype(x)
+    return torch.float32 if dt == torch.float16 else dt
 
 
 # ----------------------------------------------------------------------------------------------
@@ -196,7 +209,7 @@ class LinearMeta:
     def desc(self, M: int) -> L.LinearDesc:
         d = L.LinearDesc()
         d.M, d.K, d.N = M, self.K, self.N
-        d.dtype = L.BF16 if self.dtype == torch.bfloat16 else L.F32
+        d.dtype = _DT_CODE[self.dtype]
         d.mode, d.T, d.r_s = self.mode, self.T, self.r_s
         for i, r in enumerate(self.r_t):
             d.r_t[i] = r
@@ -429,7 +442,7 @@ class AttnMeta:
         d.window_size, d.shift = self.window_size, self.shift
         d.num_heads, d.head_dim = self.num_heads, self.head_dim
         d.image_layout = 1 if self.image_layout else 0
-        d.dtype = L.BF16 if dtype == torch.bfloat16 else L.F32
+        d.dtype = _DT_CODE[dtype]
         d.scale = self.scale
         d.mask_value = self.mask_value
         return d
@@ -444,8 +457,8 @@ class WindowAttentionFn(torch.autograd.Function):
     def forward(ctx, meta: AttnMeta, qkv, bias, mask, mask_ids):
         L.require_gpu(qkv, bias, mask, mask_ids)
         dt = qkv.dtype
-        if dt not in (torch.float32, torch.bfloat16):
-            raise RuntimeError(f"mtlora_amd: window attention supports fp32/bf16, got {dt}")
+        if dt not in _HOT_DTYPES:
+            raise RuntimeError(f"mtlora_amd: window attention supports fp32 / bf16 / fp16, got {dt}")
         qkv_c = qkv.contiguous()
         bias_c = bias.detach().float().contiguous()
         if mask_ids is not None:
@@ -717,7 +730,7 @@ def residual_layer_norm_multi(mod: torch.nn.Module, shortcut: torch.Tensor, bran
           and 1 <= n <= L.MAX_TASKS + 1 and all(b.shape == shortcut.shape for b in branches) and torch.is_grad_enabled()
           and (shortcut.requires_grad or any(b.requires_grad for b in branches)))
     if ok:
-        out_dtype = compute_dtype(shortcut)
+        out_dtype = glue_dtype(shortcut)
         ok = all(b.dtype == out_dtype for b in branches)
     if not ok:
         r = residual_droppath(shortcut, list(branches), drop_prob, training)
@@ -740,7 +753,7 @@ def residual_layer_norm(mod: torch.nn.Module, shortcut: torch.Tensor, branch: to
           and C % 8 == 0 and C <= (2048 if shortcut.dtype == torch.float32 else 4096) and branch.shape == shortcut.shape
           and shortcut.dim() == 3 and torch.is_grad_enabled() and (shortcut.requires_grad or branch.requires_grad))
     if ok:
-        out_dtype = compute_dtype(shortcut)
+        out_dtype = glue_dtype(shortcut)
         ok = branch.dtype == out_dtype
     if not ok:
         x = residual_droppath(shortcut, [branch], drop_prob, training)[0]
@@ -771,7 +784,7 @@ def layer_norm_merge(mod: torch.nn.Module, x: torch.Tensor, H: int, W: int) -> t
     if not ok:
         g = x.view(B, H // 2, 2, W // 2, 2, C).permute(0, 1, 3, 4, 2, 5).reshape(B, (H // 2) * (W // 2), 4 * C)
         return layer_norm(mod, g)
-    return LayerNormFn.apply(x, mod.weight, mod.bias, mod.eps, compute_dtype(x), (H, W))
+    return LayerNormFn.apply(x, mod.weight, mod.bias, mod.eps, glue_dtype(x), (H, W))
 
 
 class LayerNormMergeMultiFn(torch.autograd.Function):
@@ -888,7 +901,7 @@ def residual_merge_norm_streams(mod: torch.nn.Module, res, branches, H: int, W: 
           and res[0].dtype in (torch.float32, torch.bfloat16) and C % ve == 0 and Lt == H * W and H % 2 == 0 and W % 2 == 0
           and 4 * C <= (2048 if res[0].dtype == torch.float32 else 4096) and torch.is_grad_enabled())
     if ok:
-        out_dtype = compute_dtype(res[0])
+        out_dtype = glue_dtype(res[0])
         ok = branches[0].dtype == out_dtype
     if not ok:
         return None
@@ -909,7 +922,7 @@ def layer_norm_merge_multi(mod: torch.nn.Module, xs, H: int, W: int):
           and 4 * C <= (2048 if xs[0].dtype == torch.float32 else 4096))
     if not ok:
         return None
-    return LayerNormMergeMultiFn.apply(mod.weight, mod.bias, mod.eps, compute_dtype(xs[0]), H, W, len(xs), *xs)
+    return LayerNormMergeMultiFn.apply(mod.weight, mod.bias, mod.eps, glue_dtype(xs[0]), H, W, len(xs), *xs)
 
 
 def layer_norm(mod: torch.nn.Module, x: torch.Tensor, feeds_linear: bool = True, _fork: bool = False):
@@ -924,7 +937,7 @@ def layer_norm(mod: torch.nn.Module, x: torch.Tensor, feeds_linear: bool = True,
     if not ok:
         return mod(x)
     if feeds_linear:
-        out_dtype = compute_dtype(x)
+        out_dtype = glue_dtype(x)
     else:
         out_dtype = torch.float32 if torch.is_autocast_enabled() else x.dtype
     if _fork and x.requires_grad:
@@ -1247,7 +1260,7 @@ def gemm_tn(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
         raise RuntimeError(f"mtlora_amd: invalid gemm_tn shape M={M} Na={Na} Nb={Nb}")
     scratch = torch.empty(sb, dtype=torch.uint8, device=a.device)
     out = torch.empty((Na, Nb), dtype=torch.float32, device=a.device)
-    st = lib.mtlora_gemm_tn(L.ptr(a), L.ptr(b), L.ptr(out), M, Na, Nb, Na, Nb, L.BF16 if a.dtype == torch.bfloat16 else L.F32,
+    st = lib.mtlora_gemm_tn(L.ptr(a), L.ptr(b), L.ptr(out), M, Na, Nb, Na, Nb, _DT_CODE[a.dtype],
                             L.ptr(scratch), sb, L.stream_ptr())
     L.check(st, "mtlora_gemm_tn")
     return out
@@ -1258,7 +1271,7 @@ _PLAIN_VIA_KNT = os.environ.get("MTLORA_HEAD_GEMM", "knt") != "blas"
 
 def _big_linear(x, weight, bias, S, feeds_batchnorm, cdtype):
     K, N = weight.shape[1], weight.shape[0]
-    if (_PLAIN_VIA_KNT and cdtype in (torch.float32, torch.bfloat16) and K % 8 == 0 and N % 8 == 0
+    if (_PLAIN_VIA_KNT and cdtype in _HOT_DTYPES and K % 8 == 0 and N % 8 == 0
             and x.dtype == cdtype):
         return PlainLinearFn.apply(x, weight, bias, S, feeds_batchnorm, cdtype)
     return SplitKLinearFn.apply(x, weight, bias, S, feeds_batchnorm, cdtype)

@@ -54,7 +54,7 @@ def pytest_collection_modifyitems(config, items):
             wants = any(k in it.name for k in _PANEL_TESTS)
             import torch
             vals = list(getattr(getattr(it, "callspec", None), "params", {}).values())
-            fp32_only = ("fp32" in it.name) or (torch.float32 in vals and torch.bfloat16 not in vals)  # the engine is bf16-only
+            fp32_only = ("fp32" in it.name) or ((torch.float32 in vals or torch.float16 in vals) and torch.bfloat16 not in vals)  # the engine is bf16-only
             if not (is_gpu and wants) or fp32_only:
                 continue
         keep.append(it)

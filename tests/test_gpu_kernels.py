@@ -12,7 +12,7 @@ from oracle import mtlora_oracle as O
 
 pytestmark = pytest.mark.gpu
 
-TOL = {torch.float32: 1e-3, torch.bfloat16: 1e-2}
+TOL = {torch.float32: 1e-3, torch.bfloat16: 1e-2, torch.float16: 2e-3}  # fp16: 11-bit significand, fp32 accumulation
 
 
 def dev():
@@ -168,7 +168,7 @@ def _oracle_linear(m, x, xt, keep=None, p=0.0):
     return P, xs, xts, y, yt
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("shape", [
     # (M, K, N, r_s, r_t, T, x_tasks)   Swin-T stage shapes at reduced M, incl. ragged M and K % 32 != 0
     (1000, 96, 288, 64, 4, 0, False),     # qkv stage 0
@@ -200,7 +200,7 @@ def test_linear_random_vs_oracle(shape, dtype):
     with torch.no_grad():
         for n, p in m.named_parameters():
             p.copy_(torch.randn_like(p) * (0.05 if "lora" in n else 0.02))
-            if dtype == torch.bfloat16:
+            if dtype != torch.float32:
                 p.copy_(p.to(dtype).float())  # parameters exactly representable -> only accumulation order differs
     m.linear.weight.requires_grad_(False)
     m.linear.bias.requires_grad_(False)
@@ -336,7 +336,7 @@ def _regions(H, W, ws, shift):
     return ids
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("cfg", [
     # (B, H, W, heads, ws, shift)
     (2, 14, 14, 3, 7, 3), (2, 14, 14, 3, 7, 0), (1, 14, 21, 2, 7, 2), (3, 7, 7, 6, 7, 0), (2, 8, 8, 1, 4, 2),
@@ -416,7 +416,7 @@ def test_window_attention_module_golden(golden, case, dtype):
 # block / backbone
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("layout", ["image", "windows"])
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("case", ["shift_lora", "noshift_plain"])
 def test_swin_block_golden(golden, case, dtype, layout):
     from mtlora_amd.swin_transformer_mtlora import SwinTransformerBlock
@@ -429,7 +429,7 @@ def test_swin_block_golden(golden, case, dtype, layout):
     blk = blk.to(dev()).eval()
     blk.attention_layout = layout
     x = c["x"].to(dev()).float().requires_grad_(True)
-    ctx = torch.autocast("cuda", dtype=torch.bfloat16) if dtype == torch.bfloat16 else torch.autocast("cuda", enabled=False)
+    ctx = torch.autocast("cuda", dtype=dtype) if dtype != torch.float32 else torch.autocast("cuda", enabled=False)
     with ctx:
         y, yt = blk(x)
     assert_close(y, c["y"], dtype, "y")
@@ -452,7 +452,7 @@ def test_swin_block_golden(golden, case, dtype, layout):
             assert_close(named[n].grad, g, dtype, f"grad {n}", mult=3)
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 def test_backbone_small_golden(golden, dtype):
     from mtlora_amd.swin_transformer_mtlora import SwinTransformerMTLoRA
     c = golden("backbone_small.pt")
@@ -465,7 +465,7 @@ def test_backbone_small_golden(golden, dtype):
     O.det_fill_(bb.named_parameters())
     bb = bb.to(dev()).eval()
     x = O.det_tensor("bbs.x", (1, 3, 56, 56), 1.0).to(dev())
-    ctx = torch.autocast("cuda", dtype=torch.bfloat16) if dtype == torch.bfloat16 else torch.autocast("cuda", enabled=False)
+    ctx = torch.autocast("cuda", dtype=dtype) if dtype != torch.float32 else torch.autocast("cuda", enabled=False)
     with ctx:
         stages = bb(x, return_stages=True)
     loss = 0

@@ -410,3 +410,41 @@ def test_prepacked_factors_are_bit_identical():
         assert torch.equal(a, b), (a.item(), b.item())
     for n in runs[0][1]:
         assert torch.equal(runs[0][1][n], runs[1][1][n]), n
+
+
+@pytest.mark.gpu
+def test_fp16_autocast_train_steps_with_grad_scaler():
+    """The reference's default mixed precision (torch.cuda.amp.autocast() = fp16 + GradScaler, main.py:329-354) on the HIP path:
+    MTLoRALinear / window attention run their fp16 kernels (v_mfma_f32_32x32x16_f16), the block glue leaves fp32 / goes through
+    ATen.  Three scaled steps: finite loss and gradients, the scaler never skips, and the first loss agrees with the bf16 run of
+    the same model to mixed-precision accuracy."""
+    from mtlora_amd import functional as Fn
+    from mtlora_amd import mtl_harness as H
+    tasks = ["semseg", "normals", "sal", "human_parts"]
+    img, tg = H.synthetic_batch(2, 224, tasks, seed=23, device=dev())
+    first = {}
+    for dt in (torch.bfloat16, torch.float16):
+        torch.manual_seed(11)
+        Fn._seed_counter = 0
+        Fn.droppath_reset()
+        model = H.build_model(img_size=224, tasks=tasks, depths=(2, 2, 2, 2), r_shared=16, r_task=4, drop_path_rate=0.0, seed=6,
+                              DROPOUT=[0.0] * 4).to(dev()).train()
+        crit, opt = H.MultiTaskLoss(tasks), H.build_optimizer(model, lr=1e-3)
+        scaler = torch.amp.GradScaler("cuda", init_scale=1024.0, enabled=dt == torch.float16)
+        for step in range(3):
+            with torch.autocast("cuda", dtype=dt):
+                loss, _ = crit.forward_low(model(img, upsample=False), tg)
+            assert torch.isfinite(loss).all()
+            if step == 0:
+                first[dt] = loss.item()
+            scaler.scale(loss).backward()
+            scaler.unscale_(opt)
+            grads = [p.grad for p in model.parameters() if p.grad is not None]
+            assert grads and all(torch.isfinite(g).all() for g in grads)
+            scale_before = scaler.get_scale() if dt == torch.float16 else None
+            scaler.step(opt)
+            scaler.update()
+            if dt == torch.float16:
+                assert scaler.get_scale() >= scale_before  # no inf / nan step was skipped
+            opt.zero_grad(set_to_none=True)
+    assert abs(first[torch.float16] - first[torch.bfloat16]) <= 2e-2 * abs(first[torch.bfloat16]), first

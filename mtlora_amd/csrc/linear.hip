@@ -81,7 +81,7 @@ static Segs make_segs(const mtlora_linear_desc* d) {
 }
 
 struct CtxLayout {
-    int64_t a_cat, b_cat, at_cat, bt_cat, alpha, a_proj, bt_proj, p, total;
+    int64_t a_cat, b_cat, at_cat, bt_cat, alpha, a_proj, bt_proj, b_frag, at_frag, p, total;
 };
 static CtxLayout ctx_layout(const mtlora_linear_desc* d, const Segs& s) {
     const int es = mtl_elem_size(d->dtype);
@@ -99,6 +99,12 @@ static CtxLayout ctx_layout(const mtlora_linear_desc* d, const Segs& s) {
     L.alpha = take((int64_t)s.R * 4);
     L.a_proj = take((int64_t)s.R * d->K * es);   // alpha * A_cat   (projection weights of the row-panel forward, k_pnl)
     L.bt_proj = take((int64_t)s.R * d->N * es);  // alpha * Bt_cat  (projection weights of the row-panel dX)
+    // expansion factors of the wave-streaming kernels (stream.h), FRAGMENT-major and k-permuted: fragment (32-row block b,
+    // 16-wide rank step t) = 1 KB, lane l = (row b*32 + (l & 31), h = l >> 5) holds the 8 rank columns
+    // 16 t + 8 (s >> 2) + 4 h + (s & 3), s = 0..7 -- the order in which a lane holds P^T / Q^T after the projection MFMA
+    // (rank steps padded to whole 32-row projection blocks: 2 * ceil(R / 32) steps per block, zero past the segments)
+    L.b_frag = take(mtl_round_up(d->N, 32) * mtl_round_up(s.R, 32) * es);   // rows = output columns n:  B_cat[n][r]
+    L.at_frag = take(mtl_round_up(d->K, 32) * mtl_round_up(s.R, 32) * es);  // rows = input columns k:   A_cat[r][k]
     L.p = take(d->M * s.R * es);
     L.total = o;
     return L;
@@ -117,8 +123,35 @@ struct PackParams {
 
 template <typename T>
 __global__ __launch_bounds__(256) void k_pack(PackParams p, T* a_cat, T* b_cat, T* at_cat, T* bt_cat, float* alpha, T* a_proj,
-                                              T* bt_proj) {
+                                              T* bt_proj, T* b_frag, T* at_frag) {
     const int R = p.s.R;
+    {   // fragment-major expansion factors (16-bit types only: the wave-streaming kernels)
+        const int N32 = (p.N + 31) & ~31, K32 = (p.K + 31) & ~31, R16 = ((R + 31) >> 5) << 1, R32 = R16 << 4;
+        const int64_t nbf = sizeof(T) == 2 ? (int64_t)N32 * R32 : 0, naf = sizeof(T) == 2 ? (int64_t)K32 * R32 : 0;
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nbf + naf; i += (int64_t)gridDim.x * 256) {
+            const bool isb = i < nbf;
+            const int64_t j = isb ? i : i - nbf;
+            const int sidx = (int)(j & 7), ln = (int)((j >> 3) & 63);
+            const int64_t f = j >> 9;  // fragment index = blk * R16 + t
+            const int blk = (int)(f / R16), t = (int)(f - (int64_t)blk * R16);
+            const int row = blk * 32 + (ln & 31);
+            const int rr = 16 * t + 8 * (sidx >> 2) + 4 * (ln >> 5) + (sidx & 3);
+            int o = 0;
+#pragma unroll
+            for (int q = 1; q < MAXO; ++q)
+                if (q < p.s.n && rr >= p.s.off[q]) o = q;
+            const int lr = rr - p.s.off[o];
+            float v = 0.f;
+            if (rr < R && lr < p.s.r[o]) {
+                if (isb) {
+                    if (row < p.N && p.B[o]) v = p.B[o][(int64_t)row * p.s.r[o] + lr];
+                } else {
+                    if (row < p.K && p.A[o]) v = p.A[o][(int64_t)lr * p.K + row];
+                }
+            }
+            (isb ? b_frag : at_frag)[j] = mtl_from_f32<T>(v);
+        }
+    }
     const int64_t na = (int64_t)R * p.K, nb = (int64_t)R * p.N;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < na + nb + R; i += (int64_t)gridDim.x * 256) {
         int64_t j = i < na ? i : (i < na + nb ? i - na : i - na - nb);
@@ -1230,6 +1263,7 @@ __global__ __launch_bounds__(512, 2) void k_nt2(const NtParams Pv) {
 }
 
 #include "panel.h"
+#include "stream.h"
 
 // ------------------------------------------------------------------------------------------------
 // k_tn : Out[a][b] = sum_m SrcA[m][a0 + a] * SrcB[m][b0 + b], split over m.
@@ -1863,6 +1897,187 @@ static void launch_pnl(PnParams& P, hipStream_t s, int kind, double alg_bytes, d
 #undef MTL_PNL_LAUNCH_NS
 }
 
+// ---- wave-streaming projection (k_sp_proj, stream.h): the P = alpha D(X) A^T / Q = alpha dY B passes
+static int sp_mode() {  // developer switch for A/B timing (tools/): MTLORA_SP=0 keeps every launch on the tiled kernels
+    static const int m = [] { const char* e = getenv("MTLORA_SP"); return e ? atoi(e) : 1; }();
+    return m;
+}
+static int sp_num_cu() {
+    static const int n_cu = [] {
+        int dev = 0, cu = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev);
+        return cu > 0 ? cu : 256;
+    }();
+    return n_cu;
+}
+// fills q.n_blk_total / n_slabs / n_items and returns the ring depth (0: not eligible).  Sources must be set.
+template <typename T>
+static int sp_proj_plan(SpProjParams& q, int& ch) {
+    if (sizeof(T) != 2 || sp_mode() == 0 || q.M <= 0 || q.n_src <= 0) return 0;
+    ch = q.K % 96 == 0 ? 96 : (q.K % 64 == 0 ? 64 : 0);
+    if (ch == 0 || q.M >= ((int64_t)1 << 31) - 64) return 0;
+    q.n_blk_total = (q.Rw + 31) / 32;
+    for (int s = 0; s < q.n_src; ++s) {
+        if (q.src[s].n_blk > SP_MAXB || q.src[s].n_blk <= 0) return 0;
+        if (((uintptr_t)q.src[s].act & 15u) != 0) return 0;
+    }
+    if ((q.ld_out % 8) != 0 || ((uintptr_t)q.out & 15u) != 0 || ((uintptr_t)q.wproj & 15u) != 0) return 0;
+    if (q.M * q.ld_out * 2 >= ((int64_t)1 << 32) - 64) return 0;  // 32-bit store offsets (buffer descriptor)
+    q.n_slabs = (int)mtl_ceil_div(q.M, 32);
+    if ((int64_t)q.n_slabs * q.n_src >= ((int64_t)1 << 30)) return 0;
+    q.n_items = q.n_slabs * q.n_src;
+    const int64_t wbytes = (int64_t)q.n_blk_total * 32 * q.K * 2;
+    const int64_t slot = 32 * ch * 2;
+    for (int ns = 3; ns >= 1; --ns)
+        if (wbytes + (int64_t)SP_WAVES * ns * slot <= SP_LDS_MAX - 1024) return ns;
+    return 0;
+}
+template <typename T>
+static void launch_sp_proj(const SpProjParams& q, int ch, int ns, hipStream_t s, int kind, double alg_bytes, double s8d, double flops) {
+    mtl_prof_tag("sp_proj M%lld K%d R%d src%d ch%d ns%d", (long long)q.M, q.K, q.Rw, q.n_src, ch, ns);
+    MtlProfScope prof(kind, alg_bytes, s, s8d, flops);
+    const size_t lds = (size_t)q.n_blk_total * 32 * q.K * 2 + (size_t)SP_WAVES * ns * 32 * ch * 2;
+    const int per_cu = lds * 2 <= (size_t)SP_LDS_MAX ? 2 : 1;
+    int64_t wgs = mtl_ceil_div(q.n_items, SP_WAVES);
+    if (wgs > (int64_t)sp_num_cu() * per_cu) wgs = (int64_t)sp_num_cu() * per_cu;
+#define MTL_SP_PROJ(CHV, NSV)                                                                                              \
+    do {                                                                                                                    \
+        static bool raised = false;                                                                                         \
+        if (!raised) {                                                                                                      \
+            (void)hipFuncSetAttribute((const void*)k_sp_proj<T, CHV, NSV>, hipFuncAttributeMaxDynamicSharedMemorySize, SP_LDS_MAX); \
+            raised = true;                                                                                                  \
+        }                                                                                                                   \
+        hipLaunchKernelGGL((k_sp_proj<T, CHV, NSV>), dim3((unsigned)wgs), dim3(64 * SP_WAVES), lds, s, q);                  \
+    } while (0)
+    if constexpr (sizeof(T) == 2) {
+        if (ch == 96) {
+            if (ns == 3) MTL_SP_PROJ(96, 3);
+            else if (ns == 2) MTL_SP_PROJ(96, 2);
+            else MTL_SP_PROJ(96, 1);
+        } else {
+            if (ns == 3) MTL_SP_PROJ(64, 3);
+            else if (ns == 2) MTL_SP_PROJ(64, 2);
+            else MTL_SP_PROJ(64, 1);
+        }
+    }
+#undef MTL_SP_PROJ
+}
+
+// ---- fused wave-streaming MTLoRALinear launch, activation-resident form (k_sp_xres, stream.h).  Fills the plan fields of q
+// (n_parts, blk_per_part, n_slabs, estep) and the launch geometry; false: not eligible (weights do not fit / unsupported shape).
+struct SpXresPlan {
+    int ch, nkc, nrb;
+    bool stg;
+    unsigned grid;
+    size_t lds;
+};
+static int sp_stg_mode() {  // developer switch: MTLORA_SP_STG=0 direct row-per-lane stores, 1 staged stores whenever they fit, unset: auto
+    static const int m = [] { const char* e = getenv("MTLORA_SP_STG"); return e ? atoi(e) : -1; }();
+    return m;
+}
+template <typename T>
+static bool sp_xres_plan(SpLinParams& q, int K, SpXresPlan& pl) {
+    if (sizeof(T) != 2 || sp_mode() == 0 || q.M <= 0 || q.M >= ((int64_t)1 << 31) - 64) return false;
+    if (K == 96 || K == 192) {
+        pl.ch = 96;
+        pl.nkc = K / 96;
+    } else if (K == 64 || K == 128) {
+        pl.ch = 64;
+        pl.nkc = K / 64;
+    } else {
+        return false;
+    }
+    if (q.R <= 0 || q.R > 128 || (q.R % 16) != 0) return false;
+    pl.nrb = q.R <= 32 ? 1 : (q.R <= 64 ? 2 : 4);
+    q.estep = 2 * ((q.R + 31) / 32);
+    if ((q.n_cols % 8) != 0 || (q.ld_out % 8) != 0 || (q.ldp % 8) != 0) return false;
+    if (q.M * q.ld_out * 2 >= ((int64_t)1 << 32) - 64 || q.M * q.ldp * 2 >= ((int64_t)1 << 32) - 64) return false;  // 32-bit store offsets
+    const void* ptrs[] = {q.act, q.w, q.proj, q.expand, q.out, q.out2, q.pout};
+    for (const void* pp : ptrs)
+        if (((uintptr_t)pp & 15u) != 0) return false;
+    const int nb_all = (q.n_cols + 31) / 32;
+    const int64_t slot = (int64_t)SP_WAVES * 32 * pl.ch * 2;
+    auto fit = [&](bool stg, int& bpp_out, size_t& lds_out) -> int {
+        const int64_t fixed = (int64_t)pl.nrb * 32 * K * 2 + slot + (stg ? (int64_t)SP_WAVES * SP_STG : 0);
+        for (int np = 1; np <= nb_all && np <= 16; ++np) {
+            const int bpp = (nb_all + np - 1) / np;
+            if ((bpp * (np - 1)) >= nb_all) continue;  // an empty last part
+            const int64_t need = fixed + (int64_t)bpp * (32 * K * 2 + 64 * pl.nrb * 32 * 2 / 2 + 128);
+            if (need <= SP_LDS_MAX - 512) {
+                bpp_out = bpp;
+                lds_out = (size_t)need;
+                return np;
+            }
+        }
+        return 0;
+    };
+    int bpp_d = 0, bpp_s = 0;
+    size_t lds_d = 0, lds_s = 0;
+    const int np_d = fit(false, bpp_d, lds_d), np_s = fit(true, bpp_s, lds_s);
+    const int mode = sp_stg_mode();
+    bool stg = np_s > 0 && (np_d == 0 || np_s <= np_d + 1);
+    if (mode == 0 && np_d > 0) stg = false;
+    if (mode == 1 && np_s > 0) stg = true;
+    const int parts = stg ? np_s : np_d;
+    if (parts == 0) return false;
+    pl.stg = stg;
+    q.blk_per_part = stg ? bpp_s : bpp_d;
+    pl.lds = stg ? lds_s : lds_d;
+    q.n_parts = parts;
+    {
+        const char* e = getenv("MTLORA_SP_DBG");  // ablation timing only (tools/): results are wrong with any bit set
+        q.dbg = e ? atoi(e) : 0;
+    }
+    q.n_slabs = (int)mtl_ceil_div(q.M, 32);
+    const int64_t g8_max = sp_num_cu() / (8 * parts) > 0 ? sp_num_cu() / (8 * parts) : 1;
+    int64_t g8 = mtl_ceil_div(mtl_ceil_div(q.n_slabs, SP_WAVES), 8);
+    if (g8 > g8_max) g8 = g8_max;
+    pl.grid = (unsigned)(8 * parts * g8);
+    return true;
+}
+template <typename T>
+static void launch_sp_xres(const SpLinParams& q, const SpXresPlan& pl, bool act, hipStream_t s, int kind, double alg_bytes, double s8d,
+                           double flops) {
+    mtl_prof_tag("sp_xres M%lld K%d N%d R%d parts%d stg%d", (long long)q.M, pl.ch * pl.nkc, q.n_cols, q.R, q.n_parts, pl.stg ? 1 : 0);
+    MtlProfScope prof(kind, alg_bytes, s, s8d, flops);
+#define MTL_SP_X(CHV, NKCV, NRBV, ACTV, STGV)                                                                                          \
+    do {                                                                                                                                \
+        static bool raised = false;                                                                                                     \
+        if (!raised) {                                                                                                                  \
+            (void)hipFuncSetAttribute((const void*)k_sp_xres<T, CHV, NKCV, NRBV, ACTV, STGV>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                      SP_LDS_MAX);                                                                                      \
+            raised = true;                                                                                                              \
+        }                                                                                                                               \
+        hipLaunchKernelGGL((k_sp_xres<T, CHV, NKCV, NRBV, ACTV, STGV>), dim3(pl.grid), dim3(64 * SP_WAVES), pl.lds, s, q);              \
+    } while (0)
+#define MTL_SP_X_S(CHV, NKCV, NRBV, ACTV)                        \
+    do {                                                         \
+        if (pl.stg) MTL_SP_X(CHV, NKCV, NRBV, ACTV, true);       \
+        else MTL_SP_X(CHV, NKCV, NRBV, ACTV, false);             \
+    } while (0)
+#define MTL_SP_X_R(CHV, NKCV, ACTV)                            \
+    do {                                                       \
+        if (pl.nrb == 1) MTL_SP_X_S(CHV, NKCV, 1, ACTV);       \
+        else if (pl.nrb == 2) MTL_SP_X_S(CHV, NKCV, 2, ACTV);  \
+        else MTL_SP_X_S(CHV, NKCV, 4, ACTV);                   \
+    } while (0)
+#define MTL_SP_X_K(ACTV)                                                  \
+    do {                                                                  \
+        if (pl.ch == 96 && pl.nkc == 1) MTL_SP_X_R(96, 1, ACTV);          \
+        else if (pl.ch == 96) MTL_SP_X_R(96, 2, ACTV);                    \
+        else if (pl.nkc == 1) MTL_SP_X_R(64, 1, ACTV);                    \
+        else MTL_SP_X_R(64, 2, ACTV);                                     \
+    } while (0)
+    if constexpr (sizeof(T) == 2) {
+        if (act) MTL_SP_X_K(true);
+        else MTL_SP_X_K(false);
+    }
+#undef MTL_SP_X_K
+#undef MTL_SP_X_R
+#undef MTL_SP_X_S
+#undef MTL_SP_X
+}
+
 // k_pack of one layer into the packed-factor region at `pk` (the head of a forward's ctx buffer, or the caller's persistent
 // buffer of mtlora_linear_pack)
 template <typename T>
@@ -1893,7 +2108,7 @@ static void launch_pack(const mtlora_linear_desc* d, const Segs& sg, const CtxLa
     hipLaunchKernelGGL(k_pack<T>, dim3((unsigned)blocks), dim3(256), 0, s, pp, reinterpret_cast<T*>(pk + L.a_cat),
                        reinterpret_cast<T*>(pk + L.b_cat), reinterpret_cast<T*>(pk + L.at_cat), reinterpret_cast<T*>(pk + L.bt_cat),
                        reinterpret_cast<float*>(pk + L.alpha), reinterpret_cast<T*>(pk + L.a_proj),
-                       reinterpret_cast<T*>(pk + L.bt_proj));
+                       reinterpret_cast<T*>(pk + L.bt_proj), reinterpret_cast<T*>(pk + L.b_frag), reinterpret_cast<T*>(pk + L.at_frag));
 }
 
 template <typename T>
@@ -1922,6 +2137,33 @@ static int fwd_impl(const mtlora_linear_desc* d, const void* x, const void* cons
     if (sg.R > 0) {
         if (!(d->pack && d->prepacked)) launch_pack<T>(d, sg, L, pk, A_s, B_s, A_t, B_t, s);
 
+        // T = 0 layers with a short reduction: ONE wave-streaming launch (projection in registers, stream.h)
+        if (d->T == 0 && d->mode == 0 && !pnl) {
+            SpLinParams q = {};
+            q.act = x;
+            q.w = W;
+            q.proj = pk + L.a_proj;
+            q.expand = pk + L.b_frag;
+            q.bias = bias;
+            q.out = y_s;
+            q.out2 = a_s;
+            q.pout = Pm;
+            q.ld_out = d->N;
+            q.ldp = sg.R;
+            q.M = d->M;
+            q.n_cols = (int)d->N;
+            q.R = sg.R;
+            q.mask_act = 1;
+            q.mask_lr = 0;
+            q.drop = dc;
+            SpXresPlan pl;
+            if (sp_xres_plan<T>(q, (int)d->K, pl)) {
+                const double b8d = (double)sizeof(T) * d->M * (d->K + (double)d->N);
+                const double fl = 2.0 * d->M * (double)d->K * d->N + 2.0 * d->M * (double)sg.r[0] * (d->K + d->N);
+                launch_sp_xres<T>(q, pl, a_s != nullptr, s, PK_NT_FWD_MAIN, b8d + (a_s ? (double)sizeof(T) * d->M * d->N : 0.0), b8d, fl);
+                return MTLORA_OK;
+            }
+        }
         groups = (a_s || pnl) ? 0 : fuse_groups(d, sg, d->N);
         fuse = groups > 0;
         if (!fuse && !pnl) {
@@ -1960,7 +2202,33 @@ static int fwd_impl(const mtlora_linear_desc* d, const void* x, const void* cons
                 const double xb = (double)sizeof(T) * (d->has_x_tasks ? d->T : 0) * d->M * d->K;
                 double rsum = 0.0;  // un-padded ranks
                 for (int o = 0; o < sg.n; ++o) rsum += sg.r[o];
-                launch_nt<T>(q, s, PK_NT_FWD_P, xb, xb, 2.0 * d->M * d->K * rsum);
+                // wave-streaming form (stream.h) when the alpha-scaled factor rows fit in LDS next to the slab ring
+                SpProjParams sp = {};
+                sp.wproj = pk + L.a_proj;
+                sp.out = Pm;
+                sp.ld_out = sg.R;
+                sp.M = d->M;
+                sp.K = (int)d->K;
+                sp.Rw = sg.R;
+                sp.drop = dc;
+                for (int o = 0; o < sg.n; ++o) {
+                    const bool own = d->T > 0 && d->has_x_tasks;
+                    if (!own && o > 0) break;
+                    if (own && sg.rp[o] == 0) continue;
+                    SpSrc& ss = sp.src[sp.n_src++];
+                    ss.act = (o == 0) ? x : x_t[o - 1];
+                    ss.col_lo = own ? sg.off[o] : 0;
+                    ss.col_hi = own ? sg.off[o] + sg.rp[o] : sg.used;
+                    ss.blk_lo = ss.col_lo / 32;
+                    ss.n_blk = (ss.col_hi - 1) / 32 - ss.blk_lo + 1;
+                    ss.mask = (o == 0) ? 1 : 0;
+                }
+                int ch = 0;
+                const int ns = sp_proj_plan<T>(sp, ch);
+                if (ns > 0)
+                    launch_sp_proj<T>(sp, ch, ns, s, PK_NT_FWD_P, xb, xb, 2.0 * d->M * d->K * rsum);
+                else
+                    launch_nt<T>(q, s, PK_NT_FWD_P, xb, xb, 2.0 * d->M * d->K * rsum);
             }
         }
     }
@@ -2321,7 +2589,30 @@ static int bwd_impl(const mtlora_linear_desc* d, const void* x, const void* cons
             double rsum = 0.0;
             for (int o = 0; o < sg.n; ++o)
                 if (sg.rp[o] > 0 && dyo[o]) rsum += sg.r[o];
-            launch_nt<T>(q, s, PK_NT_BWD_Q, 0.0, 0.0, 2.0 * d->M * d->N * rsum);
+            SpProjParams sp = {};
+            sp.wproj = pk + L.bt_proj;
+            sp.out = Qm;
+            sp.ld_out = sg.R;
+            sp.M = d->M;
+            sp.K = (int)d->N;
+            sp.Rw = sg.R;
+            sp.drop = dc;
+            for (int o = 0; o < sg.n; ++o) {
+                if (sg.rp[o] == 0 || !dyo[o]) continue;
+                SpSrc& ss = sp.src[sp.n_src++];
+                ss.act = dyo[o];
+                ss.col_lo = sg.off[o];
+                ss.col_hi = sg.off[o] + sg.rp[o];
+                ss.blk_lo = ss.col_lo / 32;
+                ss.n_blk = (ss.col_hi - 1) / 32 - ss.blk_lo + 1;
+                ss.mask = 0;
+            }
+            int ch = 0;
+            const int ns = sp_proj_plan<T>(sp, ch);
+            if (ns > 0)
+                launch_sp_proj<T>(sp, ch, ns, s, PK_NT_BWD_Q, 0.0, 0.0, 2.0 * d->M * d->N * rsum);
+            else
+                launch_nt<T>(q, s, PK_NT_BWD_Q, 0.0, 0.0, 2.0 * d->M * d->N * rsum);
         }
     }
 

@@ -1,0 +1,579 @@
+// stream.h -- k_sp*: wave-streaming kernels for the HBM-side MTLoRALinear launches (16-bit types).  Included by linear.hip
+// inside its anonymous namespace (after Segs / CtxLayout / g_zero16 / gelu_* / MtlProfScope are visible).
+//
+// Why another family: the tiled kernels (k_nt / k_ntl) run a workgroup as ONE serial chain
+//     global -> registers -> LDS -> barrier -> MFMA -> barrier -> ... -> epilogue -> exit
+// with two workgroups per CU to overlap it: at K = 96 a tile is one or two k-steps, so a CU has ~20 KB of HBM reads in flight
+// on average and nothing in flight while its workgroups store -- 2.6-3.8 TB/s at best, and a layer needs three launches
+// (P pass, outputs, and the Q pass on the way back) that re-read X / dY.  Here a WAVE is the unit of work:
+//   * every wave owns 32-row slabs of the activation (slab s of wave w: w + i * n_waves), streams them through its PRIVATE
+//     LDS slots with LDS-DMA loads (global_load_lds_dwordx4, no staging registers), reads them back as MFMA fragments and
+//     keeps going -- no workgroup barrier after the prologue, so the load, MFMA and store phases of the 8 (x1 or x2) waves
+//     of a CU interleave freely and the next slab's DMA is in flight while the current one is multiplied and stored;
+//   * the weight-like operands are STATIONARY: loaded once per workgroup into LDS in fragment-major order (one 1 KB,
+//     conflict-free ds_read_b128 per fragment), the grid is persistent (<= 1-2 workgroups per CU);
+//   * the low-rank projection never leaves registers: P^T = (alpha A) D(X)^T comes out of the MFMA with a lane holding,
+//     for its row m, rank rows r = 8 q + 4 h + e -- exactly a B-operand fragment of the NEXT MFMA once the expansion
+//     factor's fragments are packed with the same k permutation (k_pack does that): no P image in LDS, no P pass, no
+//     re-read of X, and (with the Z-form factor gradients) no P / Q in HBM at all;
+//   * the epilogue writes 16 bytes per lane straight from the accumulators (v_permlane32_swap pairs the two half-waves'
+//     8-byte pieces, T21 of the CDNA guide): no LDS transpose, no barrier.
+// Slab layout in a slot: 32 rows x CH elements, dense (LDS-DMA writes lane-linear), with the 16-byte chunks of a row
+// permuted on the SOURCE side so that the ds_read_b128 fragment reads (16 lanes = 16 rows of one logical chunk per LDS
+// cycle) are conflict-free:  CH = 96 (192-byte rows, 12 chunks): physical = (logical + (row >> 2)) mod 12;
+//                            CH = 64 (128-byte rows,  8 chunks): physical = logical ^ ((row >> 1) & 7).
+// vmcnt discipline: a wave's loads return in order, its stores may not be ordered against them, so a wait for chunk t uses
+// vmcnt(#DMA instructions of the YOUNGER chunks only): whatever the stores do, the count can only be reached once every
+// older load has landed (it may additionally wait for store acknowledgements -- the other waves of the CU cover that).
+#pragma once
+
+#ifndef MTL_SP_WAVES
+#define MTL_SP_WAVES 8
+#endif
+constexpr int SP_WAVES = MTL_SP_WAVES;
+constexpr int SP_LDS_MAX = 160 * 1024;
+constexpr int SP_MAXB = 4;  // 32-row weight blocks per projection source (rank segment <= 128 columns)
+
+template <int CH>
+struct SpGeom {
+    static constexpr int CPR = CH / 8;        // 16-byte chunks per row
+    static constexpr int ROWB = CH * 2;       // bytes per row
+    static constexpr int SLOT = 32 * ROWB;    // bytes per slab chunk (6 KB / 4 KB)
+    static constexpr int NDMA = SLOT / 1024;  // LDS-DMA wave instructions per chunk
+    static constexpr int KS = CH / 16;        // MFMA k-steps per chunk
+    static __device__ __forceinline__ int phys(int row, int q) {
+        if constexpr (CH == 96) {
+            const int p = q + (row >> 2);
+            return p >= 12 ? p - 12 : p;
+        } else {
+            return q ^ ((row >> 1) & 7);
+        }
+    }
+    static __device__ __forceinline__ int logical(int row, int p) {
+        if constexpr (CH == 96) {
+            const int q = p - (row >> 2);
+            return q < 0 ? q + 12 : q;
+        } else {
+            return p ^ ((row >> 1) & 7);
+        }
+    }
+};
+
+constexpr int sp_vmcnt(int n) { return (n & 0xF) | ((n >> 4) << 14) | 0x0F70; }  // s_waitcnt vmcnt(n) only
+#define SP_WAIT_VM(n) __builtin_amdgcn_s_waitcnt(sp_vmcnt(n))
+#define SP_WAIT_LGKM0() __builtin_amdgcn_s_waitcnt(0xc07f)
+
+__device__ __forceinline__ void sp_dma16(const void* g, unsigned char* lds) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)lds, 16, 0,
+                                     0);
+}
+
+// 16-byte store through a buffer descriptor: 32-bit byte offset, rows past the end of the tensor are dropped by the bounds
+// check (offset >= num_records), an invalid column is expressed as offset 0xFFFFFFFF -- no exec-masked branches around the
+// stores, no 64-bit address arithmetic, and every store instruction is issued (the vmcnt bookkeeping relies on that)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t sp_rsrc(void* p, int64_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(p, 0, (int)(bytes > 0xFFFFFFF0ll ? 0xFFFFFFF0ll : bytes), 0x00020000);
+}
+__device__ __forceinline__ void sp_bstore(const u32x4& v, __amdgpu_buffer_rsrc_t r, uint32_t off) {
+    __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)off, 0, 0);
+}
+
+template <typename T>
+__device__ __forceinline__ void sp_mma1(const u32x4& a, const u32x4& b, f32x16& c) {
+    if constexpr (__is_same(T, f16))
+        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    else
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+// wait for the oldest outstanding chunk given how many YOUNGER chunks of NDMA instructions each are still in flight
+template <int NDMA>
+__device__ __forceinline__ void sp_wait_chunk(int younger) {
+    if (younger >= 2)
+        SP_WAIT_VM(2 * NDMA);
+    else if (younger == 1)
+        SP_WAIT_VM(NDMA);
+    else
+        SP_WAIT_VM(0);
+}
+
+// accumulator block (32 weight rows x 32 activation rows) -> global rows m (lane & 31), columns col0 + [0, 32):
+// lane (m, h) holds, for q = 0..3, the four consecutive columns 8 q + 4 h + e.  permlane32_swap pairs the half-waves'
+// 8-byte pieces: lanes < 32 end up with columns 8 q .. 8 q + 7 (q even), lanes >= 32 with 8 q + 8 .. 8 q + 15 -> one
+// 16-byte store per lane and pair.  `lo` / `hi`: only columns in [lo, hi) are written (multiples of 8).
+template <typename T>
+__device__ __forceinline__ void sp_pack_pair(const f32x16& a, int q, int hl, u32x4& v) {
+    uint32_t a0 = mtl_pack2<T>(a[4 * q + 0], a[4 * q + 1]), a1 = mtl_pack2<T>(a[4 * q + 2], a[4 * q + 3]);
+    uint32_t b0 = mtl_pack2<T>(a[4 * q + 4], a[4 * q + 5]), b1 = mtl_pack2<T>(a[4 * q + 6], a[4 * q + 7]);
+    const auto r0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
+    const auto r1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+    (void)hl;
+    v = u32x4{r0[0], r1[0], r0[1], r1[1]};
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_sp_proj : Out[m][c] = sum_k Wp[c][k] * f_s(X_s[m][k])   for the columns c of source s   (P = alpha D(X) A^T per source,
+// Q = alpha dY_o B_o per output: the P / Q passes).  Work item = (slab of 32 rows, source); the reduction streams through
+// the wave's slots in chunks of CH, the weights (all sources' rows) are stationary in LDS.
+// ------------------------------------------------------------------------------------------------
+struct SpSrc {
+    const void* act;  // (M x K) contiguous
+    int blk_lo, n_blk;  // 32-row weight blocks that cover the source's columns
+    int col_lo, col_hi; // columns of Out (= rows of Wp) this source owns
+    int mask;           // dropout keep-mask on the activation
+    int pad_;
+};
+struct SpProjParams {
+    const void* wproj;  // (Rw x K) row-major
+    void* out;          // (M x ld_out)
+    int64_t ld_out;
+    int64_t M;
+    int K, Rw, n_src, n_blk_total;
+    int n_slabs, n_items;
+    DropoutCfg drop;
+    SpSrc src[MAXO];
+};
+typedef const __attribute__((address_space(4))) SpProjParams* SpProjPtr;
+
+template <typename T, int CH, int NS>
+__global__ __launch_bounds__(64 * SP_WAVES, SP_WAVES / 4) void k_sp_proj(const SpProjParams Pv) {
+    typedef SpGeom<CH> G;
+    (void)Pv;
+    SpProjPtr P = (SpProjPtr)__builtin_amdgcn_kernarg_segment_ptr();
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5, rl = lane & 31;
+    const int K = P->K, KST = K >> 4, NCH = K / CH;
+    const int n_items = P->n_items, n_src = P->n_src;
+    const int64_t M = P->M;
+    unsigned char* wl = smem;                                                     // weights, fragment-major
+    unsigned char* slots = smem + (size_t)P->n_blk_total * KST * 1024 + (size_t)wave * NS * G::SLOT;
+    DropoutCfg drop;
+    drop.seed_lo = P->drop.seed_lo;
+    drop.seed_hi = P->drop.seed_hi;
+    drop.thr16 = P->drop.thr16;
+    drop.off = P->drop.off;
+    mtl_dropout_resolve(drop);
+
+    // ---- stationary weights: fragment f = blk * KST + ks <- rows blk*32 + (lane & 31), elements ks*16 + 8 h .. + 8
+    {
+        const T* wp = reinterpret_cast<const T*>(P->wproj);
+        const int nfrag = P->n_blk_total * KST;
+        for (int f = wave; f < nfrag; f += SP_WAVES) {
+            const int blk = f / KST, ks = f - blk * KST;
+            const int row = blk * 32 + rl;
+            const void* g = row < P->Rw ? (const void*)(wp + (int64_t)row * K + ks * 16 + 8 * h) : (const void*)g_zero16;
+            sp_dma16(g, wl + (size_t)f * 1024);
+        }
+    }
+    // per-lane constants of the slab traffic
+    int goff[G::NDMA], grow[G::NDMA], fo[G::KS];
+#pragma unroll
+    for (int j = 0; j < G::NDMA; ++j) {
+        const int c = j * 64 + lane, row = c / G::CPR, p = c - row * G::CPR;
+        grow[j] = row;
+        goff[j] = row * K + G::logical(row, p) * 8;
+    }
+#pragma unroll
+    for (int ks = 0; ks < G::KS; ++ks) fo[ks] = rl * G::ROWB + G::phys(rl, 2 * ks + h) * 16;
+
+    SP_WAIT_VM(0);
+    __syncthreads();
+
+    const int n_waves = gridDim.x * SP_WAVES;
+    const int w_gid = blockIdx.x * SP_WAVES + wave;
+    // loader cursor
+    int l_item = w_gid, l_ch = 0;
+    auto issue = [&](int slot) __attribute__((always_inline)) -> bool {
+        if (l_item >= n_items) return false;
+        const int slab = l_item / n_src, s = l_item - slab * n_src;
+        const T* base = reinterpret_cast<const T*>(P->src[s].act) + (int64_t)slab * 32 * K + l_ch * CH;
+        unsigned char* dst = slots + slot * G::SLOT;
+        if ((int64_t)slab * 32 + 32 <= M) {
+#pragma unroll
+            for (int j = 0; j < G::NDMA; ++j) sp_dma16(base + goff[j], dst + j * 1024);
+        } else {  // last slab: rows past M re-read row M - 1 (never stored)
+            const int last = (int)(M - 1 - (int64_t)slab * 32);
+#pragma unroll
+            for (int j = 0; j < G::NDMA; ++j) {
+                const int r = grow[j] < last ? grow[j] : last;
+                sp_dma16(base + goff[j] + (r - grow[j]) * K, dst + j * 1024);
+            }
+        }
+        if (++l_ch == NCH) {
+            l_ch = 0;
+            l_item += n_waves;
+        }
+        return true;
+    };
+    int ahead = 0;  // chunks in flight
+#pragma unroll
+    for (int i = 0; i < NS; ++i) ahead += issue(i) ? 1 : 0;
+
+    f32x16 acc[SP_MAXB];
+    int slot = 0;
+    const __amdgpu_buffer_rsrc_t orsrc = sp_rsrc(P->out, M * P->ld_out * 2);
+    for (int item = w_gid; item < n_items; item += n_waves) {
+        const int slab = item / n_src, s = item - slab * n_src;
+        const int blk_lo = P->src[s].blk_lo, n_blk = P->src[s].n_blk;
+        const bool masked = P->src[s].mask != 0 && drop.thr16 != 0;
+        const int64_t m = (int64_t)slab * 32 + rl;
+        const uint32_t rh = mtl_dropout_rowhash(drop, 0u, (uint32_t)m);
+#pragma unroll
+        for (int b = 0; b < SP_MAXB; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
+        for (int ch = 0; ch < NCH; ++ch) {
+            sp_wait_chunk<G::NDMA>(ahead - 1);
+            const unsigned char* sl = slots + slot * G::SLOT;
+            u32x4 xf[G::KS];
+#pragma unroll
+            for (int ks = 0; ks < G::KS; ++ks) xf[ks] = *reinterpret_cast<const u32x4*>(sl + fo[ks]);
+            SP_WAIT_LGKM0();
+            --ahead;
+            ahead += issue(slot) ? 1 : 0;
+            slot = slot + 1 == NS ? 0 : slot + 1;
+            if (masked) {
+#pragma unroll
+                for (int ks = 0; ks < G::KS; ++ks) VOps<T>::drop(xf[ks], drop, rh, (uint32_t)(ch * CH + ks * 16 + 8 * h));
+            }
+            const unsigned char* wb = wl + ((size_t)blk_lo * KST + ch * G::KS) * 1024 + lane * 16;
+#pragma unroll
+            for (int b = 0; b < SP_MAXB; ++b) {
+                if (b < n_blk) {
+#pragma unroll
+                    for (int ks = 0; ks < G::KS; ++ks) {
+                        const u32x4 wf = *reinterpret_cast<const u32x4*>(wb + ((size_t)b * KST + ks) * 1024);
+                        sp_mma1<T>(wf, xf[ks], acc[b]);
+                    }
+                }
+            }
+        }
+        // epilogue: columns [col_lo, col_hi) of the rows of this slab
+        const int col_lo = P->src[s].col_lo, col_hi = P->src[s].col_hi;
+        const uint32_t rowoff = (uint32_t)m * (uint32_t)(P->ld_out * 2);
+#pragma unroll
+        for (int b = 0; b < SP_MAXB; ++b) {
+            if (b < n_blk) {
+#pragma unroll
+                for (int q = 0; q < 4; q += 2) {
+                    u32x4 v;
+                    sp_pack_pair<T>(acc[b], q, h, v);
+                    const int col = (blk_lo + b) * 32 + 8 * q + 8 * h;
+                    sp_bstore(v, orsrc, (col >= col_lo && col < col_hi) ? rowoff + (uint32_t)col * 2u : 0xFFFFFFFFu);
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_sp_xres : fused MTLoRALinear launch, "activation-resident" form (short reduction: K = NKC * CH <= 192).
+//   forward (T = 0):   Y = X W^T + b + Bp (alpha A D(X)^T)          one read of X, one write of Y [+ gelu(Y)] [+ P for the backward]
+//   dX of a wide layer: dX = dY W + keep .* (At (alpha Bt dY^T))     (reduction over the layer's N <= 192, K output columns)
+// A wave loads its 32-row slab (NKC chunks through its slot), keeps the fragments in registers, forms the projection
+// P^T / Q^T = proj . act^T with the stationary projection rows (NRB 32-row blocks), converts the accumulators in place into the
+// B-operand fragments of the rank step (k-permuted expansion factors, see k_pack) and then walks the output blocks of its
+// workgroup's part:  acc = bias | 0 ;  acc += expand[nb] . pf ;  [acc *= keep] ;  acc += w[nb] . xf ;  store.
+// The fragment reads of block nb + 1 are issued before the epilogue of block nb (they land while it converts and stores).
+// The output columns are split into n_parts parts (a workgroup owns one: its weights are stationary in LDS); the parts of
+// one slab group sit on the same XCD (blockIdx b -> XCD b % 8) so that the slab is re-read from that L2.
+// STG: the epilogue goes through a per-wave LDS image (32 rows x 64 columns) so that a store instruction writes 8 rows x
+// 128 contiguous bytes: a row-per-lane store (32 rows x 32 bytes) costs the texture-addresser ~80 cycles per instruction --
+// with 20 of them per slab the store ISSUE alone is 45 us of a 57 us launch (tools/sp_ablate.sh).
+// ------------------------------------------------------------------------------------------------
+struct SpLinParams {
+    const void* act;     // (M x K) contiguous
+    const void* w;       // (n_cols x K) row-major: output column -> reduction row
+    const void* proj;    // (R x K) row-major, alpha-scaled projection rows
+    const void* expand;  // fragment-major k-permuted expansion factors: [ceil(n_cols/32)][estep][64][8]
+    const float* bias;   // (n_cols) or null
+    void* out;           // (M x ld_out)
+    void* out2;          // ACT: gelu(out), same layout
+    void* pout;          // (M x ldp) projection image for the factor gradients, nullable
+    int64_t ld_out, ldp, M;
+    int n_cols, R, n_parts, blk_per_part;
+    int n_slabs, mask_act, mask_lr, dbg;  // dbg: developer ablation bits (MTLORA_SP_DBG): 1 no output stores, 2 no slab loads, 4 no block MFMAs, 8 no P store
+    int estep, pad_;     // rank steps per block in `expand` (2 * ceil(R / 32))
+    DropoutCfg drop;
+};
+typedef const __attribute__((address_space(4))) SpLinParams* SpLinPtr;
+
+constexpr int SP_STG_ROW = 64 * 2 + 8;        // row stride of a wave's 32 x 64 output image
+constexpr int SP_STG = 32 * SP_STG_ROW;       // 4352 bytes per wave
+
+// wait until at most min(n, known ladder step) vector-memory operations are outstanding (n = operations issued AFTER the one
+// waited for: loads return in order, stores are counted in order with them -- the compiler's own model on gfx9 -- and an
+// under-estimate only waits longer)
+__device__ __forceinline__ void sp_wait_younger(int n) {
+    if (n >= 48)
+        SP_WAIT_VM(48);
+    else if (n >= 32)
+        SP_WAIT_VM(32);
+    else if (n >= 20)
+        SP_WAIT_VM(20);
+    else if (n >= 12)
+        SP_WAIT_VM(12);
+    else if (n >= 6)
+        SP_WAIT_VM(6);
+    else
+        SP_WAIT_VM(0);
+}
+
+template <typename T, int CH, int NKC, int NRB, bool ACT, bool STG>
+__global__ __launch_bounds__(64 * SP_WAVES, SP_WAVES / 4) void k_sp_xres(const SpLinParams Pv) {
+    typedef SpGeom<CH> G;
+    constexpr int KST = NKC * G::KS;  // MFMA k-steps of the whole reduction
+    constexpr int K = NKC * CH;
+    constexpr int RST = 2 * NRB;      // rank steps
+    (void)Pv;
+    SpLinPtr P = (SpLinPtr)__builtin_amdgcn_kernarg_segment_ptr();
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5, rl = lane & 31;
+    const int64_t M = P->M;
+    const int n_cols = P->n_cols;
+    // (part, slab group) of this workgroup: b, b + 8, b + 16, ... (one XCD) are the parts of one group
+    const int n_parts = P->n_parts;
+    const int b = blockIdx.x;
+    const int part = (b >> 3) % n_parts;
+    const int grp = (b & 7) + 8 * (b / (8 * n_parts));
+    const int n_grp = gridDim.x / n_parts;
+    const int nb_all = (n_cols + 31) >> 5;
+    const int bpp = P->blk_per_part;
+    const int nb0 = part * bpp;
+    const int nbn = nb0 + bpp <= nb_all ? bpp : nb_all - nb0;  // blocks of this part (> 0 by construction)
+    // LDS: [w frags bpp*KST][proj frags NRB*KST][expand frags bpp*RST][bias 32*bpp floats][slots][output images]
+    unsigned char* wl = smem;
+    unsigned char* pl = wl + (size_t)bpp * KST * 1024;
+    unsigned char* el = pl + (size_t)NRB * KST * 1024;
+    float* bl = reinterpret_cast<float*>(el + (size_t)bpp * RST * 1024);
+    unsigned char* slots = reinterpret_cast<unsigned char*>(bl + bpp * 32) + (size_t)wave * G::SLOT;
+    unsigned char* img = reinterpret_cast<unsigned char*>(bl + bpp * 32) + (size_t)SP_WAVES * G::SLOT + (size_t)wave * SP_STG;
+    (void)img;
+    DropoutCfg drop;
+    drop.seed_lo = P->drop.seed_lo;
+    drop.seed_hi = P->drop.seed_hi;
+    drop.thr16 = P->drop.thr16;
+    drop.off = P->drop.off;
+    mtl_dropout_resolve(drop);
+    const bool mask_act = P->mask_act != 0 && drop.thr16 != 0, mask_lr = P->mask_lr != 0 && drop.thr16 != 0;
+    const int dbg = P->dbg;
+
+    {   // stationary operands
+        const T* wp = reinterpret_cast<const T*>(P->w);
+        for (int f = wave; f < nbn * KST; f += SP_WAVES) {
+            const int blk = f / KST, ks = f - blk * KST;
+            const int row = (nb0 + blk) * 32 + rl;
+            const void* g = row < n_cols ? (const void*)(wp + (int64_t)row * K + ks * 16 + 8 * h) : (const void*)g_zero16;
+            sp_dma16(g, wl + (size_t)f * 1024);
+        }
+        const T* pp = reinterpret_cast<const T*>(P->proj);
+        for (int f = wave; f < NRB * KST; f += SP_WAVES) {
+            const int blk = f / KST, ks = f - blk * KST;
+            const int row = blk * 32 + rl;
+            const void* g = row < P->R ? (const void*)(pp + (int64_t)row * K + ks * 16 + 8 * h) : (const void*)g_zero16;
+            sp_dma16(g, pl + (size_t)f * 1024);
+        }
+        const unsigned char* ep = reinterpret_cast<const unsigned char*>(P->expand);
+        const int estep = P->estep;
+        for (int f = wave; f < nbn * RST; f += SP_WAVES) {
+            const int blk = f / RST, t = f - blk * RST;
+            const void* g = t < estep ? (const void*)(ep + ((size_t)(nb0 + blk) * estep + t) * 1024 + lane * 16) : (const void*)g_zero16;
+            sp_dma16(g, el + (size_t)f * 1024);
+        }
+        for (int i = tid; i < bpp * 32; i += 64 * SP_WAVES) {
+            const int c = nb0 * 32 + i;
+            bl[i] = (P->bias && c < n_cols) ? P->bias[c] : 0.f;
+        }
+    }
+    int goff[G::NDMA], grow[G::NDMA], fo[G::KS];
+#pragma unroll
+    for (int j = 0; j < G::NDMA; ++j) {
+        const int c = j * 64 + lane, row = c / G::CPR, p = c - row * G::CPR;
+        grow[j] = row;
+        goff[j] = row * K + G::logical(row, p) * 8;
+    }
+#pragma unroll
+    for (int ks = 0; ks < G::KS; ++ks) fo[ks] = rl * G::ROWB + G::phys(rl, 2 * ks + h) * 16;
+    SP_WAIT_VM(0);
+    __syncthreads();
+
+    const int n_slabs = P->n_slabs;
+    const int stride = n_grp * SP_WAVES;
+    // loader cursor (one slot per wave: the next chunk is issued as soon as the current one is in registers)
+    int l_slab = grp * SP_WAVES + wave, l_ch = 0;
+    auto issue = [&]() __attribute__((always_inline)) -> bool {
+        if (l_slab >= n_slabs) return false;
+        const T* base = reinterpret_cast<const T*>(P->act) + (int64_t)l_slab * 32 * K + l_ch * CH;
+        if (dbg & 2) {
+        } else if ((int64_t)l_slab * 32 + 32 <= M) {
+#pragma unroll
+            for (int j = 0; j < G::NDMA; ++j) sp_dma16(base + goff[j], slots + j * 1024);
+        } else {
+            const int last = (int)(M - 1 - (int64_t)l_slab * 32);
+#pragma unroll
+            for (int j = 0; j < G::NDMA; ++j) {
+                const int r = grow[j] < last ? grow[j] : last;
+                sp_dma16(base + goff[j] + (r - grow[j]) * K, slots + j * 1024);
+            }
+        }
+        if (++l_ch == NKC) {
+            l_ch = 0;
+            l_slab += stride;
+        }
+        return true;
+    };
+    issue();
+    const __amdgpu_buffer_rsrc_t orsrc = sp_rsrc(P->out, M * P->ld_out * 2), o2rsrc = sp_rsrc(P->out2, P->out2 ? M * P->ld_out * 2 : 0),
+                                 prsrc = sp_rsrc(P->pout, P->pout ? M * P->ldp * 2 : 0);
+    (void)o2rsrc;
+    const uint32_t ldo2 = (uint32_t)(P->ld_out * 2);
+    int st_since = 0;  // store instructions certainly issued since the chunk now in flight was requested
+
+    for (int slab = grp * SP_WAVES + wave; slab < n_slabs; slab += stride) {
+        const int64_t m = (int64_t)slab * 32 + rl;
+        u32x4 xf[KST];
+#pragma unroll
+        for (int c = 0; c < NKC; ++c) {
+            sp_wait_younger(st_since);
+#pragma unroll
+            for (int ks = 0; ks < G::KS; ++ks) xf[c * G::KS + ks] = *reinterpret_cast<const u32x4*>(slots + fo[ks]);
+            SP_WAIT_LGKM0();
+            issue();
+            st_since = 0;
+        }
+        // ---- projection: accP[rb] = proj[rb] . f(act)^T
+        f32x16 accP[NRB];
+#pragma unroll
+        for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) accP[rb][r] = 0.f;
+        const uint32_t rh = mtl_dropout_rowhash(drop, 0u, (uint32_t)m);
+#pragma unroll
+        for (int ks = 0; ks < KST; ++ks) {
+            u32x4 pw[NRB];
+#pragma unroll
+            for (int rb = 0; rb < NRB; ++rb) pw[rb] = *reinterpret_cast<const u32x4*>(pl + ((size_t)rb * KST + ks) * 1024 + lane * 16);
+            u32x4 a = xf[ks];
+            if (mask_act) VOps<T>::drop(a, drop, rh, (uint32_t)(ks * 16 + 8 * h));
+#pragma unroll
+            for (int rb = 0; rb < NRB; ++rb) sp_mma1<T>(pw[rb], a, accP[rb]);
+        }
+        // the accumulators ARE the rank-step fragments: step t = 2 rb + t', slot s <-> register 8 t' + s
+        u32x4 pf[RST];
+#pragma unroll
+        for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+                pf[2 * rb + t] = u32x4{mtl_pack2<T>(accP[rb][8 * t + 0], accP[rb][8 * t + 1]), mtl_pack2<T>(accP[rb][8 * t + 2], accP[rb][8 * t + 3]),
+                                       mtl_pack2<T>(accP[rb][8 * t + 4], accP[rb][8 * t + 5]), mtl_pack2<T>(accP[rb][8 * t + 6], accP[rb][8 * t + 7])};
+        if (P->pout && part == 0 && !(dbg & 8)) {
+            const uint32_t prow = (uint32_t)m * (uint32_t)(P->ldp * 2);
+#pragma unroll
+            for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+                for (int q = 0; q < 4; q += 2) {
+                    u32x4 v;
+                    sp_pack_pair<T>(accP[rb], q, h, v);
+                    const int col = rb * 32 + 8 * q + 8 * h;
+                    sp_bstore(v, prsrc, col < P->R ? prow + (uint32_t)col * 2u : 0xFFFFFFFFu);
+                }
+            st_since += 2 * NRB;
+        }
+        // ---- output blocks of this part
+        u32x4 wf[KST], ef[RST];
+        f32x4 bv[4];
+        auto load_blk = [&](int nb) __attribute__((always_inline)) {
+            const unsigned char* eb = el + (size_t)nb * RST * 1024 + lane * 16;
+#pragma unroll
+            for (int t = 0; t < RST; ++t) ef[t] = *reinterpret_cast<const u32x4*>(eb + t * 1024);
+            const unsigned char* wb = wl + (size_t)nb * KST * 1024 + lane * 16;
+#pragma unroll
+            for (int ks = 0; ks < KST; ++ks) wf[ks] = *reinterpret_cast<const u32x4*>(wb + ks * 1024);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) bv[q] = *reinterpret_cast<const f32x4*>(bl + nb * 32 + 8 * q + 4 * h);
+        };
+        constexpr bool PF = KST <= 8 && SP_WAVES <= 8;  // register room for the next block's fragments next to the epilogue's temporaries
+        if constexpr (PF) load_blk(0);
+        for (int nb = 0; nb < nbn; ++nb) {
+            if constexpr (!PF) load_blk(nb);
+            f32x16 acc;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[4 * q + e] = bv[q][e];
+#pragma unroll
+            for (int t = 0; t < RST; ++t) sp_mma1<T>(ef[t], pf[t], acc);
+            const int col0 = (nb0 + nb) * 32;
+            if (mask_lr) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int n = col0 + 8 * q + 4 * h;
+                    const uint32_t h0 = mtl_dropout_pairbits(drop, rh, (uint32_t)n);
+                    const uint32_t h1 = mtl_dropout_pairbits(drop, rh, (uint32_t)(n + 2));
+                    if ((h0 & 0xFFFFu) < drop.thr16) acc[4 * q + 0] = 0.f;
+                    if ((h0 >> 16) < drop.thr16) acc[4 * q + 1] = 0.f;
+                    if ((h1 & 0xFFFFu) < drop.thr16) acc[4 * q + 2] = 0.f;
+                    if ((h1 >> 16) < drop.thr16) acc[4 * q + 3] = 0.f;
+                }
+            }
+            if (!(dbg & 4)) {
+#pragma unroll
+                for (int ks = 0; ks < KST; ++ks) sp_mma1<T>(wf[ks], xf[ks], acc);
+            }
+            if constexpr (PF) {
+                if (nb + 1 < nbn) load_blk(nb + 1);  // lands while this block is converted and stored
+            }
+            if constexpr (STG) {
+                // image columns (nb & 1) * 32 + 8 q + 4 h .. + 4 of row rl; flushed after the odd block of a pair / the last block
+                unsigned char* ip = img + rl * SP_STG_ROW + ((nb & 1) * 32 + 4 * h) * 2;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    *reinterpret_cast<u32x2*>(ip + q * 16) =
+                        u32x2{mtl_pack2<T>(acc[4 * q + 0], acc[4 * q + 1]), mtl_pack2<T>(acc[4 * q + 2], acc[4 * q + 3])};
+                if ((nb & 1) || nb + 1 == nbn) {
+                    const int c0 = (nb0 + (nb & ~1)) * 32;  // first column of the pair
+                    SP_WAIT_LGKM0();
+                    __builtin_amdgcn_wave_barrier();
+                    u32x4 v[4];
+#pragma unroll
+                    for (int it = 0; it < 4; ++it) v[it] = *reinterpret_cast<const u32x4*>(img + (it * 8 + (lane >> 3)) * SP_STG_ROW + (lane & 7) * 16);
+                    const int c16 = lane & 7, col = c0 + c16 * 8;
+                    const bool colok = col < n_cols && (c16 < 4 || (nb & 1));
+                    const uint32_t o0 = ((uint32_t)slab * 32u + (uint32_t)(lane >> 3)) * ldo2 + (uint32_t)col * 2u;
+#pragma unroll
+                    for (int it = 0; it < 4; ++it) {
+                        const uint32_t off = (colok && !(dbg & 1)) ? o0 + (uint32_t)(it * 8) * ldo2 : 0xFFFFFFFFu;
+                        sp_bstore(v[it], orsrc, off);
+                        if constexpr (ACT) {
+                            u32x4 av;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) av[e] = mtl_pack2<T>(gelu_fwd(mtl_lo2<T>(v[it][e])), gelu_fwd(mtl_hi2<T>(v[it][e])));
+                            sp_bstore(av, o2rsrc, off);
+                        }
+                    }
+                    st_since += ACT ? 8 : 4;
+                    __builtin_amdgcn_wave_barrier();
+                }
+            } else {
+                const uint32_t rowoff = (uint32_t)m * ldo2;
+#pragma unroll
+                for (int q = 0; q < 4; q += 2) {
+                    u32x4 v;
+                    sp_pack_pair<T>(acc, q, h, v);
+                    const int col = col0 + 8 * q + 8 * h;
+                    const uint32_t off = (col < n_cols && !(dbg & 1)) ? rowoff + (uint32_t)col * 2u : 0xFFFFFFFFu;
+                    sp_bstore(v, orsrc, off);
+                    if constexpr (ACT) {
+                        u32x4 av;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) av[e] = mtl_pack2<T>(gelu_fwd(mtl_lo2<T>(v[e])), gelu_fwd(mtl_hi2<T>(v[e])));
+                        sp_bstore(av, o2rsrc, off);
+                    }
+                }
+                st_since += ACT ? 4 : 2;
+            }
+        }
+    }
+}

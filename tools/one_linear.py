@@ -1,4 +1,5 @@
-"""One MTLoRALinear shape, forward only, repeated (profiling target):  python tools/one_linear.py M K N [iters] [r]"""
+"""One MTLoRALinear shape, forward only, repeated (profiling target):  python tools/one_linear.py M K N [iters] [r] [train]
+`train` (any 6th argument): train mode with lora_dropout 0.05 (the masked projection path) instead of eval."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -6,8 +7,12 @@ from mtlora_amd.lora import MTLoRALinear
 M, K, N = (int(v) for v in sys.argv[1:4])
 iters = int(sys.argv[4]) if len(sys.argv) > 4 else 20
 r = int(sys.argv[5]) if len(sys.argv) > 5 else 64
+train = len(sys.argv) > 6
 dev = torch.device("cuda")
-m = MTLoRALinear(K, N, r={"shared": r}, lora_shared_scale=4.0, lora_dropout=0.0, tasks=None).to(dev).eval()
+m = MTLoRALinear(K, N, r={"shared": r}, lora_shared_scale=4.0, lora_dropout=0.05 if train else 0.0, tasks=None).to(dev)
+m = m.train() if train else m.eval()
+with torch.no_grad():
+    m.lora_shared_B.normal_(0, 0.02)
 x = torch.randn(M, K, device=dev, dtype=torch.bfloat16)
 with torch.no_grad():
     for _ in range(3):

@@ -151,16 +151,26 @@ __device__ __forceinline__ Vec16<T> mtl_zero16() {
 
 // register-only vector helpers (no unions: element access through a union can push the staging registers of a
 // big kernel into scratch)
+__device__ __forceinline__ uint32_t mtl_pack_bf16(float a, float b) {
+    bf16 x = (bf16)a, y = (bf16)b;
+    return (uint32_t)__builtin_bit_cast(uint16_t, x) | ((uint32_t)__builtin_bit_cast(uint16_t, y) << 16);
+}
+__device__ __forceinline__ uint32_t mtl_pack_f16(float a, float b) {
+    f16 x = (f16)a, y = (f16)b;  // v_cvt_f16_f32: round to nearest even
+    return (uint32_t)__builtin_bit_cast(uint16_t, x) | ((uint32_t)__builtin_bit_cast(uint16_t, y) << 16);
+}
+// the same packing as ONE instruction (a vector conversion: v_cvt_pk_bf16_f32 / v_cvt_pk_f16_f32, round to nearest even, bit-identical
+// results) for the wave-streaming kernels, whose epilogues are VALU-bound.  NOT used by the tiled kernels: with it the 8-wave
+// masked-low-rank variants of k_nt (at the 128-VGPR cap) re-schedule into ~970 bytes of scratch per lane and run 8x slower.
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
-// (a vector conversion: ONE v_cvt_pk_bf16_f32 / v_cvt_pk_f16_f32, round to nearest even -- two scalar casts compile to two
-// conversions plus a shift and an or, four VALU operations per packed dword in every epilogue)
-__device__ __forceinline__ uint32_t mtl_pack_bf16(float a, float b) {
-    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{a, b}, bf16x2));
-}
-__device__ __forceinline__ uint32_t mtl_pack_f16(float a, float b) {
-    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{a, b}, f16x2));
+template <typename T>
+__device__ __forceinline__ uint32_t mtl_pk2(float a, float b) {
+    if constexpr (__is_same(T, f16))
+        return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{a, b}, f16x2));
+    else
+        return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{a, b}, bf16x2));
 }
 // two 16-bit elements of T in one dword <-> two floats (lo = element 0).  bf16: shifts; f16: conversions
 template <typename T>

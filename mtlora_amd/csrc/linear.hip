@@ -2078,6 +2078,73 @@ static void launch_sp_xres(const SpLinParams& q, const SpXresPlan& pl, bool act,
 #undef MTL_SP_X
 }
 
+// ---- fused wave-streaming launch, accumulator-resident form (k_sp_ares, stream.h): few output columns, any reduction length
+struct SpAresPlan {
+    int ch, nob, nrb;
+    unsigned grid;
+    size_t lds;
+};
+template <typename T>
+static bool sp_ares_plan(SpLinParams& q, int Kred, SpAresPlan& pl) {
+    if (sizeof(T) != 2 || sp_mode() == 0 || q.M <= 0 || q.M >= ((int64_t)1 << 31) - 64) return false;
+    pl.ch = Kred % 96 == 0 ? 96 : (Kred % 64 == 0 ? 64 : 0);
+    if (pl.ch == 0) return false;
+    pl.nob = pl.ch == 96 ? 3 : 4;
+    if (q.R <= 0 || q.R > 128 || (q.R % 16) != 0) return false;
+    pl.nrb = q.R <= 64 ? 2 : 4;
+    q.estep = 2 * ((q.R + 31) / 32);
+    q.estep2 = Kred;
+    if ((q.n_cols % 8) != 0 || (q.ld_out % 8) != 0 || (q.ldp % 8) != 0) return false;
+    if (q.M * q.ld_out * 2 >= ((int64_t)1 << 32) - 64 || q.M * q.ldp * 2 >= ((int64_t)1 << 32) - 64) return false;
+    const void* ptrs[] = {q.act, q.w, q.proj, q.expand, q.out, q.pout};
+    for (const void* pp : ptrs)
+        if (((uintptr_t)pp & 15u) != 0) return false;
+    const int nb_all = (q.n_cols + 31) / 32;
+    const int parts = (nb_all + pl.nob - 1) / pl.nob;
+    if (parts > 2) return false;  // every part re-reads the activation: only worth it for narrow outputs
+    const int64_t kst = Kred / 16;
+    const int64_t need = (int64_t)pl.nob * kst * 1024 + (int64_t)pl.nrb * kst * 1024 + (int64_t)pl.nob * 2 * pl.nrb * 1024 + pl.nob * 128 +
+                         (int64_t)SP_WAVES * 32 * pl.ch * 2;
+    if (need > SP_LDS_MAX - 512) return false;
+    pl.lds = (size_t)need;
+    q.n_parts = parts;
+    q.blk_per_part = pl.nob;
+    {
+        const char* e = getenv("MTLORA_SP_DBG");
+        q.dbg = e ? atoi(e) : 0;
+    }
+    q.n_slabs = (int)mtl_ceil_div(q.M, 32);
+    const int64_t g8_max = sp_num_cu() / (8 * parts) > 0 ? sp_num_cu() / (8 * parts) : 1;
+    int64_t g8 = mtl_ceil_div(mtl_ceil_div(q.n_slabs, SP_WAVES), 8);
+    if (g8 > g8_max) g8 = g8_max;
+    pl.grid = (unsigned)(8 * parts * g8);
+    return true;
+}
+template <typename T>
+static void launch_sp_ares(const SpLinParams& q, const SpAresPlan& pl, hipStream_t s, int kind, double alg_bytes, double s8d, double flops) {
+    mtl_prof_tag("sp_ares M%lld Kred%d N%d R%d parts%d", (long long)q.M, q.estep2, q.n_cols, q.R, q.n_parts);
+    MtlProfScope prof(kind, alg_bytes, s, s8d, flops);
+#define MTL_SP_A(CHV, NOBV, NRBV)                                                                                                  \
+    do {                                                                                                                            \
+        static bool raised = false;                                                                                                 \
+        if (!raised) {                                                                                                              \
+            (void)hipFuncSetAttribute((const void*)k_sp_ares<T, CHV, NOBV, NRBV>, hipFuncAttributeMaxDynamicSharedMemorySize, SP_LDS_MAX); \
+            raised = true;                                                                                                          \
+        }                                                                                                                           \
+        hipLaunchKernelGGL((k_sp_ares<T, CHV, NOBV, NRBV>), dim3(pl.grid), dim3(64 * SP_WAVES), pl.lds, s, q);                      \
+    } while (0)
+    if constexpr (sizeof(T) == 2) {
+        if (pl.ch == 96) {
+            if (pl.nrb == 2) MTL_SP_A(96, 3, 2);
+            else MTL_SP_A(96, 3, 4);
+        } else {
+            if (pl.nrb == 2) MTL_SP_A(64, 4, 2);
+            else MTL_SP_A(64, 4, 4);
+        }
+    }
+#undef MTL_SP_A
+}
+
 // k_pack of one layer into the packed-factor region at `pk` (the head of a forward's ctx buffer, or the caller's persistent
 // buffer of mtlora_linear_pack)
 template <typename T>
@@ -2556,9 +2623,36 @@ static int bwd_impl(const mtlora_linear_desc* d, const void* x, const void* cons
         // segments whose output got no gradient: the image holds zeros there and so does the HBM copy (written whole)
     }
 
+    // T = 0 layers whose input is narrow: Q, the masked rank part and dY W in ONE wave-streaming pass over dY (stream.h)
+    bool sp_dx_done = false;
+    if (d->T == 0 && d->mode == 0 && !pnl && do_dx && dx && dyo[0] && sg.R > 0 && !gate_s) {
+        SpLinParams q = {};
+        q.act = dyo[0];
+        q.w = Wt;
+        q.proj = pk + L.bt_proj;
+        q.expand = pk + L.at_frag;
+        q.out = dx;
+        q.pout = Qm;
+        q.ld_out = d->K;
+        q.ldp = sg.R;
+        q.M = d->M;
+        q.n_cols = (int)d->K;
+        q.R = sg.R;
+        q.mask_act = 0;
+        q.mask_lr = 1;
+        q.drop = dc;
+        SpAresPlan pl;
+        if (sp_ares_plan<T>(q, (int)d->N, pl)) {
+            const double b8d = (double)sizeof(T) * d->M * ((double)d->N + d->K);
+            const double fl = 2.0 * d->M * (double)d->N * d->K + 2.0 * d->M * (double)sg.r[0] * (d->K + d->N);
+            launch_sp_ares<T>(q, pl, s, PK_NT_BWD_DX, b8d, b8d, fl);
+            sp_dx_done = true;
+        }
+    }
+
     // Q[:, seg_o] = alpha_o * dY_o B_o   (zero where the output got no gradient)
     const int groups = (!pnl && dx && dyo[0] && !gate_s) ? fuse_groups(d, sg, d->K) : 0;  // row-panel form: Q is formed inside the dX kernel
-    if (sg.R > 0 && groups == 0 && !pnl && do_dx) {
+    if (sg.R > 0 && groups == 0 && !pnl && do_dx && !sp_dx_done) {
         bool any_missing = false;
         for (int o = 0; o < sg.n; ++o)
             if (sg.rp[o] > 0 && !dyo[o]) any_missing = true;
@@ -2617,7 +2711,7 @@ static int bwd_impl(const mtlora_linear_desc* d, const void* x, const void* cons
     }
 
     // dX = G W + keep .* (Q_s A_s [+ sum_t Q_t A_t]),  dX_t = Q_t A_t
-    if (!pnl && do_dx) {
+    if (!pnl && do_dx && !sp_dx_done) {
         NtParams m = {};
         if (presum && have_g) {
             m.n_act = 1;

@@ -103,8 +103,8 @@ __device__ __forceinline__ void sp_wait_chunk(int younger) {
 // 16-byte store per lane and pair.  `lo` / `hi`: only columns in [lo, hi) are written (multiples of 8).
 template <typename T>
 __device__ __forceinline__ void sp_pack_pair(const f32x16& a, int q, int hl, u32x4& v) {
-    uint32_t a0 = mtl_pack2<T>(a[4 * q + 0], a[4 * q + 1]), a1 = mtl_pack2<T>(a[4 * q + 2], a[4 * q + 3]);
-    uint32_t b0 = mtl_pack2<T>(a[4 * q + 4], a[4 * q + 5]), b1 = mtl_pack2<T>(a[4 * q + 6], a[4 * q + 7]);
+    uint32_t a0 = mtl_pk2<T>(a[4 * q + 0], a[4 * q + 1]), a1 = mtl_pk2<T>(a[4 * q + 2], a[4 * q + 3]);
+    uint32_t b0 = mtl_pk2<T>(a[4 * q + 4], a[4 * q + 5]), b1 = mtl_pk2<T>(a[4 * q + 6], a[4 * q + 7]);
     const auto r0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
     const auto r1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
     (void)hl;
@@ -294,7 +294,7 @@ struct SpLinParams {
     int64_t ld_out, ldp, M;
     int n_cols, R, n_parts, blk_per_part;
     int n_slabs, mask_act, mask_lr, dbg;  // dbg: developer ablation bits (MTLORA_SP_DBG): 1 no output stores, 2 no slab loads, 4 no block MFMAs, 8 no P store
-    int estep, pad_;     // rank steps per block in `expand` (2 * ceil(R / 32))
+    int estep, estep2;   // rank steps per block in `expand` (2 * ceil(R / 32)); k_sp_ares: the reduction length K
     DropoutCfg drop;
 };
 typedef const __attribute__((address_space(4))) SpLinParams* SpLinPtr;
@@ -466,8 +466,8 @@ __global__ __launch_bounds__(64 * SP_WAVES, SP_WAVES / 4) void k_sp_xres(const S
         for (int rb = 0; rb < NRB; ++rb)
 #pragma unroll
             for (int t = 0; t < 2; ++t)
-                pf[2 * rb + t] = u32x4{mtl_pack2<T>(accP[rb][8 * t + 0], accP[rb][8 * t + 1]), mtl_pack2<T>(accP[rb][8 * t + 2], accP[rb][8 * t + 3]),
-                                       mtl_pack2<T>(accP[rb][8 * t + 4], accP[rb][8 * t + 5]), mtl_pack2<T>(accP[rb][8 * t + 6], accP[rb][8 * t + 7])};
+                pf[2 * rb + t] = u32x4{mtl_pk2<T>(accP[rb][8 * t + 0], accP[rb][8 * t + 1]), mtl_pk2<T>(accP[rb][8 * t + 2], accP[rb][8 * t + 3]),
+                                       mtl_pk2<T>(accP[rb][8 * t + 4], accP[rb][8 * t + 5]), mtl_pk2<T>(accP[rb][8 * t + 6], accP[rb][8 * t + 7])};
         if (P->pout && part == 0 && !(dbg & 8)) {
             const uint32_t prow = (uint32_t)m * (uint32_t)(P->ldp * 2);
 #pragma unroll
@@ -531,7 +531,7 @@ __global__ __launch_bounds__(64 * SP_WAVES, SP_WAVES / 4) void k_sp_xres(const S
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
                     *reinterpret_cast<u32x2*>(ip + q * 16) =
-                        u32x2{mtl_pack2<T>(acc[4 * q + 0], acc[4 * q + 1]), mtl_pack2<T>(acc[4 * q + 2], acc[4 * q + 3])};
+                        u32x2{mtl_pk2<T>(acc[4 * q + 0], acc[4 * q + 1]), mtl_pk2<T>(acc[4 * q + 2], acc[4 * q + 3])};
                 if ((nb & 1) || nb + 1 == nbn) {
                     const int c0 = (nb0 + (nb & ~1)) * 32;  // first column of the pair
                     SP_WAIT_LGKM0();
@@ -549,7 +549,7 @@ __global__ __launch_bounds__(64 * SP_WAVES, SP_WAVES / 4) void k_sp_xres(const S
                         if constexpr (ACT) {
                             u32x4 av;
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) av[e] = mtl_pack2<T>(gelu_fwd(mtl_lo2<T>(v[it][e])), gelu_fwd(mtl_hi2<T>(v[it][e])));
+                            for (int e = 0; e < 4; ++e) av[e] = mtl_pk2<T>(gelu_fwd(mtl_lo2<T>(v[it][e])), gelu_fwd(mtl_hi2<T>(v[it][e])));
                             sp_bstore(av, o2rsrc, off);
                         }
                     }
@@ -568,11 +568,232 @@ __global__ __launch_bounds__(64 * SP_WAVES, SP_WAVES / 4) void k_sp_xres(const S
                     if constexpr (ACT) {
                         u32x4 av;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) av[e] = mtl_pack2<T>(gelu_fwd(mtl_lo2<T>(v[e])), gelu_fwd(mtl_hi2<T>(v[e])));
+                        for (int e = 0; e < 4; ++e) av[e] = mtl_pk2<T>(gelu_fwd(mtl_lo2<T>(v[e])), gelu_fwd(mtl_hi2<T>(v[e])));
                         sp_bstore(av, o2rsrc, off);
                     }
                 }
                 st_since += ACT ? 4 : 2;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_sp_ares : fused MTLoRALinear launch, "accumulator-resident" form (few output columns: n_cols <= 32 * NOB per part, any
+// reduction length K = n_ch * CH): the dX of a T = 0 layer whose output is wider than its input,
+//     dX = dY W + keep .* ((alpha dY B) A)        reduction over the layer's N, K <= 192 output columns,
+// in ONE pass over dY.  A wave streams its 32-row slab of the activation chunk by chunk through its slot; every chunk feeds
+// the NOB output accumulators (w fragments) AND the NRB projection accumulators (proj fragments: Q^T = alpha Bt dY^T); after
+// the last chunk the projection accumulators become the rank-step fragments (as in k_sp_xres), the rank part of every
+// output block is formed in a scratch accumulator, masked, added, and the block is stored.  [mask_act: the projection sees
+// the dropout-masked activation -- the forward of a narrow layer, Y = X W^T + b + Bp (alpha A D(X)^T).]
+// ------------------------------------------------------------------------------------------------
+template <typename T, int CH, int NOB, int NRB>
+__global__ __launch_bounds__(64 * SP_WAVES, SP_WAVES / 4) void k_sp_ares(const SpLinParams Pv) {
+    typedef SpGeom<CH> G;
+    constexpr int RST = 2 * NRB;
+    (void)Pv;
+    SpLinPtr P = (SpLinPtr)__builtin_amdgcn_kernarg_segment_ptr();
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5, rl = lane & 31;
+    const int64_t M = P->M;
+    const int n_cols = P->n_cols;
+    const int K = P->estep2;              // reduction length (elements), a multiple of CH
+    const int KST = K >> 4, NCH = K / CH;
+    const int n_parts = P->n_parts;
+    const int b = blockIdx.x;
+    const int part = (b >> 3) % n_parts;
+    const int grp = (b & 7) + 8 * (b / (8 * n_parts));
+    const int n_grp = gridDim.x / n_parts;
+    const int nb_all = (n_cols + 31) >> 5;
+    constexpr int bpp = NOB;              // blocks per part (blocks past the last column have zero weights and are not stored)
+    const int nb0 = part * bpp;
+    (void)nb_all;
+    // LDS: [w frags bpp*KST][proj frags NRB*KST][expand frags bpp*RST][bias 32*bpp floats][slots]
+    unsigned char* wl = smem;
+    unsigned char* pl = wl + (size_t)bpp * KST * 1024;
+    unsigned char* el = pl + (size_t)NRB * KST * 1024;
+    float* bl = reinterpret_cast<float*>(el + (size_t)bpp * RST * 1024);
+    unsigned char* slots = reinterpret_cast<unsigned char*>(bl + bpp * 32) + (size_t)wave * G::SLOT;
+    DropoutCfg drop;
+    drop.seed_lo = P->drop.seed_lo;
+    drop.seed_hi = P->drop.seed_hi;
+    drop.thr16 = P->drop.thr16;
+    drop.off = P->drop.off;
+    mtl_dropout_resolve(drop);
+    const bool mask_act = P->mask_act != 0 && drop.thr16 != 0, mask_lr = P->mask_lr != 0 && drop.thr16 != 0;
+    const int dbg = P->dbg;
+
+    {   // stationary operands
+        const T* wp = reinterpret_cast<const T*>(P->w);
+        for (int f = wave; f < bpp * KST; f += SP_WAVES) {
+            const int blk = f / KST, ks = f - blk * KST;
+            const int row = (nb0 + blk) * 32 + rl;
+            const void* g = row < n_cols ? (const void*)(wp + (int64_t)row * K + ks * 16 + 8 * h) : (const void*)g_zero16;
+            sp_dma16(g, wl + (size_t)f * 1024);
+        }
+        const T* pp = reinterpret_cast<const T*>(P->proj);
+        for (int f = wave; f < NRB * KST; f += SP_WAVES) {
+            const int blk = f / KST, ks = f - blk * KST;
+            const int row = blk * 32 + rl;
+            const void* g = row < P->R ? (const void*)(pp + (int64_t)row * K + ks * 16 + 8 * h) : (const void*)g_zero16;
+            sp_dma16(g, pl + (size_t)f * 1024);
+        }
+        const unsigned char* ep = reinterpret_cast<const unsigned char*>(P->expand);
+        const int estep = P->estep;
+        for (int f = wave; f < bpp * RST; f += SP_WAVES) {
+            const int blk = f / RST, t = f - blk * RST;
+            const void* g = (t < estep && (nb0 + blk) * 32 < n_cols) ? (const void*)(ep + ((size_t)(nb0 + blk) * estep + t) * 1024 + lane * 16) : (const void*)g_zero16;
+            sp_dma16(g, el + (size_t)f * 1024);
+        }
+        for (int i = tid; i < bpp * 32; i += 64 * SP_WAVES) {
+            const int c = nb0 * 32 + i;
+            bl[i] = (P->bias && c < n_cols) ? P->bias[c] : 0.f;
+        }
+    }
+    int goff[G::NDMA], grow[G::NDMA], fo[G::KS];
+#pragma unroll
+    for (int j = 0; j < G::NDMA; ++j) {
+        const int c = j * 64 + lane, row = c / G::CPR, p = c - row * G::CPR;
+        grow[j] = row;
+        goff[j] = row * K + G::logical(row, p) * 8;
+    }
+#pragma unroll
+    for (int ks = 0; ks < G::KS; ++ks) fo[ks] = rl * G::ROWB + G::phys(rl, 2 * ks + h) * 16;
+    SP_WAIT_VM(0);
+    __syncthreads();
+
+    const int n_slabs = P->n_slabs;
+    const int stride = n_grp * SP_WAVES;
+    int l_slab = grp * SP_WAVES + wave, l_ch = 0;
+    auto issue = [&]() __attribute__((always_inline)) -> bool {
+        if (l_slab >= n_slabs) return false;
+        const T* base = reinterpret_cast<const T*>(P->act) + (int64_t)l_slab * 32 * K + l_ch * CH;
+        if (dbg & 2) {
+        } else if ((int64_t)l_slab * 32 + 32 <= M) {
+#pragma unroll
+            for (int j = 0; j < G::NDMA; ++j) sp_dma16(base + goff[j], slots + j * 1024);
+        } else {
+            const int last = (int)(M - 1 - (int64_t)l_slab * 32);
+#pragma unroll
+            for (int j = 0; j < G::NDMA; ++j) {
+                const int r = grow[j] < last ? grow[j] : last;
+                sp_dma16(base + goff[j] + (r - grow[j]) * K, slots + j * 1024);
+            }
+        }
+        if (++l_ch == NCH) {
+            l_ch = 0;
+            l_slab += stride;
+        }
+        return true;
+    };
+    issue();
+    const __amdgpu_buffer_rsrc_t orsrc = sp_rsrc(P->out, M * P->ld_out * 2), prsrc = sp_rsrc(P->pout, P->pout ? M * P->ldp * 2 : 0);
+    const uint32_t ldo2 = (uint32_t)(P->ld_out * 2);
+    int st_since = 0;
+
+    for (int slab = grp * SP_WAVES + wave; slab < n_slabs; slab += stride) {
+        const int64_t m = (int64_t)slab * 32 + rl;
+        const uint32_t rh = mtl_dropout_rowhash(drop, 0u, (uint32_t)m);
+        f32x16 acc[NOB], accP[NRB];
+#pragma unroll
+        for (int ob = 0; ob < NOB; ++ob)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+                bv = *reinterpret_cast<const f32x4*>(bl + ob * 32 + 8 * q + 4 * h);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[ob][4 * q + e] = bv[e];
+            }
+#pragma unroll
+        for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) accP[rb][r] = 0.f;
+        for (int ch = 0; ch < NCH; ++ch) {
+            sp_wait_younger(st_since);
+            u32x4 xf[G::KS];
+#pragma unroll
+            for (int ks = 0; ks < G::KS; ++ks) xf[ks] = *reinterpret_cast<const u32x4*>(slots + fo[ks]);
+            SP_WAIT_LGKM0();
+            issue();
+            st_since = 0;
+            const unsigned char* wb = wl + (size_t)(ch * G::KS) * 1024 + lane * 16;
+            const unsigned char* pb = pl + (size_t)(ch * G::KS) * 1024 + lane * 16;
+#pragma unroll
+            for (int ks = 0; ks < G::KS; ++ks) {
+                if (ks & 1) __builtin_amdgcn_sched_barrier(0);  // at most two k-steps' fragments in flight (register room)
+                u32x4 wfr[NOB], pfr[NRB];
+#pragma unroll
+                for (int ob = 0; ob < NOB; ++ob)
+                    wfr[ob] = *reinterpret_cast<const u32x4*>(wb + ((size_t)ob * KST + ks) * 1024);
+#pragma unroll
+                for (int rb = 0; rb < NRB; ++rb) pfr[rb] = *reinterpret_cast<const u32x4*>(pb + ((size_t)rb * KST + ks) * 1024);
+                u32x4 a = xf[ks];
+                if (!(dbg & 4)) {
+#pragma unroll
+                    for (int ob = 0; ob < NOB; ++ob)
+                        sp_mma1<T>(wfr[ob], a, acc[ob]);
+                }
+                if (mask_act) VOps<T>::drop(a, drop, rh, (uint32_t)(ch * CH + ks * 16 + 8 * h));
+#pragma unroll
+                for (int rb = 0; rb < NRB; ++rb) sp_mma1<T>(pfr[rb], a, accP[rb]);
+            }
+        }
+        u32x4 pf[RST];
+#pragma unroll
+        for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+                pf[2 * rb + t] = u32x4{mtl_pk2<T>(accP[rb][8 * t + 0], accP[rb][8 * t + 1]), mtl_pk2<T>(accP[rb][8 * t + 2], accP[rb][8 * t + 3]),
+                                       mtl_pk2<T>(accP[rb][8 * t + 4], accP[rb][8 * t + 5]), mtl_pk2<T>(accP[rb][8 * t + 6], accP[rb][8 * t + 7])};
+        if (P->pout && part == 0 && !(dbg & 8)) {
+            const uint32_t prow = (uint32_t)m * (uint32_t)(P->ldp * 2);
+#pragma unroll
+            for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+                for (int q = 0; q < 4; q += 2) {
+                    u32x4 v;
+                    sp_pack_pair<T>(accP[rb], q, h, v);
+                    const int col = rb * 32 + 8 * q + 8 * h;
+                    sp_bstore(v, prsrc, col < P->R ? prow + (uint32_t)col * 2u : 0xFFFFFFFFu);
+                }
+            st_since += 2 * NRB;
+        }
+        const uint32_t rowoff = (uint32_t)m * ldo2;
+#pragma unroll
+        for (int ob = 0; ob < NOB; ++ob) {
+            {
+                const int col0 = (nb0 + ob) * 32;
+                const unsigned char* eb = el + (size_t)ob * RST * 1024 + lane * 16;
+                if (mask_lr) {
+                    f32x16 lr;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) lr[r] = 0.f;
+#pragma unroll
+                    for (int t = 0; t < RST; ++t) sp_mma1<T>(*reinterpret_cast<const u32x4*>(eb + t * 1024), pf[t], lr);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int n = col0 + 8 * q + 4 * h;
+                        const uint32_t h0 = mtl_dropout_pairbits(drop, rh, (uint32_t)n);
+                        const uint32_t h1 = mtl_dropout_pairbits(drop, rh, (uint32_t)(n + 2));
+                        if ((h0 & 0xFFFFu) >= drop.thr16) acc[ob][4 * q + 0] += lr[4 * q + 0];
+                        if ((h0 >> 16) >= drop.thr16) acc[ob][4 * q + 1] += lr[4 * q + 1];
+                        if ((h1 & 0xFFFFu) >= drop.thr16) acc[ob][4 * q + 2] += lr[4 * q + 2];
+                        if ((h1 >> 16) >= drop.thr16) acc[ob][4 * q + 3] += lr[4 * q + 3];
+                    }
+                } else {
+#pragma unroll
+                    for (int t = 0; t < RST; ++t) sp_mma1<T>(*reinterpret_cast<const u32x4*>(eb + t * 1024), pf[t], acc[ob]);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; q += 2) {
+                    u32x4 v;
+                    sp_pack_pair<T>(acc[ob], q, h, v);
+                    const int col = col0 + 8 * q + 8 * h;
+                    sp_bstore(v, orsrc, (col < n_cols && !(dbg & 1)) ? rowoff + (uint32_t)col * 2u : 0xFFFFFFFFu);
+                }
+                st_since += 2;
             }
         }
     }

@@ -1,23 +1,21 @@
 #!/usr/bin/env python3
-"""VGPRs / scratch / occupancy of every kernel in a .hip file (cross-compiles for gfx950; no GPU needed):
-    python tools/kernel_regs.py mtlora_amd/csrc/linear.hip [name-filter]"""
-import re, subprocess, sys, os
-src = sys.argv[1]; filt = sys.argv[2] if len(sys.argv) > 2 else ""
-out = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value",
-                      "-Wno-unused-result", "-c", os.path.basename(src), "-o", "/dev/null", "-Rpass-analysis=kernel-resource-usage"],
-                     capture_output=True, text=True, cwd=os.path.dirname(os.path.abspath(src))).stderr
-cur = None
-rows = {}
-for line in out.splitlines():
+"""VGPRs / scratch of every kernel of a translation unit: hipcc ... -Rpass-analysis=kernel-resource-usage 2> remarks.txt ;
+python tools/kernel_regs.py remarks.txt [--scratch-only]"""
+import re, sys
+cur, rows = None, []
+for line in open(sys.argv[1]):
     m = re.search(r"Function Name: (\S+)", line)
     if m:
-        cur = m.group(1); rows[cur] = {}
+        cur = {"name": m.group(1)}
+        rows.append(cur)
         continue
-    for key in ("VGPRs", "ScratchSize \[bytes/lane\]", "Occupancy \[waves/SIMD\]", "SGPRs Spill", "VGPRs Spill"):
-        m = re.search(r"remark:\s+" + key + r": (\d+)", line)
-        if m and cur:
-            rows[cur][key.split(" ")[0] + ("Spill" if "Spill" in key else "")] = int(m.group(1))
-for n, r in rows.items():
-    if filt in n:
-        d = subprocess.run(["c++filt", n], capture_output=True, text=True).stdout.strip()
-        print(f"{r.get('VGPRs', '?'):>4} vgpr  scratch {r.get('ScratchSize', '?'):>3}  occ {r.get('Occupancy', '?')}  sgprspill {r.get('SGPRsSpill', '?'):>3}  {d[:110]}")
+    for key, pat in (("vgpr", r" VGPRs: (\d+)"), ("agpr", r"AGPRs: (\d+)"), ("scratch", r"ScratchSize \[bytes/lane\]: (\d+)"),
+                     ("occ", r"Occupancy \[waves/SIMD\]: (\d+)"), ("sgpr", r"TotalSGPRs: (\d+)")):
+        m = re.search(pat, line)
+        if m and cur is not None:
+            cur[key] = int(m.group(1))
+only = "--scratch-only" in sys.argv
+for r in rows:
+    if only and not r.get("scratch"):
+        continue
+    print(f"{r.get('vgpr', 0):4d} vgpr {r.get('agpr', 0):4d} agpr {r.get('sgpr', 0):4d} sgpr {r.get('scratch', 0):5d} B scratch  occ {r.get('occ', 0)}  {r['name'][:110]}")

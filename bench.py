@@ -43,6 +43,7 @@ sys.path.insert(0, ROOT)
 os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")  # no exhaustive conv search for the (few) MIOpen ops left
 
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s achievable)
+HBM_ACHIEVABLE_GBS = 6290.0  # same guide: measured float4 copy
 MFMA_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak
 
 
@@ -62,6 +63,11 @@ def parse():
     ap.add_argument("--capturable", action="store_true", help="AdamW(capturable=True) in the eager step too (step counters on the device)")
     ap.add_argument("--force-reducer", action="store_true", help="run the gradient pack / RCCL all-reduce / unpack path even at 1 rank")
     ap.add_argument("--no-fused-loss", action="store_true", help="final upsample + losses through ATen instead of csrc/loss.hip")
+    ap.add_argument("--cores", type=int, default=0,
+                    help="pin this process to N host cores (sched_setaffinity + torch.set_num_threads): the host budget of one rank "
+                         "when 8 ranks share a node (16 cores / 8 ranks = 2)")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the short c4 / c5:4 legs the default (c2, 1 GPU) run appends under `other_configs`")
     return ap.parse_args()
 
 
@@ -153,7 +159,7 @@ def roofline(step_fn, steps):
     # HBM bytes per launch from the committed PMC passes of this same workload (separate `--pmc` runs cannot be collected
     # from inside the timed process): STATIC, and only quoted when the launch structure matches the profiled run
     traffic, traffic_src = None, None
-    for fn in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for fn in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         try:
             pm = json.load(open(os.path.join(ROOT, "profiles", fn)))
             if abs(pm["k_nt"]["launches_per_step"] - agg(nt + ["k_nt:plain_fwd", "k_nt:plain_dX"])[0] / steps) < 0.5:
@@ -162,9 +168,11 @@ def roofline(step_fn, steps):
         except Exception:
             continue
     return {"bound": "hbm" if hbm_frac >= mfma_frac else "mfma",
-            "kernel": "k_nt<bf16> hot-path launches (fused MTLoRALinear GEMM: fwd outputs, low-rank P/Q, bwd dX)",
+            "kernel": "MTLoRALinear hot-path launches: fused forward / dX (k_sp_xres / k_sp_ares wave-streaming, k_nt / k_ntl tiled) "
+                      "and the low-rank P / Q passes that remain (k_sp_proj / k_nt)",
             "achieved": round(ach8, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hbm_frac, 4),
-            "definition": "SURVEY 8(d) bytes of the k_nt launches / their HIP-event time / 8 TB/s",
+            "frac_achievable": round(ach8 / HBM_ACHIEVABLE_GBS, 4),
+            "definition": "SURVEY 8(d) bytes of these launches / their HIP-event time / 8 TB/s (frac_achievable: / 6.29 TB/s)",
             "traffic": traffic, "traffic_source": traffic_src,
             "launches_per_step": n / steps, "avg_launch_us": round(1e3 * ms / max(n, 1), 2),
             "alg_bytes_per_launch": round(b8 / max(n, 1)), "kernel_ms_per_step": round(ms / steps, 3),
@@ -263,21 +271,14 @@ def cpu_baseline(cfgrow):
             "sample": f"{cfgrow['what']}: train step, B={B}, fp32, 1 warm-up + {k} timed steps ({dt:.2f} s/step)"}
 
 
-def main():
-    args = parse()
-    rank, world, local = init_dist(args)
-    dev = torch.device("cuda", local)
-    from mtlora_amd import _lib as L
+def run_config(args, name, rank, world, dev, steps, warmup, want_roofline, batch=0):
+    """build the config's model, time `steps` train steps, optionally profile the library launches.  Returns (row, B, ips, fields)."""
     from mtlora_amd import mtl_harness as H
     from mtlora_amd.ddp import GradReducer
-    L.lib()  # fail loudly if the HIP extension is missing
-    if world > 1:  # N ranks share one host: keep each rank's intra-op CPU pool small (the step has no CPU-side compute)
-        torch.set_num_threads(max(1, min(4, usable_cores() // world)))
-
-    row = H.config(args.config)
+    row = H.config(name)
     tasks = list(row["tasks"])
-    B = args.batch or row["batch"]
-    model = H.build_config_model(args.config, seed=0, drop_path_rate=0.2).to(dev)
+    B = batch or row["batch"]
+    model = H.build_config_model(name, seed=0, drop_path_rate=0.2).to(dev)
     model.train()
     crit = H.MultiTaskLoss(tasks)
     opt = H.build_optimizer(model, lr=5e-4 * B * world / 512.0,  # main.py:578-583 linear LR scaling
@@ -303,33 +304,73 @@ def main():
             print(f"bench: HIP-graph replay not used, running eagerly: {gstep.why}", file=sys.stderr)
         step = gstep
 
-    dt, t_issue = time_steps(step, args.steps, args.warmup, world)
-    ips = B * world * args.steps / dt
+    dt, t_issue = time_steps(step, steps, warmup, world)
+    ips = B * world * steps / dt
     n_train = sum(p.numel() for p in model.parameters() if p.requires_grad)
-    default = args.config == "c2"
-    result = {
-        "metric": "images/sec (train step) Swin-T/448 r=64 4-task" if default else f"images/sec (train step) {args.config}",
-        "value": round(ips, 2), "unit": "images/sec",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+    fields = {
+        "value": round(ips, 2), "unit": "images/sec", "ms_per_step": round(1e3 * dt / steps, 3),
         "config": {"workload": row["what"] + "; train step (fwd+loss+bwd+clip+AdamW), dropout .05, drop_path .2",
-                   "name": args.config, "per_gpu_batch": B, "global_batch": B * world,
+                   "name": name, "per_gpu_batch": B, "global_batch": B * world,
                    "img_size": row["img_size"], "parallelism": f"dp{world}", "trainable_params": n_train,
                    "allreduce_bytes": reducer.nbytes if reducer else 0, "hip_graph": graph_info,
-                   "host_issue_ms_per_step": round(1e3 * t_issue / args.steps, 3)},
+                   "host_issue_ms_per_step": round(1e3 * t_issue / steps, 3), "host_cores": len(os.sched_getaffinity(0))},
     }
-    if rank == 0 and not args.no_roofline:
+    if rank == 0 and want_roofline:
         # profiled EAGERLY: the library's HIP-event brackets are recorded at launch time (same kernels as the graph)
-        result["roofline"] = roofline(eager_step, max(2, min(args.steps, 5)))
-    elif not args.no_roofline and world > 1:
-        for _ in range(1 + max(2, min(args.steps, 5))):  # keep ranks in lock-step with rank 0's profiled steps
+        fields["roofline"] = roofline(eager_step, max(2, min(steps, 5)))
+    elif want_roofline and world > 1:
+        for _ in range(1 + max(2, min(steps, 5))):  # keep ranks in lock-step with rank 0's profiled steps
             eager_step()
     del model, opt
     torch.cuda.empty_cache()
+    return row, B, ips, fields
+
+
+def main():
+    args = parse()
+    if args.cores > 0:  # the host budget of one rank on a shared node (before any thread pool starts)
+        allowed = sorted(os.sched_getaffinity(0))
+        os.sched_setaffinity(0, set(allowed[:max(1, min(args.cores, len(allowed)))]))
+        torch.set_num_threads(max(1, min(args.cores, len(allowed))))
+    rank, world, local = init_dist(args)
+    dev = torch.device("cuda", local)
+    from mtlora_amd import _lib as L
+    L.lib()  # fail loudly if the HIP extension is missing
+    if world > 1 and args.cores <= 0:  # N ranks share one host: keep each rank's intra-op CPU pool small (no CPU-side compute)
+        torch.set_num_threads(max(1, min(4, usable_cores() // world)))
+
+    row, B, ips, fields = run_config(args, args.config, rank, world, dev, args.steps, args.warmup, not args.no_roofline, args.batch)
+    default = args.config == "c2"
+    result = {
+        "metric": "images/sec (train step) Swin-T/448 r=64 4-task" if default else f"images/sec (train step) {args.config}",
+        "value": fields["value"], "unit": "images/sec",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": fields["ms_per_step"],
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": fields["config"],
+    }
+    if "roofline" in fields:
+        result["roofline"] = fields["roofline"]
     if rank == 0 and world == 1 and not args.no_eager_gpu:
         result["eager_gpu"] = eager_gpu(row, B, dev, ips)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(row)
+    if default and world == 1 and not args.no_other_configs and not args.batch:
+        # the other single-GPU BASELINE configs, short legs (5 steps, no baselines): Swin-B r=128 and the 8-task r=4 sweep point
+        others = {}
+        for name in ("c4", "c5:4"):
+            try:
+                _, Bo, _, f = run_config(args, name, rank, world, dev, 5, 2, not args.no_roofline)
+                o = {"value": f["value"], "unit": "images/sec", "ms_per_step": f["ms_per_step"], "per_gpu_batch": Bo,
+                     "workload": f["config"]["workload"], "host_issue_ms_per_step": f["config"]["host_issue_ms_per_step"]}
+                if "roofline" in f:
+                    r = f["roofline"]
+                    o["roofline"] = {k: r[k] for k in ("bound", "achieved", "peak", "unit", "frac", "frac_achievable", "kernel_ms_per_step",
+                                                         "launches_per_step", "traffic") if k in r}
+                    o["roofline"]["mfma_frac"] = r["mfma"]["frac"]
+                others[name] = o
+            except Exception as e:  # noqa: BLE001  (a failing side leg must not lose the headline line)
+                others[name] = {"error": f"{type(e).__name__}: {str(e)[:120]}"}
+        result["other_configs"] = others
     if world > 1:
         barrier(world)
         import torch.distributed as dist

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define MTLORA_ABI_VERSION 4
+#define MTLORA_ABI_VERSION 5
 #define MTLORA_MAX_TASKS 8
 
 typedef enum mtlora_dtype {
@@ -105,23 +105,10 @@ typedef struct mtlora_linear_desc {
                             put them on a second stream next to the rest of the backward chain: call phase 1 on stream s1,
                             order s2 after it (event), call phase 2 with the SAME arguments on s2, and join s2 before the
                             gradients are read.  Nothing but dA / dB depends on phase 2. */
-    int32_t prepacked;   /* ABI v4, with `pack`: 1 = `pack` already holds this call's packed factors (mtlora_linear_pack ran for
-                            the current A / B / scales / dropout_p): the forward does not launch k_pack */
-    const void* pack;    /* ABI v4, optional (NULL = none): a caller-owned buffer of mtlora_linear_pack_bytes(d) bytes that holds
-                            the packed low-rank factors INSTEAD of the head of `ctx` -- forward and backward of the call read
-                            them from here, so the caller can pack every layer once per optimizer step, ahead of time and off the
-                            forward's stream (parameters only, no activation involved).  Must stay untouched until the
-                            backward of the call has run. */
 } mtlora_linear_desc;
 
 /* bytes of the context buffer written by fwd and read by bwd (packed low-rank factors + P). */
 int64_t mtlora_linear_ctx_bytes(const mtlora_linear_desc* d);
-/* packed-factor buffer of `mtlora_linear_desc.pack` (ABI v4): its size (independent of d->M), and the k_pack launch that fills
- * it from the fp32 factors -- what `mtlora_linear_fwd` otherwise does first thing (reference: the `lora_*_A / lora_*_B` reads of
- * models/lora.py:253-284, repeated every call). */
-int64_t mtlora_linear_pack_bytes(const mtlora_linear_desc* d);
-int mtlora_linear_pack(const mtlora_linear_desc* d, const float* A_s, const float* B_s, const float* const* A_t,
-                       const float* const* B_t, void* pack, int64_t pack_bytes, void* stream);
 /* bytes of the backward scratch buffer. */
 int64_t mtlora_linear_bwd_scratch_bytes(const mtlora_linear_desc* d);
 

@@ -12,7 +12,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int6
 import torch
 
 MAX_TASKS = 8
-ABI_VERSION = 4
+ABI_VERSION = 5
 F32, BF16, F16 = 0, 1, 2
 _DT = {torch.float32: F32, torch.bfloat16: BF16, torch.float16: F16}
 
@@ -24,8 +24,7 @@ class LinearDesc(Structure):
     _fields_ = [("M", c_int64), ("K", c_int64), ("N", c_int64), ("dtype", c_int32), ("mode", c_int32),
                 ("T", c_int32), ("r_s", c_int32), ("r_t", c_int32 * MAX_TASKS), ("scale_s", c_float),
                 ("scale_t", c_float * MAX_TASKS), ("has_x_tasks", c_int32), ("dropout_p", c_float),
-                ("seed", c_uint64), ("seed_offset", c_void_p), ("bwd_phase", c_int32), ("prepacked", c_int32),
-                ("pack", c_void_p)]
+                ("seed", c_uint64), ("seed_offset", c_void_p), ("bwd_phase", c_int32)]
 
 
 class AttnDesc(Structure):
@@ -54,9 +53,6 @@ _SIGS = {
     "mtlora_window_merge_and_roll_forward": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int, c_int, c_int, c_void_p]),
     "mtlora_window_merge_and_roll_backward": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int, c_int, c_int, c_void_p]),
     "mtlora_linear_ctx_bytes": (c_int64, [POINTER(LinearDesc)]),
-    "mtlora_linear_pack_bytes": (c_int64, [POINTER(LinearDesc)]),
-    "mtlora_linear_pack": (c_int, [POINTER(LinearDesc), c_void_p, c_void_p, POINTER(c_void_p), POINTER(c_void_p), c_void_p,
-                                   c_int64, c_void_p]),
     "mtlora_linear_bwd_scratch_bytes": (c_int64, [POINTER(LinearDesc)]),
     "mtlora_linear_fwd": (c_int, [POINTER(LinearDesc), c_void_p, POINTER(c_void_p), c_void_p, c_void_p, c_void_p, c_void_p,
                                   POINTER(c_void_p), POINTER(c_void_p), c_void_p, POINTER(c_void_p), c_void_p, c_int64,

@@ -3,27 +3,31 @@
 //
 // Kernel families (all hand-written MFMA, 64-wide waves):
 //
-//   k_pack   fp32 LoRA masters -> compute-dtype packed factors, every rank padded to 16:
-//              A_cat (R x K), B_cat (N x R), At_cat (K x R), Bt_cat (R x N), alpha (R)   R = sum_o rp(o)
+//   k_pack   fp32 LoRA masters -> compute-dtype packed factors: A_cat (R x K), B_cat (N x R), At_cat (K x R), Bt_cat (R x N),
+//              alpha (R), the alpha-scaled projection rows a_proj / bt_proj and the fragment-major, k-permuted expansion
+//              factors b_frag / at_frag of the wave-streaming kernels;   R = sum_o rp(o), every rank padded to 8 columns
+//   k_sp_*   (stream.h) WAVE-STREAMING kernels, the default wherever a launch is eligible (16-bit types, stationary operands
+//            fit in LDS): k_sp_xres / k_sp_ares = ONE launch per T = 0 layer and direction (projection kept in registers, no
+//            P / Q pass, no re-read of X / dY), k_sp_proj = the P / Q passes of every other layer
 //   k_nt     "NT" tile GEMM  D[n][m] = sum_k Wgt[n][k] * Act[m][k]  (128 x 128 tile, 4 or 8 waves per workgroup) run
 //            as ONE software-pipelined stream of k-tiles over the base GEMM and every output's rank segment, with
 //              - multi-source activation (sum of up to 1+T tensors formed while staging: G = dY_s + sum dY_t)
 //              - optional dropout mask applied to the staged activation at LDS-store time (P = alpha * D(X) A^T)
-//              - bias / per-row alpha epilogue
+//              - bias / per-row alpha epilogue, GELU second output (ACT), GELU' gate (GATE)
 //              - multi-output low-rank parts: for each output o, extra k-tiles over the o-th rank segment of
 //                L (M x R) and R (N x R) chained onto the base accumulator (Y_o = base + L_o R_o^T), optionally
 //                masked (dX = G W + keep .* (Q A))
-//              - optional row-panel form (FUSE): the projection L is formed by the workgroup itself in LDS
 //            The MFMA "A" operand is the weight tile and "B" the activation tile, so a lane's four consecutive
 //            accumulator registers are four consecutive output COLUMNS; the bf16 epilogue goes through LDS so that
-//            stores are whole 128-byte row segments.
+//            stores are whole 128-byte row segments.   k_ntl = its single-output bf16 launches as straight-line code.
 //   k_tn     "TN" split-M reduction  Out[a][b] = sum_m SrcA[m][a] * SrcB[m][b]  (dA = Q^T D(X), dB^T = P^T dY) with
 //            64 (rank side) x 256 (wide side) tiles: both operands are read with the LDS transpose load
 //            (ds_read_b64_tr_b16) for bf16; per-split partials (deterministic) + k_tn_reduce.
 //   k_sum    G = sum of the output gradients (matrixv2 factors; pre-summed dX operand of wide outputs).
 //
-// Forward  = k_pack, k_nt (P = alpha D(X) A^T, per source), k_nt (all 1+T outputs, base shared).
-// Backward = [k_sum], k_nt (Q = alpha dY_o B_o per output), k_nt (dX [+ dX_t]), k_tn + k_tn_reduce for dA / dB.
+// Forward  = k_pack, then  k_sp_xres (T = 0, K <= 192)                       |  k_sp_proj / k_nt (P), k_nt (all 1+T outputs).
+// Backward = [k_sum], then k_sp_ares (T = 0, narrow input: Q + dX together)  |  k_sp_proj / k_nt (Q), k_nt (dX [+ dX_t]);
+//            k_tn + k_tn_reduce for dA / dB.
 // DESIGN.md section 4.1 / 4.3 has the measurements and the experiments that were tried and dropped.
 #include <stdlib.h>
 #include <type_traits>
@@ -97,8 +101,8 @@ static CtxLayout ctx_layout(const mtlora_linear_desc* d, const Segs& s) {
     L.at_cat = take((int64_t)d->K * s.R * es);
     L.bt_cat = take((int64_t)s.R * d->N * es);
     L.alpha = take((int64_t)s.R * 4);
-    L.a_proj = take((int64_t)s.R * d->K * es);   // alpha * A_cat   (projection weights of the row-panel forward, k_pnl)
-    L.bt_proj = take((int64_t)s.R * d->N * es);  // alpha * Bt_cat  (projection weights of the row-panel dX)
+    L.a_proj = take((int64_t)s.R * d->K * es);   // alpha * A_cat   (projection rows of the wave-streaming forward / P pass)
+    L.bt_proj = take((int64_t)s.R * d->N * es);  // alpha * Bt_cat  (projection rows of the wave-streaming dX / Q pass)
     // expansion factors of the wave-streaming kernels (stream.h), FRAGMENT-major and k-permuted: fragment (32-row block b,
     // 16-wide rank step t) = 1 KB, lane l = (row b*32 + (l & 31), h = l >> 5) holds the 8 rank columns
     // 16 t + 8 (s >> 2) + 4 h + (s & 3), s = 0..7 -- the order in which a lane holds P^T / Q^T after the projection MFMA
@@ -217,17 +221,6 @@ struct NtParams {
     int nz;
     const void* zact[MAXO];
     int zrow0[MAXO], zrows[MAXO], zmask[MAXO];
-    // fused low-rank projection (forward): P = alpha * D(src) A_cat^T is formed by the workgroup itself into an
-    // LDS image [128 m][pR] before the base GEMM; the rank-segment parts then read their activation operand from
-    // that image instead of a global P.  np sources (shared x, then x_t per task), each owning rank rows [lo,hi).
-    int np;
-    const void* pact[MAXO];
-    int pseg_lo[MAXO], pseg_hi[MAXO], pmask[MAXO];
-    const void* pA;        // A_cat (pR x pK)
-    int pK, pR;
-    const float* palpha;   // (pR)
-    void* pout;            // global P (M x pR), written by the n-group-0 workgroups for the backward
-    int n_groups;          // fused form: a workgroup owns a 128-row panel and 1/n_groups of its n-tiles (it loops over them)
     int dbg;               // MTLORA_NT_DBG ablation bits (tools only): 1 no global stores, 2 no global loads, 4 no MFMA, 8 no epilogue
     DropoutCfg drop;
 };
@@ -327,7 +320,7 @@ __device__ __forceinline__ void nt_load(TileRegs<T, RI>& rg, int tid, const T* w
 
 template <typename T, int RI>
 __device__ __forceinline__ void nt_store_lds(TileRegs<T, RI>& rg, int tid, unsigned char* sW, unsigned char* sA,
-                                             const DropoutCfg& dc, int64_t a_row0, bool with_act = true) {
+                                             const DropoutCfg& dc, int64_t a_row0) {
     constexpr int VEC = ET<T>::VEC;
 #pragma unroll
     for (int sl = 0; sl < 3 * RI; ++sl) {
@@ -338,7 +331,7 @@ __device__ __forceinline__ void nt_store_lds(TileRegs<T, RI>& rg, int tid, unsig
             VOps<T>::drop(rg.a[sl], dc, rh, (uint32_t)(rg.k0 + v * VEC));
         }
         *reinterpret_cast<u32x4*>(sW + r * LDSB + v * 16) = rg.w[sl];
-        if (with_act) *reinterpret_cast<u32x4*>(sA + r * LDSB + v * 16) = rg.a[sl];
+        *reinterpret_cast<u32x4*>(sA + r * LDSB + v * 16) = rg.a[sl];
     }
 }
 
@@ -389,7 +382,7 @@ struct NtCursor {
     int k_hi;      // end of the part's k range
     int lr;        // 1: rank-segment part (L x Rm), 0: base part (act x wgt)
     int valid;
-    int bn;        // n-tile the part belongs to (fused form: the stream runs on across the workgroup's n-tiles)
+    int bn;        // n-tile of the workgroup
 };
 
 __device__ __forceinline__ NtOut nt_out(NtPtr P, int o) {
@@ -407,16 +400,8 @@ __device__ __forceinline__ NtOut nt_out(NtPtr P, int o) {
 
 // k range of part q.  MULTI: q = 0 base, q = 1 + o rank segment of output o.
 // lean: q = 2 o rank segment of output o, q = 2 o + 1 base (if that output uses it).
-template <bool MULTI, bool FUSE>
+template <bool MULTI>
 __device__ __forceinline__ void nt_part(NtPtr P, int q, int& lr, int& k_lo, int& k_hi) {
-    const int np = FUSE ? P->np : 0;
-    if (q < np) {  // fused low-rank projection of source q
-        lr = 2;
-        k_lo = 0;
-        k_hi = P->pK;
-        return;
-    }
-    q -= np;
     if (MULTI) {
         if (q == 0) {
             lr = 0;
@@ -442,31 +427,24 @@ __device__ __forceinline__ void nt_part(NtPtr P, int q, int& lr, int& k_lo, int&
     }
 }
 
-template <bool MULTI, bool FUSE>
-__device__ __forceinline__ NtCursor nt_seek(NtPtr P, int q, int nseq, int bn, int bn_hi) {
+template <bool MULTI>
+__device__ __forceinline__ NtCursor nt_seek(NtPtr P, int q, int nseq, int bn) {
     NtCursor c;
     c.valid = 0;
     c.q = q;
     c.k0 = c.k_hi = c.lr = 0;
     c.bn = bn;
-    const int np = FUSE ? P->np : 0;
-    for (;;) {
-        for (; q < nseq; ++q) {
-            int lr, lo, hi;
-            nt_part<MULTI, FUSE>(P, q, lr, lo, hi);
-            if (hi > lo) {
-                c.q = q;
-                c.k0 = lo;
-                c.k_hi = hi;
-                c.lr = lr;
-                c.valid = 1;
-                c.bn = bn;
-                return c;
-            }
+    for (; q < nseq; ++q) {
+        int lr, lo, hi;
+        nt_part<MULTI>(P, q, lr, lo, hi);
+        if (hi > lo) {
+            c.q = q;
+            c.k0 = lo;
+            c.k_hi = hi;
+            c.lr = lr;
+            c.valid = 1;
+            return c;
         }
-        if (!FUSE || bn + 1 >= bn_hi) break;
-        ++bn;  // next n-tile of the panel: the projection parts are not repeated
-        q = np;
     }
     return c;
 }
@@ -508,7 +486,7 @@ __device__ __forceinline__ float gelu_fwd(float h) {
     return h * (0.5f + 0.5f * copysignf(erf_abs, h));
 }
 
-template <typename T, bool MULTI, bool MS, bool FUSE, bool MLR, int NW, bool GATE = false, bool ACT = false>
+template <typename T, bool MULTI, bool MS, bool MLR, int NW, bool GATE = false, bool ACT = false>
 __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void k_nt(const NtParams Pv) {
     constexpr int SM = 8 / NW;       // 32-row m sub-blocks per wave
     constexpr int MW = 32 * SM;      // m rows per wave
@@ -516,10 +494,9 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void k_nt(const NtParams 
     (void)Pv;
     NtPtr P = (NtPtr)__builtin_amdgcn_kernarg_segment_ptr();
     constexpr int KE = ROWB / (int)sizeof(T);
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // staging (2 x 128 x LDSB) [+ P image]
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // staging (2 x 128 x LDSB)
     unsigned char* sW = smem;
     unsigned char* sA = smem + TILE * LDSB;
-    unsigned char* sP = smem + STAGE_BYTES;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wn = NW == 4 ? wave >> 1 : wave >> 2, wm = NW == 4 ? wave & 1 : wave & 3;
 
@@ -540,28 +517,19 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void k_nt(const NtParams 
 
     // XCD-aware tile order: hardware places block b on XCD b % 8; give every XCD a contiguous run of
     // logical tiles so that the n-tiles sharing one activation row-block hit the same L2 (T1, bijective).
-    // Fused form: a workgroup = (row panel, n-group) and walks the n-tiles of its group itself.
     const int n_tiles = (n_rows + TILE - 1) / TILE;
-    const int G = FUSE ? P->n_groups : n_tiles;
     const int64_t m_tiles = (P->M + TILE - 1) / TILE;
-    const int64_t nwg = m_tiles * G;
+    const int64_t nwg = m_tiles * n_tiles;
     int64_t b = blockIdx.x;
     if (b >= nwg) return;
     {
         const int64_t q = nwg / 8, r = nwg % 8, xcd = b % 8;
         b = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + b / 8;
     }
-    const int64_t bm = b / G;
-    const int grp = (int)(b % G);
-    int bn_lo = grp, bn_hi = grp + 1;
-    if (FUSE) {
-        const int per = (n_tiles + G - 1) / G;
-        bn_lo = grp * per;
-        bn_hi = bn_lo + per < n_tiles ? bn_lo + per : n_tiles;
-        if (bn_lo >= bn_hi) return;
-    }
+    const int64_t bm = b / n_tiles;
+    const int bn0 = (int)(b % n_tiles);
     const int64_t m0 = bm * TILE;
-    int n0 = bn_lo * TILE;
+    const int n0 = bn0 * TILE;
 
     const T* wgt = reinterpret_cast<const T*>(P->wgt) + (int64_t)row_off * P->ld_wgt;
     DropoutCfg drop;
@@ -570,48 +538,36 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void k_nt(const NtParams 
     drop.thr16 = P->drop.thr16;
     drop.off = P->drop.off;
     mtl_dropout_resolve(drop);
-    const int np = FUSE ? P->np : 0;
-    const int PRS = P->pR * (int)sizeof(T) + 80;  // row stride of the LDS P image: pR columns + 64 zeroed bytes (a
-                                                  // 64-byte sub-tile may start 32 B before the end) + 16 B of skew
-    const int nseq = np + (MULTI ? 1 + P->n_out : 2 * P->n_out);
+    const int nseq = MULTI ? 1 + P->n_out : 2 * P->n_out;
 
     // ---- loader side of the stream (register prefetch, one wide tile ahead)
     TileRegs<T, SM> rg;
-    NtCursor ld = nt_seek<MULTI, FUSE>(P, 0, nseq, bn_lo, bn_hi);
+    NtCursor ld = nt_seek<MULTI>(P, 0, nseq, bn0);
     auto issue = [&](const NtCursor& c) __attribute__((always_inline)) {
-        if (FUSE && c.lr == 2)  // fused projection: weights = A_cat rows of source c.q, activation = that source
-            nt_load<T, false, SM>(rg, tid, reinterpret_cast<const T*>(P->pA), P->pK, 0, P->pseg_hi[c.q], P->pact[c.q], P, 1,
-                              P->pK, m0, P->M, c.k0, c.k_hi, P->pmask[c.q] != 0 && drop.thr16 != 0, P->pseg_lo[c.q]);
-        else if (c.lr)  // rank segment: weights = Rm; activation = L, or the LDS P image when the projection is fused
-            nt_load<T, false, SM>(rg, tid, reinterpret_cast<const T*>(P->Rm), P->ldR, c.bn * TILE, n_rows, np > 0 ? nullptr : P->L, P, 1,
-                              P->ldL, m0, P->M, c.k0, c.k_hi, false);
+        if (c.lr)  // rank segment: weights = Rm, activation = L
+            nt_load<T, false, SM>(rg, tid, reinterpret_cast<const T*>(P->Rm), P->ldR, c.bn * TILE, n_rows, P->L, P, 1, P->ldL, m0, P->M, c.k0,
+                                  c.k_hi, false);
         else
             nt_load<T, MS, SM>(rg, tid, wgt, P->ld_wgt, c.bn * TILE, n_rows, act0, P, P->n_act, P->ld_act, m0, P->M, c.k0, c.k_hi, act_mask);
     };
     const int dbg = P->dbg & NT_DBG_MASK;
     if (ld.valid && !(dbg & 2)) issue(ld);
     // consume one tile: registers -> LDS, prefetch the next tile of the stream, multiply
-    auto step = [&](f32x16(&acc)[2][SM], int k_left, int from_p, int k0) __attribute__((always_inline)) {
-        if (!(dbg & 64)) nt_store_lds<T, SM>(rg, tid, sW, sA, drop, m0, !from_p);
+    auto step = [&](f32x16(&acc)[2][SM], int k_left) __attribute__((always_inline)) {
+        if (!(dbg & 64)) nt_store_lds<T, SM>(rg, tid, sW, sA, drop, m0);
         if (!(dbg & 128)) __syncthreads();
         ld.k0 += KE;
-        if (ld.k0 >= ld.k_hi) ld = nt_seek<MULTI, FUSE>(P, ld.q + 1, nseq, ld.bn, bn_hi);
+        if (ld.k0 >= ld.k_hi) ld = nt_seek<MULTI>(P, ld.q + 1, nseq, bn0);
         if (ld.valid && !(dbg & 2)) issue(ld);
         // a wave whose 64 output columns lie entirely past n_rows (P / Q passes: <= 64 of the tile's 128 columns exist)
         // only helps staging: no LDS fragment reads, no MFMAs (wave-uniform test)
-        if (n0 + wn * 64 < n_rows && !(dbg & 4)) {
-            if (from_p)
-                nt_compute<T, SM>(acc, sW, sP + k0 * (int)sizeof(T), lane, wn, wm, k_left, PRS);
-            else
-                nt_compute<T, SM>(acc, sW, sA, lane, wn, wm, k_left);
-        }
+        if (n0 + wn * 64 < n_rows && !(dbg & 4)) nt_compute<T, SM>(acc, sW, sA, lane, wn, wm, k_left);
         if (!(dbg & 128)) __syncthreads();
     };
     auto run_part = [&](int q, f32x16(&acc)[2][SM]) __attribute__((always_inline)) {
         int lr, lo, hi;
-        nt_part<MULTI, FUSE>(P, q, lr, lo, hi);
-        const int from_p = (FUSE && lr == 1 && np > 0) ? 1 : 0;
-        for (int k0 = lo; k0 < hi; k0 += KE) step(acc, hi - k0, from_p, k0);
+        nt_part<MULTI>(P, q, lr, lo, hi);
+        for (int k0 = lo; k0 < hi; k0 += KE) step(acc, hi - k0);
         return hi > lo;
     };
     auto zero = [](f32x16(&a)[2][SM]) __attribute__((always_inline)) {
@@ -754,91 +710,42 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void k_nt(const NtParams 
         }
     };
 
-    // park the projected tile: acc holds P^T [rank r][m]; scale by alpha, write the LDS image [m][r] (and the global
-    // copy for the backward from the n-tile-0 workgroups)
-    auto park_p = [&](f32x16(&a)[2][SM]) __attribute__((always_inline)) {
-        T* pg = reinterpret_cast<T*>(P->pout);
-        for (int i = tid; i < TILE * 4; i += NT)  // zero the 64-byte tail of every row (0 * garbage could be NaN)
-            *reinterpret_cast<u32x4*>(sP + (i >> 2) * PRS + P->pR * (int)sizeof(T) + (i & 3) * 16) = u32x4{0u, 0u, 0u, 0u};
-#pragma unroll
-        for (int sm = 0; sm < SM; ++sm) {
-            const int ml = wm * MW + sm * 32 + (lane & 31);
-            const int64_t m = m0 + ml;
-#pragma unroll
-            for (int sn = 0; sn < 2; ++sn)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int r = wn * 64 + sn * 32 + 8 * q + 4 * (lane >> 5);
-                    if (r < P->pR) {
-                        const f32x4 al = *reinterpret_cast<const f32x4*>(P->palpha + r);
-                        const float v0 = a[sn][sm][q * 4] * al[0], v1 = a[sn][sm][q * 4 + 1] * al[1],
-                                    v2 = a[sn][sm][q * 4 + 2] * al[2], v3 = a[sn][sm][q * 4 + 3] * al[3];
-                        if constexpr (sizeof(T) == 4) {
-                            *reinterpret_cast<f32x4*>(sP + ml * PRS + r * 4) = f32x4{v0, v1, v2, v3};
-                            if (pg && grp == 0 && m < P->M) *reinterpret_cast<f32x4*>(pg + m * P->pR + r) = f32x4{v0, v1, v2, v3};
-                        } else {
-                            const u32x2 pk = {mtl_pack2<T>(v0, v1), mtl_pack2<T>(v2, v3)};
-                            *reinterpret_cast<u32x2*>(sP + ml * PRS + r * 2) = pk;
-                            if (pg && grp == 0 && m < P->M) *reinterpret_cast<u32x2*>(pg + m * P->pR + r) = pk;
-                        }
-                    }
-                }
-        }
-        __syncthreads();
-    };
-
     if constexpr (MULTI) {
         f32x16 base[2][SM], acc[2][SM];
-        if constexpr (FUSE) {
-            zero(acc);
-            for (int q = 0; q < np; ++q) run_part(q, acc);
-            if (np > 0) park_p(acc);
-        }
-        for (int bn = bn_lo; bn < bn_hi; ++bn) {
-            n0 = bn * TILE;
-            zero(base);
-            run_part(np, base);
-            affine(base);
-            for (int o = 0; o < P->n_out; ++o) {
-                const NtOut O = nt_out(P, o);
+        zero(base);
+        run_part(0, base);
+        affine(base);
+        for (int o = 0; o < P->n_out; ++o) {
+            const NtOut O = nt_out(P, o);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < SM; ++j) acc[i][j] = base[i][j];
+            run_part(1 + o, acc);
+            if (O.fold) {
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int j = 0; j < SM; ++j) acc[i][j] = base[i][j];
-                run_part(np + 1 + o, acc);
-                if (O.fold) {
-#pragma unroll
-                    for (int i = 0; i < 2; ++i)
-#pragma unroll
-                        for (int j = 0; j < SM; ++j) base[i][j] = acc[i][j];
-                }
-                store(acc, O.ptr, O.gate, O.act);
-                __syncthreads();  // the output image lives in the staging buffers
+                    for (int j = 0; j < SM; ++j) base[i][j] = acc[i][j];
             }
+            store(acc, O.ptr, O.gate, O.act);
+            __syncthreads();  // the output image lives in the staging buffers
         }
     } else {
         f32x16 acc[2][SM];
-        if constexpr (FUSE) {
+        for (int o = 0; o < P->n_out; ++o) {
+            const NtOut O = nt_out(P, o);
             zero(acc);
-            for (int q = 0; q < np; ++q) run_part(q, acc);
-            if (np > 0) park_p(acc);
-        }
-        for (int bn = bn_lo; bn < bn_hi; ++bn) {
-            n0 = bn * TILE;
-            for (int o = 0; o < P->n_out; ++o) {
-                const NtOut O = nt_out(P, o);
-                zero(acc);
-                const bool had_lr = run_part(np + 2 * o, acc);
-                if constexpr (MLR) {
-                    if (had_lr && O.mask_lr && drop.enabled()) apply_mask(acc);
-                } else {
-                    (void)had_lr;
-                }
-                run_part(np + 2 * o + 1, acc);
-                if (O.use_base) affine(acc);
-                store(acc, O.ptr, O.gate, O.act);
-                __syncthreads();  // the output image lives in the staging buffers
+            const bool had_lr = run_part(2 * o, acc);
+            if constexpr (MLR) {
+                if (had_lr && O.mask_lr && drop.enabled()) apply_mask(acc);
+            } else {
+                (void)had_lr;
             }
+            run_part(2 * o + 1, acc);
+            if (O.use_base) affine(acc);
+            store(acc, O.ptr, O.gate, O.act);
+            __syncthreads();  // the output image lives in the staging buffers
         }
     }
 }
@@ -1036,233 +943,6 @@ __global__ __launch_bounds__(512, 4) void k_ntl(const NlParams P) {
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// k_nt2 : the lean single-output case of k_nt (bf16; one rank segment + base GEMM, optional masked low-rank part and
-// GELU' gate) with a DIRECT-TO-LDS load path for the MFMA-dense launches (stages 2 / 3, decoder heads):
-//   * 256 (m) x 128 (n) workgroup tile, 8 waves of 64 x 64, k-tiles of 64 elements (128-byte rows);
-//   * tiles are fetched with global_load_lds_dwordx4 (no staging registers): a wave instruction fills 1 KB = 8 rows of
-//     LDS linearly; WHICH 16-byte chunk of its row a lane fetches is XOR-swizzled (chunk ^ ((row >> 1) & 7)) so that the
-//     ds_read_b128 fragment reads (16 lanes per LDS cycle: 16 rows, one logical chunk) touch all 64 banks once;
-//     chunks past the k range / rows past M, N come from a 16-byte zero page;
-//   * 3-stage LDS ring (3 x 48 KB), ONE barrier per k-tile: wait own loads of tile t (vmcnt), barrier, issue tile t + 2
-//     into the slot tile t - 1 just vacated, multiply tile t.
-// Same accumulator / epilogue conventions as k_nt (A operand = weights, bf16 output transposed through LDS).
-// ------------------------------------------------------------------------------------------------
-constexpr int T2_M = 256, T2_N = 128, T2_K = 64;
-constexpr int T2_ROWB = T2_K * 2;                        // 128 bytes per row per k-tile
-constexpr int T2_STAGE = (T2_M + T2_N) * T2_ROWB;        // 48 KB
-constexpr int T2_NSTAGE = 3;
-constexpr int T2_LDS = T2_NSTAGE * T2_STAGE;             // 144 KB (epilogue images 8 x 64 x 136 B reuse it)
-template <bool MLR, bool GATE>
-__global__ __launch_bounds__(512, 2) void k_nt2(const NtParams Pv) {
-    (void)Pv;
-    NtPtr P = (NtPtr)__builtin_amdgcn_kernarg_segment_ptr();
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wn = wave >> 2, wm = wave & 3;
-    const int n_rows = P->n_rows;
-    const int n_tiles = (n_rows + T2_N - 1) / T2_N;
-    const int64_t m_tiles = (P->M + T2_M - 1) / T2_M;
-    const int64_t nwg = m_tiles * n_tiles;
-    int64_t b = blockIdx.x;
-    if (b >= nwg) return;
-    {
-        const int64_t q = nwg / 8, r = nwg % 8, xcd = b % 8;
-        b = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + b / 8;
-    }
-    const int64_t m0 = (b / n_tiles) * T2_M;
-    const int n0 = (int)(b % n_tiles) * T2_N;
-    const NtOut O = nt_out(P, 0);
-    DropoutCfg drop;
-    drop.seed_lo = P->drop.seed_lo;
-    drop.seed_hi = P->drop.seed_hi;
-    drop.thr16 = P->drop.thr16;
-    drop.off = P->drop.off;
-    mtl_dropout_resolve(drop);
-
-    // tile sequence: rank segment [seg_lo, seg_hi) of (L, Rm) first, then the base GEMM [0, K) of (act, wgt)
-    const int r_tiles = (O.seg_hi - O.seg_lo + T2_K - 1) / T2_K;
-    const int b_tiles = O.use_base ? (P->K + T2_K - 1) / T2_K : 0;
-    const int n_t = r_tiles + b_tiles;
-
-    // loader: wave-instruction j of wave w fills the 8 rows [8 q, 8 q + 8), q = 6 w + j, of the stage's 384 rows
-    // (rows 0..127 = weight-side operand, 128..383 = activation-side operand)
-    const bf16* wgt = reinterpret_cast<const bf16*>(P->wgt);
-    const bf16* act = reinterpret_cast<const bf16*>(P->act[0]);
-    const bf16* Rm = reinterpret_cast<const bf16*>(P->Rm);
-    const bf16* Lm = reinterpret_cast<const bf16*>(P->L);
-    int64_t grow[6];   // global row of this lane's chunk (weight row n or activation row m), -1 when out of range
-    int kchunk[6];     // logical 16-byte chunk (0..7) this lane fetches = physical position ^ swizzle(row)
-#pragma unroll
-    for (int j = 0; j < 6; ++j) {
-        const int q = wave * 6 + j;
-        const int row = q * 8 + (lane >> 3);  // 0..383
-        const bool is_w = row < T2_N;
-        const int rl = is_w ? row : row - T2_N;
-        kchunk[j] = (lane & 7) ^ ((rl >> 1) & 7);
-        if (is_w)
-            grow[j] = (n0 + rl < n_rows) ? (int64_t)(n0 + rl) : -1;
-        else
-            grow[j] = (m0 + rl < P->M) ? m0 + rl : -1;
-    }
-    auto issue = [&](int t) __attribute__((always_inline)) {
-        unsigned char* stage = smem + (t % T2_NSTAGE) * T2_STAGE;
-        const bool lr = t < r_tiles;
-        const int k0 = lr ? O.seg_lo + t * T2_K : (t - r_tiles) * T2_K;
-        const int k_hi = lr ? O.seg_hi : P->K;
-        const bf16* wsrc = lr ? Rm : wgt;
-        const bf16* asrc = lr ? Lm : act;
-        const int64_t ldw = lr ? P->ldR : P->ld_wgt, lda = lr ? P->ldL : P->ld_act;
-#pragma unroll
-        for (int j = 0; j < 6; ++j) {
-            const int q = wave * 6 + j;
-            const bool is_w = q < T2_N / 8;  // wave-uniform
-            const int k = k0 + kchunk[j] * 8;
-            const bf16* src = (is_w ? wsrc + grow[j] * ldw : asrc + grow[j] * lda) + k;
-            const void* g = (grow[j] >= 0 && k < k_hi) ? (const void*)src : (const void*)g_zero16;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                             (__attribute__((address_space(3))) void*)(stage + q * 1024), 16, 0, 0);
-        }
-    };
-
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    const int h = lane >> 5, rl32 = lane & 31;
-    // byte offsets of this lane's fragment rows inside a stage (row * 128) and their swizzle
-    int wrow[2], arow[2], wsw[2], asw[2];
-#pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2) {
-        const int rw = wn * 64 + s2 * 32 + rl32, ra = wm * 64 + s2 * 32 + rl32;
-        wrow[s2] = rw * T2_ROWB;
-        arow[s2] = T2_N * T2_ROWB + ra * T2_ROWB;
-        wsw[s2] = (rw >> 1) & 7;
-        asw[s2] = (ra >> 1) & 7;
-    }
-    auto compute = [&](int t) __attribute__((always_inline)) {
-        const unsigned char* stage = smem + (t % T2_NSTAGE) * T2_STAGE;
-        Frag<bf16> fw[2][2], fa[2][2];  // [sub-tile][32-row block]
-#pragma unroll
-        for (int u = 0; u < 2; ++u)
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                fw[u][s2].v[0] = *reinterpret_cast<const u32x4*>(stage + wrow[s2] + (((4 * u + h) ^ wsw[s2]) << 4));
-                fw[u][s2].v[1] = *reinterpret_cast<const u32x4*>(stage + wrow[s2] + (((4 * u + 2 + h) ^ wsw[s2]) << 4));
-                fa[u][s2].v[0] = *reinterpret_cast<const u32x4*>(stage + arow[s2] + (((4 * u + h) ^ asw[s2]) << 4));
-                fa[u][s2].v[1] = *reinterpret_cast<const u32x4*>(stage + arow[s2] + (((4 * u + 2 + h) ^ asw[s2]) << 4));
-            }
-#pragma unroll
-        for (int u = 0; u < 2; ++u)
-#pragma unroll
-            for (int sn = 0; sn < 2; ++sn)
-#pragma unroll
-                for (int sm = 0; sm < 2; ++sm) mtl_mma(fw[u][sn], fa[u][sm], acc[sn][sm]);
-    };
-    auto apply_mask = [&]() __attribute__((always_inline)) {
-#pragma unroll
-        for (int sm = 0; sm < 2; ++sm) {
-            const int64_t m = m0 + wm * 64 + sm * 32 + (lane & 31);
-            const uint32_t rh = mtl_dropout_rowhash(drop, 0u, (uint32_t)m);
-#pragma unroll
-            for (int sn = 0; sn < 2; ++sn)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int n = n0 + wn * 64 + sn * 32 + 8 * q + 4 * (lane >> 5);
-                    const uint32_t h0 = mtl_dropout_pairbits(drop, rh, (uint32_t)n);
-                    const uint32_t h1 = mtl_dropout_pairbits(drop, rh, (uint32_t)(n + 2));
-                    if ((h0 & 0xFFFFu) < drop.thr16) acc[sn][sm][q * 4 + 0] = 0.f;
-                    if ((h0 >> 16) < drop.thr16) acc[sn][sm][q * 4 + 1] = 0.f;
-                    if ((h1 & 0xFFFFu) < drop.thr16) acc[sn][sm][q * 4 + 2] = 0.f;
-                    if ((h1 >> 16) < drop.thr16) acc[sn][sm][q * 4 + 3] = 0.f;
-                }
-        }
-    };
-
-    if (n_t > 0) issue(0);
-    if (n_t > 1) issue(1);
-    for (int t = 0; t < n_t; ++t) {
-        if (t + 1 < n_t)
-            __builtin_amdgcn_s_waitcnt(0x0F76);  // vmcnt(6): this wave's loads of tile t have landed (tile t + 1 may be in flight)
-        else
-            __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
-        // (a bare s_barrier: __syncthreads() carries a workgroup fence, for which the compiler drains vmcnt to 0 -- i.e.
-        // also waits for tile t + 1 -- because LDS-DMA loads write LDS)
-        asm volatile("s_barrier" ::: "memory");  // ... and everybody else's; slot (t - 1) % 3 is free again
-        if (t + 2 < n_t) issue(t + 2);
-        compute(t);
-        if constexpr (MLR) {
-            if (t + 1 == r_tiles && O.mask_lr && drop.enabled()) apply_mask();
-        }
-    }
-
-    // acc = acc * alpha[n] + bias[n]
-    if (O.use_base && (P->alpha || P->bias)) {
-#pragma unroll
-        for (int sn = 0; sn < 2; ++sn)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int n = n0 + wn * 64 + sn * 32 + 8 * q + 4 * (lane >> 5);
-                if (n < n_rows) {
-                    f32x4 al = {1.f, 1.f, 1.f, 1.f}, bi = {0.f, 0.f, 0.f, 0.f};
-                    if (P->alpha) al = *reinterpret_cast<const f32x4*>(P->alpha + n);
-                    if (P->bias) bi = *reinterpret_cast<const f32x4*>(P->bias + n);
-#pragma unroll
-                    for (int sm = 0; sm < 2; ++sm)
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) acc[sn][sm][q * 4 + e] = acc[sn][sm][q * 4 + e] * al[e] + bi[e];
-                }
-            }
-    }
-    __syncthreads();  // all fragment reads done: the ring becomes the per-wave output images
-    bf16* outp = reinterpret_cast<bf16*>(O.ptr);
-    if (!outp || n0 + wn * 64 >= n_rows) return;
-    const bf16* gate = reinterpret_cast<const bf16*>(O.gate);
-    (void)gate;
-    constexpr int ORS = EPI_ROW;
-    unsigned char* img = smem + wave * (64 * ORS);
-#pragma unroll
-    for (int sm = 0; sm < 2; ++sm)
-#pragma unroll
-        for (int sn = 0; sn < 2; ++sn)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int ml = sm * 32 + (lane & 31), nl = sn * 32 + 8 * q + 4 * (lane >> 5);
-                u32x2 pk = {mtl_pack_bf16(acc[sn][sm][q * 4], acc[sn][sm][q * 4 + 1]),
-                            mtl_pack_bf16(acc[sn][sm][q * 4 + 2], acc[sn][sm][q * 4 + 3])};
-                *reinterpret_cast<u32x2*>(img + ml * ORS + nl * 2) = pk;
-            }
-    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the image is private to this wave
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int it = 0; it < 8; ++it) {
-        const int ml = it * 8 + (lane >> 3), c16 = lane & 7;
-        const int64_t m = m0 + wm * 64 + ml;
-        const int n = n0 + wn * 64 + c16 * 8;
-        u32x4 v = *reinterpret_cast<const u32x4*>(img + ml * ORS + c16 * 16);
-        if (m < P->M && n < n_rows) {
-            if constexpr (GATE) {
-                if (gate) {
-                    const u32x4 hv = *reinterpret_cast<const u32x4*>(gate + m * P->ld_out + n);
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const float g0 = __builtin_bit_cast(float, v[q] << 16) * gelu_grad(__builtin_bit_cast(float, hv[q] << 16));
-                        const float g1 = __builtin_bit_cast(float, v[q] & 0xFFFF0000u) *
-                                         gelu_grad(__builtin_bit_cast(float, hv[q] & 0xFFFF0000u));
-                        v[q] = mtl_pack_bf16(g0, g1);
-                    }
-                }
-            }
-            *reinterpret_cast<u32x4*>(outp + m * P->ld_out + n) = v;
-        }
-    }
-}
-
-#include "panel.h"
 #include "stream.h"
 
 // ------------------------------------------------------------------------------------------------
@@ -1564,46 +1244,11 @@ static int check_desc(const mtlora_linear_desc* d) {
         if (d->r_t[t] <= 0) return MTLORA_ERR_SHAPE;
     if (d->mode != 0 && d->mode != 1) return MTLORA_ERR_UNSUPPORTED;
     if (d->bwd_phase < 0 || d->bwd_phase > 2) return MTLORA_ERR_UNSUPPORTED;
-    if (d->pack && ((uintptr_t)d->pack & 15u)) return MTLORA_ERR_ALIGN;
     if (d->dropout_p < 0.f || d->dropout_p >= 1.f) return MTLORA_ERR_SHAPE;
     return MTLORA_OK;
 }
 
 static bool misaligned(const void* p) { return ((uintptr_t)p & 15u) != 0; }
-
-static int nt_waves() {
-    static const int w = [] {
-        const char* e = getenv("MTLORA_NT_WAVES");
-        return (e && e[0] == '4') ? 4 : 8;
-    }();
-    return w;
-}
-
-// k_nt2 is OPT-IN (MTLORA_NT2=1: whenever eligible; 2: eligible AND MFMA-dense).  Measured against k_nt on the C2 shapes
-// (tools/one_linear_prof.sh): within +-6 % everywhere (25088 x 384 -> 1536: 66.6 vs 67.2 us; 6272 x 3072 -> 768: 67.1 vs
-// 71.7; 100352 x 272 -> 1080: 190 vs 179) -- both kernels have the same ~650-700 TFLOP/s marginal rate and the same
-// ~20 us of per-launch fixed cost at K = 384 (4.59 residency rounds -> tail, cold start, epilogue), so the load path is
-// not what limits the MFMA-dense launches.  Kept as the base for a persistent / stream-K form.
-static int nt2_mode() {
-    static const int m = [] {
-        const char* e = getenv("MTLORA_NT2");
-        return !e ? 0 : (e[0] == '1' ? 1 : (e[0] == '2' ? 2 : 0));
-    }();
-    return m;
-}
-static bool nt2_wanted(const NtParams& P, int variant, bool fuse) {
-    const int mode = nt2_mode();
-    if (mode == 0 || variant != 2 || fuse || P.nz > 0 || P.n_out != 1 || P.n_act != 1 || P.act_mask) return false;
-    const NtOut& O = P.out[0];
-    const bool has_lr = O.seg_hi > O.seg_lo;
-    if (!O.ptr || (!O.use_base && !has_lr)) return false;
-    if (O.use_base && (P.K <= 0 || (P.ld_act % 8) || (P.ld_wgt % 8))) return false;
-    if (has_lr && ((P.ldL % 8) || (P.ldR % 8) || (O.seg_lo % 8))) return false;
-    if (P.ld_out % 8) return false;
-    if (mode == 1) return true;
-    // dense: enough reduction length and output width that the 128 x 128 kernel's tile loads, not HBM, are the limit
-    return O.use_base && P.K >= 256 && P.n_rows >= 256 && mtl_ceil_div(P.M, T2_M) * mtl_ceil_div(P.n_rows, T2_N) >= 256;
-}
 
 template <typename T>
 static void launch_nt(const NtParams& P_in, hipStream_t s, int kind, double alg_bytes, double s8d_bytes = 0.0, double flops = 0.0) {
@@ -1622,47 +1267,27 @@ static void launch_nt(const NtParams& P_in, hipStream_t s, int kind, double alg_
     const int64_t m_tiles = mtl_ceil_div(P.M, TILE);
     const int64_t n_tiles = mtl_ceil_div(max_rows, TILE);
     if (m_tiles * n_tiles == 0) return;
-    const bool fuse = P.np > 0;
-    dim3 g((unsigned)(m_tiles * (fuse ? P.n_groups : n_tiles)), 1, (unsigned)(P.nz > 0 ? P.nz : 1));
+    dim3 g((unsigned)(m_tiles * n_tiles), 1, (unsigned)(P.nz > 0 ? P.nz : 1));
     int base_users = 0;
     for (int o = 0; o < P.n_out; ++o) base_users += P.out[o].use_base ? 1 : 0;
-    const size_t lds = (size_t)STAGE_BYTES + (P.np > 0 ? (size_t)TILE * (P.pR * sizeof(T) + 80) : 0);
-    // (> 64 KiB of dynamic LDS must be opted into once per kernel)
+    const size_t lds = (size_t)STAGE_BYTES;
+    // variant 0: several outputs share the base GEMM (MULTI: two accumulator sets, 4 waves); 1: multi-source activation (the dX
+    // launch of a layer with task outputs); 2: one output, one source.  The 16-bit single-accumulator-set variants run 8 waves
+    // per workgroup (<= 128 VGPRs, 4 waves per SIMD); MULTI and f32 (wider fragments) would spill at 128 and run 4.
     const int variant = base_users > 1 ? 0 : (P.n_act > 1 ? 1 : 2);
-#define MTL_NT_LAUNCH_W(MU, MSRC, FU, ML, W)                                                                      \
-    do {                                                                                                       \
-        static bool raised = false;                                                                            \
-        if (lds > 64 * 1024 && !raised) {                                                                      \
-            (void)hipFuncSetAttribute((const void*)k_nt<T, MU, MSRC, FU, ML, W>,                                \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);            \
-            raised = true;                                                                                     \
-        }                                                                                                      \
-        hipLaunchKernelGGL((k_nt<T, MU, MSRC, FU, ML, W>), g, dim3(64 * W), lds, s, P);                         \
-    } while (0)
-    // bf16 single-accumulator-set variants: 8 waves per workgroup (<= 128 VGPRs, 4 waves per SIMD) unless
-    // MTLORA_NT_WAVES=4; MULTI (two accumulator sets), the row-panel form and f32 (wider fragments) would spill at 128
-#define MTL_NT_LAUNCH(MU, MSRC, FU, ML)                                                                          \
-    do {                                                                                                       \
-        if (sizeof(T) == 2 && !(MU) && !(FU) && nt_waves() == 8)                                               \
-            MTL_NT_LAUNCH_W(false, MSRC, false, ML, 8);                                                        \
-        else                                                                                                   \
-            MTL_NT_LAUNCH_W(MU, MSRC, FU, ML, 4);                                                              \
-    } while (0)
-    bool mlr = false, gated = false;
+    constexpr bool W8 = sizeof(T) == 2;
+    bool mlr = false, gated = false, acted = false;
     for (int o = 0; o < P.n_out; ++o) {
         mlr = mlr || P.out[o].mask_lr != 0;
         gated = gated || P.out[o].gate != nullptr;
+        acted = acted || P.out[o].act != nullptr;
     }
     mlr = mlr && P.drop.enabled();
-    bool acted = false;
-    for (int o = 0; o < P.n_out; ++o) acted = acted || P.out[o].act != nullptr;
-    if constexpr (std::is_same<T, bf16>::value) {  // bf16-only kernels
-        // lean single-output launches: the straight-line kernel (MTLORA_NTL=0 keeps them on k_nt, for A/B timing)
-        static const bool ntl_on = [] { const char* e = getenv("MTLORA_NTL"); return !(e && e[0] == '0'); }();
+    if constexpr (std::is_same<T, bf16>::value) {
+        // lean single-output bf16 launches: the straight-line kernel
         const bool ml0 = P.n_out == 1 && P.out[0].mask_lr != 0 && P.drop.enabled();
-        if (ntl_on && variant == 2 && P.n_out == 1 && !ml0 && P.out[0].gate == nullptr && P.nz == 0 && !fuse && nt_waves() == 8 &&
-            P.M < (int64_t)0x7FFFFF00 && m_tiles * n_tiles < ((int64_t)1 << 28) && P.n_rows >= 8 && P.n_rows % 8 == 0 &&
-            !nt2_wanted(P, variant, fuse)) {
+        if (variant == 2 && P.n_out == 1 && !ml0 && P.out[0].gate == nullptr && P.nz == 0 && P.M < (int64_t)0x7FFFFF00 &&
+            m_tiles * n_tiles < ((int64_t)1 << 28) && P.n_rows >= 8 && P.n_rows % 8 == 0) {
             NlParams q;
             q.act = reinterpret_cast<const bf16*>(P.act[0]);
             q.wgt = reinterpret_cast<const bf16*>(P.wgt);
@@ -1700,207 +1325,41 @@ static void launch_nt(const NtParams& P_in, hipStream_t s, int kind, double alg_
             return;
         }
     }
-    if (acted) {  // forward outputs with the GELU second output (fc1 of the Mlp): lean or MULTI, never the row-panel form
+#define MTL_NT_GO(MU, MSRC, ML, GA, AC)                                                                   \
+    do {                                                                                                \
+        if (W8 && !(MU))                                                                                \
+            hipLaunchKernelGGL((k_nt<T, false, MSRC, ML, 8, GA, AC>), g, dim3(512), lds, s, P);         \
+        else                                                                                            \
+            hipLaunchKernelGGL((k_nt<T, MU, MSRC, ML, 4, GA, AC>), g, dim3(256), lds, s, P);            \
+    } while (0)
+    if (acted) {  // forward outputs with the GELU second output (fc1 of the Mlp): lean or MULTI
         if (variant == 0)
-            hipLaunchKernelGGL((k_nt<T, true, false, false, false, 4, false, true>), g, dim3(256), lds, s, P);
-        else if (sizeof(T) == 2 && nt_waves() == 8)
-            hipLaunchKernelGGL((k_nt<T, false, false, false, false, 8, false, true>), g, dim3(512), lds, s, P);
+            MTL_NT_GO(true, false, false, false, true);
         else
-            hipLaunchKernelGGL((k_nt<T, false, false, false, false, 4, false, true>), g, dim3(256), lds, s, P);
-        return;
-    }
-    if constexpr (std::is_same<T, bf16>::value) {  // bf16-only kernels
-        if (nt2_wanted(P, variant, fuse)) {  // MFMA-dense lean launches: direct-to-LDS 256 x 128 kernel
-            const int64_t tiles2 = mtl_ceil_div(P.M, T2_M) * mtl_ceil_div(P.n_rows, T2_N);
-#define MTL_NT2_LAUNCH(ML, GA)                                                                                       \
-    do {                                                                                                             \
-        static bool raised2 = false;                                                                                 \
-        if (!raised2) {                                                                                              \
-            (void)hipFuncSetAttribute((const void*)k_nt2<ML, GA>, hipFuncAttributeMaxDynamicSharedMemorySize, T2_LDS); \
-            raised2 = true;                                                                                          \
-        }                                                                                                            \
-        hipLaunchKernelGGL((k_nt2<ML, GA>), dim3((unsigned)tiles2), dim3(512), T2_LDS, s, P);                        \
-    } while (0)
-            if (mlr && gated)
-                MTL_NT2_LAUNCH(true, true);
-            else if (mlr)
-                MTL_NT2_LAUNCH(true, false);
-            else if (gated)
-                MTL_NT2_LAUNCH(false, true);
-            else
-                MTL_NT2_LAUNCH(false, false);
-#undef MTL_NT2_LAUNCH
-            return;
-        }
-    }
-    if (gated) {  // dX * gelu'(h) epilogue: the lean (single accumulator set) variants, never the row-panel form
-#define MTL_NT_LAUNCH_G(MSRC, ML)                                                               \
-    do {                                                                                        \
-        if (sizeof(T) == 2 && nt_waves() == 8)                                                  \
-            hipLaunchKernelGGL((k_nt<T, false, MSRC, false, ML, 8, true>), g, dim3(512), lds, s, P); \
-        else                                                                                    \
-            hipLaunchKernelGGL((k_nt<T, false, MSRC, false, ML, 4, true>), g, dim3(256), lds, s, P); \
-    } while (0)
+            MTL_NT_GO(false, false, false, false, true);
+    } else if (gated) {  // dX * gelu'(h) epilogue: the lean (single accumulator set) variants
         if (variant == 1)
-            MTL_NT_LAUNCH_G(true, true);
+            MTL_NT_GO(false, true, true, true, false);
         else if (mlr)
-            MTL_NT_LAUNCH_G(false, true);
+            MTL_NT_GO(false, false, true, true, false);
         else
-            MTL_NT_LAUNCH_G(false, false);
-#undef MTL_NT_LAUNCH_G
+            MTL_NT_GO(false, false, false, true, false);
     } else if (variant == 0) {
-        if (fuse)
-            MTL_NT_LAUNCH(true, false, true, false);
-        else
-            MTL_NT_LAUNCH(true, false, false, false);
+        MTL_NT_GO(true, false, false, false, false);
     } else if (variant == 1) {
-        MTL_NT_LAUNCH(false, true, false, true);  // multi-source = the dX launch
-    } else {
-        if (fuse && mlr)
-            MTL_NT_LAUNCH(false, false, true, true);
-        else if (fuse)
-            MTL_NT_LAUNCH(false, false, true, false);
-        else if (mlr)
-            MTL_NT_LAUNCH(false, false, false, true);
-        else
-            MTL_NT_LAUNCH(false, false, false, false);
-    }
-#undef MTL_NT_LAUNCH_W
-#undef MTL_NT_LAUNCH
-}
-
-// Row-panel ("fused") form, OPT-IN (MTLORA_FUSE_P=1): the workgroup that owns 128 rows forms their low-rank
-// projection itself (P forward, Q backward) into LDS, then walks the n-tiles of the output: no separate P / Q pass,
-// no re-read of X / dY for it, and the tile stream pipelines across n-tiles.  Eligible when (a) the LDS image leaves
-// room for 2 workgroups per CU (R <= 64), (b) there is one output (T = 0: the lean variant) and (c) there are enough
-// row panels to fill the GPU; n_groups > 1 splits a panel's n-tiles over several workgroups (each repeats the
-// projection).  Parity-tested forward and backward (test_linear_fused_projection).  Measured at C2 (10 eligible
-// layers of 48): the P / Q launches it removes are worth 1.06 ms/step, but the fused variants need 256 VGPRs plus
-// 80-96 B of scratch and their forward / dX launches grow by 1.7 ms/step (k_nt 16.98 vs 16.33 ms/step with n_groups
-// = 1, worse with more groups), so the two-pass form stays the default.
-static bool fuse_p_allowed() {
-    static const bool on = [] {
-        const char* e = getenv("MTLORA_FUSE_P");
-        return e && e[0] == '1';
-    }();
-    return on;
-}
-static int fuse_groups(const mtlora_linear_desc* d, const Segs& sg, int64_t out_cols) {  // 0 = do not fuse
-    if (!fuse_p_allowed() || d->T != 0 || sg.R <= 0 || sg.R > 64) return 0;
-    static const int64_t min_tiles = [] { const char* e = getenv("MTLORA_FUSE_MIN_TILES"); return e ? atoll(e) : 384ll; }();
-    static const int64_t target = [] { const char* e = getenv("MTLORA_FUSE_TARGET"); return e ? atoll(e) : 1536ll; }();
-    const int64_t m_tiles = mtl_ceil_div(d->M, TILE), n_tiles = mtl_ceil_div(out_cols, TILE);
-    if (m_tiles < min_tiles) return 0;
-    int g = 1;
-    while (m_tiles * g < target && g < n_tiles) ++g;
-    return g;
-}
-
-// ---- row-panel engine (k_pnl, panel.h).  OPT-IN (MTLORA_PNL=1): parity-tested forward and dX (every bf16 MTLoRALinear GPU
-// test also runs through it), but on the C2 shapes it is not faster than the pack + P / Q + main launches it replaces
-// (tools/bench_linear.py: 0.95-1.05x on stage 0, 0.75x on stage 1): with loads AND stores disabled it still takes 70 % of
-// its time -- it is instruction-issue bound (PMC, profiles/r02_pnl_pmc.csv: ~190 VALU + SALU instructions per wave per
-// 64-wide k-step, half of them the transposing epilogue / accumulator set-up that a K = 96 layer pays every 3.7 steps),
-// DESIGN.md 4.1b.  MTLORA_PNL_MIN_M sets the row threshold (default 32768: enough 128-row panels for every CU); both are
-// read per call, so the tests switch it in-process.
-static int64_t pnl_min_m() {
-    const char* on = getenv("MTLORA_PNL");
-    if (!(on && on[0] == '1')) return (int64_t)1 << 62;
-    const char* e = getenv("MTLORA_PNL_MIN_M");
-    return e ? (int64_t)atoll(e) : (int64_t)32768;
-}
-static int pnl_stages(int R) {  // ring depth that fits the 160 KB of LDS next to the epilogue images, the P image and the step table
-    const int64_t img = (R > 0 ? (int64_t)PN_BM * (R * 2 + PN_PPAD) : 0) + PN_TABLE;
-    if (3 * PN_STAGE + PN_EPI + img <= PN_LDS_MAX) return 3;
-    if (2 * PN_STAGE + PN_EPI + img <= PN_LDS_MAX) return 2;
-    return 0;
-}
-static int64_t pnl_steps(int64_t k) { return mtl_ceil_div(k, PN_BK); }
-// worst-case k-steps per panel of the forward / dX programs (the step table holds PN_MAXSTEPS)
-static bool pnl_eligible(const mtlora_linear_desc* d, const Segs& sg) {
-    if (!(d->dtype == MTLORA_BF16 && d->M >= pnl_min_m() && d->mode == 0 && sg.R <= 128 && pnl_stages(sg.R) > 0)) return false;
-    const int64_t src = 1 + d->T;
-    const int64_t fwd = src * pnl_steps(d->K) + mtl_ceil_div(d->N, PN_TN) * (pnl_steps(d->K) + src * 2);
-    const int64_t bwd = src * pnl_steps(d->N) + mtl_ceil_div(d->K, PN_TN) * (src * pnl_steps(d->N) + src * 2);
-    return fwd <= PN_MAXSTEPS && bwd <= PN_MAXSTEPS;
-}
-static void launch_pnl(PnParams& P, hipStream_t s, int kind, double alg_bytes, double s8d_bytes, double flops) {
-    P.nstage = pnl_stages(P.R);
-    {
-        const char* e = getenv("MTLORA_PNL_DBG");
-        P.dbg = e ? atoi(e) : 0;
-        const char* ns = getenv("MTLORA_PNL_STAGES");
-        if (ns && ns[0] == '2') P.nstage = 2;
-    }
-    mtl_prof_tag("pnl M%lld N%d R%d np%d nt%d ns%d", (long long)P.M, P.n_rows, P.R, P.n_proj, P.n_parts, P.nstage);
-    MtlProfScope prof(kind, alg_bytes, s, s8d_bytes, flops);
-    const int64_t n_panels = mtl_ceil_div(P.M, PN_BM);
-    if (n_panels == 0 || P.n_parts == 0) return;
-    P.n_proj_steps = P.n_tile_steps = 0;
-    for (int j = 0; j < P.n_proj; ++j) {
-        P.proj[j].step0 = P.n_proj_steps;
-        P.n_proj_steps += (int)pnl_steps(P.proj[j].k_hi - P.proj[j].k_lo);
-    }
-    for (int j = 0; j < P.n_parts; ++j) {
-        P.part[j].step0 = P.n_tile_steps;
-        P.n_tile_steps += (int)pnl_steps(P.part[j].k_hi - P.part[j].k_lo);
-    }
-    static const int n_cu = [] {
-        int dev = 0, cu = 256;
-        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev);
-        return cu > 0 ? cu : 256;
-    }();
-    const unsigned grid = (unsigned)(n_panels < n_cu ? n_panels : n_cu);  // one persistent workgroup per CU
-    const size_t lds = (size_t)P.nstage * PN_STAGE + PN_EPI + (P.R > 0 ? (size_t)PN_BM * (P.R * 2 + PN_PPAD) : 0) + PN_TABLE;
-    bool multi = false, mlr = false, gate = false, act = false;
-    for (int j = 0; j < P.n_parts; ++j) {
-        multi = multi || (P.part[j].flags & (PF_LOADBASE | PF_SAVEBASE)) != 0;
-        mlr = mlr || (P.part[j].flags & PF_MASK) != 0;
-    }
-    mlr = mlr && P.drop.enabled();
-    for (int o = 0; o < MAXO; ++o) {
-        gate = gate || P.out[o].gate != nullptr;
-        act = act || P.out[o].act != nullptr;
-    }
-#define MTL_PNL_LAUNCH_NS(MU, ML, GA, AC, NSTG)                                                                          \
-    do {                                                                                                                 \
-        static bool raised = false;                                                                                      \
-        if (!raised) {                                                                                                   \
-            (void)hipFuncSetAttribute((const void*)k_pnl<MU, ML, GA, AC, NSTG>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                      PN_LDS_MAX);                                                                       \
-            raised = true;                                                                                               \
-        }                                                                                                                \
-        hipLaunchKernelGGL((k_pnl<MU, ML, GA, AC, NSTG>), dim3(grid), dim3(512), lds, s, P);                             \
-    } while (0)
-#define MTL_PNL_LAUNCH(MU, ML, GA, AC)                       \
-    do {                                                     \
-        if (P.nstage == 3)                                   \
-            MTL_PNL_LAUNCH_NS(MU, ML, GA, AC, 3);            \
-        else                                                 \
-            MTL_PNL_LAUNCH_NS(MU, ML, GA, AC, 2);            \
-    } while (0)
-    // forward: [MULTI] x [ACT];  dX: MLR x [GATE]  (the combinations the two programs can produce)
-    if (act) {
-        if (multi) MTL_PNL_LAUNCH(true, false, false, true);
-        else MTL_PNL_LAUNCH(false, false, false, true);
-    } else if (gate) {
-        if (mlr) MTL_PNL_LAUNCH(false, true, true, false);
-        else MTL_PNL_LAUNCH(false, false, true, false);
+        MTL_NT_GO(false, true, true, false, false);  // multi-source = the dX launch
     } else if (mlr) {
-        MTL_PNL_LAUNCH(false, true, false, false);
-    } else if (multi) {
-        MTL_PNL_LAUNCH(true, false, false, false);
+        MTL_NT_GO(false, false, true, false, false);
     } else {
-        MTL_PNL_LAUNCH(false, false, false, false);
+        MTL_NT_GO(false, false, false, false, false);
     }
-#undef MTL_PNL_LAUNCH
-#undef MTL_PNL_LAUNCH_NS
+#undef MTL_NT_GO
 }
 
 // ---- wave-streaming projection (k_sp_proj, stream.h): the P = alpha D(X) A^T / Q = alpha dY B passes
-static int sp_mode() {  // developer switch for A/B timing (tools/): MTLORA_SP=0 keeps every launch on the tiled kernels
-    static const int m = [] { const char* e = getenv("MTLORA_SP"); return e ? atoi(e) : 1; }();
-    return m;
+static int sp_mode() {  // MTLORA_SP=0 keeps every launch on the tiled kernels (read per call: the "[tiled]" test variants, A/B timing)
+    const char* e = getenv("MTLORA_SP");
+    return e ? atoi(e) : 1;
 }
 static int sp_num_cu() {
     static const int n_cu = [] {
@@ -2186,8 +1645,7 @@ static int fwd_impl(const mtlora_linear_desc* d, const void* x, const void* cons
     const Segs sg = make_segs(d);
     const CtxLayout L = ctx_layout(d, sg);
     unsigned char* c = reinterpret_cast<unsigned char*>(ctx);
-    // packed factors: inside ctx, or in the caller's persistent buffer (desc.pack, ABI v4)
-    unsigned char* pk = d->pack ? reinterpret_cast<unsigned char*>(const_cast<void*>(d->pack)) : c;
+    unsigned char* pk = c;
     T* a_cat = reinterpret_cast<T*>(pk + L.a_cat);
     T* b_cat = reinterpret_cast<T*>(pk + L.b_cat);
     T* at_cat = reinterpret_cast<T*>(pk + L.at_cat);
@@ -2197,15 +1655,12 @@ static int fwd_impl(const mtlora_linear_desc* d, const void* x, const void* cons
     (void)bt_cat;
     T* Pm = reinterpret_cast<T*>(c + L.p);
     const DropoutCfg dc = mtl_make_dropout(d->dropout_p, d->seed, d->seed_offset);
-    bool fuse = false;
-    int groups = 0;
-    const bool pnl = std::is_same<T, bf16>::value && pnl_eligible(d, sg);
 
     if (sg.R > 0) {
-        if (!(d->pack && d->prepacked)) launch_pack<T>(d, sg, L, pk, A_s, B_s, A_t, B_t, s);
+        launch_pack<T>(d, sg, L, pk, A_s, B_s, A_t, B_t, s);
 
         // T = 0 layers with a short reduction: ONE wave-streaming launch (projection in registers, stream.h)
-        if (d->T == 0 && d->mode == 0 && !pnl) {
+        if (d->T == 0 && d->mode == 0) {
             SpLinParams q = {};
             q.act = x;
             q.w = W;
@@ -2231,9 +1686,7 @@ static int fwd_impl(const mtlora_linear_desc* d, const void* x, const void* cons
                 return MTLORA_OK;
             }
         }
-        groups = (a_s || pnl) ? 0 : fuse_groups(d, sg, d->N);
-        fuse = groups > 0;
-        if (!fuse && !pnl) {
+        {
             // P = alpha * D(X) A^T  (per source)
             NtParams q = {};
             q.n_act = 1;
@@ -2300,72 +1753,6 @@ static int fwd_impl(const mtlora_linear_desc* d, const void* x, const void* cons
         }
     }
 
-    if (pnl) {  // row-panel engine: projection + all outputs in ONE persistent launch
-        PnParams q = {};
-        q.M = d->M;
-        q.n_rows = (int)d->N;
-        q.ld_out = d->N;
-        q.bias = bias;
-        q.R = sg.R;
-        q.pout = sg.R > 0 ? (void*)Pm : nullptr;
-        q.drop = dc;
-        const T* a_proj = reinterpret_cast<const T*>(pk + L.a_proj);
-        const bool own_x = d->T > 0 && d->has_x_tasks;
-        for (int o = 0; o < sg.n && sg.R > 0; ++o) {
-            if (!own_x && o > 0) break;
-            if (own_x && sg.rp[o] == 0) continue;
-            PnPart& pt = q.proj[q.n_proj++];
-            pt.act = (o == 0) ? x : x_t[o - 1];
-            pt.wgt = a_proj;
-            pt.ld_act = pt.ld_wgt = d->K;
-            pt.w_lo = own_x ? sg.off[o] : 0;
-            pt.w_hi = own_x ? sg.off[o] + sg.rp[o] : sg.R;
-            pt.k_lo = 0;
-            pt.k_hi = (int)d->K;
-            pt.flags = (o == 0 && dc.enabled()) ? PF_DROPACT : 0;  // tasks without their own input see the same D(x)
-        }
-        int n_actout = 0;
-        for (int o = 0; o < sg.n; ++o) {
-            q.out[o].ptr = (o == 0) ? y_s : y_t[o - 1];
-            q.out[o].act = (o == 0) ? a_s : (a_t ? a_t[o - 1] : nullptr);
-            n_actout += q.out[o].act ? 1 : 0;
-        }
-        const bool multi = sg.n > 1;
-        {
-            PnPart& pt = q.part[q.n_parts++];
-            pt.act = x;
-            pt.wgt = W;
-            pt.ld_act = pt.ld_wgt = d->K;
-            pt.w_lo = 0;
-            pt.w_hi = (int)d->N;
-            pt.k_lo = 0;
-            pt.k_hi = (int)d->K;
-            pt.flags = PF_ZERO | (bias ? PF_BIAS : 0) | (multi ? PF_SAVEBASE : 0) | (sg.rp[0] == 0 ? PF_EPI : 0);
-            pt.out = 0;
-        }
-        for (int o = 0; o < sg.n; ++o) {
-            if (sg.rp[o] == 0) continue;
-            PnPart& pt = q.part[q.n_parts++];
-            pt.act = nullptr;
-            pt.wgt = b_cat;
-            pt.ld_wgt = sg.R;
-            pt.w_lo = 0;
-            pt.w_hi = (int)d->N;
-            pt.k_lo = sg.off[o];
-            pt.k_hi = sg.off[o] + sg.rp[o];
-            pt.flags = PF_RANK | PF_EPI | ((multi && o > 0) ? PF_LOADBASE : 0);
-            pt.out = o;
-        }
-        double rsum = 0.0;
-        for (int o = 0; o < sg.n; ++o) rsum += sg.r[o];
-        const double b8d = (double)sizeof(T) * d->M * ((double)(1 + (own_x ? d->T : 0)) * d->K + (double)(1 + d->T) * d->N);
-        const double fl = 2.0 * d->M * d->K * d->N + 2.0 * d->M * d->N * rsum + 2.0 * d->M * d->K * rsum;
-        const bool plain = sg.R == 0;
-        launch_pnl(q, s, plain ? PK_NT_PLAIN_FWD : PK_NT_FWD_MAIN, b8d + (double)sizeof(T) * d->M * (double)n_actout * d->N,
-                   plain ? 0.0 : b8d, fl);
-        return MTLORA_OK;
-    }
-
     // all outputs
     NtParams m = {};
     m.act[0] = x;
@@ -2394,39 +1781,13 @@ static int fwd_impl(const mtlora_linear_desc* d, const void* x, const void* cons
         O.fold = (o == 0 && d->mode == 1 && d->T > 0) ? 1 : 0;
         O.act = (o == 0) ? a_s : (a_t ? a_t[o - 1] : nullptr);
     }
-    if (fuse) {
-        m.pA = a_cat;
-        m.pK = (int)d->K;
-        m.pR = sg.R;
-        m.palpha = alpha;
-        m.pout = Pm;
-        m.n_groups = groups;
-        m.np = 0;
-        if (d->T > 0 && d->has_x_tasks) {
-            for (int o = 0; o < sg.n; ++o) {
-                if (sg.rp[o] == 0) continue;
-                m.pact[m.np] = (o == 0) ? x : x_t[o - 1];
-                m.pseg_lo[m.np] = sg.off[o];
-                m.pseg_hi[m.np] = sg.off[o] + sg.rp[o];
-                m.pmask[m.np] = (o == 0) ? 1 : 0;
-                ++m.np;
-            }
-        } else {
-            m.pact[0] = x;
-            m.pseg_lo[0] = 0;
-            m.pseg_hi[0] = sg.R;
-            m.pmask[0] = 1;
-            m.np = 1;
-        }
-    }
-    const double xt_bytes = fuse ? (double)sizeof(T) * (d->has_x_tasks ? d->T : 0) * d->M * d->K : 0.0;
     int n_actout = 0;  // GELU second outputs: one more M x N write each
     for (int o = 0; o < m.n_out; ++o) n_actout += m.out[o].act ? 1 : 0;
     {
-        const double b8d = (double)sizeof(T) * d->M * (d->K + (double)(1 + d->T) * d->N) + xt_bytes;
+        const double b8d = (double)sizeof(T) * d->M * (d->K + (double)(1 + d->T) * d->N);
         double rsum = 0.0;
         for (int o = 0; o < sg.n; ++o) rsum += sg.r[o];
-        const double fl = 2.0 * d->M * d->K * d->N + 2.0 * d->M * d->N * rsum + (fuse ? 2.0 * d->M * d->K * rsum : 0.0);
+        const double fl = 2.0 * d->M * d->K * d->N + 2.0 * d->M * d->N * rsum;
         const bool plain = sg.R == 0;
         launch_nt<T>(m, s, plain ? PK_NT_PLAIN_FWD : PK_NT_FWD_MAIN, b8d + (double)sizeof(T) * d->M * (double)n_actout * d->N,
                      plain ? 0.0 : b8d, fl);
@@ -2485,7 +1846,7 @@ static int bwd_impl(const mtlora_linear_desc* d, const void* x, const void* cons
     const CtxLayout L = ctx_layout(d, sg);
     const BwdScratch S = bwd_scratch(d, sg);
     const unsigned char* c = reinterpret_cast<const unsigned char*>(ctx);
-    const unsigned char* pk = d->pack ? reinterpret_cast<const unsigned char*>(d->pack) : c;
+    const unsigned char* pk = c;
     const T* at_cat = reinterpret_cast<const T*>(pk + L.at_cat);
     const T* bt_cat = reinterpret_cast<const T*>(pk + L.bt_cat);
     const float* alpha = reinterpret_cast<const float*>(pk + L.alpha);
@@ -2512,11 +1873,8 @@ static int bwd_impl(const mtlora_linear_desc* d, const void* x, const void* cons
     //    each of the ceil(K/128) n-tiles: 3..24x for fc2): one k_sum pass + the single-source kernel moves
     //    (n_dy + 1 + n_tiles) MN bytes instead of n_dy * n_tiles * MN.
     const void* dy_shared = dy[0];
-    // row-panel engine (k_pnl): Q = alpha dY B and every dX / dX_t in ONE persistent launch; no k_sum either -- the base GEMM
-    // runs once per gradient source into the same accumulators
     const bool do_dx = d->bwd_phase != 2, do_factors = d->bwd_phase != 1;  // (phase 2 re-derives the same operand table)
-    const bool pnl = std::is_same<T, bf16>::value && pnl_eligible(d, sg) && dx != nullptr && n_dy > 0;
-    const bool presum = !pnl && n_dy > 1 && dx && mtl_ceil_div(d->K, TILE) >= 3;
+    const bool presum = n_dy > 1 && dx && mtl_ceil_div(d->K, TILE) >= 3;
     bool have_g = false;
     if ((v2 || presum) && n_dy > 1) {
         have_g = true;
@@ -2537,95 +1895,9 @@ static int bwd_impl(const mtlora_linear_desc* d, const void* x, const void* cons
     const void* dyo[MAXO];  // gradient feeding factor o
     for (int o = 0; o < sg.n; ++o) dyo[o] = (o == 0) ? dy_shared : dy[o];
 
-    if (pnl && do_dx) {
-        PnParams q = {};
-        q.M = d->M;
-        q.n_rows = (int)d->K;
-        q.ld_out = d->K;
-        q.R = sg.R;
-        q.pout = sg.R > 0 ? (void*)Qm : nullptr;
-        q.drop = dc;
-        const T* bt_proj = reinterpret_cast<const T*>(pk + L.bt_proj);
-        double rsum = 0.0;
-        for (int o = 0; o < sg.n && sg.R > 0; ++o) {
-            if (sg.rp[o] == 0 || !dyo[o]) continue;  // a segment without a gradient stays zero in the image
-            PnPart& pt = q.proj[q.n_proj++];
-            pt.act = dyo[o];
-            pt.wgt = bt_proj;
-            pt.ld_act = pt.ld_wgt = d->N;
-            pt.w_lo = sg.off[o];
-            pt.w_hi = sg.off[o] + sg.rp[o];
-            pt.k_lo = 0;
-            pt.k_hi = (int)d->N;
-            pt.flags = 0;
-            rsum += sg.r[o];
-        }
-        const bool own_x = d->T > 0 && d->has_x_tasks;
-        int n_gate = 0;
-        q.out[0].ptr = dx;
-        q.out[0].gate = gate_s;
-        n_gate += gate_s ? 1 : 0;
-        // dX = keep .* (Q A) + sum_o dY_o W : the masked rank part first, then one base part per gradient source
-        const int lr_lo = own_x ? sg.off[0] : 0, lr_hi = own_x ? sg.off[0] + sg.rp[0] : sg.used;
-        bool zeroed = false;
-        if (q.n_proj > 0 && lr_hi > lr_lo) {
-            PnPart& pt = q.part[q.n_parts++];
-            pt.act = nullptr;
-            pt.wgt = at_cat;
-            pt.ld_wgt = sg.R;
-            pt.w_lo = 0;
-            pt.w_hi = (int)d->K;
-            pt.k_lo = lr_lo;
-            pt.k_hi = lr_hi;
-            pt.flags = PF_RANK | PF_ZERO | (dc.enabled() ? PF_MASK : 0);
-            pt.out = 0;
-            zeroed = true;
-        }
-        for (int i = 0; i < n_dy; ++i) {
-            PnPart& pt = q.part[q.n_parts++];
-            pt.act = dy_all[i];
-            pt.wgt = Wt;
-            pt.ld_act = pt.ld_wgt = d->N;
-            pt.w_lo = 0;
-            pt.w_hi = (int)d->K;
-            pt.k_lo = 0;
-            pt.k_hi = (int)d->N;
-            pt.flags = (!zeroed && i == 0 ? PF_ZERO : 0) | (i == n_dy - 1 ? PF_EPI : 0);
-            pt.out = 0;
-        }
-        int n_dxt = 0;
-        for (int t = 0; own_x && t < d->T; ++t) {
-            if (!dx_t || !dx_t[t]) continue;
-            ++n_dxt;
-            if (sg.rp[t + 1] == 0 || q.n_proj == 0 || !dyo[t + 1]) {  // no gradient reaches this input
-                mtl_zero_async(dx_t[t], (size_t)(d->M * d->K * sizeof(T)), s);
-                continue;
-            }
-            q.out[t + 1].ptr = dx_t[t];
-            q.out[t + 1].gate = gate_t ? gate_t[t] : nullptr;
-            n_gate += q.out[t + 1].gate ? 1 : 0;
-            PnPart& pt = q.part[q.n_parts++];
-            pt.act = nullptr;
-            pt.wgt = at_cat;
-            pt.ld_wgt = sg.R;
-            pt.w_lo = 0;
-            pt.w_hi = (int)d->K;
-            pt.k_lo = sg.off[t + 1];
-            pt.k_hi = sg.off[t + 1] + sg.rp[t + 1];
-            pt.flags = PF_RANK | PF_ZERO | PF_EPI;
-            pt.out = t + 1;
-        }
-        const double b8d = (double)sizeof(T) * d->M * ((double)n_dy * d->N + (double)(1 + n_dxt) * d->K);
-        const double fl = 2.0 * d->M * d->N * d->K * n_dy + 2.0 * d->M * d->K * rsum + 2.0 * d->M * d->N * rsum;
-        const bool plain = sg.R == 0;
-        launch_pnl(q, s, plain ? PK_NT_PLAIN_DX : PK_NT_BWD_DX, b8d + (double)sizeof(T) * d->M * (double)n_gate * d->K,
-                   plain ? 0.0 : b8d, fl);
-        // segments whose output got no gradient: the image holds zeros there and so does the HBM copy (written whole)
-    }
-
     // T = 0 layers whose input is narrow: Q, the masked rank part and dY W in ONE wave-streaming pass over dY (stream.h)
     bool sp_dx_done = false;
-    if (d->T == 0 && d->mode == 0 && !pnl && do_dx && dx && dyo[0] && sg.R > 0 && !gate_s) {
+    if (d->T == 0 && d->mode == 0 && do_dx && dx && dyo[0] && sg.R > 0 && !gate_s) {
         SpLinParams q = {};
         q.act = dyo[0];
         q.w = Wt;
@@ -2651,8 +1923,7 @@ static int bwd_impl(const mtlora_linear_desc* d, const void* x, const void* cons
     }
 
     // Q[:, seg_o] = alpha_o * dY_o B_o   (zero where the output got no gradient)
-    const int groups = (!pnl && dx && dyo[0] && !gate_s) ? fuse_groups(d, sg, d->K) : 0;  // row-panel form: Q is formed inside the dX kernel
-    if (sg.R > 0 && groups == 0 && !pnl && do_dx && !sp_dx_done) {
+    if (sg.R > 0 && do_dx && !sp_dx_done) {
         bool any_missing = false;
         for (int o = 0; o < sg.n; ++o)
             if (sg.rp[o] > 0 && !dyo[o]) any_missing = true;
@@ -2711,7 +1982,7 @@ static int bwd_impl(const mtlora_linear_desc* d, const void* x, const void* cons
     }
 
     // dX = G W + keep .* (Q_s A_s [+ sum_t Q_t A_t]),  dX_t = Q_t A_t
-    if (!pnl && do_dx && !sp_dx_done) {
+    if (do_dx && !sp_dx_done) {
         NtParams m = {};
         if (presum && have_g) {
             m.n_act = 1;
@@ -2738,19 +2009,6 @@ static int bwd_impl(const mtlora_linear_desc* d, const void* x, const void* cons
         O.use_base = 1;
         O.mask_lr = 1;
         O.gate = gate_s;
-        if (groups > 0) {  // T == 0: one gradient source, one rank segment
-            m.np = 1;
-            m.pact[0] = dyo[0];
-            m.pseg_lo[0] = 0;
-            m.pseg_hi[0] = sg.R;
-            m.pmask[0] = 0;
-            m.pA = bt_cat;
-            m.pK = (int)d->N;
-            m.pR = sg.R;
-            m.palpha = alpha;
-            m.pout = Qm;
-            m.n_groups = groups;
-        }
         if (d->T > 0 && d->has_x_tasks) {
             O.seg_lo = sg.off[0];
             O.seg_hi = sg.off[0] + sg.rp[0];
@@ -2776,8 +2034,7 @@ static int bwd_impl(const mtlora_linear_desc* d, const void* x, const void* cons
             double rsum = 0.0;
             for (int o = 0; o < sg.n; ++o)
                 if (sg.rp[o] > 0 && dyo[o]) rsum += sg.r[o];
-            const double fl = (n_dy > 0 ? 2.0 * d->M * d->N * d->K : 0.0) + 2.0 * d->M * d->K * rsum +
-                              (groups > 0 ? 2.0 * d->M * d->N * rsum : 0.0);
+            const double fl = (n_dy > 0 ? 2.0 * d->M * d->N * d->K : 0.0) + 2.0 * d->M * d->K * rsum;
             const bool plain = sg.R == 0;
             launch_nt<T>(m, s, plain ? PK_NT_PLAIN_DX : PK_NT_BWD_DX, b8d + (double)sizeof(T) * d->M * (double)n_gate * d->K,
                          plain ? 0.0 : b8d, fl);
@@ -2869,36 +2126,6 @@ int64_t mtlora_linear_ctx_bytes(const mtlora_linear_desc* d) {
     if (check_desc(d) != MTLORA_OK) return -1;
     const Segs sg = make_segs(d);
     return ctx_layout(d, sg).total + 256;
-}
-
-int64_t mtlora_linear_pack_bytes(const mtlora_linear_desc* d) {
-    if (check_desc(d) != MTLORA_OK) return -1;
-    const Segs sg = make_segs(d);
-    return ctx_layout(d, sg).p + 256;  // the packed-factor region precedes P in the ctx layout and does not depend on M
-}
-
-int mtlora_linear_pack(const mtlora_linear_desc* d, const float* A_s, const float* B_s, const float* const* A_t,
-                       const float* const* B_t, void* pack, int64_t pack_bytes, void* stream) {
-    int st = check_desc(d);
-    if (st != MTLORA_OK) return st;
-    const Segs sg = make_segs(d);
-    if (sg.R <= 0) return MTLORA_OK;
-    if (!pack) return MTLORA_ERR_NULL;
-    if (misaligned(pack)) return MTLORA_ERR_ALIGN;
-    if (d->r_s > 0 && (!A_s || !B_s)) return MTLORA_ERR_NULL;
-    for (int t = 0; t < d->T; ++t)
-        if (!A_t || !B_t || !A_t[t] || !B_t[t]) return MTLORA_ERR_NULL;
-    const CtxLayout L = ctx_layout(d, sg);
-    if (pack_bytes < L.p) return MTLORA_ERR_WORKSPACE;
-    hipStream_t s = (hipStream_t)stream;
-    if (d->dtype == MTLORA_F32)
-        launch_pack<float>(d, sg, L, reinterpret_cast<unsigned char*>(pack), A_s, B_s, A_t, B_t, s);
-    else if (d->dtype == MTLORA_F16)
-        launch_pack<f16>(d, sg, L, reinterpret_cast<unsigned char*>(pack), A_s, B_s, A_t, B_t, s);
-    else
-        launch_pack<bf16>(d, sg, L, reinterpret_cast<unsigned char*>(pack), A_s, B_s, A_t, B_t, s);
-    MTL_CHECK_LAUNCH();
-    return MTLORA_OK;
 }
 
 int64_t mtlora_linear_bwd_scratch_bytes(const mtlora_linear_desc* d) {

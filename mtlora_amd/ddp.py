@@ -24,7 +24,7 @@ import torch.distributed as dist
 
 
 class _Bucket:
-    __slots__ = ("params", "offsets", "flat", "pending", "handle", "seen", "arrived")
+    __slots__ = ("params", "offsets", "flat", "pending", "handle", "seen", "arrived", "launched")
 
     def __init__(self, params: List[torch.nn.Parameter]):
         self.params = params
@@ -38,6 +38,7 @@ class _Bucket:
         self.handle = None
         self.seen = [False] * len(params)      # has a gradient this step
         self.arrived = [False] * len(params)   # its accumulation node ran (possibly with an undefined gradient)
+        self.launched = False
 
 
 class GradReducer:
@@ -143,6 +144,8 @@ class GradReducer:
             b.handle = None
             b.seen = [False] * len(b.params)
             b.arrived = [False] * len(b.params)
+            b.launched = False
+        self._next = 0  # buckets are launched strictly in index order (see _launch_ready)
         self._armed = True
 
     def _pack(self, b: _Bucket) -> None:
@@ -165,8 +168,25 @@ class GradReducer:
 
     def _launch(self, b: _Bucket) -> None:
         self._pack(b)
+        b.launched = True
         if self.active and not getattr(self, "_defer", False):
             b.handle = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def _launch_ready(self, flush: bool = False) -> None:
+        """issue the collectives in BUCKET ORDER, whatever order the buckets complete in: RCCL / NCCL match collectives by issue
+        order, and a rank on which one parameter of bucket i gets no gradient this step would otherwise issue bucket i from
+        ``finish`` -- after buckets the other ranks issued later -- and hang or sum mismatched buckets.  A complete bucket
+        behind an incomplete one waits for it (``flush``: backward is over, incomplete buckets count their missing gradients
+        as zero).  Buckets follow the reverse parameter order, i.e. roughly the order backward completes them in."""
+        while self._next < len(self.buckets):
+            b = self.buckets[self._next]
+            if b.pending > 0:
+                if not flush:
+                    return
+                b.pending = 0
+            if not b.launched:
+                self._launch(b)
+            self._next += 1
 
     def _on_grad(self, p: torch.nn.Parameter) -> None:
         if not self._armed:
@@ -181,15 +201,12 @@ class GradReducer:
         b.seen[pi] = p.grad is not None
         b.pending -= 1
         if b.pending == 0:
-            self._launch(b)
+            self._launch_ready()
 
     def finish(self) -> None:
         """call after backward: flush incomplete buckets, wait, write the mean back into ``.grad``."""
         self._armed = False
-        for b in self.buckets:
-            if b.pending > 0:  # some parameters produced no gradient on this rank this step: they count as zero
-                b.pending = 0
-                self._launch(b)
+        self._launch_ready(flush=True)  # parameters that produced no gradient on this rank this step count as zero
         if self.active and self.buckets and (self._global_seen is None or not self.static_graph):
             self._agree_on_used()
         inv = 1.0 / self.world
@@ -214,10 +231,7 @@ class GradReducer:
     def flush_packs(self) -> None:
         """after backward, inside the backward capture: pack the buckets whose last gradient never arrived."""
         self._armed = False
-        for b in self.buckets:
-            if b.pending > 0:
-                b.pending = 0
-                self._pack(b)
+        self._launch_ready(flush=True)  # (deferred mode: "launch" = pack; also the complete buckets held back behind an incomplete one)
 
     def all_reduce_packed(self) -> None:
         if self.active:

@@ -46,30 +46,20 @@ _factor_stream: Optional["torch.cuda.Stream"] = None
 _FACTOR_MIN_M = int(os.environ.get("MTLORA_FACTOR_MIN_M", "16384"))
 
 
+# parameters whose factor gradient is being written on the side stream in the backward now running (ids): a second use of the
+# same layer in one graph, or an accumulating backward racing it, must not touch that .grad on the main stream meanwhile
+_side_inflight: set = set()
+
+
 def set_factor_stream(stream: Optional["torch.cuda.Stream"]) -> None:
+    """install (or, with None, remove) the side stream; (re)installing it starts a new backward: nothing is in flight"""
     global _factor_stream
     _factor_stream = stream
+    _side_inflight.clear()
 
 
 def factor_stream() -> Optional["torch.cuda.Stream"]:
     return _factor_stream
-
-
-# the event after which the packed factors written by ``MTLoRALinear.prepack`` calls (on a side stream) are complete; the first
-# forward that uses one makes its stream wait for it
-_prepack_event: Optional["torch.cuda.Event"] = None
-
-
-def set_prepack_event(ev: Optional["torch.cuda.Event"]) -> None:
-    global _prepack_event
-    _prepack_event = ev
-
-
-def wait_prepack() -> None:
-    global _prepack_event
-    if _prepack_event is not None:
-        torch.cuda.current_stream().wait_event(_prepack_event)
-        _prepack_event = None
 
 
 # ----------------------------------------------------------------------------------------------
@@ -200,7 +190,6 @@ class LinearMeta:
     n_scale_t: int = 0        # >0: per-task scales are trainable Parameters passed after B_t
     n_gate: int = 0           # >0: x (and x_t) = gelu(gate): the LAST n_gate args are the pre-activations; dx *= gelu'(gate)
     gelu_out: bool = False    # also return gelu(y) for every output (fc1 of the Mlp): outputs = (y_s, *y_t, a_s, *a_t)
-    pack_buf: Optional[torch.Tensor] = None  # packed factors filled ahead of the call (MTLoRALinear.prepack; desc.pack, ABI v4)
 
     @property
     def T(self) -> int:
@@ -219,8 +208,6 @@ class LinearMeta:
         d.dropout_p = self.dropout_p
         d.seed = self.seed
         d.seed_offset = 0 if _seed_offset is None else _seed_offset.data_ptr()
-        if self.pack_buf is not None:
-            d.pack, d.prepacked = self.pack_buf.data_ptr(), 1
         return d
 
 
@@ -367,7 +354,13 @@ class MTLoRALinearFn(torch.autograd.Function):
         use_side = (side is not None and fgrads and not ctx.has_scale_s and meta.n_scale_t == 0
                     and side.device == dev and M >= _FACTOR_MIN_M
                     and all(p is None or p.grad is None for p in ctx.factor_params))
+        if side is not None and any(p is not None and id(p) in _side_inflight for p in ctx.factor_params):
+            # the same layer was applied twice in this graph (or a second backward accumulates into it): its first factor
+            # gradient is still being written on the side stream -- join before anything here accumulates into that .grad
+            torch.cuda.current_stream(dev).wait_stream(side)
+            use_side = False
         if use_side:
+            _side_inflight.update(id(p) for p in ctx.factor_params if p is not None)
             d.bwd_phase = 1
             launch(L.stream_ptr())
             ev = torch.cuda.Event()

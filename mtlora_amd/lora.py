@@ -8,7 +8,6 @@ Only the classes the reference actually instantiates are provided (``LoRALinear`
 """
 from __future__ import annotations
 
-import ctypes
 import math
 from typing import Any, Dict, Mapping, Optional, Tuple, Union
 
@@ -86,8 +85,6 @@ class MTLoRALinear(LoRALayer):
                 self.lora_shared_scale = lora_shared_scale
             self.reset_parameters()
         self._wcache: Dict[Any, Any] = {}
-        self._pack_state: Optional[Dict[str, Any]] = None  # persistent packed-factor buffer (prepack)
-        self._pack_last = None                              # (key, meta) of the last training forward
 
     def reset_parameters(self):
         """A ~ kaiming_uniform(a=sqrt 5), B = 0 (reference lora.py:236-247)."""
@@ -117,6 +114,9 @@ class MTLoRALinear(LoRALayer):
         merged).  Returns True when the layer was merged; ``unmerge`` / ``train()`` undo it."""
         if self.merged or not self._mergeable():
             return False
+        if self.training:
+            raise RuntimeError("mtlora_amd: merge() folds the shared update into the frozen weight for inference; call .eval() "
+                               "first (the train-time dropout in front of A cannot be merged)")
         with torch.no_grad():
             self.linear.weight.data.add_(self._shared_delta().to(self.linear.weight.dtype))
         self.merged = True
@@ -142,74 +142,56 @@ class MTLoRALinear(LoRALayer):
             hit = None  # trained by an optimizer every step: never serve a cached copy
         if hit is None or hit[0] != ver:
             with torch.no_grad():
-                wc = w.detach().to(dtype).contiguous()
-                wt = w.detach().t().to(dtype).contiguous()
-                bf = None if b is None else b.detach().float().contiguous()
+                if hit is not None and hit[1].shape == w.shape and (b is None) == (hit[3] is None):
+                    # refresh IN PLACE: a captured HIP graph (GraphedTrainStep) has the addresses of these copies baked in
+                    wc, wt, bf = hit[1], hit[2], hit[3]
+                    wc.copy_(w.detach())
+                    wt.copy_(w.detach().t())
+                    if bf is not None:
+                        bf.copy_(b.detach())
+                else:
+                    wc = w.detach().to(dtype).contiguous()
+                    wt = w.detach().t().to(dtype).contiguous()
+                    bf = None if b is None else b.detach().float().contiguous()
             hit = (ver, wc, wt, bf)
             self._wcache = {key: hit}
         return hit[1], hit[2], hit[3]
 
     def invalidate_weight_cache(self) -> None:
-        """drop the cached compute-dtype copies of ``linear.weight`` / ``linear.bias``.  The cache keys on the tensors'
-        version counters and storage, which in-place updates through ``.data`` (EMA, hand-written loaders, older optimizers)
-        do NOT bump: call this after such an update.  ``load_state_dict``, ``.to()`` / ``.cuda()`` and ``train()`` /
-        ``eval()`` call it themselves."""
-        self._wcache = {}
+        """mark the cached compute-dtype copies of ``linear.weight`` / ``linear.bias`` stale: the next forward re-fills the SAME
+        buffers (their addresses may be baked into a captured HIP graph).  The cache keys on the tensors' version counters and
+        storage, which in-place updates through ``.data`` (EMA, hand-written loaders, older optimizers) do NOT bump: call this
+        after such an update.  ``load_state_dict``, ``merge`` / ``unmerge`` call it themselves; ``.to()`` / ``.cuda()`` drop the
+        copies altogether."""
+        self._wcache = {k: (None,) + tuple(v[1:]) for k, v in self._wcache.items()}
 
-    def _apply(self, fn, *a, **k):  # .to() / .cuda() invalidates the cached copies
+    def _apply(self, fn, *a, **k):  # .to() / .cuda(): the copies live on the old device / dtype
         self._wcache = {}
-        self._pack_state = self._pack_last = None
         return super()._apply(fn, *a, **k)
 
-    def _load_from_state_dict(self, *a, **k):
-        self._wcache = {}
-        if self._pack_state is not None:
-            self._pack_state["ready"] = False  # packed from the old factors
-        return super()._load_from_state_dict(*a, **k)
+    def _load_from_state_dict(self, state_dict, prefix, *a, **k):
+        # a state dict always holds the UN-merged pretrained weight (see state_dict below): whatever is loaded replaces a merged
+        # weight, so the flag goes back to "not merged" (loading into a merged module used to leave the flag set: the shared update
+        # was then skipped, and the next train() subtracted a delta the loaded weight never contained)
+        self.merged = False
+        self.invalidate_weight_cache()
+        return super()._load_from_state_dict(state_dict, prefix, *a, **k)
+
+    def state_dict(self, *args, destination=None, prefix="", keep_vars=False):
+        """a merged layer saves the UN-merged pretrained weight next to its factors (saving W + s B A together with A and B would
+        apply the shared update twice after a reload)."""
+        sd = super().state_dict(*args, destination=destination, prefix=prefix, keep_vars=keep_vars)
+        if self.merged:
+            key = prefix + "linear.weight"
+            if key in sd:
+                w = sd[key]
+                sd[key] = (w.detach() - self._shared_delta().to(w.dtype)) if not keep_vars else w - self._shared_delta().to(w.dtype)
+        return sd
 
     def train(self, mode: bool = True):
         if mode and self.merged:  # a merged weight cannot be trained through (loralib convention: train() un-merges)
             self.unmerge()
-        self._wcache = {}
-        return super().train(mode)
-
-    # -- packing the low-rank factors ahead of the forward (they depend on parameters only)
-    @staticmethod
-    def _pack_key(meta):
-        return (meta.K, meta.N, meta.r_s, meta.r_t, meta.scale_s, meta.scale_t, meta.mode, meta.has_x_tasks, meta.dropout_p,
-                meta.dtype)
-
-    def prepack(self, stream_ptr) -> bool:
-        """launch this layer's ``k_pack`` on ``stream_ptr`` (a ctypes stream handle) into the layer's persistent packed-factor
-        buffer, for a call shaped like the last training forward; the next such forward uses it instead of packing itself
-        (``mtlora_linear_desc.pack``).  The caller orders the stream after the optimizer step / the previous backward and
-        publishes an event through ``functional.set_prepack_event``.  Returns False when there is nothing to do (no previous
-        call to copy the description from, trainable scales, no low-rank update)."""
-        last = getattr(self, "_pack_last", None)
-        if last is None:
-            return False
-        key, meta = last
-        lib = Fn.L.lib()
-        d = meta.desc(0)
-        d.pack, d.prepacked = 0, 0
-        st = self._pack_state
-        if st is None or st["key"] != key or st["buf"].device != self.linear.weight.device:
-            nbytes = lib.mtlora_linear_pack_bytes(ctypes.byref(d))
-            if nbytes <= 0:
-                return False
-            st = {"key": key, "buf": torch.empty(nbytes, dtype=torch.uint8, device=self.linear.weight.device), "ready": False}
-            self._pack_state = st
-        tasks = list(self.tasks) if (self.tasks is not None and self.r > 0) else []
-        f32 = lambda p: p.detach()  # fp32 contiguous Parameters (checked by the kernels' alignment test)
-        shared = meta.r_s > 0
-        rc = lib.mtlora_linear_pack(ctypes.byref(d), Fn.L.ptr(f32(self.lora_shared_A) if shared else None),
-                                    Fn.L.ptr(f32(self.lora_shared_B) if shared else None),
-                                    Fn.L.ptr_array([f32(self.lora_tasks_A[t]) for t in tasks]),
-                                    Fn.L.ptr_array([f32(self.lora_tasks_B[t]) for t in tasks]),
-                                    Fn.L.ptr(st["buf"]), st["buf"].numel(), stream_ptr)
-        Fn.L.check(rc, "mtlora_linear_pack")
-        st["ready"] = True
-        return True
+        return super().train(mode)  # (the cached copies stay: W did not change, and a captured graph may hold their addresses)
 
     def forward(self, x: torch.Tensor, x_tasks: Optional[Dict[str, torch.Tensor]] = None, gelu_gate=None, gelu_out: bool = False
                 ) -> Tuple[torch.Tensor, Optional[Dict[str, torch.Tensor]]]:
@@ -245,19 +227,6 @@ class MTLoRALinear(LoRALayer):
         if gelu_gate is not None:
             gates = [gelu_gate[0]] + ([gelu_gate[1][t] for t in tasks] if meta.has_x_tasks else [])
             meta.n_gate = len(gates)
-        # packed factors filled ahead of time (``prepack``, called for every layer at the start of a train step): usable once,
-        # for a call with exactly the description they were packed for
-        can_prepack = (has_lora and torch.is_grad_enabled() and par(ss) is None and meta.n_scale_t == 0 and x.is_cuda)
-        if can_prepack:
-            key = self._pack_key(meta)
-            st = self._pack_state
-            if st is not None and st["ready"] and st["key"] == key:
-                st["ready"] = False
-                Fn.wait_prepack()
-                meta.pack_buf = st["buf"]
-            self._pack_last = (key, meta)
-        else:
-            self._pack_last = None
         args = [meta, x, wc, wt, bf, self.linear.weight, self.linear.bias,
                 self.lora_shared_A if shared else None, self.lora_shared_B if shared else None, par(ss)]
         if meta.has_x_tasks:

@@ -182,10 +182,13 @@ class HighResolutionHead(nn.Module):
             bn.num_batches_tracked.add_(1)
         if bn.training and h.is_cuda and h.dtype in (torch.float32, torch.bfloat16) and h.shape[1] % 8 == 0:
             # fused training-mode BatchNorm + ReLU on the (pixels, channels) matrix (csrc/glue.hip)
-            h = BatchNormReluFn.apply(h, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps, True)
+            h = BatchNormReluFn.apply(h, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps,
+                                      getattr(self, "relu", True))
         else:
-            h = F.relu(F.batch_norm(h, bn.running_mean, bn.running_var, bn.weight, bn.bias,
-                                    bn.training or not bn.track_running_stats, bn.momentum, bn.eps))
+            h = F.batch_norm(h, bn.running_mean, bn.running_var, bn.weight, bn.bias, bn.training or not bn.track_running_stats,
+                             bn.momentum, bn.eps)
+            if getattr(self, "relu", True):  # (False only in the kink-free parity probe of tests/test_gpu_models.py)
+                h = F.relu(h)
         w3, b3, nc = c3.weight.view(c3.out_channels, c3.in_channels), c3.bias, c3.out_channels
         if h.is_cuda and nc % 8:  # zero rows up to a multiple of 8 classes: the library's GEMM kernels take 16-byte rows
             pad = 8 - nc % 8
@@ -416,38 +419,6 @@ def _factor_side_stream(device):
     return _factor_streams[key]
 
 
-_PREPACK = os.environ.get("MTLORA_PREPACK", "0") == "1"
-
-
-def _prepack_linears(model, device) -> None:
-    """pack the low-rank factors of every MTLoRALinear for the coming forward on the side stream (``MTLoRALinear.prepack``):
-    48 small k_pack launches leave the forward's critical path (they depend on parameters only, i.e. can run as soon as the
-    previous optimizer step is done).  OPT-IN (MTLORA_PREPACK=1): measured neutral at C2 (925 vs 928 img/s) -- the step boundary
-    has nothing on the main stream for the packs to overlap with except the patch embedding, and the host issues the 48 launches
-    before it can start issuing the forward; bit-identical to the in-line packing (test_prepacked_factors_are_bit_identical)."""
-    if not _PREPACK or torch.cuda.is_current_stream_capturing():
-        return
-    side = _factor_side_stream(device)
-    if side is None:
-        return
-    mods = getattr(model, "_mtl_linears", None)
-    if mods is None:
-        mods = [m for m in model.modules() if isinstance(m, MTLoRALinear) and m.r > 0]
-        try:
-            model._mtl_linears = mods
-        except Exception:  # noqa: BLE001
-            pass
-    if not mods:
-        return
-    side.wait_stream(torch.cuda.current_stream(device))  # after the optimizer step and the previous backward's reads
-    sp = ctypes.c_void_p(side.cuda_stream)
-    n = sum(1 for m in mods if m.prepack(sp))
-    if n:
-        ev = torch.cuda.Event()
-        ev.record(side)
-        Fn.set_prepack_event(ev)
-
-
 def train_step(model, criterion, optimizer, images, targets, clip_grad: float = 5.0, reducer=None,
                amp_dtype: Optional[torch.dtype] = torch.bfloat16, fused_loss: bool = True):
     """one reference train step (main.py:329-354): autocast fwd + weighted multi-task loss, backward,
@@ -463,7 +434,6 @@ def train_step(model, criterion, optimizer, images, targets, clip_grad: float = 
 
     if images.is_cuda:
         Fn.droppath_begin_step(images.device)  # DropPath factors of the whole step from one draw (functional._DropPathPool)
-        _prepack_linears(model, images.device)  # (opt-in) every layer's k_pack on the side stream
     try:
         if amp_dtype is not None:
             with torch.autocast("cuda", dtype=amp_dtype):

@@ -467,7 +467,9 @@ def mtl_heads(P, stages, cfg, train=False):
         cat = torch.cat([maps[0]] + [F.interpolate(m, (h, w), mode="bilinear") for m in maps[1:]], 1)
         pre = f"decoders.decoders.{t}.last_layer"
         y = F.conv2d(cat, P[pre + ".0.weight"], P[pre + ".0.bias"])
-        y = F.relu(_bn(P, pre + ".1", y, train))
+        y = _bn(P, pre + ".1", y, train)
+        if cfg.get("head_relu", True):  # (False: the kink-free probe of tests/test_gpu_models.py)
+            y = F.relu(y)
         y = F.conv2d(y, P[pre + ".3.weight"], P[pre + ".3.bias"])
         out[t] = F.interpolate(y, (cfg["img_size"], cfg["img_size"]), mode="bilinear")
     return out

@@ -28,34 +28,33 @@ def golden():
     return load
 
 
-# ---- the row-panel engine (csrc/panel.h) is opt-in (MTLORA_PNL=1) and then only takes launches with >= 32768 rows; every
-# GPU test that runs an MTLoRALinear in bf16 is ALSO run with it switched on and the threshold at 1 row ("[panel]"
-# variants), so the golden / oracle cases cover it.  (The library reads both variables at every call.)
-_PANEL_TESTS = ("linear", "mlp", "swin_block", "backbone", "config_model", "module_golden", "c1_reference", "task_streams",
+# ---- two kernel families serve the MTLoRALinear launches: the wave-streaming kernels (csrc/stream.h: fused T = 0 forward / dX,
+# P / Q passes -- the default wherever a shape is eligible) and the tiled kernels (k_nt / k_ntl: everything else).  Every GPU
+# test that runs an MTLoRALinear in a 16-bit type is ALSO run with the streaming family switched off ("[tiled]" variants:
+# MTLORA_SP=0, read by the library at every call), so the golden / oracle cases pin both the default path and the fallback.
+_TILED_TESTS = ("linear", "mlp", "swin_block", "backbone", "config_model", "module_golden", "c1_reference", "task_streams",
                 "reducer_on_the_real_model")
 
 
-@pytest.fixture(autouse=True, params=["auto", "panel"])
-def _panel_engine(request, monkeypatch):
-    if request.param == "panel":
-        monkeypatch.setenv("MTLORA_PNL", "1")
-        monkeypatch.setenv("MTLORA_PNL_MIN_M", "1")
+@pytest.fixture(autouse=True, params=["auto", "tiled"])
+def _kernel_family(request, monkeypatch):
+    if request.param == "tiled":
+        monkeypatch.setenv("MTLORA_SP", "0")
     else:
-        monkeypatch.delenv("MTLORA_PNL", raising=False)
-        monkeypatch.delenv("MTLORA_PNL_MIN_M", raising=False)
+        monkeypatch.delenv("MTLORA_SP", raising=False)
     yield
 
 
 def pytest_collection_modifyitems(config, items):
     keep = []
     for it in items:
-        if "[panel" in it.name or "-panel]" in it.name:
+        if "[tiled" in it.name or "-tiled]" in it.name:
             is_gpu = it.get_closest_marker("gpu") is not None
-            wants = any(k in it.name for k in _PANEL_TESTS)
+            wants = any(k in it.name for k in _TILED_TESTS)
             import torch
             vals = list(getattr(getattr(it, "callspec", None), "params", {}).values())
-            fp32_only = ("fp32" in it.name) or ((torch.float32 in vals or torch.float16 in vals) and torch.bfloat16 not in vals)  # the engine is bf16-only
-            if not (is_gpu and wants) or fp32_only:
+            fp32_only = ("fp32" in it.name) or (torch.float32 in vals and torch.bfloat16 not in vals and torch.float16 not in vals)
+            if not (is_gpu and wants) or fp32_only:  # (the streaming kernels are 16-bit only: fp32 cases have one path)
                 continue
         keep.append(it)
     items[:] = keep

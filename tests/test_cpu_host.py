@@ -120,13 +120,26 @@ def test_module_api_parity(golden):
     m = MTLoRALinear(16, 24, r=4, lora_shared_scale=2.0)
     torch.nn.init.normal_(m.lora_shared_B, std=0.1)
     w0 = m.linear.weight.detach().clone()
+    with pytest.raises(RuntimeError):                   # merging is an inference-time operation: refused in train mode
+        m.merge()
+    m.eval()
     assert m.merge() and m.merged and not m.merge()
     assert torch.allclose(m.linear.weight, w0 + 2.0 * m.lora_shared_B @ m.lora_shared_A, atol=1e-6)
+    # a merged layer SAVES the un-merged weight (W + s B A next to A and B would apply the update twice after a reload) ...
+    sd = m.state_dict()
+    assert torch.allclose(sd["linear.weight"], w0, atol=1e-6) and m.merged
+    fresh = MTLoRALinear(16, 24, r=4, lora_shared_scale=2.0)
+    fresh.load_state_dict(sd)
+    assert not fresh.merged and torch.allclose(fresh.linear.weight, w0, atol=1e-6)
+    # ... and loading a checkpoint INTO a merged layer resets the flag (the loaded weight never contained the delta)
+    m.load_state_dict(sd)
+    assert not m.merged and torch.allclose(m.linear.weight, w0, atol=1e-6)
+    assert m.merge() and m.merged
     m.train()                                            # train() un-merges
     assert not m.merged and torch.allclose(m.linear.weight, w0, atol=1e-6)
-    mt = MTLoRALinear(16, 24, r={"shared": 4, "a": 2}, lora_task_scale={"a": 2.0}, tasks=["a"])
+    mt = MTLoRALinear(16, 24, r={"shared": 4, "a": 2}, lora_task_scale={"a": 2.0}, tasks=["a"]).eval()
     assert mt.merge() is False
-    mv2 = MTLoRALinear(16, 24, r={"shared": 4, "a": 2}, lora_task_scale={"a": 2.0}, tasks=["a"], shared_mode="matrixv2")
+    mv2 = MTLoRALinear(16, 24, r={"shared": 4, "a": 2}, lora_task_scale={"a": 2.0}, tasks=["a"], shared_mode="matrixv2").eval()
     assert mv2.merge() is True and mv2.unmerge() is True
     c = golden("c2_structure.pt")
     model = H.build_model(img_size=448, freeze=True)

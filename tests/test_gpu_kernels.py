@@ -891,69 +891,6 @@ def test_mlp_gelu_fused_both_ways(dtype, with_tasks):
         assert_close(p1[k], p0[k].double(), dtype, k, mult=3)
 
 
-def test_linear_direct_to_lds_variant():
-    """k_nt2 (opt-in MTLORA_NT2=1: 256 x 128 tiles, global_load_lds tile loads, XOR-swizzled LDS, 3-stage ring) replaces the
-    lean single-output launches: the linear parity tests (oracle, golden shapes, GELU' gate, dropout masks) must pass
-    unchanged with it forced on.  Subprocess: the switch is read once per process."""
-    import os, subprocess, sys
-    if os.environ.get("MTLORA_NT2") == "1":
-        pytest.skip("already running under MTLORA_NT2=1")
-    env = dict(os.environ, MTLORA_NT2="1")
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_kernels.py"), "-q", "-x", "-m", "gpu",
-                        "-k", "linear_random_vs_oracle or linear_bwd_gelu or split_reduction or linear_golden"],
-                       env=env, cwd=root, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    assert " passed" in r.stdout
-
-
-def test_linear_fused_projection():
-    """Row-panel form of k_nt (projection P / Q formed inside the output kernel, workgroup loops over its n-tiles):
-    forward AND backward against the two-pass form, in subprocesses (the switches are read once per process).
-    Production enables it only for M >= 49k rows; MTLORA_FUSE_MIN_TILES=1 forces it at test sizes, and
-    MTLORA_FUSE_TARGET selects one workgroup per panel (n-loop, G = 1) or one per n-tile (G = n_tiles)."""
-    import os, subprocess, sys
-    code = r'''
-import sys, torch
-sys.path.insert(0, %r)
-from mtlora_amd.lora import MTLoRALinear
-from mtlora_amd import functional as Fn
-torch.manual_seed(0)
-dev = torch.device("cuda")
-outs = []
-for (M, K, N, dt, p) in [(777, 96, 288, torch.bfloat16, 0.1), (1000, 96, 384, torch.bfloat16, 0.05), (515, 384, 96, torch.bfloat16, 0.1),
-                        (300, 192, 576, torch.float32, 0.1), (260, 96, 96, torch.float32, 0.0), (129, 768, 200, torch.bfloat16, 0.1)]:
-    m = MTLoRALinear(K, N, r={"shared": 64}, lora_shared_scale=4.0, lora_task_scale=1.0, lora_dropout=p, tasks=None).to(dev)
-    g = torch.Generator(device="cuda").manual_seed(M)
-    with torch.no_grad():
-        for q in m.parameters():
-            q.copy_(torch.randn(q.shape, device=dev, generator=g) * 0.05)
-    m.linear.weight.requires_grad_(False)
-    m.train()
-    x = torch.randn(M, K, device=dev, generator=g).to(dt).requires_grad_(True)
-    Fn._seed_counter = 100
-    y, _ = m(x, None)
-    gy = torch.randn(M, N, device=dev, generator=g).to(dt)
-    y.backward(gy)
-    outs += [y.float().cpu(), x.grad.float().cpu(), m.lora_shared_A.grad.float().cpu(), m.lora_shared_B.grad.float().cpu()]
-torch.save(outs, sys.argv[1])
-''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    import tempfile
-    res = {}
-    for tag, extra in (("two_pass", {"MTLORA_FUSE_P": "0"}),
-                       ("panel_g1", {"MTLORA_FUSE_P": "1", "MTLORA_FUSE_MIN_TILES": "1", "MTLORA_FUSE_TARGET": "1"}),
-                       ("panel_gn", {"MTLORA_FUSE_P": "1", "MTLORA_FUSE_MIN_TILES": "1", "MTLORA_FUSE_TARGET": "1000000"})):
-        with tempfile.NamedTemporaryFile(suffix=".pt") as f:
-            r = subprocess.run([sys.executable, "-c", code, f.name], env=dict(os.environ, **extra), capture_output=True,
-                               text=True, timeout=300)
-            assert r.returncode == 0, r.stderr[-2000:]
-            res[tag] = torch.load(f.name)
-    for tag in ("panel_g1", "panel_gn"):
-        for i, (a, b) in enumerate(zip(res["two_pass"], res[tag])):
-            assert torch.isfinite(b).all(), (tag, i)
-            err = ((a - b).abs().max() / a.abs().max().clamp_min(1e-12)).item()
-            assert err < 2e-2, (tag, i, err)   # same dropout seed, same math; bf16 rounding of P / Q differs in order only
-
 
 # ------------------------------------------------------------------------------------------------
 # fused bilinear upsample + loss (+ backward)

@@ -73,11 +73,20 @@ def _grad_errors(grads, ref, skip=()):
     return errs, gmax
 
 
+# parameter families whose fp32 gradient may move by more than the per-tensor tolerance because ONE forward value rounds across a
+# kink (see test_config_model_vs_oracle): the heads' own convolutions / BatchNorm (the ReLU sits right behind them) and the
+# per-task downsamplers that feed them, and the TASK-SPECIFIC low-rank factors, whose whole gradient arrives through that one head
+# (c5:4 fp32: `lora_tasks_*.t2` at 3.5e-3 .. 5e-3 behind `decoders.t2.last_layer.0.weight` at 2e-2, eager fp32 at 1e-5: the same
+# flipped element).  Everything shared between the tasks (shared factors, norms, tables, patch embedding) has to meet the tolerance.
+KINK_AFFECTED = ("decoders.decoders.", "downsampler.", "lora_tasks_")
+
 MODEL_CASES = {
     # name: (config row, overrides)
     "c2_swin_t_r64_4": ("c2", {}),
     "c4_swin_b_r128": ("c4", {}),
     "c5_8task_r4": ("c5:4", {}),
+    "c5_8task_r16": ("c5:16", {}),
+    "c5_8task_r64": ("c5:64", {}),
     "c5_8task_r256": ("c5:256", {}),
 }
 
@@ -135,9 +144,19 @@ def test_config_model_vs_oracle(case, amp):
     # flips other elements).  So single tensors are held to a cap that still catches a wrong formula (those give O(1)), and
     # the population is held tight:
     if not amp:
-        assert med <= 2e-3, med                                      # typical tensor at the north-star fp32 tolerance
+        # typical tensor at the north-star fp32 tolerance -- or at what the reference's own fp32 eager path resolves when the kinks
+        # dominate the whole population (c5:256: eager median 1.2e-3, HIP 1.6e-3; kink-free probe below: 5e-6)
+        assert med <= max(1e-3, 1.5 * emed), (med, emed)
+        # per tensor: the north-star 1e-3 with k = 3 of head-room for fp32 accumulation over 100k pixels, or twice what the
+        # reference's own fp32 eager path resolves.  Only the KINK_AFFECTED families may exceed it (and stay capped): their
+        # gradients are piecewise constant in a pre-activation (ReLU behind the heads' BatchNorm, |.| and 1 / ||.|| in NormalsLoss), so
+        # one element rounding across the kink moves them by percents in fp32 on EITHER path -- test_config_model_kinkfree_probe
+        # pins that those same tensors agree to 1e-3 once the kinks are taken out.
+        over = {n: e for n, e in errs.items() if e > max(3e-3, 2.0 * eerrs[n])}
+        stray = {n: e for n, e in over.items() if not any(k in n for k in KINK_AFFECTED)}
+        assert not stray, sorted(stray.items(), key=lambda kv: -kv[1])[:5]
         assert max(errs.values()) <= max(5e-2, 2.0 * max(eerrs.values())), sorted(errs.items(), key=lambda kv: -kv[1])[:3]
-        assert len(bad) <= 0.15 * len(errs), len(bad)
+        assert len(over) <= 0.10 * len(errs), len(over)
         return
     # bf16: in aggregate the HIP path must be as accurate as the reference's own eager bf16-autocast path ...
     assert med <= max(floor, 1.25 * emed), (med, emed)
@@ -174,6 +193,51 @@ def _report(case, amp, stats):
             f.write(json.dumps({"case": case, "amp": amp, **{k: (v if not isinstance(v, list) else str(v)) for k, v in stats.items()}}) + "\n")
     except OSError:
         pass
+
+
+@pytest.mark.parametrize("case", ["c5_8task_r4", "c5_8task_r256", "c2_swin_t_r64_4"])
+def test_config_model_kinkfree_probe(case):
+    """fp32 whole-model gradients with the KINKS taken out on both sides: heads' ReLU = identity, loss = a smooth quadratic probe of
+    the upsampled outputs (no |.|, no 1 / ||.||, no argmax-like ignore masks).  Every gradient of the model is then a smooth
+    function of the arithmetic and EVERY tensor must agree with the fp64 oracle to the north-star fp32 tolerance -- in
+    particular the tensors that exceed it in test_config_model_vs_oracle (decoders.*.last_layer.0.weight at 1e-2 with the ReLU
+    in place): a real bug in the rank-0 k_nt / k_tn plain_dW / BatchNorm-backward chain would show here as well."""
+    from mtlora_amd import mtl_harness as H
+    name, over = MODEL_CASES[case]
+    row = H.config(name)
+    tasks = list(row["tasks"])
+    model = H.build_config_model(name, seed=3, img_size=224, drop_path_rate=0.0, DROPOUT=[0.0] * 4, **over).to(dev())
+    for t in tasks:
+        model.decoders.decoders[t].relu = False
+    model.train()
+    img, _ = H.synthetic_batch(2, 224, tasks, seed=5, device=dev())
+    probes = {t: O.det_tensor("probe." + t, (1, H.num_output(t), 1, 1), 1.0).to(dev()) for t in tasks}
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+
+    def probe_loss(outs, cast):
+        return sum((0.5 * (cast(outs[t]) * cast(probes[t])) ** 2).mean() + 0.1 * (cast(outs[t]) * cast(probes[t])).mean() for t in tasks)
+
+    loss = probe_loss(model(img), lambda v: v.float())
+    loss.backward()
+    torch.cuda.synchronize()
+    cfg = O.swin_t_cfg(img_size=224, tasks=tasks, r_shared=row["r_shared"], r_task=row["r_task"], embed_dim=row["embed_dim"],
+                       depths=row["depths"], num_heads=row["num_heads"], drop_path_rate=0.0, dropout=0.0)
+    cfg["head_relu"] = False
+    trainable = {n for n, p in model.named_parameters() if p.requires_grad}
+    P = {k: v.detach().to(device=dev(), dtype=torch.float64).clone() for k, v in sd.items() if v.is_floating_point()}
+    for k in P:
+        if k in trainable:
+            P[k].requires_grad_(True)
+    rl = probe_loss(O.full_model(P, img.double(), cfg, train=True, rng=torch.Generator().manual_seed(0)), lambda v: v.double())
+    rl.backward()
+    assert abs(loss.item() - rl.item()) <= 1e-3 * abs(rl.item()), (loss.item(), rl.item())
+    grads = {n: p.grad for n, p in model.named_parameters() if p.requires_grad}
+    rg = {k: (None if P[k].grad is None else P[k].grad.cpu()) for k in trainable}
+    bn_bias = {n for n in trainable if n.endswith("last_layer.0.bias")}
+    errs, gmax = _grad_errors(grads, rg, skip=bn_bias)
+    worst = sorted(errs.items(), key=lambda kv: -kv[1])[:5]
+    _report(case + ":kinkfree", False, dict(n=len(errs), med=sorted(errs.values())[len(errs) // 2], max=worst[0][1], worst=worst))
+    assert worst[0][1] <= 1e-3, worst
 
 
 @pytest.mark.parametrize("amp", [False, True], ids=["fp32", "bf16"])
@@ -375,41 +439,6 @@ def test_graphed_train_step_replays_the_eager_step():
     num = sum((out[0][1][n] * out[1][1][n]).sum().item() for n in out[0][1])
     den = (sum((out[0][1][n] ** 2).sum().item() for n in out[0][1]) * sum((out[1][1][n] ** 2).sum().item() for n in out[1][1])) ** 0.5
     assert num / den >= 0.98, num / den
-
-
-@pytest.mark.gpu
-def test_prepacked_factors_are_bit_identical():
-    """train_step packs every MTLoRALinear's low-rank factors on the side stream at the start of the step
-    (MTLoRALinear.prepack -> mtlora_linear_pack, desc.pack of ABI v4) instead of a k_pack launch inside each layer's forward:
-    three steps must leave loss and every parameter bit-identical to the in-line packing, and the layers must really have
-    consumed their persistent buffers."""
-    from mtlora_amd import functional as Fn
-    from mtlora_amd import mtl_harness as H
-    from mtlora_amd.lora import MTLoRALinear
-    tasks = ["semseg", "normals", "sal", "human_parts"]
-    img, tg = H.synthetic_batch(2, 224, tasks, seed=19, device=dev())
-    runs = []
-    keep = H._PREPACK
-    try:
-        for on in (False, True):
-            H._PREPACK = on
-            torch.manual_seed(5)
-            Fn._seed_counter = 0
-            Fn.droppath_reset()
-            model = H.build_model(img_size=224, tasks=tasks, depths=(2, 2, 2, 2), r_shared=16, r_task=4, seed=3).to(dev()).train()
-            crit, opt = H.MultiTaskLoss(tasks), H.build_optimizer(model, lr=1e-3)
-            losses = [H.train_step(model, crit, opt, img, tg)[0].clone() for _ in range(3)]
-            torch.cuda.synchronize()
-            lin = [m for m in model.modules() if isinstance(m, MTLoRALinear) and m.r > 0]
-            used = sum(1 for m in lin if m._pack_state is not None and not m._pack_state["ready"])
-            assert used == (len(lin) if on else 0), (used, len(lin))
-            runs.append((losses, {n: p.detach().clone() for n, p in model.named_parameters()}))
-    finally:
-        H._PREPACK = keep
-    for a, b in zip(runs[0][0], runs[1][0]):
-        assert torch.equal(a, b), (a.item(), b.item())
-    for n in runs[0][1]:
-        assert torch.equal(runs[0][1][n], runs[1][1][n]), n
 
 
 @pytest.mark.gpu

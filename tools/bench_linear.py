@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Per-layer timing of the MTLoRALinear forward / backward on the C2 shapes (B=32), k_nt path vs the row-panel engine
-(MTLORA_PNL_MIN_M is read by the library per call).   python tools/bench_linear.py [--shapes s0 s1 ...] [--iters 20]"""
+"""Per-layer kernel time of the MTLoRALinear forward / backward on the C2 shapes (B=32): default path (wave-streaming kernels
+where eligible) vs the tiled kernels only (MTLORA_SP=0, read by the library per call).
+    python tools/bench_linear.py [--shapes s0.qkv ...] [--iters 5] [--kinds] [--knt-only: default path only]"""
 import argparse, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -41,8 +42,11 @@ def run(name, iters, r_s=64, r_t=4):
     x = torch.randn(M, K, device=dev, dtype=torch.bfloat16, requires_grad=True)
     xts = {t: torch.randn(M, K, device=dev, dtype=torch.bfloat16, requires_grad=True) for t in TASKS} if xt else None
     res = {}
-    for mode, env in ((("k_nt", "0"),) if os.environ.get("MTLORA_PNL_DBG") is None else ()) + ((("panel", None),) if not KNT_ONLY else ()):
-        os.environ["MTLORA_PNL"] = "1" if env is None else env
+    for mode, env in ((("k_nt", "0"),) if not KNT_ONLY else ()) + (("panel", None),):  # "k_nt": tiled only; "panel": default path
+        if env is None:
+            os.environ.pop("MTLORA_SP", None)
+        else:
+            os.environ["MTLORA_SP"] = env
         with torch.autocast("cuda", dtype=torch.bfloat16):
             y, yt = m(x, xts)
         outs = [y] + ([yt[t] for t in TASKS] if yt else [])
@@ -85,8 +89,7 @@ def run(name, iters, r_s=64, r_t=4):
     T = len(TASKS) if wt else 0
     fb = es * M * ((1 + (T if xt else 0)) * K + (1 + T) * N)
     bb = es * M * ((1 + T) * N + 2 * (1 + (T if xt else 0)) * K)
-    res.setdefault("k_nt", (0.0, 0.0))
-    res.setdefault("panel", res["k_nt"])
+    res.setdefault("k_nt", res["panel"])
     print(f"{name:9s} M{M} K{K} N{N} T{T}: fwd {res['k_nt'][0]:7.1f} -> {res['panel'][0]:7.1f} us ({fb / res['panel'][0] / 1e6:5.2f} TB/s) | "
           f"bwd {res['k_nt'][1]:7.1f} -> {res['panel'][1]:7.1f} us ({bb / res['panel'][1] / 1e6:5.2f} TB/s)", flush=True)
 
@@ -95,7 +98,7 @@ if __name__ == "__main__":
     ap.add_argument("--shapes", nargs="*", default=list(SHAPES))
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--kinds", action="store_true", help="per-kind kernel time of every leg")
-    ap.add_argument("--knt-only", action="store_true")
+    ap.add_argument("--knt-only", action="store_true", help="default path only (no tiled-only leg)")
     a = ap.parse_args()
     KINDS, KNT_ONLY = a.kinds, a.knt_only
     for s in a.shapes:

@@ -1422,6 +1422,35 @@ static void launch_sp_proj(const SpProjParams& q, int ch, int ns, hipStream_t s,
 #undef MTL_SP_PROJ
 }
 
+template <typename T>
+static void launch_sp_projsum(const SpProjParams& q, int ch, int ns, T* gsum, hipStream_t s, int kind, double alg_bytes, double s8d,
+                              double flops) {
+    mtl_prof_tag("sp_projsum M%lld K%d R%d src%d ch%d ns%d", (long long)q.M, q.K, q.Rw, q.n_src, ch, ns);
+    MtlProfScope prof(kind, alg_bytes, s, s8d, flops);
+    const size_t lds = (size_t)q.n_blk_total * 32 * q.K * 2 + (size_t)SP_WAVES * ns * 32 * ch * 2;
+    int64_t wgs = mtl_ceil_div(q.n_slabs, SP_WAVES);
+    if (wgs > (int64_t)sp_num_cu()) wgs = sp_num_cu();
+#define MTL_SP_PS(CHV, NSV)                                                                                                    \
+    do {                                                                                                                        \
+        static bool raised = false;                                                                                             \
+        if (!raised) {                                                                                                          \
+            (void)hipFuncSetAttribute((const void*)k_sp_projsum<T, CHV, NSV>, hipFuncAttributeMaxDynamicSharedMemorySize, SP_LDS_MAX); \
+            raised = true;                                                                                                      \
+        }                                                                                                                       \
+        hipLaunchKernelGGL((k_sp_projsum<T, CHV, NSV>), dim3((unsigned)wgs), dim3(64 * SP_WAVES), lds, s, q, gsum);             \
+    } while (0)
+    if constexpr (sizeof(T) == 2) {
+        if (ch == 96) {
+            if (ns >= 2) MTL_SP_PS(96, 2);
+            else MTL_SP_PS(96, 1);
+        } else {
+            if (ns >= 2) MTL_SP_PS(64, 2);
+            else MTL_SP_PS(64, 1);
+        }
+    }
+#undef MTL_SP_PS
+}
+
 // ---- fused wave-streaming MTLoRALinear launch, activation-resident form (k_sp_xres, stream.h).  Fills the plan fields of q
 // (n_parts, blk_per_part, n_slabs, estep) and the launch geometry; false: not eligible (weights do not fit / unsupported shape).
 struct SpXresPlan {
@@ -1874,12 +1903,49 @@ static int bwd_impl(const mtlora_linear_desc* d, const void* x, const void* cons
     //    (n_dy + 1 + n_tiles) MN bytes instead of n_dy * n_tiles * MN.
     const void* dy_shared = dy[0];
     const bool do_dx = d->bwd_phase != 2, do_factors = d->bwd_phase != 1;  // (phase 2 re-derives the same operand table)
-    const bool presum = n_dy > 1 && dx && mtl_ceil_div(d->K, TILE) >= 3;
+    bool presum = n_dy > 1 && dx && mtl_ceil_div(d->K, TILE) >= 3;
     bool have_g = false;
+    // layers with task outputs ('matrix' mode, every output has a gradient): ONE wave-streaming pass over the 1 + T gradient
+    // tensors forms Q (all segments) AND G = sum_o dY_o (k_sp_projsum, stream.h); the dX launch then reads G alone
+    bool q_done = false;
+    if constexpr (sizeof(T) == 2) {
+        if (d->T >= 1 && d->T <= SP_PS_MAXT && d->mode == 0 && do_dx && dx && n_dy == 1 + d->T && sg.rp[0] > 0 && sg.rp[0] <= 64) {
+            SpProjParams sp = {};
+            sp.wproj = pk + L.bt_proj;
+            sp.out = Qm;
+            sp.ld_out = sg.R;
+            sp.M = d->M;
+            sp.K = (int)d->N;
+            sp.Rw = sg.R;
+            sp.drop = dc;
+            bool ok = true;
+            for (int o = 0; o < sg.n; ++o) {
+                if (sg.rp[o] == 0 || (o > 0 && sg.rp[o] > 32)) ok = false;
+                SpSrc& ss = sp.src[sp.n_src++];
+                ss.act = dy[o];
+                ss.col_lo = sg.off[o];
+                ss.col_hi = sg.off[o] + sg.rp[o];
+                ss.blk_lo = ss.col_lo / 32;
+                ss.n_blk = (ss.col_hi - 1) / 32 - ss.blk_lo + 1;
+                ss.mask = 0;
+                if (o > 0 && ss.n_blk != 1) ok = false;
+            }
+            int ch = 0;
+            const int ns = ok ? sp_proj_plan<T>(sp, ch) : 0;
+            if (ns > 0 && d->M * d->N * 2 < ((int64_t)1 << 32) - 64) {
+                double rsum = 0.0;
+                for (int o = 0; o < sg.n; ++o) rsum += sg.r[o];
+                launch_sp_projsum<T>(sp, ch, ns, Gm, s, PK_NT_BWD_Q, 0.0, 0.0, 2.0 * d->M * d->N * rsum);
+                q_done = true;
+                presum = true;
+                have_g = true;
+            }
+        }
+    }
     if ((v2 || presum) && n_dy > 1) {
         have_g = true;
     }
-    if (have_g && do_dx) {
+    if (have_g && do_dx && !q_done) {
         SumParams sp;
         sp.n = n_dy;
         for (int i = 0; i < n_dy; ++i) sp.src[i] = dy_all[i];
@@ -1923,7 +1989,7 @@ static int bwd_impl(const mtlora_linear_desc* d, const void* x, const void* cons
     }
 
     // Q[:, seg_o] = alpha_o * dY_o B_o   (zero where the output got no gradient)
-    if (sg.R > 0 && do_dx && !sp_dx_done) {
+    if (sg.R > 0 && do_dx && !sp_dx_done && !q_done) {
         bool any_missing = false;
         for (int o = 0; o < sg.n; ++o)
             if (sg.rp[o] > 0 && !dyo[o]) any_missing = true;

@@ -798,3 +798,164 @@ __global__ __launch_bounds__(64 * SP_WAVES, SP_WAVES / 4) void k_sp_ares(const S
         }
     }
 }
+
+// ------------------------------------------------------------------------------------------------
+// k_sp_projsum : the Q pass of a layer WITH task outputs, fused with the sum of the output gradients:
+//     Q[:, seg_o] = alpha_o dY_o B_o  (o = shared, tasks)      and      G = sum_o dY_o   (fp32 sum, rounded once)
+// in ONE pass over the 1 + T gradient tensors.  The tiled path reads them twice here (k_sum or the multi-source staging of the dX
+// kernel, and the Q pass); with G written next to Q the dX launch becomes single-source (dX = G W + keep .* (Q_s A_s), dX_t =
+// Q_t A_t) and k_sum disappears.  Work item = slab of 32 rows; per reduction chunk the wave walks the sources (one DMA chunk
+// each, same slot ring as k_sp_proj), adds the fragments into the chunk's fp32 sum and feeds that source's projection blocks
+// (shared: <= 2 blocks of 32 rank rows, every task: 1 block).  Layers with more than 4 task outputs keep the two-pass form.
+// ------------------------------------------------------------------------------------------------
+constexpr int SP_PS_MAXT = 4;
+template <typename T, int CH, int NS>
+__global__ __launch_bounds__(64 * SP_WAVES, SP_WAVES / 4) void k_sp_projsum(const SpProjParams Pv, T* __restrict__ gsum) {
+    typedef SpGeom<CH> G;
+    (void)Pv;
+    SpProjPtr P = (SpProjPtr)__builtin_amdgcn_kernarg_segment_ptr();
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5, rl = lane & 31;
+    const int K = P->K, KST = K >> 4, NCH = K / CH;
+    const int n_src = P->n_src, n_slabs = P->n_slabs;
+    const int64_t M = P->M;
+    unsigned char* wl = smem;
+    unsigned char* slots = smem + (size_t)P->n_blk_total * KST * 1024 + (size_t)wave * NS * G::SLOT;
+    {
+        const T* wp = reinterpret_cast<const T*>(P->wproj);
+        const int nfrag = P->n_blk_total * KST;
+        for (int f = wave; f < nfrag; f += SP_WAVES) {
+            const int blk = f / KST, ks = f - blk * KST;
+            const int row = blk * 32 + rl;
+            const void* g = row < P->Rw ? (const void*)(wp + (int64_t)row * K + ks * 16 + 8 * h) : (const void*)g_zero16;
+            sp_dma16(g, wl + (size_t)f * 1024);
+        }
+    }
+    int goff[G::NDMA], grow[G::NDMA], fo[G::KS];
+#pragma unroll
+    for (int j = 0; j < G::NDMA; ++j) {
+        const int c = j * 64 + lane, row = c / G::CPR, p = c - row * G::CPR;
+        grow[j] = row;
+        goff[j] = row * K + G::logical(row, p) * 8;
+    }
+#pragma unroll
+    for (int ks = 0; ks < G::KS; ++ks) fo[ks] = rl * G::ROWB + G::phys(rl, 2 * ks + h) * 16;
+    SP_WAIT_VM(0);
+    __syncthreads();
+
+    const int n_waves = gridDim.x * SP_WAVES;
+    const int w_gid = blockIdx.x * SP_WAVES + wave;
+    // loader cursor over (slab, chunk, source)
+    int l_slab = w_gid, l_ch = 0, l_s = 0;
+    auto issue = [&](int slot) __attribute__((always_inline)) -> bool {
+        if (l_slab >= n_slabs) return false;
+        const T* base = reinterpret_cast<const T*>(P->src[l_s].act) + (int64_t)l_slab * 32 * K + l_ch * CH;
+        unsigned char* dst = slots + slot * G::SLOT;
+        if ((int64_t)l_slab * 32 + 32 <= M) {
+#pragma unroll
+            for (int j = 0; j < G::NDMA; ++j) sp_dma16(base + goff[j], dst + j * 1024);
+        } else {
+            const int last = (int)(M - 1 - (int64_t)l_slab * 32);
+#pragma unroll
+            for (int j = 0; j < G::NDMA; ++j) {
+                const int r = grow[j] < last ? grow[j] : last;
+                sp_dma16(base + goff[j] + (r - grow[j]) * K, dst + j * 1024);
+            }
+        }
+        if (++l_s == n_src) {
+            l_s = 0;
+            if (++l_ch == NCH) {
+                l_ch = 0;
+                l_slab += n_waves;
+            }
+        }
+        return true;
+    };
+    int ahead = 0;
+#pragma unroll
+    for (int i = 0; i < NS; ++i) ahead += issue(i) ? 1 : 0;
+    const __amdgpu_buffer_rsrc_t orsrc = sp_rsrc(P->out, M * P->ld_out * 2), grsrc = sp_rsrc(gsum, M * (int64_t)K * 2);
+
+    int slot = 0;
+    for (int slab = w_gid; slab < n_slabs; slab += n_waves) {
+        const uint32_t m = (uint32_t)slab * 32u + (uint32_t)rl;
+        f32x16 accS[2], accT[SP_PS_MAXT];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            accS[0][r] = accS[1][r] = 0.f;
+#pragma unroll
+            for (int t = 0; t < SP_PS_MAXT; ++t) accT[t][r] = 0.f;
+        }
+        for (int ch = 0; ch < NCH; ++ch) {
+            float gs[G::KS][8];
+#pragma unroll
+            for (int ks = 0; ks < G::KS; ++ks)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) gs[ks][e] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 1 + SP_PS_MAXT; ++s) {
+                if (s < n_src) {
+                    sp_wait_chunk<G::NDMA>(ahead - 1);
+                    const unsigned char* sl = slots + slot * G::SLOT;
+                    u32x4 xf[G::KS];
+#pragma unroll
+                    for (int ks = 0; ks < G::KS; ++ks) xf[ks] = *reinterpret_cast<const u32x4*>(sl + fo[ks]);
+                    SP_WAIT_LGKM0();
+                    --ahead;
+                    ahead += issue(slot) ? 1 : 0;
+                    slot = slot + 1 == NS ? 0 : slot + 1;
+#pragma unroll
+                    for (int ks = 0; ks < G::KS; ++ks) {
+                        float f[8];
+                        VOps<T>::unpack(xf[ks], f);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) gs[ks][e] += f[e];
+                    }
+                    const int blk_lo = P->src[s].blk_lo;
+                    const unsigned char* wb = wl + ((size_t)blk_lo * KST + ch * G::KS) * 1024 + lane * 16;
+                    if (s == 0) {
+                        const int nb = P->src[0].n_blk;
+#pragma unroll
+                        for (int ks = 0; ks < G::KS; ++ks) {
+                            sp_mma1<T>(*reinterpret_cast<const u32x4*>(wb + (size_t)ks * 1024), xf[ks], accS[0]);
+                            if (nb > 1) sp_mma1<T>(*reinterpret_cast<const u32x4*>(wb + ((size_t)KST + ks) * 1024), xf[ks], accS[1]);
+                        }
+                    } else {
+#pragma unroll
+                        for (int ks = 0; ks < G::KS; ++ks)
+                            sp_mma1<T>(*reinterpret_cast<const u32x4*>(wb + (size_t)ks * 1024), xf[ks], accT[s - 1]);
+                    }
+                }
+            }
+            // the chunk of G: lane (row m, half h) holds columns ch*CH + ks*16 + 8 h .. + 8 of its row
+#pragma unroll
+            for (int ks = 0; ks < G::KS; ++ks) {
+                u32x4 v;
+                if constexpr (sizeof(T) == 2) v = u32x4{mtl_pk2<T>(gs[ks][0], gs[ks][1]), mtl_pk2<T>(gs[ks][2], gs[ks][3]), mtl_pk2<T>(gs[ks][4], gs[ks][5]),
+                                                        mtl_pk2<T>(gs[ks][6], gs[ks][7])};
+                sp_bstore(v, grsrc, m * (uint32_t)(K * 2) + (uint32_t)(ch * CH + ks * 16 + 8 * h) * 2u);
+            }
+        }
+        // Q segments
+        const uint32_t rowoff = m * (uint32_t)(P->ld_out * 2);
+#pragma unroll
+        for (int s = 0; s < 1 + SP_PS_MAXT; ++s) {
+            if (s < n_src) {
+                const int col_lo = P->src[s].col_lo, col_hi = P->src[s].col_hi, blk_lo = P->src[s].blk_lo;
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    if (b == 0 || (s == 0 && P->src[0].n_blk > 1)) {
+#pragma unroll
+                        for (int q = 0; q < 4; q += 2) {
+                            u32x4 v;
+                            sp_pack_pair<T>(s == 0 ? accS[b] : accT[s == 0 ? 0 : s - 1], q, h, v);
+                            const int col = (blk_lo + b) * 32 + 8 * q + 8 * h;
+                            sp_bstore(v, orsrc, (col >= col_lo && col < col_hi) ? rowoff + (uint32_t)col * 2u : 0xFFFFFFFFu);
+                        }
+                    }
+                }
+            }
+        }
+    }
+}

@@ -790,12 +790,18 @@ struct NlParams {
     DropoutCfg drop;
 };
 
-template <bool ACT>
+// SN = 32-column sub-blocks per wave: 2 (128 x 128 tile) or 3 (128 rows x 192 columns).  The wide tile exists for the launches
+// whose 128 x 128 tile count lands just above a whole number of residency rounds (2 workgroups per CU = 512 slots): the
+// N = 384 outputs of stage 2 (196 x 3 = 588 tiles = 1.15 rounds -> 2 rounds, the second one 15 % full) run as 196 x 2 = 392
+// tiles of 1.5x the work in ONE round.  MLR: the low-rank part (rank tiles come first in the stream) is multiplied by the dropout
+// keep-mask of (m, n) before the base tiles are added -- the dX launches (dX = keep .* (Q A) + dY W).
+template <bool ACT, bool MLR, int SN>
 __global__ __launch_bounds__(512, 4) void k_ntl(const NlParams P) {
     constexpr int KE = ROWB / 2;  // 96 elements per staged k-tile
+    constexpr int TN = 64 * SN;   // tile columns
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* sW = smem;
-    unsigned char* sA = smem + TILE * LDSB;
+    unsigned char* sA = smem + TN * LDSB;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wn = wave >> 2, wm = wave & 3;
 
@@ -807,7 +813,7 @@ __global__ __launch_bounds__(512, 4) void k_ntl(const NlParams P) {
     }
     const uint32_t bm = P.n_tiles == 1 ? b : __umulhi(b, P.nt_magic);
     const int bn = (int)(b - bm * (uint32_t)P.n_tiles);
-    const int m0 = (int)bm * TILE, n0 = bn * TILE;
+    const int m0 = (int)bm * TILE, n0 = bn * TN;
     const int M = P.M, n_rows = P.n_rows;
 
     DropoutCfg drop = P.drop;
@@ -819,25 +825,26 @@ __global__ __launch_bounds__(512, 4) void k_ntl(const NlParams P) {
     const int n2 = (P.use_base && P.K > 0) ? (P.K + KE - 1) / KE : 0;
     const int total = n1 + n2;
 
-    f32x16 acc[2][1];
-    // accumulator start: the bias (when nothing multiplies the sum afterwards)
-    const bool bias_first = P.bias != nullptr && P.alpha == nullptr && P.use_base != 0;
+    f32x16 acc[SN];
+    // accumulator start: the bias (when nothing multiplies the sum afterwards and no mask is applied to the running sum)
+    const bool bias_first = !MLR && P.bias != nullptr && P.alpha == nullptr && P.use_base != 0;
 #pragma unroll
-    for (int sn = 0; sn < 2; ++sn)
+    for (int sn = 0; sn < SN; ++sn)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             f32x4 bi = {0.f, 0.f, 0.f, 0.f};
             if (bias_first) {
-                int n = n0 + wn * 64 + sn * 32 + 8 * q + 4 * (lane >> 5);
+                int n = n0 + wn * (32 * SN) + sn * 32 + 8 * q + 4 * (lane >> 5);
                 n = n < n_rows - 4 ? n : n_rows - 4;  // (columns >= n_rows are never stored)
                 bi = *reinterpret_cast<const f32x4*>(P.bias + n);
             }
 #pragma unroll
-            for (int e = 0; e < 4; ++e) acc[sn][0][q * 4 + e] = bi[e];
+            for (int e = 0; e < 4; ++e) acc[sn][q * 4 + e] = bi[e];
         }
 
-    TileRegs<bf16, 1> rg;
-    int cur_mask = 0, cur_k0 = 0;  // of the tile sitting in rg
+    u32x4 rw[3], rw2[SN == 3 ? 3 : 1], ra[3];  // staged k-tile: weight rows 0..127, weight rows 128..191 (SN = 3), activation rows
+    (void)rw2;
+    int cur_mask = 0, cur_k0 = 0;  // of the tile sitting in the registers
     auto issue = [&](int i) __attribute__((always_inline)) {
         const bool lr = i < n1;
         const bf16* wp = lr ? P.Rm : P.wgt;
@@ -857,10 +864,13 @@ __global__ __launch_bounds__(512, 4) void k_ntl(const NlParams P) {
             int wr = n0 + r, ar = m0 + r;
             wr = wr < n_rows ? wr : n_rows - 1;
             ar = ar < M ? ar : M - 1;
-            const bf16* pw = kin ? wp + (int64_t)wr * ldw + k : zp;
-            const bf16* pa = kin ? ap + (int64_t)ar * lda + k : zp;
-            rg.w[sl] = *reinterpret_cast<const u32x4*>(pw);
-            rg.a[sl] = *reinterpret_cast<const u32x4*>(pa);
+            rw[sl] = *reinterpret_cast<const u32x4*>(kin ? wp + (int64_t)wr * ldw + k : zp);
+            ra[sl] = *reinterpret_cast<const u32x4*>(kin ? ap + (int64_t)ar * lda + k : zp);
+            if constexpr (SN == 3) {  // weight rows 128 .. 191: the same map on a second 128-row panel, upper half unused
+                int wr2 = n0 + 128 + r;
+                wr2 = wr2 < n_rows ? wr2 : n_rows - 1;
+                if (r < 64) rw2[sl] = *reinterpret_cast<const u32x4*>(kin ? wp + (int64_t)wr2 * ldw + k : zp);
+            }
         }
     };
     auto stage = [&]() __attribute__((always_inline)) {
@@ -870,13 +880,35 @@ __global__ __launch_bounds__(512, 4) void k_ntl(const NlParams P) {
             nt_map<1>(tid, sl, r, v);
             if (cur_mask) {  // uniform
                 const uint32_t rh = mtl_dropout_rowhash(drop, 0u, (uint32_t)(m0 + r));
-                VOps<bf16>::drop(rg.a[sl], drop, rh, (uint32_t)(cur_k0 + v * 8));
+                VOps<bf16>::drop(ra[sl], drop, rh, (uint32_t)(cur_k0 + v * 8));
             }
-            *reinterpret_cast<u32x4*>(sW + r * LDSB + v * 16) = rg.w[sl];
-            *reinterpret_cast<u32x4*>(sA + r * LDSB + v * 16) = rg.a[sl];
+            *reinterpret_cast<u32x4*>(sW + r * LDSB + v * 16) = rw[sl];
+            *reinterpret_cast<u32x4*>(sA + r * LDSB + v * 16) = ra[sl];
+            if constexpr (SN == 3) {
+                if (r < 64) *reinterpret_cast<u32x4*>(sW + (128 + r) * LDSB + v * 16) = rw2[sl];
+            }
         }
     };
-    const bool wave_live = n0 + wn * 64 < n_rows;  // P / Q passes: a wave whose 64 columns do not exist only helps staging
+    auto compute = [&](int k_left) __attribute__((always_inline)) {
+        const int h = lane >> 5, rl = lane & 31;
+#pragma unroll
+        for (int t = 0; t < SUBT; ++t) {
+            if (t * 32 >= k_left) break;
+            Frag<bf16> fw[SN], fa;
+#pragma unroll
+            for (int sn = 0; sn < SN; ++sn) {
+                const unsigned char* pw = sW + (wn * (32 * SN) + sn * 32 + rl) * LDSB + t * 64;
+                fw[sn].v[0] = *reinterpret_cast<const u32x4*>(pw + h * 16);
+                fw[sn].v[1] = *reinterpret_cast<const u32x4*>(pw + (2 + h) * 16);
+            }
+            const unsigned char* pa = sA + (wm * 32 + rl) * LDSB + t * 64;
+            fa.v[0] = *reinterpret_cast<const u32x4*>(pa + h * 16);
+            fa.v[1] = *reinterpret_cast<const u32x4*>(pa + (2 + h) * 16);
+#pragma unroll
+            for (int sn = 0; sn < SN; ++sn) mtl_mma(fw[sn], fa, acc[sn]);
+        }
+    };
+    const bool wave_live = n0 + wn * (32 * SN) < n_rows;  // P / Q passes: a wave whose columns do not exist only helps staging
     if (total > 0 && !(dbg & 2)) issue(0);
     for (int i = 0; i < total; ++i) {
         const bool lr = i < n1;
@@ -884,46 +916,64 @@ __global__ __launch_bounds__(512, 4) void k_ntl(const NlParams P) {
         if (!(dbg & 64)) stage();
         __syncthreads();
         if (i + 1 < total && !(dbg & 2)) issue(i + 1);
-        if (wave_live && !(dbg & 4)) nt_compute<bf16, 1>(acc, sW, sA, lane, wn, wm, k_left);
+        if (wave_live && !(dbg & 4)) compute(k_left);
+        if constexpr (MLR) {
+            if (i + 1 == n1 && wave_live && drop.thr16 != 0) {  // the rank part is complete: acc *= keep(m, n)
+                const uint32_t rh = mtl_dropout_rowhash(drop, 0u, (uint32_t)(m0 + wm * 32 + (lane & 31)));
+#pragma unroll
+                for (int sn = 0; sn < SN; ++sn)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int n = n0 + wn * (32 * SN) + sn * 32 + 8 * q + 4 * (lane >> 5);
+                        const uint32_t h0 = mtl_dropout_pairbits(drop, rh, (uint32_t)n);
+                        const uint32_t h1 = mtl_dropout_pairbits(drop, rh, (uint32_t)(n + 2));
+                        if ((h0 & 0xFFFFu) < drop.thr16) acc[sn][q * 4 + 0] = 0.f;
+                        if ((h0 >> 16) < drop.thr16) acc[sn][q * 4 + 1] = 0.f;
+                        if ((h1 & 0xFFFFu) < drop.thr16) acc[sn][q * 4 + 2] = 0.f;
+                        if ((h1 >> 16) < drop.thr16) acc[sn][q * 4 + 3] = 0.f;
+                    }
+            }
+        }
         __syncthreads();
     }
     if (!wave_live || (dbg & 8)) return;
 
     if (!bias_first && (P.alpha || P.bias) && P.use_base) {  // acc = acc * alpha[n] + bias[n]
 #pragma unroll
-        for (int sn = 0; sn < 2; ++sn)
+        for (int sn = 0; sn < SN; ++sn)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                int n = n0 + wn * 64 + sn * 32 + 8 * q + 4 * (lane >> 5);
+                int n = n0 + wn * (32 * SN) + sn * 32 + 8 * q + 4 * (lane >> 5);
                 n = n < n_rows - 4 ? n : n_rows - 4;
                 f32x4 al = {1.f, 1.f, 1.f, 1.f}, bi = {0.f, 0.f, 0.f, 0.f};
                 if (P.alpha) al = *reinterpret_cast<const f32x4*>(P.alpha + n);
                 if (P.bias) bi = *reinterpret_cast<const f32x4*>(P.bias + n);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) acc[sn][0][q * 4 + e] = acc[sn][0][q * 4 + e] * al[e] + bi[e];
+                for (int e = 0; e < 4; ++e) acc[sn][q * 4 + e] = acc[sn][q * 4 + e] * al[e] + bi[e];
             }
     }
 
-    // epilogue (k_nt's): transpose the wave's 64 (n) x 32 (m) tile through a private LDS image -> 128-byte row-segment stores
+    // epilogue: transpose the wave's (32 SN) (n) x 32 (m) tile through a private LDS image -> whole row-segment stores
     {
-        constexpr int ORS = EPI_ROW;
+        constexpr int ORS = 64 * SN + 8;       // image row stride (bytes)
+        constexpr int CPRW = 4 * SN;           // 16-byte chunks per image row
         unsigned char* img = smem + wave * (32 * ORS);
 #pragma unroll
-        for (int sn = 0; sn < 2; ++sn)
+        for (int sn = 0; sn < SN; ++sn)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int ml = lane & 31, nl = sn * 32 + 8 * q + 4 * (lane >> 5);
-                u32x2 pk = {mtl_pack_bf16(acc[sn][0][q * 4], acc[sn][0][q * 4 + 1]),
-                            mtl_pack_bf16(acc[sn][0][q * 4 + 2], acc[sn][0][q * 4 + 3])};
+                u32x2 pk = {mtl_pack_bf16(acc[sn][q * 4], acc[sn][q * 4 + 1]), mtl_pack_bf16(acc[sn][q * 4 + 2], acc[sn][q * 4 + 3])};
                 *reinterpret_cast<u32x2*>(img + ml * ORS + nl * 2) = pk;
             }
         __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the image is private to this wave
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int ml = it * 8 + (lane >> 3), c16 = lane & 7;
+        for (int it = 0; it < 2 * SN; ++it) {
+            const int idx = it * 64 + lane;
+            const int ml = idx / CPRW, c16 = idx - ml * CPRW;
             const int m = m0 + wm * 32 + ml;
-            const int n = n0 + wn * 64 + c16 * 8;
+            const int n = n0 + wn * (32 * SN) + c16 * 8;
             u32x4 v = *reinterpret_cast<const u32x4*>(img + ml * ORS + c16 * 16);
             if (m < M && n < n_rows && !(dbg & 1)) {
                 const int64_t o = (int64_t)m * P.ld_out + n;
@@ -1250,6 +1300,8 @@ static int check_desc(const mtlora_linear_desc* d) {
 
 static bool misaligned(const void* p) { return ((uintptr_t)p & 15u) != 0; }
 
+static int sp_num_cu();
+
 template <typename T>
 static void launch_nt(const NtParams& P_in, hipStream_t s, int kind, double alg_bytes, double s8d_bytes = 0.0, double flops = 0.0) {
     NtParams P = P_in;
@@ -1284,9 +1336,9 @@ static void launch_nt(const NtParams& P_in, hipStream_t s, int kind, double alg_
     }
     mlr = mlr && P.drop.enabled();
     if constexpr (std::is_same<T, bf16>::value) {
-        // lean single-output bf16 launches: the straight-line kernel
-        const bool ml0 = P.n_out == 1 && P.out[0].mask_lr != 0 && P.drop.enabled();
-        if (variant == 2 && P.n_out == 1 && !ml0 && P.out[0].gate == nullptr && P.nz == 0 && P.M < (int64_t)0x7FFFFF00 &&
+        // lean single-output bf16 launches (forward outputs, P / Q passes, rank-0 GEMMs, and the dX of layers without task
+        // outputs -- masked rank part): the straight-line kernel
+        if (variant == 2 && P.n_out == 1 && P.out[0].gate == nullptr && P.nz == 0 && P.M < (int64_t)0x7FFFFF00 &&
             m_tiles * n_tiles < ((int64_t)1 << 28) && P.n_rows >= 8 && P.n_rows % 8 == 0) {
             NlParams q;
             q.act = reinterpret_cast<const bf16*>(P.act[0]);
@@ -1307,9 +1359,16 @@ static void launch_nt(const NtParams& P_in, hipStream_t s, int kind, double alg_
             q.K = P.act[0] ? P.K : 0;
             q.seg_lo = P.L ? P.out[0].seg_lo : 0;
             q.seg_hi = P.L ? P.out[0].seg_hi : 0;
-            q.n_tiles = (int)n_tiles;
-            q.nt_magic = (uint32_t)(((uint64_t)1 << 32) / (uint64_t)n_tiles) + 1u;
-            const uint32_t nwg = (uint32_t)(m_tiles * n_tiles);
+            // tile width: 128 columns, or 192 when that saves residency rounds (512 workgroup slots at 128 columns, 2 per CU either way;
+            // a 192-wide tile is 1.5x the work)
+            const int64_t t128 = m_tiles * mtl_ceil_div(P.n_rows, 128), t192 = m_tiles * mtl_ceil_div(P.n_rows, 192);
+            const int64_t slots = 2 * (int64_t)sp_num_cu();
+            const double c128 = (double)mtl_ceil_div(t128, slots), c192 = 1.5 * (double)mtl_ceil_div(t192, slots);
+            const bool wide = !q.act2 && P.n_rows >= 192 && c192 < c128 - 0.01;
+            const int64_t nt = wide ? mtl_ceil_div(P.n_rows, 192) : n_tiles;
+            q.n_tiles = (int)nt;
+            q.nt_magic = (uint32_t)(((uint64_t)1 << 32) / (uint64_t)nt) + 1u;
+            const uint32_t nwg = (uint32_t)(m_tiles * nt);
             q.q8 = nwg / 8u;
             q.r8 = nwg % 8u;
             q.act_mask = P.act_mask;
@@ -1318,10 +1377,28 @@ static void launch_nt(const NtParams& P_in, hipStream_t s, int kind, double alg_
             q.pad_ = 0;
             q.drop = P.drop;
             if (q.out == nullptr) return;
+            const bool ml0 = P.out[0].mask_lr != 0 && P.drop.enabled() && q.seg_hi > q.seg_lo;
+            constexpr size_t LDS192 = (size_t)(192 + 128) * LDSB;
+#define MTL_NTL_GO(AC, ML, SNV, LDSV)                                                                                     \
+    do {                                                                                                                  \
+        static bool raised = false;                                                                                       \
+        if ((LDSV) > 64 * 1024 && !raised) {                                                                              \
+            (void)hipFuncSetAttribute((const void*)k_ntl<AC, ML, SNV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512); \
+            raised = true;                                                                                                \
+        }                                                                                                                 \
+        hipLaunchKernelGGL((k_ntl<AC, ML, SNV>), dim3(nwg), dim3(512), (size_t)(LDSV), s, q);                             \
+    } while (0)
             if (q.act2)
-                hipLaunchKernelGGL((k_ntl<true>), dim3(nwg), dim3(512), (size_t)STAGE_BYTES, s, q);
+                MTL_NTL_GO(true, false, 2, STAGE_BYTES);
+            else if (wide && ml0)
+                MTL_NTL_GO(false, true, 3, LDS192);
+            else if (wide)
+                MTL_NTL_GO(false, false, 3, LDS192);
+            else if (ml0)
+                MTL_NTL_GO(false, true, 2, STAGE_BYTES);
             else
-                hipLaunchKernelGGL((k_ntl<false>), dim3(nwg), dim3(512), (size_t)STAGE_BYTES, s, q);
+                MTL_NTL_GO(false, false, 2, STAGE_BYTES);
+#undef MTL_NTL_GO
             return;
         }
     }

@@ -9,7 +9,7 @@ export MTLORA_TASK_STREAMS=${MTLORA_TASK_STREAMS:-0}
 export MTLORA_FACTOR_STREAM=${MTLORA_FACTOR_STREAM:-0}
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/pm
-timeout 900 rocprofv3 --pmc $CTRS --kernel-trace --output-format csv -d /tmp/pm -- ${PMC_CMD:-python $REPO/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-eager-gpu --no-roofline} > /tmp/pm.log 2>&1 || { tail -5 /tmp/pm.log; exit 1; }
+timeout 900 rocprofv3 --pmc $CTRS --kernel-trace --output-format csv -d /tmp/pm -- ${PMC_CMD:-python $REPO/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-eager-gpu --no-roofline --no-other-configs $BENCH_ARGS} > /tmp/pm.log 2>&1 || { tail -5 /tmp/pm.log; exit 1; }
 F=$(find /tmp/pm -name '*counter_collection.csv' | head -1)
 mkdir -p $REPO/gpurun_out
 python - "$F" "$REPO/gpurun_out/pmc_${TAG}.csv" <<'PY'

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""profiles/r02_pmc_traffic.json from the two PMC passes of tools/pmc.sh (FETCH_SIZE and WRITE_SIZE, KB, summed per kernel):
-    python tools/pmc_traffic.py gpurun_out/pmc_fetch.csv gpurun_out/pmc_write.csv [steps=2] > profiles/r02_pmc_traffic.json
+"""profiles/rNN_pmc_traffic[_cfg].json from the two PMC passes of tools/pmc.sh (FETCH_SIZE and WRITE_SIZE, KB, summed per kernel):
+    python tools/pmc_traffic.py gpurun_out/pmc_fetch.csv gpurun_out/pmc_write.csv [steps=2] [fetch.csv write.csv names to cite] > profiles/...json
+"k_nt" = every MTLoRALinear GEMM launch: the tiled kernels (k_nt / k_ntl) AND the wave-streaming ones (k_sp_*).
 FETCH_SIZE is doubled (gfx950 note in MI355X_MICROARCH.md, HBM section: wide coalesced reads are tallied at half their bytes)."""
 import csv, json, sys
 
@@ -21,9 +22,11 @@ def main():
     res = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) over `python bench.py "
                      "--steps 1 --warmup 1 --no-cpu-baseline --no-roofline` (tools/pmc.sh, tools/pmc_traffic.py); FETCH_SIZE (KB) "
                      "doubled per the gfx950 note of MI355X_MICROARCH.md (HBM section); WRITE_SIZE (KB) as reported",
-           "files": ["profiles/r02_pmc_fetch.csv", "profiles/r02_pmc_write.csv"]}
+           "files": sys.argv[4:6] if len(sys.argv) > 5 else ["profiles/r03_pmc_fetch.csv", "profiles/r03_pmc_write.csv"]}
     for g, key in GROUPS.items():
         def match(n):
+            if g == "k_nt":
+                return "k_nt" in n or "k_sp_" in n
             return key in n and not (g == "k_tn" and "k_tn_reduce" in n)
         d = sum(v[0] for n, v in fetch.items() if match(n))
         if d == 0:

@@ -1465,7 +1465,7 @@ static int sp_proj_plan(SpProjParams& q, int& ch) {
     const int64_t wbytes = (int64_t)q.n_blk_total * 32 * q.K * 2;
     const int64_t slot = 32 * ch * 2;
     for (int ns = 3; ns >= 1; --ns)
-        if (wbytes + (int64_t)SP_WAVES * ns * slot <= SP_LDS_MAX - 1024) return ns;
+        if (wbytes + (int64_t)SP_WAVES * ns * slot <= SP_LDS_MAX) return ns;
     return 0;
 }
 template <typename T>
@@ -1568,7 +1568,7 @@ static bool sp_xres_plan(SpLinParams& q, int K, SpXresPlan& pl) {
             const int bpp = (nb_all + np - 1) / np;
             if ((bpp * (np - 1)) >= nb_all) continue;  // an empty last part
             const int64_t need = fixed + (int64_t)bpp * (32 * K * 2 + 64 * pl.nrb * 32 * 2 / 2 + 128);
-            if (need <= SP_LDS_MAX - 512) {
+            if (need <= SP_LDS_MAX) {
                 bpp_out = bpp;
                 lds_out = (size_t)need;
                 return np;
@@ -1670,7 +1670,7 @@ static bool sp_ares_plan(SpLinParams& q, int Kred, SpAresPlan& pl) {
     const int64_t kst = Kred / 16;
     const int64_t need = (int64_t)pl.nob * kst * 1024 + (int64_t)pl.nrb * kst * 1024 + (int64_t)pl.nob * 2 * pl.nrb * 1024 + pl.nob * 128 +
                          (int64_t)SP_WAVES * 32 * pl.ch * 2;
-    if (need > SP_LDS_MAX - 512) return false;
+    if (need > SP_LDS_MAX) return false;
     pl.lds = (size_t)need;
     q.n_parts = parts;
     q.blk_per_part = pl.nob;

@@ -29,9 +29,9 @@ extern "C" {
 typedef enum mtlora_dtype {
     MTLORA_F32 = 0,  /* exact-f32 MFMA path (v_mfma_f32_32x32x2_f32) */
     MTLORA_BF16 = 1, /* bf16 in/out, fp32 accumulate (v_mfma_f32_32x32x16_bf16) */
-    MTLORA_F16 = 2   /* fp16 in/out, fp32 accumulate (v_mfma_f32_32x32x16_f16): MTLoRALinear, window attention, gemm_tn and the
-                        window_process copies -- the reference's default autocast dtype (main.py:341); the block-glue entries
-                        (LayerNorm, residuals, BatchNorm, upsample, loss) take fp32 / bf16 only */
+    MTLORA_F16 = 2   /* fp16 in/out, fp32 accumulate (v_mfma_f32_32x32x16_f16): MTLoRALinear, window attention, gemm_tn, the
+                        window_process copies and the block glue (LayerNorm family, residual + DropPath, BatchNorm + ReLU) -- the
+                        reference's default autocast dtype (main.py:341); upsample / loss / column-sum entries take fp32 / bf16 */
 } mtlora_dtype;
 
 typedef enum mtlora_status {

@@ -158,11 +158,12 @@ def check(status: int, what: str) -> None:
         raise RuntimeError(f"mtlora_amd: {what} failed: {msg} (status {status})")
 
 
-def dtype_code(t: torch.Tensor, allow_f16: bool = False) -> int:
+def dtype_code(t: torch.Tensor, allow_f16: bool = True) -> int:
+    """MTLORA_F32 / BF16 / F16 code of a tensor (the entry points that take no fp16 -- upsample, losses, column sums -- return
+    MTLORA_ERR_DTYPE for it; their callers route fp16 tensors around them)."""
     code = _DT.get(t.dtype)
     if code is None or (code == F16 and not allow_f16):
-        raise RuntimeError(f"mtlora_amd: unsupported dtype {t.dtype} (fp32 and bf16 are supported"
-                           + (", fp16 for window_process" if allow_f16 else "") + ")")
+        raise RuntimeError(f"mtlora_amd: unsupported dtype {t.dtype} (fp32, bf16 and fp16 are supported)")
     return code
 
 

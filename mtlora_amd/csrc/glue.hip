@@ -30,6 +30,12 @@ __device__ __forceinline__ void ld_vec<bf16>(const bf16* p, float (&f)[8]) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) f[e] = (float)v.e[e];
 }
+template <>
+__device__ __forceinline__ void ld_vec<f16>(const f16* p, float (&f)[8]) {
+    Vec16<f16> v = mtl_ld16<f16>(p);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f[e] = (float)v.e[e];
+}
 // store NE consecutive elements
 template <typename T, int NE>
 __device__ __forceinline__ void st_vec(T* p, const float* f) {
@@ -37,13 +43,12 @@ __device__ __forceinline__ void st_vec(T* p, const float* f) {
 #pragma unroll
         for (int e = 0; e < NE; e += 4) *reinterpret_cast<f32x4*>(p + e) = f32x4{f[e], f[e + 1], f[e + 2], f[e + 3]};
     } else if constexpr (NE == 8) {
-        Vec16<bf16> v;
+        Vec16<T> v;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v.e[e] = (bf16)f[e];
+        for (int e = 0; e < 8; ++e) v.e[e] = (T)f[e];
         *reinterpret_cast<u32x4*>(p) = v.raw;
     } else {
-        bf16x4 v = {(bf16)f[0], (bf16)f[1], (bf16)f[2], (bf16)f[3]};
-        *reinterpret_cast<bf16x4*>(p) = v;
+        *reinterpret_cast<u32x2*>(p) = u32x2{mtl_pack2<T>(f[0], f[1]), mtl_pack2<T>(f[2], f[3])};
     }
 }
 
@@ -153,6 +158,14 @@ __device__ __forceinline__ void cvt_vec<bf16>(const u32x4& r, float (&f)[8]) {
         f[2 * q + 1] = __builtin_bit_cast(float, r[q] & 0xFFFF0000u);
     }
 }
+template <>
+__device__ __forceinline__ void cvt_vec<f16>(const u32x4& r, float (&f)[8]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        f[2 * q] = mtl_lo2<f16>(r[q]);
+        f[2 * q + 1] = mtl_hi2<f16>(r[q]);
+    }
+}
 
 // UNR row groups per wave iteration: their loads are issued back to back and kept as raw 16-byte vectors (a wave with a
 // single 1.5 KB row group in flight per iteration ran at 1.5-2.8 TB/s for the stage-1..3 shapes)
@@ -169,13 +182,13 @@ __device__ __forceinline__ void ld_n(const T* p, float (&f)[8]) {
             f[e + 3] = v[3];
         }
     } else if constexpr (NE == 8) {
-        cvt_vec<bf16>(*reinterpret_cast<const u32x4*>(p), f);
+        cvt_vec<T>(*reinterpret_cast<const u32x4*>(p), f);
     } else {
         const u32x2 r = *reinterpret_cast<const u32x2*>(p);
-        f[0] = __builtin_bit_cast(float, r[0] << 16);
-        f[1] = __builtin_bit_cast(float, r[0] & 0xFFFF0000u);
-        f[2] = __builtin_bit_cast(float, r[1] << 16);
-        f[3] = __builtin_bit_cast(float, r[1] & 0xFFFF0000u);
+        f[0] = mtl_lo2<T>(r[0]);
+        f[1] = mtl_hi2<T>(r[0]);
+        f[2] = mtl_lo2<T>(r[1]);
+        f[3] = mtl_hi2<T>(r[1]);
     }
 }
 // floats -> one raw 16-byte vector of T (4 fp32 or 8 bf16)
@@ -184,9 +197,9 @@ __device__ __forceinline__ u32x4 pack_vec(const float (&f)[8]) {
     if constexpr (sizeof(T) == 4) {
         return __builtin_bit_cast(u32x4, f32x4{f[0], f[1], f[2], f[3]});
     } else {
-        Vec16<bf16> v;
+        Vec16<T> v;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v.e[e] = (bf16)f[e];
+        for (int e = 0; e < 8; ++e) v.e[e] = (T)f[e];
         return v.raw;
     }
 }
@@ -312,12 +325,12 @@ __global__ __launch_bounds__(256) void k_ln_fwd(const LnParams p) {
                             fb[2] = q4[2];
                             fb[3] = q4[3];
                         } else if constexpr (VE == 8) {
-                            cvt_vec<bf16>(braw[u][i], fb);
+                            cvt_vec<TO>(braw[u][i], fb);
                         } else {
-                            fb[0] = __builtin_bit_cast(float, braw[u][i][0] << 16);
-                            fb[1] = __builtin_bit_cast(float, braw[u][i][0] & 0xFFFF0000u);
-                            fb[2] = __builtin_bit_cast(float, braw[u][i][1] << 16);
-                            fb[3] = __builtin_bit_cast(float, braw[u][i][1] & 0xFFFF0000u);
+                            fb[0] = mtl_lo2<TO>(braw[u][i][0]);
+                            fb[1] = mtl_hi2<TO>(braw[u][i][0]);
+                            fb[2] = mtl_lo2<TO>(braw[u][i][1]);
+                            fb[3] = mtl_hi2<TO>(braw[u][i][1]);
                         }
                         cvt_vec<TI>(raw[u][i], fx);
 #pragma unroll
@@ -475,10 +488,10 @@ __global__ __launch_bounds__(256) void k_ln_bwd(const LnParams p) {
                 if constexpr (GW == 4) {
                     cvt_vec<TG>(u32x4{rg[u][i][0], rg[u][i][1], rg[u][i][2], rg[u][i][3]}, fg);
                 } else if constexpr (GW == 2) {  // x fp32 (4 per vector), dy bf16
-                    fg[0] = __builtin_bit_cast(float, rg[u][i][0] << 16);
-                    fg[1] = __builtin_bit_cast(float, rg[u][i][0] & 0xFFFF0000u);
-                    fg[2] = __builtin_bit_cast(float, rg[u][i][1] << 16);
-                    fg[3] = __builtin_bit_cast(float, rg[u][i][1] & 0xFFFF0000u);
+                    fg[0] = mtl_lo2<TG>(rg[u][i][0]);
+                    fg[1] = mtl_hi2<TG>(rg[u][i][0]);
+                    fg[2] = mtl_lo2<TG>(rg[u][i][1]);
+                    fg[3] = mtl_hi2<TG>(rg[u][i][1]);
                 } else {  // x bf16 (8 per vector), dy fp32
 #pragma unroll
                     for (int q = 0; q < 8; ++q) fg[q] = __builtin_bit_cast(float, rg[u][i][q]);
@@ -629,10 +642,10 @@ __global__ __launch_bounds__(256) void k_resln_bwd_multi(const LnParams p) {
                 if constexpr (GW == 4) {
                     cvt_vec<TG>(u32x4{R.rg[i][0], R.rg[i][1], R.rg[i][2], R.rg[i][3]}, fg);
                 } else if constexpr (GW == 2) {
-                    fg[0] = __builtin_bit_cast(float, R.rg[i][0] << 16);
-                    fg[1] = __builtin_bit_cast(float, R.rg[i][0] & 0xFFFF0000u);
-                    fg[2] = __builtin_bit_cast(float, R.rg[i][1] << 16);
-                    fg[3] = __builtin_bit_cast(float, R.rg[i][1] & 0xFFFF0000u);
+                    fg[0] = mtl_lo2<TG>(R.rg[i][0]);
+                    fg[1] = mtl_hi2<TG>(R.rg[i][0]);
+                    fg[2] = mtl_lo2<TG>(R.rg[i][1]);
+                    fg[3] = mtl_hi2<TG>(R.rg[i][1]);
                 } else {
 #pragma unroll
                     for (int q = 0; q < 8; ++q) fg[q] = __builtin_bit_cast(float, R.rg[i][q]);
@@ -774,7 +787,8 @@ int ln_merge(LnParams& p, int64_t M, int64_t C, int xdt, int mh, int mw) {
 }
 
 int ln_check(int64_t M, int64_t C, int xdt, int ydt) {
-    if ((xdt != MTLORA_F32 && xdt != MTLORA_BF16) || (ydt != MTLORA_F32 && ydt != MTLORA_BF16)) return MTLORA_ERR_DTYPE;
+    if (xdt < MTLORA_F32 || xdt > MTLORA_F16 || ydt < MTLORA_F32 || ydt > MTLORA_F16) return MTLORA_ERR_DTYPE;
+    if (xdt != MTLORA_F32 && ydt != MTLORA_F32 && xdt != ydt) return MTLORA_ERR_DTYPE;  // (bf16 <-> fp16 mixes: none)
     const int ve = xdt == MTLORA_F32 ? 4 : 8;
     if (M < 0 || C <= 0 || C % ve) return MTLORA_ERR_SHAPE;
     if (mtl_ceil_div(C / ve, 64) > LN_MAXV) return MTLORA_ERR_UNSUPPORTED;
@@ -844,6 +858,14 @@ static int ln_fwd_impl(const void* x, const float* gamma, const float* beta, voi
 #define LN_EXTRA , true
         if (x_dtype == MTLORA_F32 && y_dtype == MTLORA_F32) {
             LN_DISPATCH_LPR(k_ln_fwd, float, float)
+        } else if (x_dtype == MTLORA_F16 || y_dtype == MTLORA_F16) {  // fp16 autocast (the reference's default, main.py:341)
+            if (x_dtype == MTLORA_F32) {
+                LN_DISPATCH_LPR(k_ln_fwd, float, f16)
+            } else if (y_dtype == MTLORA_F32) {
+                LN_DISPATCH_LPR(k_ln_fwd, f16, float)
+            } else {
+                LN_DISPATCH_LPR(k_ln_fwd, f16, f16)
+            }
         } else if (x_dtype == MTLORA_F32) {
             LN_DISPATCH_LPR(k_ln_fwd, float, bf16)
         } else if (y_dtype == MTLORA_F32) {
@@ -856,6 +878,14 @@ static int ln_fwd_impl(const void* x, const float* gamma, const float* beta, voi
 #define LN_EXTRA , false
         if (x_dtype == MTLORA_F32 && y_dtype == MTLORA_F32) {
             LN_DISPATCH_LPR(k_ln_fwd, float, float)
+        } else if (x_dtype == MTLORA_F16 || y_dtype == MTLORA_F16) {  // fp16 autocast (the reference's default, main.py:341)
+            if (x_dtype == MTLORA_F32) {
+                LN_DISPATCH_LPR(k_ln_fwd, float, f16)
+            } else if (y_dtype == MTLORA_F32) {
+                LN_DISPATCH_LPR(k_ln_fwd, f16, float)
+            } else {
+                LN_DISPATCH_LPR(k_ln_fwd, f16, f16)
+            }
         } else if (x_dtype == MTLORA_F32) {
             LN_DISPATCH_LPR(k_ln_fwd, float, bf16)
         } else if (y_dtype == MTLORA_F32) {
@@ -927,6 +957,14 @@ static int ln_bwd_impl(const void* dy, const void* x, const float* gamma, const 
 #define LN_EXTRA
         if (x_dtype == MTLORA_F32 && dy_dtype == MTLORA_F32) {
             LN_DISPATCH_LPR(k_ln_bwd, float, float)
+        } else if (x_dtype == MTLORA_F16 || dy_dtype == MTLORA_F16) {  // fp16 autocast (the reference's default, main.py:341)
+            if (x_dtype == MTLORA_F32) {
+                LN_DISPATCH_LPR(k_ln_bwd, float, f16)
+            } else if (dy_dtype == MTLORA_F32) {
+                LN_DISPATCH_LPR(k_ln_bwd, f16, float)
+            } else {
+                LN_DISPATCH_LPR(k_ln_bwd, f16, f16)
+            }
         } else if (x_dtype == MTLORA_F32) {
             LN_DISPATCH_LPR(k_ln_bwd, float, bf16)
         } else if (dy_dtype == MTLORA_F32) {
@@ -1025,6 +1063,14 @@ static int ln_multi_fwd_impl(int n, const void* const* x, const float* gamma, co
 #define LN_EXTRA , true
         if (x_dtype == MTLORA_F32 && y_dtype == MTLORA_F32) {
             LN_DISPATCH_LPR(k_ln_fwd, float, float)
+        } else if (x_dtype == MTLORA_F16 || y_dtype == MTLORA_F16) {  // fp16 autocast (the reference's default, main.py:341)
+            if (x_dtype == MTLORA_F32) {
+                LN_DISPATCH_LPR(k_ln_fwd, float, f16)
+            } else if (y_dtype == MTLORA_F32) {
+                LN_DISPATCH_LPR(k_ln_fwd, f16, float)
+            } else {
+                LN_DISPATCH_LPR(k_ln_fwd, f16, f16)
+            }
         } else if (x_dtype == MTLORA_F32) {
             LN_DISPATCH_LPR(k_ln_fwd, float, bf16)
         } else if (y_dtype == MTLORA_F32) {
@@ -1037,6 +1083,14 @@ static int ln_multi_fwd_impl(int n, const void* const* x, const float* gamma, co
 #define LN_EXTRA , false
         if (x_dtype == MTLORA_F32 && y_dtype == MTLORA_F32) {
             LN_DISPATCH_LPR(k_ln_fwd, float, float)
+        } else if (x_dtype == MTLORA_F16 || y_dtype == MTLORA_F16) {  // fp16 autocast (the reference's default, main.py:341)
+            if (x_dtype == MTLORA_F32) {
+                LN_DISPATCH_LPR(k_ln_fwd, float, f16)
+            } else if (y_dtype == MTLORA_F32) {
+                LN_DISPATCH_LPR(k_ln_fwd, f16, float)
+            } else {
+                LN_DISPATCH_LPR(k_ln_fwd, f16, f16)
+            }
         } else if (x_dtype == MTLORA_F32) {
             LN_DISPATCH_LPR(k_ln_fwd, float, bf16)
         } else if (y_dtype == MTLORA_F32) {
@@ -1128,6 +1182,14 @@ static int ln_multi_bwd_impl(int n, const void* const* dy, const void* const* x,
 #define LN_EXTRA
         if (x_dtype == MTLORA_F32 && dy_dtype == MTLORA_F32) {
             LN_DISPATCH_LPR(k_ln_bwd, float, float)
+        } else if (x_dtype == MTLORA_F16 || dy_dtype == MTLORA_F16) {  // fp16 autocast (the reference's default, main.py:341)
+            if (x_dtype == MTLORA_F32) {
+                LN_DISPATCH_LPR(k_ln_bwd, float, f16)
+            } else if (dy_dtype == MTLORA_F32) {
+                LN_DISPATCH_LPR(k_ln_bwd, f16, float)
+            } else {
+                LN_DISPATCH_LPR(k_ln_bwd, f16, f16)
+            }
         } else if (x_dtype == MTLORA_F32) {
             LN_DISPATCH_LPR(k_ln_bwd, float, bf16)
         } else if (dy_dtype == MTLORA_F32) {
@@ -1214,6 +1276,14 @@ int mtlora_residual_layernorm_multi_fwd(int n, const void* shortcut, const void*
 #define LN_EXTRA , true
     if (x_dtype == MTLORA_F32 && y_dtype == MTLORA_F32) {
         LN_DISPATCH_LPR(k_ln_fwd, float, float)
+    } else if (x_dtype == MTLORA_F16 || y_dtype == MTLORA_F16) {  // fp16 autocast (the reference's default, main.py:341)
+        if (x_dtype == MTLORA_F32) {
+            LN_DISPATCH_LPR(k_ln_fwd, float, f16)
+        } else if (y_dtype == MTLORA_F32) {
+            LN_DISPATCH_LPR(k_ln_fwd, f16, float)
+        } else {
+            LN_DISPATCH_LPR(k_ln_fwd, f16, f16)
+        }
     } else if (x_dtype == MTLORA_F32) {
         LN_DISPATCH_LPR(k_ln_fwd, float, bf16)
     } else if (y_dtype == MTLORA_F32) {
@@ -1278,6 +1348,14 @@ int mtlora_residual_layernorm_multi_bwd(int n, const void* const* dy, const void
 #define LN_EXTRA
         if (x_dtype == MTLORA_F32 && dy_dtype == MTLORA_F32) {
             LN_DISPATCH_LPR(k_resln_bwd_multi, float, float)
+        } else if (x_dtype == MTLORA_F16 || dy_dtype == MTLORA_F16) {  // fp16 autocast (the reference's default, main.py:341)
+            if (x_dtype == MTLORA_F32) {
+                LN_DISPATCH_LPR(k_resln_bwd_multi, float, f16)
+            } else if (dy_dtype == MTLORA_F32) {
+                LN_DISPATCH_LPR(k_resln_bwd_multi, f16, float)
+            } else {
+                LN_DISPATCH_LPR(k_resln_bwd_multi, f16, f16)
+            }
         } else if (x_dtype == MTLORA_F32) {
             LN_DISPATCH_LPR(k_resln_bwd_multi, float, bf16)
         } else if (dy_dtype == MTLORA_F32) {
@@ -1557,7 +1635,7 @@ __global__ __launch_bounds__(512) void k_bn_apply(const BnParams p) {
 }
 
 int bn_setup(BnParams& p, int64_t R, int64_t C, int dtype) {
-    if (dtype != MTLORA_F32 && dtype != MTLORA_BF16) return MTLORA_ERR_DTYPE;
+    if (dtype != MTLORA_F32 && dtype != MTLORA_BF16 && dtype != MTLORA_F16) return MTLORA_ERR_DTYPE;
     const int ve = dtype == MTLORA_F32 ? 4 : 8;
     if (R <= 0 || C <= 0 || C % ve) return MTLORA_ERR_SHAPE;
     p.R = R;
@@ -1617,6 +1695,8 @@ int mtlora_bn_relu_fwd(const void* x, const float* gamma, const float* beta, flo
         MtlProfScope prof(PK_BN, (double)R * C * es, s);
         if (dtype == MTLORA_F32)
             hipLaunchKernelGGL((k_bn_colsum<float, false>), dim3(p.nblk), dim3(threads), lds, s, p);
+        else if (dtype == MTLORA_F16)
+            hipLaunchKernelGGL((k_bn_colsum<f16, false>), dim3(p.nblk), dim3(threads), lds, s, p);
         else
             hipLaunchKernelGGL((k_bn_colsum<bf16, false>), dim3(p.nblk), dim3(threads), lds, s, p);
     }
@@ -1625,6 +1705,8 @@ int mtlora_bn_relu_fwd(const void* x, const float* gamma, const float* beta, flo
         MtlProfScope prof(PK_BN, (double)R * C * es * 2, s);
         if (dtype == MTLORA_F32)
             hipLaunchKernelGGL((k_bn_apply<float, false>), dim3(apply_blocks), dim3(threads), 0, s, p);
+        else if (dtype == MTLORA_F16)
+            hipLaunchKernelGGL((k_bn_apply<f16, false>), dim3(apply_blocks), dim3(threads), 0, s, p);
         else
             hipLaunchKernelGGL((k_bn_apply<bf16, false>), dim3(apply_blocks), dim3(threads), 0, s, p);
     }
@@ -1664,6 +1746,8 @@ int mtlora_bn_relu_bwd(const void* dy, const void* x, const float* save_mean, co
         MtlProfScope prof(PK_BN, (double)R * C * es * 2, s);
         if (dtype == MTLORA_F32)
             hipLaunchKernelGGL((k_bn_colsum<float, true>), dim3(p.nblk), dim3(threads), lds, s, p);
+        else if (dtype == MTLORA_F16)
+            hipLaunchKernelGGL((k_bn_colsum<f16, true>), dim3(p.nblk), dim3(threads), lds, s, p);
         else
             hipLaunchKernelGGL((k_bn_colsum<bf16, true>), dim3(p.nblk), dim3(threads), lds, s, p);
     }
@@ -1672,6 +1756,8 @@ int mtlora_bn_relu_bwd(const void* dy, const void* x, const float* save_mean, co
         MtlProfScope prof(PK_BN, (double)R * C * es * 3, s);
         if (dtype == MTLORA_F32)
             hipLaunchKernelGGL((k_bn_apply<float, true>), dim3(apply_blocks), dim3(threads), 0, s, p);
+        else if (dtype == MTLORA_F16)
+            hipLaunchKernelGGL((k_bn_apply<f16, true>), dim3(apply_blocks), dim3(threads), 0, s, p);
         else
             hipLaunchKernelGGL((k_bn_apply<bf16, true>), dim3(apply_blocks), dim3(threads), 0, s, p);
     }
@@ -1773,7 +1859,8 @@ __global__ __launch_bounds__(256) void k_residual_bwd(const ResParams p) {
 }
 
 int res_check(int n, int64_t M, int64_t C, int64_t B, int rdt, int ydt) {
-    if ((rdt != MTLORA_F32 && rdt != MTLORA_BF16) || (ydt != MTLORA_F32 && ydt != MTLORA_BF16)) return MTLORA_ERR_DTYPE;
+    if (rdt < MTLORA_F32 || rdt > MTLORA_F16 || ydt < MTLORA_F32 || ydt > MTLORA_F16) return MTLORA_ERR_DTYPE;
+    if (rdt != MTLORA_F32 && ydt != MTLORA_F32 && rdt != ydt) return MTLORA_ERR_DTYPE;
     if (n < 1 || n > MTLORA_MAX_TASKS + 1 || M < 0 || C <= 0 || C % 8 || B <= 0 || M % B) return MTLORA_ERR_SHAPE;
     return MTLORA_OK;
 }
@@ -1811,7 +1898,14 @@ int mtlora_residual_droppath_fwd(int n, const void* const* res, const void* cons
     MtlProfScope prof(PK_RESIDUAL, (double)n * M * C * (2 * er + ey), s);
     if (res_dtype == MTLORA_F32 && y_dtype == MTLORA_F32)
         hipLaunchKernelGGL((k_residual_fwd<float, float>), g, dim3(256), 0, s, p);
-    else if (res_dtype == MTLORA_F32)
+    else if (res_dtype == MTLORA_F16 || y_dtype == MTLORA_F16) {
+        if (res_dtype == MTLORA_F32)
+            hipLaunchKernelGGL((k_residual_fwd<float, f16>), g, dim3(256), 0, s, p);
+        else if (y_dtype == MTLORA_F32)
+            hipLaunchKernelGGL((k_residual_fwd<f16, float>), g, dim3(256), 0, s, p);
+        else
+            hipLaunchKernelGGL((k_residual_fwd<f16, f16>), g, dim3(256), 0, s, p);
+    } else if (res_dtype == MTLORA_F32)
         hipLaunchKernelGGL((k_residual_fwd<float, bf16>), g, dim3(256), 0, s, p);
     else if (y_dtype == MTLORA_F32)
         hipLaunchKernelGGL((k_residual_fwd<bf16, float>), g, dim3(256), 0, s, p);
@@ -1848,7 +1942,14 @@ int mtlora_residual_droppath_bwd(int n, const void* const* g, void* const* dy, v
     MtlProfScope prof(PK_RESIDUAL, (double)M * C * (n * (er + ey) + (dres ? er : 0)), s);
     if (res_dtype == MTLORA_F32 && y_dtype == MTLORA_F32)
         hipLaunchKernelGGL((k_residual_bwd<float, float>), dim3((unsigned)blocks), dim3(256), 0, s, p);
-    else if (res_dtype == MTLORA_F32)
+    else if (res_dtype == MTLORA_F16 || y_dtype == MTLORA_F16) {
+        if (res_dtype == MTLORA_F32)
+            hipLaunchKernelGGL((k_residual_bwd<float, f16>), dim3((unsigned)blocks), dim3(256), 0, s, p);
+        else if (y_dtype == MTLORA_F32)
+            hipLaunchKernelGGL((k_residual_bwd<f16, float>), dim3((unsigned)blocks), dim3(256), 0, s, p);
+        else
+            hipLaunchKernelGGL((k_residual_bwd<f16, f16>), dim3((unsigned)blocks), dim3(256), 0, s, p);
+    } else if (res_dtype == MTLORA_F32)
         hipLaunchKernelGGL((k_residual_bwd<float, bf16>), dim3((unsigned)blocks), dim3(256), 0, s, p);
     else if (y_dtype == MTLORA_F32)
         hipLaunchKernelGGL((k_residual_bwd<bf16, float>), dim3((unsigned)blocks), dim3(256), 0, s, p);

@@ -144,6 +144,7 @@ def next_seed() -> int:
 
 
 _HOT_DTYPES = (torch.float32, torch.bfloat16, torch.float16)
+_GLUE_DTYPES = (torch.float32, torch.bfloat16, torch.float16)  # LayerNorm family, residual + DropPath, BatchNorm + ReLU kernels
 _DT_CODE = {torch.float32: L.F32, torch.bfloat16: L.BF16, torch.float16: L.F16}
 
 
@@ -163,10 +164,9 @@ def compute_dtype(x: torch.Tensor) -> torch.dtype:
 
 
 def glue_dtype(x: torch.Tensor) -> torch.dtype:
-    """output dtype of the fused glue kernels in front of an MTLoRALinear: the compute dtype, except fp16, which they do not
-    write -- the normalised activations then leave in fp32 (what ATen's autocast layer_norm returns) and the linear casts."""
-    dt = compute_dtype(x)
-    return torch.float32 if dt == torch.float16 else dt
+    """output dtype of the fused glue kernels in front of an MTLoRALinear: the compute dtype (fp32, or bf16 / fp16 under
+    autocast -- the LayerNorm-family, residual and BatchNorm kernels are instantiated for all three)."""
+    return compute_dtype(x)
 
 
 # ----------------------------------------------------------------------------------------------
@@ -558,7 +558,7 @@ def _ln_backward(ctx, dy, addend=None):
     M, C = ctx.MC
     mh, mw = ctx.merge
     dy2 = dy.reshape(M, C).contiguous()
-    if dy2.dtype not in (torch.float32, torch.bfloat16):
+    if dy2.dtype not in _GLUE_DTYPES:
         dy2 = dy2.float()
     add2 = None
     if addend is not None:
@@ -718,7 +718,7 @@ def residual_layer_norm_multi(mod: torch.nn.Module, shortcut: torch.Tensor, bran
     the fused multi-stream kernels when they apply, else residual_droppath + layer_norm_fork per stream."""
     C, n = shortcut.shape[-1], len(branches)
     ok = (type(mod) is torch.nn.LayerNorm and mod.elementwise_affine and mod.bias is not None
-          and len(mod.normalized_shape) == 1 and shortcut.is_cuda and shortcut.dtype in (torch.float32, torch.bfloat16)
+          and len(mod.normalized_shape) == 1 and shortcut.is_cuda and shortcut.dtype in _GLUE_DTYPES
           and C % 8 == 0 and C <= (1024 if shortcut.dtype == torch.float32 else 1536) and shortcut.dim() == 3
           and 1 <= n <= L.MAX_TASKS + 1 and all(b.shape == shortcut.shape for b in branches) and torch.is_grad_enabled()
           and (shortcut.requires_grad or any(b.requires_grad for b in branches)))
@@ -742,7 +742,7 @@ def residual_layer_norm(mod: torch.nn.Module, shortcut: torch.Tensor, branch: to
     the last dim, branch already in the dtype the LayerNorm output takes), else residual_droppath + layer_norm_fork."""
     C = shortcut.shape[-1]
     ok = (type(mod) is torch.nn.LayerNorm and mod.elementwise_affine and mod.bias is not None
-          and len(mod.normalized_shape) == 1 and shortcut.is_cuda and shortcut.dtype in (torch.float32, torch.bfloat16)
+          and len(mod.normalized_shape) == 1 and shortcut.is_cuda and shortcut.dtype in _GLUE_DTYPES
           and C % 8 == 0 and C <= (2048 if shortcut.dtype == torch.float32 else 4096) and branch.shape == shortcut.shape
           and shortcut.dim() == 3 and torch.is_grad_enabled() and (shortcut.requires_grad or branch.requires_grad))
     if ok:
@@ -772,7 +772,7 @@ def layer_norm_merge(mod: torch.nn.Module, x: torch.Tensor, H: int, W: int) -> t
     B, Lt, C = x.shape
     ve = 4 if x.dtype == torch.float32 else 8
     ok = (type(mod) is torch.nn.LayerNorm and mod.elementwise_affine and mod.bias is not None and x.is_cuda
-          and x.dtype in (torch.float32, torch.bfloat16) and C % ve == 0 and Lt == H * W and H % 2 == 0 and W % 2 == 0
+          and x.dtype in _GLUE_DTYPES and C % ve == 0 and Lt == H * W and H % 2 == 0 and W % 2 == 0
           and 4 * C <= (2048 if x.dtype == torch.float32 else 4096))
     if not ok:
         g = x.view(B, H // 2, 2, W // 2, 2, C).permute(0, 1, 3, 4, 2, 5).reshape(B, (H // 2) * (W // 2), 4 * C)
@@ -808,7 +808,7 @@ class LayerNormMergeMultiFn(torch.autograd.Function):
         w, stats, *x2 = ctx.saved_tensors
         n, M, C, H, W, shape = ctx.cfg
         g3 = g.reshape(n, M, C)
-        if g3.dtype not in (torch.float32, torch.bfloat16):
+        if g3.dtype not in _GLUE_DTYPES:
             g3 = g3.float()
         g3 = g3.contiguous()
         dev = x2[0].device
@@ -891,7 +891,7 @@ def residual_merge_norm_streams(mod: torch.nn.Module, res, branches, H: int, W: 
     ok = (type(mod) is torch.nn.LayerNorm and mod.elementwise_affine and mod.bias is not None and 2 <= n <= L.MAX_TASKS + 1
           and len(branches) == n and all(x.is_cuda and x.dtype == res[0].dtype and x.shape == res[0].shape for x in res)
           and all(x.shape == res[0].shape and x.dtype == branches[0].dtype for x in branches)
-          and res[0].dtype in (torch.float32, torch.bfloat16) and C % ve == 0 and Lt == H * W and H % 2 == 0 and W % 2 == 0
+          and res[0].dtype in _GLUE_DTYPES and C % ve == 0 and Lt == H * W and H % 2 == 0 and W % 2 == 0
           and 4 * C <= (2048 if res[0].dtype == torch.float32 else 4096) and torch.is_grad_enabled())
     if ok:
         out_dtype = glue_dtype(res[0])
@@ -911,7 +911,7 @@ def layer_norm_merge_multi(mod: torch.nn.Module, xs, H: int, W: int):
     ve = 4 if xs[0].dtype == torch.float32 else 8
     ok = (type(mod) is torch.nn.LayerNorm and mod.elementwise_affine and mod.bias is not None and 2 <= len(xs) <= L.MAX_TASKS + 1
           and all(x.is_cuda and x.dtype == xs[0].dtype and x.shape == xs[0].shape for x in xs)
-          and xs[0].dtype in (torch.float32, torch.bfloat16) and C % ve == 0 and Lt == H * W and H % 2 == 0 and W % 2 == 0
+          and xs[0].dtype in _GLUE_DTYPES and C % ve == 0 and Lt == H * W and H % 2 == 0 and W % 2 == 0
           and 4 * C <= (2048 if xs[0].dtype == torch.float32 else 4096))
     if not ok:
         return None
@@ -925,7 +925,7 @@ def layer_norm(mod: torch.nn.Module, x: torch.Tensor, feeds_linear: bool = True,
     output dtype is what the reference produces: fp32 under autocast (autocast runs layer_norm in fp32), else the
     input dtype.  Anything else (custom norm layers, no affine, exotic dtypes) goes to the module itself."""
     ok = (type(mod) is torch.nn.LayerNorm and mod.elementwise_affine and mod.bias is not None
-          and len(mod.normalized_shape) == 1 and x.is_cuda and x.dtype in (torch.float32, torch.bfloat16)
+          and len(mod.normalized_shape) == 1 and x.is_cuda and x.dtype in _GLUE_DTYPES
           and x.shape[-1] % 8 == 0 and x.shape[-1] <= (2048 if x.dtype == torch.float32 else 4096))
     if not ok:
         return mod(x)
@@ -1021,7 +1021,7 @@ class ResidualDropPathFn(torch.autograd.Function):
         dres = torch.empty(shape, dtype=rdt, device=dev) if shared else None
         st = L.lib().mtlora_residual_droppath_bwd(n, L.ptr_array9(gs), L.ptr_array9(dys), L.ptr(dres), L.ptr(scale), M, C, B,
                                                   L.dtype_code(gs[[g is not None for g in gs].index(True)]),
-                                                  L.BF16 if ydt == torch.bfloat16 else L.F32, L.stream_ptr())
+                                                  _DT_CODE.get(ydt, L.F32), L.stream_ptr())
         L.check(st, "mtlora_residual_droppath_bwd")
         dres_out = [dres] if shared else gs          # separate residuals: identity (the incoming gradient itself)
         return (None, None, None, *dres_out, *dys)
@@ -1033,7 +1033,7 @@ def residual_droppath(res, ys, drop_prob: float, training: bool):
     shared = not isinstance(res, (list, tuple))
     rl = [res] if shared else list(res)
     n = len(ys)
-    ok = (rl[0].is_cuda and rl[0].shape[-1] % 8 == 0 and all(t.dtype in (torch.float32, torch.bfloat16) for t in rl + list(ys))
+    ok = (rl[0].is_cuda and rl[0].shape[-1] % 8 == 0 and all(t.dtype in _GLUE_DTYPES for t in rl + list(ys))
           and len({t.dtype for t in rl}) == 1 and len({t.dtype for t in ys}) == 1 and n <= L.MAX_TASKS + 1
           and all(t.shape == rl[0].shape for t in list(ys) + rl))
     scale = None

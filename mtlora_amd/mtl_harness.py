@@ -180,7 +180,7 @@ class HighResolutionHead(nn.Module):
         h = Fn.linear_big_m(t, w2d, c0.bias, feeds_batchnorm=bn.training)
         if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
             bn.num_batches_tracked.add_(1)
-        if bn.training and h.is_cuda and h.dtype in (torch.float32, torch.bfloat16) and h.shape[1] % 8 == 0:
+        if bn.training and h.is_cuda and h.dtype in (torch.float32, torch.bfloat16, torch.float16) and h.shape[1] % 8 == 0:
             # fused training-mode BatchNorm + ReLU on the (pixels, channels) matrix (csrc/glue.hip)
             h = BatchNormReluFn.apply(h, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps,
                                       getattr(self, "relu", True))

@@ -545,7 +545,7 @@ def test_backbone_options_golden(golden, case, dtype):
 
 
 @pytest.mark.parametrize("xdt,ydt", [(torch.float32, torch.float32), (torch.float32, torch.bfloat16),
-                                     (torch.bfloat16, torch.bfloat16)])
+                                     (torch.bfloat16, torch.bfloat16), (torch.float32, torch.float16), (torch.float16, torch.float16)])
 @pytest.mark.parametrize("M,C", [(1000, 96), (333, 192), (257, 384), (100, 768), (65, 1536), (3, 2048), (50, 40)])
 def test_layernorm_vs_torch(M, C, xdt, ydt):
     from mtlora_amd import functional as Fn
@@ -563,11 +563,11 @@ def test_layernorm_vs_torch(M, C, xdt, ydt):
     y.backward(g)
     ref.backward(g.double().cpu())
     assert_close(x.grad, x64.grad, xdt, "dx", mult=2)
-    assert_close(w.grad, w64.grad, torch.float32 if ydt == torch.float32 else torch.bfloat16, "dgamma", mult=2)
-    assert_close(b.grad, b64.grad, torch.float32 if ydt == torch.float32 else torch.bfloat16, "dbeta", mult=2)
+    assert_close(w.grad, w64.grad, ydt, "dgamma", mult=2)
+    assert_close(b.grad, b64.grad, ydt, "dbeta", mult=2)
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("R,C,relu", [(5000, 1080, True), (777, 1080, False), (4096, 64, True), (100, 8, True)])
 def test_batchnorm_relu_vs_torch(R, C, relu, dtype):
     from mtlora_amd import functional as Fn
@@ -594,7 +594,8 @@ def test_batchnorm_relu_vs_torch(R, C, relu, dtype):
     assert_close(b.grad, b64.grad, dtype, "dbeta", mult=3)
 
 
-@pytest.mark.parametrize("rdt,ydt", [(torch.float32, torch.bfloat16), (torch.bfloat16, torch.bfloat16), (torch.float32, torch.float32)])
+@pytest.mark.parametrize("rdt,ydt", [(torch.float32, torch.bfloat16), (torch.bfloat16, torch.bfloat16), (torch.float32, torch.float32),
+                                     (torch.float32, torch.float16)])
 @pytest.mark.parametrize("shared", [True, False])
 def test_residual_droppath(shared, rdt, ydt):
     from mtlora_amd import functional as Fn
@@ -625,7 +626,8 @@ def test_residual_droppath(shared, rdt, ydt):
 
 @pytest.mark.parametrize("use_scale", [True, False])
 @pytest.mark.parametrize("B,Ltok,C", [(6, 49, 96), (3, 200, 384), (2, 50, 1536), (5, 7, 768)])
-@pytest.mark.parametrize("rdt,ydt", [(torch.float32, torch.bfloat16), (torch.bfloat16, torch.bfloat16), (torch.float32, torch.float32)])
+@pytest.mark.parametrize("rdt,ydt", [(torch.float32, torch.bfloat16), (torch.bfloat16, torch.bfloat16), (torch.float32, torch.float32),
+                                     (torch.float32, torch.float16)])
 def test_residual_layer_norm_fused(rdt, ydt, B, Ltok, C, use_scale):
     """mtlora_residual_layernorm_fwd/bwd: x_new = shortcut + DropPath-scale * branch, y = LayerNorm(x_new); backward with
     gradients arriving on BOTH outputs (skip path + normalised path) against fp64 autograd of the composition, where the

@@ -445,9 +445,10 @@ def test_graphed_train_step_replays_the_eager_step():
 @pytest.mark.gpu
 def test_fp16_autocast_train_steps_with_grad_scaler():
     """The reference's default mixed precision (torch.cuda.amp.autocast() = fp16 + GradScaler, main.py:329-354) on the HIP path:
-    MTLoRALinear / window attention run their fp16 kernels (v_mfma_f32_32x32x16_f16), the block glue leaves fp32 / goes through
-    ATen.  Three scaled steps: finite loss and gradients, the scaler never skips, and the first loss agrees with the bf16 run of
-    the same model to mixed-precision accuracy."""
+    MTLoRALinear / window attention run their fp16 kernels (v_mfma_f32_32x32x16_f16) and the block glue (LayerNorm family,
+    residual + DropPath, the heads' BatchNorm + ReLU) its fp16 instantiations -- no ATen LayerNorm / BatchNorm kernel in the step.
+    Three scaled steps: finite loss and gradients, the scaler never skips, and the first loss agrees with the bf16 run of the same
+    model to mixed-precision accuracy."""
     from mtlora_amd import functional as Fn
     from mtlora_amd import mtl_harness as H
     tasks = ["semseg", "normals", "sal", "human_parts"]
@@ -462,12 +463,20 @@ def test_fp16_autocast_train_steps_with_grad_scaler():
         crit, opt = H.MultiTaskLoss(tasks), H.build_optimizer(model, lr=1e-3)
         scaler = torch.amp.GradScaler("cuda", init_scale=1024.0, enabled=dt == torch.float16)
         for step in range(3):
+            prof = torch.profiler.profile(activities=[torch.profiler.ProfilerActivity.CPU]) if step == 2 else None
+            if prof is not None:
+                prof.__enter__()
             with torch.autocast("cuda", dtype=dt):
                 loss, _ = crit.forward_low(model(img, upsample=False), tg)
             assert torch.isfinite(loss).all()
             if step == 0:
                 first[dt] = loss.item()
             scaler.scale(loss).backward()
+            if prof is not None:
+                prof.__exit__(None, None, None)
+                ops = {e.key for e in prof.key_averages()}
+                stray = {o for o in ops if "layer_norm" in o or "batch_norm" in o}
+                assert not stray, (dt, sorted(stray))  # the fused glue kernels served every normalisation, in fp16 as in bf16
             scaler.unscale_(opt)
             grads = [p.grad for p in model.parameters() if p.grad is not None]
             assert grads and all(torch.isfinite(g).all() for g in grads)

@@ -30,6 +30,7 @@
 //            k_tn + k_tn_reduce for dA / dB.
 // DESIGN.md section 4.1 / 4.3 has the measurements and the experiments that were tried and dropped.
 #include <stdlib.h>
+#include <algorithm>
 #include <type_traits>
 
 #include "common.h"
@@ -1712,6 +1713,153 @@ static void launch_sp_ares(const SpLinParams& q, const SpAresPlan& pl, hipStream
 
 // k_pack of one layer into the packed-factor region at `pk` (the head of a forward's ctx buffer, or the caller's persistent
 // buffer of mtlora_linear_pack)
+// ---- wave-streaming factor gradients (k_sp_tn, stream.h).  Geometry is a function of the layer shape only (the scratch size
+// must not depend on the device): part width 32 nb columns (nb = 4 when K and N are multiples of 128, 3 when multiples of 96),
+// ~SP_TN_WGS workgroups dealt to the pps in row groups of 8.
+constexpr int SP_TN_WGS = 256;
+static int sp_tn_nb(const mtlora_linear_desc* d) {
+    if (mtl_elem_size(d->dtype) != 2 || d->M <= 0 || d->M >= ((int64_t)1 << 31) - 64) return 0;
+    if (d->K % 128 == 0 && d->N % 128 == 0) return 4;
+    if (d->K % 96 == 0 && d->N % 96 == 0) return 3;
+    return 0;
+}
+static int sp_tn_groups(int n_pp, int64_t M) {
+    int G = SP_TN_WGS / (n_pp > 0 ? n_pp : 1);  // one resident round of workgroups, every workgroup the same number of rows
+    const int64_t by_rows = mtl_ceil_div(mtl_ceil_div(M, 32), SP_WAVES);  // no more waves than slabs
+    if (G > by_rows) G = (int)by_rows;
+    return G < 1 ? 1 : G;
+}
+// blockIdx -> (pp, row group).  Placement units are dealt largest first, each to the XCD with the least load so far.  coarse: a unit
+// is every pp that reads the same narrow MATRIX for one row group (all dA problems read Q, all dB problems P: their column windows
+// share cache lines); fine: one (problem, narrow tile).  Coarse is kept when no XCD gets more than its 32 CUs' worth of workgroups.
+// Returns the grid size (0: does not fit the table).
+static unsigned sp_tn_map_units(SpTnParams& q, bool coarse, int& max_load) {
+    int load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    constexpr int CAP = SP_TN_MAP / 8;
+    for (int i = 0; i < SP_TN_MAP; ++i) q.map[i] = 0xFFFFFFFFu;
+    // unit list: [first problem, last problem] ranges over a problem order in which equal narrow matrices are adjacent
+    int order[2 * MAXO], n = q.n_prob;
+    for (int i = 0; i < n; ++i) order[i] = i;
+    auto size_of = [&](int i) { return q.p[i].tiles_a * q.p[i].parts; };
+    auto class_size = [&](int i) {
+        int sz = 0;
+        for (int j = 0; j < n; ++j)
+            if (q.p[j].A == q.p[i].A) sz += size_of(j);
+        return sz;
+    };
+    for (int i = 1; i < n; ++i)
+        for (int j = i; j > 0; --j) {
+            const int a = order[j], b = order[j - 1];
+            const int ka = coarse ? class_size(a) : size_of(a), kb = coarse ? class_size(b) : size_of(b);
+            const bool before = ka > kb || (ka == kb && coarse && q.p[a].A < q.p[b].A && q.p[a].A != q.p[b].A);
+            if (!before) break;
+            std::swap(order[j], order[j - 1]);
+        }
+    auto place = [&](int lo, int hi, int ta_lo, int ta_hi, int g) -> bool {  // problems order[lo..hi), narrow tiles [ta_lo, ta_hi)
+        int sz = 0;
+        for (int oi = lo; oi < hi; ++oi) sz += (std::min(ta_hi, q.p[order[oi]].tiles_a) - std::min(ta_lo, q.p[order[oi]].tiles_a)) * q.p[order[oi]].parts;
+        int x = 0;
+        for (int k = 1; k < 8; ++k)
+            if (load[k] < load[x]) x = k;
+        if (load[x] + sz > CAP) return false;
+        for (int oi = lo; oi < hi; ++oi) {
+            const SpTnProb& p = q.p[order[oi]];
+            for (int ta = ta_lo; ta < ta_hi && ta < p.tiles_a; ++ta)
+                for (int c = 0; c < p.parts; ++c) q.map[8 * (load[x]++) + x] = (uint32_t)(p.pp_lo + ta * p.parts + c) | ((uint32_t)g << 16);
+        }
+        return true;
+    };
+    for (int lo = 0; lo < n;) {
+        int hi = lo + 1;
+        if (coarse)
+            while (hi < n && q.p[order[hi]].A == q.p[order[lo]].A) ++hi;
+        int tmax = 0;
+        for (int oi = lo; oi < hi; ++oi) tmax = std::max(tmax, q.p[order[oi]].tiles_a);
+        for (int g = 0; g < q.G; ++g) {
+            if (coarse) {
+                if (!place(lo, hi, 0, tmax, g)) return 0;
+            } else {
+                for (int ta = 0; ta < tmax; ++ta)
+                    if (!place(lo, hi, ta, ta + 1, g)) return 0;
+            }
+        }
+        lo = hi;
+    }
+    max_load = 0;
+    for (int k = 0; k < 8; ++k) max_load = std::max(max_load, load[k]);
+    return (unsigned)(8 * max_load);
+}
+static unsigned sp_tn_map(SpTnParams& q) {
+    // largest row-group count (from the one-round estimate down to 3 fewer) for which no XCD holds more than 32 workgroups (a
+    // second residency round on one XCD doubles the launch); coarse units when they cost at most 5 % of the workgroups
+    int mx = 0;
+    const int G0 = q.G;
+    int g_fine = 0, g_coarse = 0;
+    for (int G = G0; G >= 1 && G >= G0 - 3 && g_fine == 0; --G) {
+        q.G = G;
+        if (sp_tn_map_units(q, false, mx) != 0 && mx <= 32) g_fine = G;
+    }
+    for (int G = G0; G >= 1 && G >= G0 - 3 && g_coarse == 0; --G) {
+        q.G = G;
+        if (sp_tn_map_units(q, true, mx) != 0 && mx <= 32) g_coarse = G;
+    }
+    if (g_coarse > 0 && g_coarse * 20 >= (g_fine > 0 ? g_fine : G0) * 19) {
+        q.G = g_coarse;
+        return sp_tn_map_units(q, true, mx);
+    }
+    q.G = g_fine > 0 ? g_fine : G0;
+    return sp_tn_map_units(q, false, mx);
+}
+// developer switch MTLORA_SP_TN: 0 tiled k_tn only, 2 streaming whenever the shape allows, unset / 1: streaming when every wave gets
+// >= 8 slabs (below that the launch is latency-bound and the tiled kernel's 64-row chunks win: measured on the stage-2 / 3 shapes)
+static int sp_tn_mode() {
+    const char* e = getenv("MTLORA_SP_TN");
+    return e ? atoi(e) : 1;
+}
+static int64_t sp_tn_part_bytes(const mtlora_linear_desc* d, const Segs& sg) {
+    const int nb = sp_tn_nb(d);
+    if (nb == 0) return 0;
+    int64_t n_pp = 0;
+    for (int o = 0; o < sg.n; ++o)
+        if (sg.rp[o] > 0) n_pp += mtl_ceil_div(sg.rp[o], 64) * (d->N / (32 * nb) + d->K / (32 * nb));
+    const int64_t wgs = n_pp > SP_TN_WGS ? n_pp : SP_TN_WGS;
+    return wgs * (2 * nb * 1024) * 4;
+}
+template <typename T>
+static void launch_sp_tn(SpTnParams& q, int nb, hipStream_t s, double xb, double fl, const char* tag) {
+    if constexpr (sizeof(T) == 2) {
+        q.n_slabs = (int)mtl_ceil_div(q.M, 32);
+        const unsigned grid = sp_tn_map(q);  // (q.G set by the caller; the caller checked that the table fits)
+        {
+            mtl_prof_tag("sp_tn %s np%d pp%d G%d nb%d", tag, q.n_prob, q.n_pp, q.G, nb);
+            MtlProfScope prof(PK_TN, xb, s, xb, fl);
+#define MTL_SP_TN(NBV, NSV)                                                                                                     \
+    do {                                                                                                                         \
+        constexpr size_t lds = (size_t)SP_WAVES * NSV * (SP_TN_NARROW + 32 * NBV * 64);                                          \
+        static bool raised = false;                                                                                              \
+        if (!raised) {                                                                                                           \
+            (void)hipFuncSetAttribute((const void*)k_sp_tn<T, NBV, NSV>, hipFuncAttributeMaxDynamicSharedMemorySize, SP_LDS_MAX); \
+            raised = true;                                                                                                       \
+        }                                                                                                                        \
+        hipLaunchKernelGGL((k_sp_tn<T, NBV, NSV>), dim3(grid), dim3(64 * SP_WAVES), lds, s, q);                                  \
+    } while (0)
+            static const int force_ns = [] { const char* e = getenv("MTLORA_SP_TN_NS"); return e ? atoi(e) : 0; }();
+            if (nb == 4)
+                MTL_SP_TN(4, 1);
+            else if (force_ns == 1)
+                MTL_SP_TN(3, 1);
+            else
+                MTL_SP_TN(3, 2);
+#undef MTL_SP_TN
+        }
+        MtlProfScope prof(PK_REDUCE, 0.0, s);
+        if (nb == 4)
+            hipLaunchKernelGGL(k_sp_tn_reduce<4>, dim3(8, (unsigned)q.n_pp), dim3(256 * SP_TN_RG), 0, s, q);
+        else
+            hipLaunchKernelGGL(k_sp_tn_reduce<3>, dim3(6, (unsigned)q.n_pp), dim3(256 * SP_TN_RG), 0, s, q);
+    }
+}
+
 template <typename T>
 static void launch_pack(const mtlora_linear_desc* d, const Segs& sg, const CtxLayout& L, unsigned char* pk, const float* A_s,
                         const float* B_s, const float* const* A_t, const float* const* B_t, hipStream_t s) {
@@ -1938,7 +2086,10 @@ static BwdScratch bwd_scratch(const mtlora_linear_desc* d, const Segs& sg) {
     int64_t rps = mtl_ceil_div(d->M > 0 ? d->M : 1, nsplit);
     rps = mtl_round_up(rps, 64);
     S.rows_per_split = rps;
-    S.part = take(tiles * nsplit * (int64_t)TN_TILE * 4);
+    {
+        const int64_t tiled = tiles * nsplit * (int64_t)TN_TILE * 4, streamed = sp_tn_part_bytes(d, sg);
+        S.part = take(tiled > streamed ? tiled : streamed);
+    }
     S.total = o;
     return S;
 }
@@ -2243,7 +2394,60 @@ static int bwd_impl(const mtlora_linear_desc* d, const void* x, const void* cons
                 if (p.tiles_a * p.tiles_b > max_tiles) max_tiles = p.tiles_a * p.tiles_b;
             }
         }
-        if (tp.n_prob > 0 && d->M > 0) {
+        bool tn_done = false;
+        if constexpr (sizeof(T) == 2) {
+            const int nb = (sp_mode() != 0 && sp_tn_mode() != 0) ? sp_tn_nb(d) : 0;
+            bool ok = nb != 0 && tp.n_prob > 0;
+            SpTnParams q = {};
+            for (int i = 0; ok && i < tp.n_prob; ++i) {
+                const TnProblem& p = tp.p[i];
+                SpTnProb& r = q.p[i];
+                ok = ok && p.b0 == 0 && p.Nb == p.ldb && p.Nb % (32 * nb) == 0 && !misaligned(p.A) && !misaligned(p.B) && (p.lda % 8) == 0 &&
+                     (p.a0 % 8) == 0;
+                r.A = p.A;
+                r.B = p.B;
+                r.lda = p.lda;
+                r.ldb = p.ldb;
+                r.a0 = p.a0;
+                r.Na = p.Na;
+                r.Nb = p.Nb;
+                r.b_mask = p.b_mask;
+                r.tiles_a = (int)mtl_ceil_div(p.Na, 64);
+                r.parts = p.Nb / (32 * nb);
+                r.pp_lo = q.n_pp;
+                r.transpose = p.transpose;
+                r.out = p.out;
+                r.out_a = p.out_a;
+                r.out_b = p.out_b;
+                r.ldo = p.ldo;
+                q.n_pp += r.tiles_a * r.parts;
+            }
+            if (ok) {
+                const int mode = sp_tn_mode();
+                q.n_prob = tp.n_prob;
+                q.G = sp_tn_groups(q.n_pp, d->M);
+                ok = q.n_pp <= SP_TN_WGS && q.G < 65536 && (mode == 2 || (mode == 1 && mtl_ceil_div(d->M, 32) >= (int64_t)8 * q.G * SP_WAVES));
+                if (ok) {
+                    SpTnParams probe = q;
+                    ok = sp_tn_map(probe) != 0;
+                    q.G = probe.G;
+                }
+            }
+            if (ok) {
+                q.n_prob = tp.n_prob;
+                q.M = d->M;
+                q.part = part;
+                q.drop = dc;
+                const double xb = (double)sizeof(T) * d->M * (double)(1 + (d->has_x_tasks ? d->T : 0)) * d->K;
+                double fl = 0.0;
+                for (int i = 0; i < tp.n_prob; ++i) fl += 2.0 * d->M * (double)tp.p[i].out_a * tp.p[i].out_b;
+                char tag[96];
+                snprintf(tag, sizeof(tag), "M%lld K%lld N%lld T%d", (long long)d->M, (long long)d->K, (long long)d->N, d->T);
+                launch_sp_tn<T>(q, nb, s, xb, fl, tag);
+                tn_done = true;
+            }
+        }
+        if (!tn_done && tp.n_prob > 0 && d->M > 0) {
             {
                 mtl_prof_tag("M%lld K%lld N%lld T%d np%d ns%d tiles%d", (long long)d->M, (long long)d->K, (long long)d->N, d->T, tp.n_prob,
                              S.nsplit, max_tiles);

@@ -959,3 +959,305 @@ __global__ __launch_bounds__(64 * SP_WAVES, SP_WAVES / 4) void k_sp_projsum(cons
         }
     }
 }
+
+// ------------------------------------------------------------------------------------------------
+// k_sp_tn : the factor gradients as a wave-streaming pass (replaces the tiled k_tn for 16-bit types):
+//     Out[a][b] = sum_m SrcA[m][a0 + a] * SrcB[m][b]     dA_o = Q_o^T D(X_o) (r_o x K),   dB_o^T = P_o^T dY_o (r_o x N)
+// SrcA is the narrow (rank-side) matrix, SrcB the wide one.  Work unit "pp" = (problem, 64-column tile of the narrow window,
+// part of 32 NB wide columns); a pp is served by G workgroups, every wave of which owns 32-row slabs (slab = wave id + i * 8 G) and keeps the
+// 2 x NB accumulator blocks (32 x 32 fp32 each) of its pp in registers for the whole launch -- nothing is written until the end.
+// Per slab the wave DMAs the narrow piece (32 rows x <= 128 B) and the wide piece (32 rows x 64 NB B) into its private slot and
+// reads both back TRANSPOSED (ds_read_b64_tr_b16: a lane gets 8 consecutive m of one column = the k axis of the MFMA), so the
+// same slot image serves as A operand (narrow) and B operand (wide).  LDS layout (dense rows, 16-byte chunks permuted on the
+// source side so that the 4 rows x 64 B a transposed read touches per cycle cover all 64 banks):
+//     narrow rows of 128 B: physical chunk = logical ^ (4 * ((row >> 1) & 1));
+//     wide rows of 192 B (NB = 3): identity (row stride = 48 dwords);  256 B (NB = 4): logical ^ (4 * (row & 3)).
+// The dropout keep-mask of D(X) is applied in LDS by the lane that loaded the chunk (once per element).  At the end the 8 waves
+// of a workgroup are summed through LDS in a fixed order and the workgroup's partial goes to HBM in raw accumulator layout
+// ([block][reg][lane]); k_sp_tn_reduce sums the G partials of a pp in a fixed order and scatters to dA / dB (deterministic).
+// ------------------------------------------------------------------------------------------------
+constexpr int SP_TN_MAP = 8 * 40;
+struct SpTnProb {
+    const void* A;   // narrow: (M x lda), window [a0, a0 + Na)
+    const void* B;   // wide:   (M x ldb), columns [0, Nb)
+    int64_t lda, ldb;
+    int a0, Na, Nb, b_mask;
+    int tiles_a, parts, pp_lo, transpose;
+    float* out;      // element (a, b) at out[a * ldo + b], or out[b * ldo + a] when transpose
+    int out_a, out_b, ldo, pad_;
+};
+struct SpTnParams {
+    SpTnProb p[2 * MAXO];
+    int n_prob, n_pp, G, n_slabs;
+    int64_t M;
+    float* part;  // [pp][g][2 * NB blocks][1024]
+    DropoutCfg drop;
+    uint32_t map[SP_TN_MAP];  // blockIdx -> pp | g << 16 (0xFFFFFFFF: idle)
+};
+typedef const __attribute__((address_space(4))) SpTnParams* SpTnPtr;
+
+constexpr int SP_TN_NARROW = 32 * 128;  // narrow area of a slot (32 rows x 64 columns)
+
+template <typename T, int NB, int NS>
+__global__ __launch_bounds__(64 * SP_WAVES, SP_WAVES / 4) void k_sp_tn(const SpTnParams Pv) {
+    constexpr int RB = NB * 64;            // wide row bytes
+    constexpr int CPR = NB * 4;            // 16-byte chunks per wide row
+    constexpr int NDW = NB * 2;            // DMA instructions of the wide piece
+    constexpr int NDN = 4;                 // DMA instructions of the narrow piece
+    constexpr int SLOT = SP_TN_NARROW + 32 * RB;
+    (void)Pv;
+    SpTnPtr P = (SpTnPtr)__builtin_amdgcn_kernarg_segment_ptr();
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // ---- which pp / row group: a host-built table.  The pps that share a narrow slab (same problem, same narrow tile, same row
+    // group) are placed on ONE XCD (blockIdx b -> XCD b % 8) next to each other in dispatch order, so the narrow slab is re-read
+    // from that L2 (10-25 % of the launch time on the T = 4 layers), and the XCDs are loaded evenly (<= 32 workgroups each)
+    const int G = P->G;
+    const uint32_t ent = P->map[blockIdx.x];
+    if (ent == 0xFFFFFFFFu) return;
+    const int pp = (int)(ent & 0xFFFFu), g = (int)(ent >> 16);
+    int pi = 0;
+    for (int i = 1; i < P->n_prob; ++i)
+        if (pp >= P->p[i].pp_lo) pi = i;
+    const int local = pp - P->p[pi].pp_lo;
+    const int parts = P->p[pi].parts;
+    const int ta = local / parts, pc = local - ta * parts;
+    const int64_t lda = P->p[pi].lda, ldb = P->p[pi].ldb;
+    const int na_valid = min(64, P->p[pi].Na - ta * 64);
+    const bool two = na_valid > 32;
+    const int nch_valid = (na_valid + 7) >> 3;
+    const T* Ap = reinterpret_cast<const T*>(P->p[pi].A) + P->p[pi].a0 + ta * 64;
+    const T* Bp = reinterpret_cast<const T*>(P->p[pi].B) + pc * (NB * 32);
+    const int64_t M = P->M;
+    const int n_slabs = P->n_slabs;
+    DropoutCfg drop;
+    drop.seed_lo = P->drop.seed_lo;
+    drop.seed_hi = P->drop.seed_hi;
+    drop.thr16 = P->drop.thr16;
+    drop.off = P->drop.off;
+    mtl_dropout_resolve(drop);
+    const bool bmask = P->p[pi].b_mask != 0 && drop.thr16 != 0;
+
+    unsigned char* slots = smem + (size_t)wave * NS * SLOT;
+    // ---- per-lane DMA constants (32-bit byte offsets from the slab's first row: scalar base + vector offset addressing).  Narrow
+    // chunks past the window re-read its last valid chunk: they only feed accumulator rows nobody reads.
+    uint32_t goA[NDN], goB[NDW];
+#pragma unroll
+    for (int j = 0; j < NDN; ++j) {
+        const int c = j * 64 + lane, row = c >> 3, p = c & 7;
+        int q = p ^ (((row >> 1) & 1) << 2);
+        q = q < nch_valid ? q : nch_valid - 1;
+        goA[j] = (uint32_t)(row * (int)lda + q * 8) * 2u;
+    }
+#pragma unroll
+    for (int j = 0; j < NDW; ++j) {
+        const int c = j * 64 + lane, row = c / CPR, p = c - row * CPR;
+        const int q = NB == 4 ? (p ^ ((row & 3) << 2)) : p;
+        goB[j] = (uint32_t)(row * (int)ldb + q * 8) * 2u;
+    }
+    auto row_b = [&](int j) __attribute__((always_inline)) { return (j * 64 + lane) / CPR; };
+    auto col_b = [&](int j) __attribute__((always_inline)) {
+        const int c = j * 64 + lane, row = c / CPR, p = c - row * CPR;
+        return pc * (NB * 32) + (NB == 4 ? (p ^ ((row & 3) << 2)) : p) * 8;
+    };
+    // ---- transposed fragment addressing: read j (0..3) of a fragment covers rows rj = 16 (j >> 1) + 8 h + 4 (j & 1) + (i >> 2)
+    // of the slab, 8 bytes at logical chunk 4 blk + 2 (g4 & 1) + ((i & 3) >> 1), byte (i & 1) * 8 of that chunk
+    const int g4 = lane >> 4, i16 = lane & 15, hh = g4 >> 1;
+    const int clow = 2 * (g4 & 1) + ((i16 & 3) >> 1), cbyte = (i16 & 1) * 8;
+    int offA[4], offB[4], swB[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int rj = 16 * (j >> 1) + 8 * hh + 4 * (j & 1) + (i16 >> 2);
+        offA[j] = rj * 128 + ((clow ^ (((rj >> 1) & 1) << 2)) << 4) + cbyte;  // block 0; block 1: ^ 64 (chunk bit 2)
+        offB[j] = SP_TN_NARROW + rj * RB + cbyte;
+        swB[j] = NB == 4 ? (rj & 3) : 0;
+    }
+    auto frag_a = [&](const unsigned char* sl, int blk) __attribute__((always_inline)) -> Frag<T> {
+        uint32_t w[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(sl + (offA[j] ^ (blk << 6))));
+            u32x2 u = __builtin_bit_cast(u32x2, v);
+            w[2 * j] = u[0];
+            w[2 * j + 1] = u[1];
+        }
+        Frag<T> f;
+        f.v[0] = u32x4{w[0], w[1], w[2], w[3]};
+        f.v[1] = u32x4{w[4], w[5], w[6], w[7]};
+        return f;
+    };
+    auto frag_b = [&](const unsigned char* sl, int blk) __attribute__((always_inline)) -> Frag<T> {
+        uint32_t w[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int ch = (((blk ^ swB[j]) << 2) | clow) << 4;
+            s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(sl + offB[j] + ch));
+            u32x2 u = __builtin_bit_cast(u32x2, v);
+            w[2 * j] = u[0];
+            w[2 * j + 1] = u[1];
+        }
+        Frag<T> f;
+        f.v[0] = u32x4{w[0], w[1], w[2], w[3]};
+        f.v[1] = u32x4{w[4], w[5], w[6], w[7]};
+        return f;
+    };
+
+    const int stride = G * SP_WAVES;
+    const int w_gid = g * SP_WAVES + wave;
+    int l_slab = w_gid;
+    auto issue = [&](int slot) __attribute__((always_inline)) -> bool {
+        if (l_slab >= n_slabs) return false;
+        const int64_t m0 = (int64_t)l_slab * 32;
+        const unsigned char* a = reinterpret_cast<const unsigned char*>(Ap + m0 * lda);
+        const unsigned char* b = reinterpret_cast<const unsigned char*>(Bp + m0 * ldb);
+        unsigned char* dst = slots + slot * SLOT;
+        if (m0 + 32 <= M) {
+#pragma unroll
+            for (int j = 0; j < NDN; ++j) sp_dma16(a + goA[j], dst + j * 1024);
+#pragma unroll
+            for (int j = 0; j < NDW; ++j) sp_dma16(b + goB[j], dst + SP_TN_NARROW + j * 1024);
+        } else {  // last slab: rows past M re-read row M - 1; the narrow rows are zeroed in LDS before they are used
+            const int last = (int)(M - m0) - 1;
+#pragma unroll
+            for (int j = 0; j < NDN; ++j) {
+                const int row = (j * 64 + lane) >> 3;
+                sp_dma16(a + (goA[j] - (uint32_t)((row > last ? row - last : 0) * (int)lda) * 2u), dst + j * 1024);
+            }
+#pragma unroll
+            for (int j = 0; j < NDW; ++j) {
+                const int row = row_b(j);
+                sp_dma16(b + (goB[j] - (uint32_t)((row > last ? row - last : 0) * (int)ldb) * 2u), dst + SP_TN_NARROW + j * 1024);
+            }
+        }
+        l_slab += stride;
+        return true;
+    };
+    int ahead = 0;
+#pragma unroll
+    for (int i = 0; i < NS; ++i) ahead += issue(i) ? 1 : 0;
+
+    f32x16 acc[2][NB];
+#pragma unroll
+    for (int ia = 0; ia < 2; ++ia)
+#pragma unroll
+        for (int jb = 0; jb < NB; ++jb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[ia][jb][r] = 0.f;
+
+    int slot = 0;
+    for (int slab = w_gid; slab < n_slabs; slab += stride) {
+        if (ahead >= 2)
+            SP_WAIT_VM(NDN + NDW);
+        else
+            SP_WAIT_VM(0);
+        unsigned char* sl = slots + slot * SLOT;
+        if ((int64_t)slab * 32 + 32 > M) {  // ragged tail: zero the narrow rows past M (uniform branch, last slab only)
+            const int live = (int)(M - (int64_t)slab * 32);
+#pragma unroll
+            for (int j = 0; j < NDN; ++j)
+                if (((j * 64 + lane) >> 3) >= live) *reinterpret_cast<u32x4*>(sl + j * 1024 + lane * 16) = u32x4{0u, 0u, 0u, 0u};
+        }
+        if (bmask) {  // keep-mask of D(X): every lane masks the chunks it loaded
+#pragma unroll
+            for (int j = 0; j < NDW; ++j) {
+                u32x4* cp = reinterpret_cast<u32x4*>(sl + SP_TN_NARROW + j * 1024 + lane * 16);
+                u32x4 v = *cp;
+                const uint32_t rh = mtl_dropout_rowhash(drop, 0u, (uint32_t)(slab * 32 + row_b(j)));
+                VOps<T>::drop(v, drop, rh, (uint32_t)col_b(j));
+                *cp = v;
+            }
+        }
+        Frag<T> fa0 = frag_a(sl, 0), fa1;
+        if (two) fa1 = frag_a(sl, 1);
+        Frag<T> fb[NB];
+#pragma unroll
+        for (int jb = 0; jb < NB; ++jb) fb[jb] = frag_b(sl, jb);
+        SP_WAIT_LGKM0();
+        --ahead;
+        ahead += issue(slot) ? 1 : 0;
+        slot = slot + 1 == NS ? 0 : slot + 1;
+#pragma unroll
+        for (int jb = 0; jb < NB; ++jb) mtl_mma(fa0, fb[jb], acc[0][jb]);
+        if (two) {
+#pragma unroll
+            for (int jb = 0; jb < NB; ++jb) mtl_mma(fa1, fb[jb], acc[1][jb]);
+        }
+    }
+
+    // ---- workgroup sum (fixed order over the waves) and the partial in raw accumulator layout
+    SP_WAIT_VM(0);
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);  // [wave][reg][lane]
+    float* dst = P->part + ((int64_t)pp * G + g) * (2 * NB * 1024);
+    const int nblk = two ? 2 * NB : NB;
+    for (int blk = 0; blk < nblk; ++blk) {
+        const int ia = blk / NB, jb = blk - ia * NB;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float v = 0.f;
+#pragma unroll
+            for (int a2 = 0; a2 < 2; ++a2)
+#pragma unroll
+                for (int b2 = 0; b2 < NB; ++b2)
+                    if (a2 == ia && b2 == jb) v = acc[a2][b2][r];
+            red[(wave * 16 + r) * 64 + lane] = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int e = tid; e < 1024; e += 64 * SP_WAVES) {
+            float sum = 0.f;
+#pragma unroll
+            for (int w = 0; w < SP_WAVES; ++w) sum += red[w * 1024 + e];
+            dst[blk * 1024 + e] = sum;
+        }
+        __syncthreads();
+    }
+}
+
+constexpr int SP_TN_RG = 4;
+template <int NB>
+__global__ __launch_bounds__(256 * SP_TN_RG) void k_sp_tn_reduce(const SpTnParams P) {
+    // one workgroup per (pp, accumulator block): thread t of a group owns 4 consecutive lanes of one accumulator register (16-byte
+    // loads, 4 consecutive wide columns of one narrow row); the G partials are dealt round-robin to SP_TN_RG thread groups, each
+    // summing its share in a fixed order with 4 independent chains, then a fixed-order LDS combine
+    __shared__ f32x4 sm[SP_TN_RG][256];
+    const int pp = blockIdx.y, blk = blockIdx.x;
+    int pi = 0;
+    for (int i = 1; i < P.n_prob; ++i)
+        if (pp >= P.p[i].pp_lo) pi = i;
+    const SpTnProb& pr = P.p[pi];
+    const int local = pp - pr.pp_lo;
+    const int ta = local / pr.parts, pc = local - ta * pr.parts;
+    const int ia = blk / NB, jb = blk - ia * NB;
+    const int na_valid = min(64, pr.Na - ta * 64);
+    if (ia * 32 >= na_valid) return;
+    const int t = threadIdx.x & 255, grp = threadIdx.x >> 8;
+    const int G = P.G;
+    const float* src = P.part + (int64_t)pp * G * (2 * NB * 1024) + blk * 1024 + t * 4;
+    const int64_t stride = 2 * NB * 1024;
+    f32x4 acc[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int sp = grp;
+    for (; sp + 3 * SP_TN_RG < G; sp += 4 * SP_TN_RG) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc[u] += *reinterpret_cast<const f32x4*>(src + (int64_t)(sp + u * SP_TN_RG) * stride);
+    }
+    for (; sp < G; sp += SP_TN_RG) acc[0] += *reinterpret_cast<const f32x4*>(src + (int64_t)sp * stride);
+    sm[grp][t] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+    __syncthreads();
+    if (grp != 0) return;
+    f32x4 tsum = sm[0][t];
+#pragma unroll
+    for (int gI = 1; gI < SP_TN_RG; ++gI) tsum += sm[gI][t];
+    const int e = t * 4, r = e >> 6, lane = e & 63;
+    const int a = ta * 64 + ia * 32 + mtl_d_row(lane, r);
+    const int b0 = pc * (NB * 32) + jb * 32 + (lane & 31);
+    if (a >= pr.out_a) return;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (b0 + k < pr.out_b) {
+            const int64_t at = pr.transpose ? (int64_t)(b0 + k) * pr.ldo + a : (int64_t)a * pr.ldo + b0 + k;
+            pr.out[at] = tsum[k];
+        }
+}

@@ -227,12 +227,15 @@ def test_linear_random_vs_oracle(shape, dtype):
             assert_close(p.grad, P[n].grad, dtype, f"grad {n}", mult=3)
 
 
+@pytest.mark.parametrize("geom", [(333, 96, 160, torch.float32), (333, 96, 192, torch.bfloat16), (1100, 384, 96, torch.bfloat16),
+                                  (500, 128, 256, torch.float16)])
 @pytest.mark.parametrize("use_xt", [False, True])
-def test_linear_dropout_matches_specified_generator(use_xt):
-    """train mode: the kernel's counter-based mask == oracle.dropout_keep_mask, forward and backward."""
+def test_linear_dropout_matches_specified_generator(use_xt, geom):
+    """train mode: the kernel's counter-based mask == oracle.dropout_keep_mask, forward and backward (fp32 on the tiled kernels;
+    16-bit shapes that take the wave-streaming forward / dX / factor-gradient kernels, ragged M)."""
     from mtlora_amd.lora import MTLoRALinear
     from mtlora_amd import functional as Fn
-    M, K, N = 333, 96, 160
+    M, K, N, dtype = geom
     tasks = ["a", "b"]
     torch.manual_seed(3)
     m = MTLoRALinear(K, N, r={"shared": 16, "a": 4, "b": 8}, lora_shared_scale=2.0, lora_task_scale={"a": 3.0, "b": 1.5},
@@ -240,11 +243,13 @@ def test_linear_dropout_matches_specified_generator(use_xt):
     with torch.no_grad():
         for n, p in m.named_parameters():
             p.copy_(torch.randn_like(p) * 0.05)
+            if dtype != torch.float32:
+                p.copy_(p.to(dtype).float())
     m.linear.weight.requires_grad_(False)
     m.linear.bias.requires_grad_(False)
     m.train()
-    x = torch.randn(M, K, device=dev(), requires_grad=True)
-    xt = {t: torch.randn(M, K, device=dev(), requires_grad=True) for t in tasks} if use_xt else None
+    x = torch.randn(M, K, device=dev()).to(dtype).requires_grad_(True)
+    xt = {t: torch.randn(M, K, device=dev()).to(dtype).requires_grad_(True) for t in tasks} if use_xt else None
     seed_before = Fn._seed_counter
     y, yt = m(x, xt)
     # recover the seed the module drew
@@ -254,21 +259,21 @@ def test_linear_dropout_matches_specified_generator(use_xt):
     frac = keep.float().mean().item()
     assert abs(frac - 0.75) < 0.01, frac
     P, xs, xts, yo, yto = _oracle_linear(m, x, xt, keep=keep, p=0.25)
-    assert_close(y, yo, torch.float32, "y")
-    loss, loss_o = y.sum() * 0.5, yo.sum() * 0.5
+    assert_close(y, yo, dtype, "y")
+    loss, loss_o = y.float().sum() * 0.5, yo.sum() * 0.5
     for i, t in enumerate(tasks):
-        assert_close(yt[t], yto[t], torch.float32, f"y[{t}]")
-        loss, loss_o = loss + yt[t].sum() * (i + 1), loss_o + yto[t].sum() * (i + 1)
+        assert_close(yt[t], yto[t], dtype, f"y[{t}]")
+        loss, loss_o = loss + yt[t].float().sum() * (i + 1), loss_o + yto[t].sum() * (i + 1)
     loss.backward()
     loss_o.backward()
-    assert_close(x.grad, xs.grad, torch.float32, "dx", mult=2)
+    assert_close(x.grad, xs.grad, dtype, "dx", mult=2)
     for n, p in m.named_parameters():
         if p.requires_grad:
-            assert_close(p.grad, P[n].grad, torch.float32, f"grad {n}", mult=3)
+            assert_close(p.grad, P[n].grad, dtype, f"grad {n}", mult=3)
     m.eval()
     y2, _ = m(x, xt)
     P, xs, xts, yo2, _ = _oracle_linear(m, x, xt)
-    assert_close(y2, yo2, torch.float32, "eval y")
+    assert_close(y2, yo2, dtype, "eval y")
 
 
 def test_linear_unused_output_gets_none_grad():

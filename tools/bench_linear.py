@@ -16,12 +16,21 @@ SHAPES = {  # name: (M, K, N, with_tasks, x_tasks)
     "s1.fc1T": (100352, 192, 768, True, True), "s1.fc2T": (100352, 768, 192, True, True),
     "s2.qkv": (25088, 384, 1152, False, False), "s2.fc1": (25088, 384, 1536, False, False), "s2.fc2": (25088, 1536, 384, False, False),
     "head0": (100352, 272, 1080, None, False),
+    # c4 (Swin-B/448, B = 16, r = 128 shared and per task): --rs 128 --rt 128
+    "b0.qkv": (200704, 128, 384, False, False), "b0.fc1": (200704, 128, 512, False, False), "b0.fc2": (200704, 512, 128, False, False),
+    "b1.qkv": (50176, 256, 768, False, False), "b1.fc1": (50176, 256, 1024, False, False), "b1.fc2": (50176, 1024, 256, False, False),
+    "b2.qkv": (12544, 512, 1536, False, False), "b2.proj": (12544, 512, 512, False, False),
+    "b2.fc1": (12544, 512, 2048, False, False), "b2.fc2": (12544, 2048, 512, False, False),
+    "b2.fc1T": (12544, 512, 2048, True, True), "b2.fc2T": (12544, 2048, 512, True, True),
+    "b3.qkv": (3136, 1024, 3072, False, False), "b3.fc1": (3136, 1024, 4096, False, False), "b3.fc2": (3136, 4096, 1024, False, False),
 }
 
 KINDS = KNT_ONLY = False
+RS, RT = 64, 4
 
 
-def run(name, iters, r_s=64, r_t=4):
+def run(name, iters):
+    r_s, r_t = RS, RT
     M, K, N, wt, xt = SHAPES[name]
     dev = torch.device("cuda", 0)
     torch.manual_seed(0)
@@ -99,7 +108,9 @@ if __name__ == "__main__":
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--kinds", action="store_true", help="per-kind kernel time of every leg")
     ap.add_argument("--knt-only", action="store_true", help="default path only (no tiled-only leg)")
+    ap.add_argument("--rs", type=int, default=64)
+    ap.add_argument("--rt", type=int, default=4)
     a = ap.parse_args()
-    KINDS, KNT_ONLY = a.kinds, a.knt_only
-    for s in a.shapes:
+    KINDS, KNT_ONLY, RS, RT = a.kinds, a.knt_only, a.rs, a.rt
+    for s in (a.shapes if a.shapes != list(SHAPES) else [n for n in SHAPES if not n.startswith("b")]):
         run(s, a.iters)

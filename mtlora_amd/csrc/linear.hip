@@ -779,6 +779,7 @@ struct NlParams {
     const bf16* Rm;     // (n_rows x ldR)
     bf16* out;          // (M x ld_out)
     bf16* act2;         // ACT: second output gelu(out)
+    const bf16* gate;   // GATE (k_ntd): out *= gelu'(gate[m][n]), same layout as out
     const float* bias;  // per output column, nullable
     const float* alpha; // per output column multiplier, nullable
     int64_t ld_act, ld_wgt, ldL, ldR, ld_out;
@@ -995,6 +996,7 @@ __global__ __launch_bounds__(512, 4) void k_ntl(const NlParams P) {
 }
 
 #include "stream.h"
+#include "dense.h"
 
 // ------------------------------------------------------------------------------------------------
 // k_tn : Out[a][b] = sum_m SrcA[m][a0 + a] * SrcB[m][b0 + b], split over m.
@@ -1339,6 +1341,82 @@ static void launch_nt(const NtParams& P_in, hipStream_t s, int kind, double alg_
     if constexpr (std::is_same<T, bf16>::value) {
         // lean single-output bf16 launches (forward outputs, P / Q passes, rank-0 GEMMs, and the dX of layers without task
         // outputs -- masked rank part): the straight-line kernel
+        // MFMA-dense launches (long reduction, enough tiles): k_ntd (dense.h).  MTLORA_NTD: 0 never, 2 whenever the shape allows
+        static const int ntd_mode = [] { const char* e = getenv("MTLORA_NTD"); return e ? atoi(e) : 1; }();
+        bool dense = false;
+        if (variant == 2 && P.n_out == 1 && P.nz == 0 && ntd_mode != 0 && P.act_mask == 0 && P.n_rows % 8 == 0 && P.n_rows >= 64 &&
+            P.M < (int64_t)0x7FFFFF00 && P.out[0].ptr != nullptr && !(P.out[0].gate && P.out[0].act)) {
+            const int seg = P.L ? P.out[0].seg_hi - P.out[0].seg_lo : 0;
+            const int kk = (P.act[0] && P.out[0].use_base ? P.K : 0);
+            const int ksteps = (seg + ND_KE - 1) / ND_KE + (kk + ND_KE - 1) / ND_KE;
+            const int64_t tiles = mtl_ceil_div(P.M, ND_TM) * mtl_ceil_div(P.n_rows, ND_TN);
+            const int64_t lim = ((int64_t)1 << 32) - 4096;
+            const bool fits = P.M * P.ld_act * 2 < lim && P.M * P.ldL * 2 < lim && (int64_t)P.n_rows * P.ld_wgt * 2 < lim &&
+                              (int64_t)P.n_rows * P.ldR * 2 < lim && P.K % 8 == 0 && seg % 8 == 0 && (P.ld_act % 8) == 0 && (P.ld_wgt % 8) == 0 &&
+                              (P.ldL % 8) == 0 && (P.ldR % 8) == 0 && (P.L == nullptr || (P.out[0].seg_lo % 8) == 0);
+            // where it wins (tools/ntd_ab.sh): a reduction of >= 6 k-tiles, residency rounds (one workgroup per CU) at least 70 % full or
+            // a single round on at least half of the CUs, and no half-empty column tile
+            const int64_t slots = sp_num_cu();
+            const double eff = (double)tiles / (double)(mtl_ceil_div(tiles, slots) * slots);
+            dense = fits && ksteps >= 1 &&
+                    (ntd_mode == 2 || (ksteps >= 6 && (eff >= 0.7 || (tiles <= slots && tiles >= slots / 2)) && (P.n_rows % ND_TN == 0 || P.n_rows > 2 * ND_TN)));
+        }
+        if (dense) {
+            NlParams q;
+            q.act = reinterpret_cast<const bf16*>(P.act[0]);
+            q.wgt = reinterpret_cast<const bf16*>(P.wgt);
+            q.L = reinterpret_cast<const bf16*>(P.L);
+            q.Rm = reinterpret_cast<const bf16*>(P.Rm);
+            q.out = reinterpret_cast<bf16*>(P.out[0].ptr);
+            q.act2 = reinterpret_cast<bf16*>(P.out[0].act);
+            q.gate = reinterpret_cast<const bf16*>(P.out[0].gate);
+            q.bias = P.bias;
+            q.alpha = P.alpha;
+            q.ld_act = P.ld_act;
+            q.ld_wgt = P.ld_wgt;
+            q.ldL = P.ldL;
+            q.ldR = P.ldR;
+            q.ld_out = P.ld_out;
+            q.M = (int)P.M;
+            q.n_rows = P.n_rows;
+            q.K = P.act[0] ? P.K : 0;
+            q.seg_lo = P.L ? P.out[0].seg_lo : 0;
+            q.seg_hi = P.L ? P.out[0].seg_hi : 0;
+            const int64_t mt = mtl_ceil_div(P.M, ND_TM), nt = mtl_ceil_div(P.n_rows, ND_TN);
+            q.n_tiles = (int)nt;
+            q.nt_magic = (uint32_t)(((uint64_t)1 << 32) / (uint64_t)nt) + 1u;
+            const uint32_t nwg = (uint32_t)(mt * nt);
+            q.q8 = nwg / 8u;
+            q.r8 = nwg % 8u;
+            q.act_mask = 0;
+            q.use_base = P.out[0].use_base;
+            q.dbg = 0;
+            q.pad_ = 0;
+            q.drop = P.drop;
+            const bool ml0 = P.out[0].mask_lr != 0 && P.drop.enabled() && q.seg_hi > q.seg_lo;
+            const uint32_t grid = nwg < (uint32_t)sp_num_cu() ? nwg : (uint32_t)sp_num_cu();
+#define MTL_NTD_GO(AC, ML, GA)                                                                                               \
+    do {                                                                                                                     \
+        static bool raised = false;                                                                                          \
+        if (!raised) {                                                                                                       \
+            (void)hipFuncSetAttribute((const void*)k_ntd<AC, ML, GA>, hipFuncAttributeMaxDynamicSharedMemorySize, SP_LDS_MAX); \
+            raised = true;                                                                                                   \
+        }                                                                                                                    \
+        hipLaunchKernelGGL((k_ntd<AC, ML, GA>), dim3(grid), dim3(512), (size_t)ND_LDS, s, q);                                \
+    } while (0)
+            if (q.act2)
+                MTL_NTD_GO(true, false, false);
+            else if (q.gate && ml0)
+                MTL_NTD_GO(false, true, true);
+            else if (q.gate)
+                MTL_NTD_GO(false, false, true);
+            else if (ml0)
+                MTL_NTD_GO(false, true, false);
+            else
+                MTL_NTD_GO(false, false, false);
+#undef MTL_NTD_GO
+            return;
+        }
         if (variant == 2 && P.n_out == 1 && P.out[0].gate == nullptr && P.nz == 0 && P.M < (int64_t)0x7FFFFF00 &&
             m_tiles * n_tiles < ((int64_t)1 << 28) && P.n_rows >= 8 && P.n_rows % 8 == 0) {
             NlParams q;
@@ -1348,6 +1426,7 @@ static void launch_nt(const NtParams& P_in, hipStream_t s, int kind, double alg_
             q.Rm = reinterpret_cast<const bf16*>(P.Rm);
             q.out = reinterpret_cast<bf16*>(P.out[0].ptr);
             q.act2 = reinterpret_cast<bf16*>(P.out[0].act);
+            q.gate = nullptr;
             q.bias = P.bias;
             q.alpha = P.alpha;
             q.ld_act = P.ld_act;

@@ -15,7 +15,8 @@ SHAPES = {  # name: (M, K, N, with_tasks, x_tasks)
     "s1.qkv": (100352, 192, 576, False, False), "s1.fc1": (100352, 192, 768, False, False), "s1.fc2": (100352, 768, 192, False, False),
     "s1.fc1T": (100352, 192, 768, True, True), "s1.fc2T": (100352, 768, 192, True, True),
     "s2.qkv": (25088, 384, 1152, False, False), "s2.fc1": (25088, 384, 1536, False, False), "s2.fc2": (25088, 1536, 384, False, False),
-    "head0": (100352, 272, 1080, None, False),
+    "s3.qkv": (6272, 768, 2304, False, False), "s3.fc1": (6272, 768, 3072, False, False), "s3.fc2": (6272, 3072, 768, False, False),
+    "head0": (100352, 272, 1080, None, False), "head1": (100352, 1080, 272, None, False), "merge1": (125440, 768, 384, None, False),
     # c4 (Swin-B/448, B = 16, r = 128 shared and per task): --rs 128 --rt 128
     "b0.qkv": (200704, 128, 384, False, False), "b0.fc1": (200704, 128, 512, False, False), "b0.fc2": (200704, 512, 128, False, False),
     "b1.qkv": (50176, 256, 768, False, False), "b1.fc1": (50176, 256, 1024, False, False), "b1.fc2": (50176, 1024, 256, False, False),

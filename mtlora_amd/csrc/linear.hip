@@ -1579,6 +1579,54 @@ static void launch_sp_proj(const SpProjParams& q, int ch, int ns, hipStream_t s,
 #undef MTL_SP_PROJ
 }
 
+// ---- k_sp_projk (stream.h): the P / Q passes whose projection rows do not fit in LDS, for small row counts (one work item per
+// workgroup, reduction split over its waves).  Same parameter block as k_sp_proj; returns false when the shape is not eligible.
+template <typename T>
+static bool sp_projk_plan(SpProjParams& q, int& ch) {
+    if (sizeof(T) != 2 || sp_mode() == 0 || q.M <= 0 || q.n_src <= 0) return false;
+    static const int mode = [] { const char* e = getenv("MTLORA_SP_PROJK"); return e ? atoi(e) : 1; }();
+    if (mode == 0) return false;
+    ch = q.K % 96 == 0 ? 96 : (q.K % 64 == 0 ? 64 : 0);
+    if (ch == 0 || q.M >= ((int64_t)1 << 31) - 64) return false;
+    q.n_blk_total = (q.Rw + 31) / 32;
+    for (int s = 0; s < q.n_src; ++s) {
+        if (q.src[s].n_blk > SP_MAXB || q.src[s].n_blk <= 0) return false;
+        if (((uintptr_t)q.src[s].act & 15u) != 0) return false;
+    }
+    if ((q.ld_out % 8) != 0 || ((uintptr_t)q.out & 15u) != 0 || ((uintptr_t)q.wproj & 15u) != 0) return false;
+    if (q.M * q.ld_out * 2 >= ((int64_t)1 << 32) - 64) return false;
+    q.n_slabs = (int)mtl_ceil_div(q.M, 32);
+    q.n_items = q.n_slabs * q.n_src;
+    // every item re-reads the projection rows from L2 and pays three barriers: it wins while the whole launch is ONE residency round
+    // (stage 3: 196 slabs; 42 - 62 us -> 20 - 24 us), ties at two to three rounds and loses beyond (tools/projk_ab.sh)
+    return mode == 2 || ((int64_t)q.n_items <= (int64_t)sp_num_cu() && q.K / ch >= SP_WAVES);
+}
+template <typename T>
+static void launch_sp_projk(const SpProjParams& q, int ch, hipStream_t s, int kind, double alg_bytes, double s8d, double flops) {
+    mtl_prof_tag("sp_projk M%lld K%d R%d src%d ch%d", (long long)q.M, q.K, q.Rw, q.n_src, ch);
+    MtlProfScope prof(kind, alg_bytes, s, s8d, flops);
+    int64_t wgs = q.n_items;
+    if (wgs > (int64_t)sp_num_cu()) wgs = sp_num_cu();
+#define MTL_SP_PROJK(CHV, NSLV)                                                                                                 \
+    do {                                                                                                                         \
+        constexpr size_t slots = (size_t)SP_WAVES * NSLV * 32 * CHV * 2, red = (size_t)SP_WAVES * SP_MAXB * 4096;                \
+        constexpr size_t lds = slots > red ? slots : red;                                                                        \
+        static bool raised = false;                                                                                              \
+        if (!raised) {                                                                                                           \
+            (void)hipFuncSetAttribute((const void*)k_sp_projk<T, CHV, NSLV>, hipFuncAttributeMaxDynamicSharedMemorySize, SP_LDS_MAX); \
+            raised = true;                                                                                                       \
+        }                                                                                                                        \
+        hipLaunchKernelGGL((k_sp_projk<T, CHV, NSLV>), dim3((unsigned)wgs), dim3(64 * SP_WAVES), lds, s, q);                     \
+    } while (0)
+    if constexpr (sizeof(T) == 2) {
+        if (ch == 96)
+            MTL_SP_PROJK(96, 3);
+        else
+            MTL_SP_PROJK(64, 4);
+    }
+#undef MTL_SP_PROJK
+}
+
 template <typename T>
 static void launch_sp_projsum(const SpProjParams& q, int ch, int ns, T* gsum, hipStream_t s, int kind, double alg_bytes, double s8d,
                               double flops) {
@@ -2080,6 +2128,8 @@ static int fwd_impl(const mtlora_linear_desc* d, const void* x, const void* cons
                 const int ns = sp_proj_plan<T>(sp, ch);
                 if (ns > 0)
                     launch_sp_proj<T>(sp, ch, ns, s, PK_NT_FWD_P, xb, xb, 2.0 * d->M * d->K * rsum);
+                else if (sp_projk_plan<T>(sp, ch))
+                    launch_sp_projk<T>(sp, ch, s, PK_NT_FWD_P, xb, xb, 2.0 * d->M * d->K * rsum);
                 else
                     launch_nt<T>(q, s, PK_NT_FWD_P, xb, xb, 2.0 * d->M * d->K * rsum);
             }
@@ -2349,6 +2399,8 @@ static int bwd_impl(const mtlora_linear_desc* d, const void* x, const void* cons
             const int ns = sp_proj_plan<T>(sp, ch);
             if (ns > 0)
                 launch_sp_proj<T>(sp, ch, ns, s, PK_NT_BWD_Q, 0.0, 0.0, 2.0 * d->M * d->N * rsum);
+            else if (sp_projk_plan<T>(sp, ch))
+                launch_sp_projk<T>(sp, ch, s, PK_NT_BWD_Q, 0.0, 0.0, 2.0 * d->M * d->N * rsum);
             else
                 launch_nt<T>(q, s, PK_NT_BWD_Q, 0.0, 0.0, 2.0 * d->M * d->N * rsum);
         }

@@ -1261,3 +1261,146 @@ __global__ __launch_bounds__(256 * SP_TN_RG) void k_sp_tn_reduce(const SpTnParam
             pr.out[at] = tsum[k];
         }
 }
+
+// ------------------------------------------------------------------------------------------------
+// k_sp_projk : the P / Q passes whose projection rows do NOT fit in LDS next to the slots (K R too large: the fc2 forward and the
+// fc1 / qkv backward of stages 2 / 3, every layer of the r = 128 configurations) and whose row count is small.  The tiled kernel runs
+// these on ceil(M / 128) workgroups (98 - 196 of 256 CUs) with one k-tile of prefetch: 35 - 60 us for 20 - 50 MB.  Here ONE work
+// item (32-row slab, source) is a WORKGROUP and the reduction is split over its 8 waves: wave w takes the CH-wide chunks w, w + 8,
+// ... of the slab (DMA into its private slots, all of them in flight at once: a whole slab row block of 32 x K is requested in one
+// go), multiplies them with the matching columns of the projection rows -- read as MFMA fragments straight from global memory (the
+// rows are L2-resident: 0.1 - 0.5 MB shared by every workgroup) -- and the 8 partial accumulator sets are summed through LDS in a
+// fixed order (deterministic).  3 barriers per item; items are dealt round-robin to a persistent grid.
+// ------------------------------------------------------------------------------------------------
+template <typename T, int CH, int NSL>
+__global__ __launch_bounds__(64 * SP_WAVES, SP_WAVES / 4) void k_sp_projk(const SpProjParams Pv) {
+    typedef SpGeom<CH> G;
+    (void)Pv;
+    SpProjPtr P = (SpProjPtr)__builtin_amdgcn_kernarg_segment_ptr();
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5, rl = lane & 31;
+    const int K = P->K, NCH = K / CH;
+    const int n_items = P->n_items, n_src = P->n_src;
+    const int64_t M = P->M;
+    unsigned char* slots = smem + (size_t)wave * NSL * G::SLOT;
+    float* red = reinterpret_cast<float*>(smem);  // [wave][blk][reg][lane], aliases the slots (between barriers)
+    DropoutCfg drop;
+    drop.seed_lo = P->drop.seed_lo;
+    drop.seed_hi = P->drop.seed_hi;
+    drop.thr16 = P->drop.thr16;
+    drop.off = P->drop.off;
+    mtl_dropout_resolve(drop);
+    const T* wp = reinterpret_cast<const T*>(P->wproj);
+    const int Rw = P->Rw;
+
+    int goff[G::NDMA], grow[G::NDMA], fo[G::KS];
+#pragma unroll
+    for (int j = 0; j < G::NDMA; ++j) {
+        const int c = j * 64 + lane, row = c / G::CPR, p = c - row * G::CPR;
+        grow[j] = row;
+        goff[j] = row * K + G::logical(row, p) * 8;
+    }
+#pragma unroll
+    for (int ks = 0; ks < G::KS; ++ks) fo[ks] = rl * G::ROWB + G::phys(rl, 2 * ks + h) * 16;
+    const __amdgpu_buffer_rsrc_t orsrc = sp_rsrc(P->out, M * P->ld_out * 2);
+    const int nmy = wave < NCH ? (NCH - wave + SP_WAVES - 1) / SP_WAVES : 0;  // chunks of this wave: wave, wave + 8, ...
+
+    for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+        const int slab = item / n_src, s = item - slab * n_src;
+        const int blk_lo = P->src[s].blk_lo, n_blk = P->src[s].n_blk;
+        const bool masked = P->src[s].mask != 0 && drop.thr16 != 0;
+        const T* base = reinterpret_cast<const T*>(P->src[s].act) + (int64_t)slab * 32 * K;
+        const int last = (int)(M - 1 - (int64_t)slab * 32);  // >= 31 for a full slab
+        const uint32_t rh = mtl_dropout_rowhash(drop, 0u, (uint32_t)(slab * 32 + rl));
+        f32x16 acc[SP_MAXB];
+#pragma unroll
+        for (int b = 0; b < SP_MAXB; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
+        for (int j0 = 0; j0 < nmy; j0 += NSL) {  // groups of NSL chunks: all of a group's loads are in flight together
+            const int ng = nmy - j0 < NSL ? nmy - j0 : NSL;
+#pragma unroll
+            for (int u = 0; u < NSL; ++u) {
+                if (u < ng) {
+                    const T* cb = base + (wave + (j0 + u) * SP_WAVES) * CH;
+#pragma unroll
+                    for (int j = 0; j < G::NDMA; ++j) {
+                        const int r = grow[j] < last ? grow[j] : last;  // rows past M re-read row M - 1 (never stored)
+                        sp_dma16(cb + goff[j] + (r - grow[j]) * K, slots + u * G::SLOT + j * 1024);
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < NSL; ++u) {
+                if (u < ng) {
+                    const int ch = wave + (j0 + u) * SP_WAVES;
+                    // projection fragments of this chunk, straight from global memory (issued before the wait for the slab chunk)
+                    u32x4 wf[SP_MAXB][G::KS];
+#pragma unroll
+                    for (int b = 0; b < SP_MAXB; ++b) {
+                        if (b < n_blk) {
+                            const int row = (blk_lo + b) * 32 + rl;
+                            const T* wr = wp + (int64_t)(row < Rw ? row : Rw - 1) * K + ch * CH + 8 * h;
+#pragma unroll
+                            for (int ks = 0; ks < G::KS; ++ks) {
+                                wf[b][ks] = *reinterpret_cast<const u32x4*>(wr + ks * 16);
+                                if (row >= Rw) wf[b][ks] = u32x4{0u, 0u, 0u, 0u};
+                            }
+                        }
+                    }
+                    SP_WAIT_VM(0);
+                    const unsigned char* sl = slots + u * G::SLOT;
+                    u32x4 xf[G::KS];
+#pragma unroll
+                    for (int ks = 0; ks < G::KS; ++ks) xf[ks] = *reinterpret_cast<const u32x4*>(sl + fo[ks]);
+                    if (masked) {
+#pragma unroll
+                        for (int ks = 0; ks < G::KS; ++ks) VOps<T>::drop(xf[ks], drop, rh, (uint32_t)(ch * CH + ks * 16 + 8 * h));
+                    }
+#pragma unroll
+                    for (int b = 0; b < SP_MAXB; ++b) {
+                        if (b < n_blk) {
+#pragma unroll
+                            for (int ks = 0; ks < G::KS; ++ks) sp_mma1<T>(wf[b][ks], xf[ks], acc[b]);
+                        }
+                    }
+                }
+            }
+        }
+        // ---- sum of the 8 waves' partial accumulators (fixed order), conversion, store of the source's columns
+        SP_WAIT_LGKM0();
+        __syncthreads();  // every wave is done with its slots: the reduction image may alias them
+#pragma unroll
+        for (int b = 0; b < SP_MAXB; ++b) {
+            if (b < n_blk) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) red[((wave * SP_MAXB + b) * 16 + r) * 64 + lane] = acc[b][r];
+            }
+        }
+        __syncthreads();
+        {
+            // thread (m = tid & 31, cg = tid >> 5): the 8 output columns 8 cg .. 8 cg + 7 (relative to block blk_lo) of row m:
+            // column c' = 8 q + 4 hh + e of a block sits in register 4 q + e of lane m + 32 hh
+            const int m = tid & 31, cg = tid >> 5;
+            const int b = cg >> 2, q = cg & 3;
+            if (b < n_blk) {
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int hh = j >> 2, e = j & 3;
+                    float sum = 0.f;
+#pragma unroll
+                    for (int w = 0; w < SP_WAVES; ++w) sum += red[((w * SP_MAXB + b) * 16 + 4 * q + e) * 64 + m + 32 * hh];
+                    v[j] = sum;
+                }
+                const int col = (blk_lo + b) * 32 + 8 * q;
+                const int64_t row = (int64_t)slab * 32 + m;
+                const u32x4 o = u32x4{mtl_pk2<T>(v[0], v[1]), mtl_pk2<T>(v[2], v[3]), mtl_pk2<T>(v[4], v[5]), mtl_pk2<T>(v[6], v[7])};
+                const bool ok = col >= P->src[s].col_lo && col < P->src[s].col_hi && row < M;
+                sp_bstore(o, orsrc, ok ? (uint32_t)row * (uint32_t)(P->ld_out * 2) + (uint32_t)col * 2u : 0xFFFFFFFFu);
+            }
+        }
+        __syncthreads();  // the image is read: the next item's loads may overwrite it
+    }
+}

@@ -1342,7 +1342,7 @@ static void launch_nt(const NtParams& P_in, hipStream_t s, int kind, double alg_
         // lean single-output bf16 launches (forward outputs, P / Q passes, rank-0 GEMMs, and the dX of layers without task
         // outputs -- masked rank part): the straight-line kernel
         // MFMA-dense launches (long reduction, enough tiles): k_ntd (dense.h).  MTLORA_NTD: 0 never, 2 whenever the shape allows
-        static const int ntd_mode = [] { const char* e = getenv("MTLORA_NTD"); return e ? atoi(e) : 1; }();
+        const int ntd_mode = [] { const char* e = getenv("MTLORA_NTD"); return e ? atoi(e) : 1; }();  // (read per call: the "[dense]" test variants)
         bool dense = false;
         if (variant == 2 && P.n_out == 1 && P.nz == 0 && ntd_mode != 0 && P.act_mask == 0 && P.n_rows % 8 == 0 && P.n_rows >= 64 &&
             P.M < (int64_t)0x7FFFFF00 && P.out[0].ptr != nullptr && !(P.out[0].gate && P.out[0].act)) {
@@ -1584,7 +1584,7 @@ static void launch_sp_proj(const SpProjParams& q, int ch, int ns, hipStream_t s,
 template <typename T>
 static bool sp_projk_plan(SpProjParams& q, int& ch) {
     if (sizeof(T) != 2 || sp_mode() == 0 || q.M <= 0 || q.n_src <= 0) return false;
-    static const int mode = [] { const char* e = getenv("MTLORA_SP_PROJK"); return e ? atoi(e) : 1; }();
+    const int mode = [] { const char* e = getenv("MTLORA_SP_PROJK"); return e ? atoi(e) : 1; }();
     if (mode == 0) return false;
     ch = q.K % 96 == 0 ? 96 : (q.K % 64 == 0 ? 64 : 0);
     if (ch == 0 || q.M >= ((int64_t)1 << 31) - 64) return false;

@@ -36,25 +36,37 @@ _TILED_TESTS = ("linear", "mlp", "swin_block", "backbone", "config_model", "modu
                 "reducer_on_the_real_model")
 
 
-@pytest.fixture(autouse=True, params=["auto", "tiled"])
+# "dense": every launch that is ELIGIBLE for one of the shape-selected kernels takes it, whatever the size heuristics say (k_ntd for
+# the single-output GEMMs, k_sp_tn for the factor gradients, k_sp_projk for the P / Q passes with large K R): the test shapes are
+# far below the sizes at which the library picks them on its own
+_DENSE_TESTS = ("linear", "mlp", "swin_block")
+
+
+@pytest.fixture(autouse=True, params=["auto", "tiled", "dense"])
 def _kernel_family(request, monkeypatch):
+    for k in ("MTLORA_SP", "MTLORA_NTD", "MTLORA_SP_TN", "MTLORA_SP_PROJK"):
+        monkeypatch.delenv(k, raising=False)
     if request.param == "tiled":
         monkeypatch.setenv("MTLORA_SP", "0")
-    else:
-        monkeypatch.delenv("MTLORA_SP", raising=False)
+        monkeypatch.setenv("MTLORA_NTD", "0")
+    elif request.param == "dense":
+        monkeypatch.setenv("MTLORA_NTD", "2")
+        monkeypatch.setenv("MTLORA_SP_TN", "2")
+        monkeypatch.setenv("MTLORA_SP_PROJK", "2")
     yield
 
 
 def pytest_collection_modifyitems(config, items):
     keep = []
     for it in items:
-        if "[tiled" in it.name or "-tiled]" in it.name:
+        variant = next((v for v in ("tiled", "dense") if f"[{v}" in it.name or f"-{v}]" in it.name), None)
+        if variant:
             is_gpu = it.get_closest_marker("gpu") is not None
-            wants = any(k in it.name for k in _TILED_TESTS)
+            wants = any(k in it.name for k in (_TILED_TESTS if variant == "tiled" else _DENSE_TESTS))
             import torch
             vals = list(getattr(getattr(it, "callspec", None), "params", {}).values())
             fp32_only = ("fp32" in it.name) or (torch.float32 in vals and torch.bfloat16 not in vals and torch.float16 not in vals)
-            if not (is_gpu and wants) or fp32_only:  # (the streaming kernels are 16-bit only: fp32 cases have one path)
+            if not (is_gpu and wants) or fp32_only:  # (the selected kernels are 16-bit only: fp32 cases have one path)
                 continue
         keep.append(it)
     items[:] = keep

@@ -37,7 +37,8 @@ constexpr int ND_ORS = 128 + 8;                        // epilogue image row str
 
 template <bool ACT, bool MLR, bool GATE>
 __global__ __launch_bounds__(512, 2) void k_ntd(const NlParams P) {
-    constexpr int EPI_OPS = 8 * (1 + (ACT ? 1 : 0) + (GATE ? 1 : 0));  // vector-memory operations of one epilogue, per wave
+    constexpr int EPI_OPS = 8 * (1 + (ACT ? 1 : 0));  // vector-memory operations of one epilogue (its stores), per wave.  [The gate
+    // values are loaded BEFORE the last k-tile is multiplied -- older than the next tile's first stages, so they do not count here.]
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
@@ -160,6 +161,8 @@ __global__ __launch_bounds__(512, 2) void k_ntd(const NlParams P) {
             }
 
         int slot = base_slot;
+        u32x4 hv[2][4];  // GATE: the pre-activations of this wave's 64 x 64 tile, in the order the epilogue stores it
+        (void)hv;
         for (int i = 0; i < total; ++i) {
             // operations issued after stage i's loads: stage i + 1 (if any) and, for the first two stages of a tile that follows
             // another one, that tile's epilogue
@@ -174,6 +177,19 @@ __global__ __launch_bounds__(512, 2) void k_ntd(const NlParams P) {
                 SP_WAIT_VM(0);
             __syncthreads();  // stage i is complete for every wave; every wave is done reading stage i - 1 (and its epilogue images)
             if (i + 2 < total) issue(i + 2, slot >= 1 ? slot - 1 : slot + 2);
+            if constexpr (GATE) {
+                if (i + 1 == total) {  // in flight while the last k-tile is multiplied; consumed by the epilogue
+                    const int n = n0 + wn * 64 + (lane & 7) * 8;
+#pragma unroll
+                    for (int sm = 0; sm < 2; ++sm)
+#pragma unroll
+                        for (int it = 0; it < 4; ++it) {
+                            const int m = m0 + wm * 64 + sm * 32 + it * 8 + (lane >> 3);
+                            const uint32_t off = (m < M && n < n_rows) ? (uint32_t)m * ldo2 + (uint32_t)n * 2u : 0xFFFFFFFFu;
+                            hv[sm][it] = __builtin_amdgcn_raw_buffer_load_b128(grsrc, (int)off, 0, 0);
+                        }
+                }
+            }
             const unsigned char* st = smem + slot * ND_STAGE;
             const unsigned char* sw = st + w_off;
             const unsigned char* sa = st + a_off;
@@ -274,11 +290,10 @@ __global__ __launch_bounds__(512, 2) void k_ntd(const NlParams P) {
                     u32x4 v = *reinterpret_cast<const u32x4*>(img + ml * ND_ORS + c16 * 16);
                     const uint32_t off = (m < M && n < n_rows) ? (uint32_t)m * ldo2 + (uint32_t)n * 2u : 0xFFFFFFFFu;
                     if constexpr (GATE) {  // the bf16-rounded gradient times gelu'(pre-activation), rounded once (as ATen does)
-                        const u32x4 hv = __builtin_amdgcn_raw_buffer_load_b128(grsrc, (int)off, 0, 0);
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
-                            const float g0 = mtl_lo2<bf16>(v[q]) * gelu_grad(mtl_lo2<bf16>(hv[q]));
-                            const float g1 = mtl_hi2<bf16>(v[q]) * gelu_grad(mtl_hi2<bf16>(hv[q]));
+                            const float g0 = mtl_lo2<bf16>(v[q]) * gelu_grad(mtl_lo2<bf16>(hv[sm][it][q]));
+                            const float g1 = mtl_hi2<bf16>(v[q]) * gelu_grad(mtl_hi2<bf16>(hv[sm][it][q]));
                             v[q] = mtl_pack_bf16(g0, g1);
                         }
                     }

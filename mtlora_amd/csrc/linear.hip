@@ -1685,7 +1685,7 @@ static bool sp_xres_plan(SpLinParams& q, int K, SpXresPlan& pl) {
     q.estep = 2 * ((q.R + 31) / 32);
     if ((q.n_cols % 8) != 0 || (q.ld_out % 8) != 0 || (q.ldp % 8) != 0) return false;
     if (q.M * q.ld_out * 2 >= ((int64_t)1 << 32) - 64 || q.M * q.ldp * 2 >= ((int64_t)1 << 32) - 64) return false;  // 32-bit store offsets
-    const void* ptrs[] = {q.act, q.w, q.proj, q.expand, q.out, q.out2, q.pout};
+    const void* ptrs[] = {q.act, q.w, q.proj, q.expand, q.out, q.out2, q.pout, q.gate};
     for (const void* pp : ptrs)
         if (((uintptr_t)pp & 15u) != 0) return false;
     const int nb_all = (q.n_cols + 31) / 32;
@@ -1730,18 +1730,23 @@ static bool sp_xres_plan(SpLinParams& q, int K, SpXresPlan& pl) {
 }
 template <typename T>
 static void launch_sp_xres(const SpLinParams& q, const SpXresPlan& pl, bool act, hipStream_t s, int kind, double alg_bytes, double s8d,
-                           double flops) {
+                           double flops, bool gate = false) {
     mtl_prof_tag("sp_xres M%lld K%d N%d R%d parts%d stg%d", (long long)q.M, pl.ch * pl.nkc, q.n_cols, q.R, q.n_parts, pl.stg ? 1 : 0);
     MtlProfScope prof(kind, alg_bytes, s, s8d, flops);
-#define MTL_SP_X(CHV, NKCV, NRBV, ACTV, STGV)                                                                                          \
+#define MTL_SP_X1(CHV, NKCV, NRBV, ACTV, STGV, GAV)                                                                                     \
     do {                                                                                                                                \
         static bool raised = false;                                                                                                     \
         if (!raised) {                                                                                                                  \
-            (void)hipFuncSetAttribute((const void*)k_sp_xres<T, CHV, NKCV, NRBV, ACTV, STGV>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+            (void)hipFuncSetAttribute((const void*)k_sp_xres<T, CHV, NKCV, NRBV, ACTV, STGV, GAV>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                       SP_LDS_MAX);                                                                                      \
             raised = true;                                                                                                              \
         }                                                                                                                               \
-        hipLaunchKernelGGL((k_sp_xres<T, CHV, NKCV, NRBV, ACTV, STGV>), dim3(pl.grid), dim3(64 * SP_WAVES), pl.lds, s, q);              \
+        hipLaunchKernelGGL((k_sp_xres<T, CHV, NKCV, NRBV, ACTV, STGV, GAV>), dim3(pl.grid), dim3(64 * SP_WAVES), pl.lds, s, q);         \
+    } while (0)
+#define MTL_SP_X(CHV, NKCV, NRBV, ACTV, STGV)                                    \
+    do {                                                                         \
+        if (!(ACTV) && gate) MTL_SP_X1(CHV, NKCV, NRBV, false, STGV, true);      \
+        else MTL_SP_X1(CHV, NKCV, NRBV, ACTV, STGV, false);                      \
     } while (0)
 #define MTL_SP_X_S(CHV, NKCV, NRBV, ACTV)                        \
     do {                                                         \
@@ -1769,6 +1774,7 @@ static void launch_sp_xres(const SpLinParams& q, const SpXresPlan& pl, bool act,
 #undef MTL_SP_X_R
 #undef MTL_SP_X_S
 #undef MTL_SP_X
+#undef MTL_SP_X1
 }
 
 // ---- fused wave-streaming launch, accumulator-resident form (k_sp_ares, stream.h): few output columns, any reduction length
@@ -2320,7 +2326,7 @@ static int bwd_impl(const mtlora_linear_desc* d, const void* x, const void* cons
 
     // T = 0 layers whose input is narrow: Q, the masked rank part and dY W in ONE wave-streaming pass over dY (stream.h)
     bool sp_dx_done = false;
-    if (d->T == 0 && d->mode == 0 && do_dx && dx && dyo[0] && sg.R > 0 && !gate_s) {
+    if (d->T == 0 && d->mode == 0 && do_dx && dx && dyo[0] && sg.R > 0) {
         SpLinParams q = {};
         q.act = dyo[0];
         q.w = Wt;
@@ -2336,12 +2342,22 @@ static int bwd_impl(const mtlora_linear_desc* d, const void* x, const void* cons
         q.mask_act = 0;
         q.mask_lr = 1;
         q.drop = dc;
+        const double b8d = (double)sizeof(T) * d->M * ((double)d->N + d->K);
+        const double fl = 2.0 * d->M * (double)d->N * d->K + 2.0 * d->M * (double)sg.r[0] * (d->K + d->N);
         SpAresPlan pl;
-        if (sp_ares_plan<T>(q, (int)d->N, pl)) {
-            const double b8d = (double)sizeof(T) * d->M * ((double)d->N + d->K);
-            const double fl = 2.0 * d->M * (double)d->N * d->K + 2.0 * d->M * (double)sg.r[0] * (d->K + d->N);
+        SpXresPlan px;
+        if (!gate_s && sp_ares_plan<T>(q, (int)d->N, pl)) {
             launch_sp_ares<T>(q, pl, s, PK_NT_BWD_DX, b8d, b8d, fl);
             sp_dx_done = true;
+        } else {
+            // wide input, short reduction (the Mlp's fc2: dX has 4 C columns, the reduction C <= 192): the activation-resident form,
+            // with the GELU' gate of the fused Mlp in its epilogue
+            q.gate = gate_s;
+            if (sp_xres_plan<T>(q, (int)d->N, px)) {
+                launch_sp_xres<T>(q, px, false, s, PK_NT_BWD_DX, b8d + (gate_s ? (double)sizeof(T) * d->M * d->K : 0.0), b8d, fl, gate_s != nullptr);
+                sp_dx_done = true;
+            }
+            q.gate = nullptr;
         }
     }
 

@@ -290,6 +290,7 @@ struct SpLinParams {
     const float* bias;   // (n_cols) or null
     void* out;           // (M x ld_out)
     void* out2;          // ACT: gelu(out), same layout
+    const void* gate;    // GATE: out *= gelu'(gate[m][n]), same layout as out (the Mlp's fc2 dX)
     void* pout;          // (M x ldp) projection image for the factor gradients, nullable
     int64_t ld_out, ldp, M;
     int n_cols, R, n_parts, blk_per_part;
@@ -320,7 +321,7 @@ __device__ __forceinline__ void sp_wait_younger(int n) {
         SP_WAIT_VM(0);
 }
 
-template <typename T, int CH, int NKC, int NRB, bool ACT, bool STG>
+template <typename T, int CH, int NKC, int NRB, bool ACT, bool STG, bool GATE = false>
 __global__ __launch_bounds__(64 * SP_WAVES, SP_WAVES / 4) void k_sp_xres(const SpLinParams Pv) {
     typedef SpGeom<CH> G;
     constexpr int KST = NKC * G::KS;  // MFMA k-steps of the whole reduction
@@ -428,6 +429,8 @@ __global__ __launch_bounds__(64 * SP_WAVES, SP_WAVES / 4) void k_sp_xres(const S
     const __amdgpu_buffer_rsrc_t orsrc = sp_rsrc(P->out, M * P->ld_out * 2), o2rsrc = sp_rsrc(P->out2, P->out2 ? M * P->ld_out * 2 : 0),
                                  prsrc = sp_rsrc(P->pout, P->pout ? M * P->ldp * 2 : 0);
     (void)o2rsrc;
+    const __amdgpu_buffer_rsrc_t grsrc = sp_rsrc(const_cast<void*>(P->gate), (GATE && P->gate) ? M * P->ld_out * 2 : 0);
+    (void)grsrc;
     const uint32_t ldo2 = (uint32_t)(P->ld_out * 2);
     int st_since = 0;  // store instructions certainly issued since the chunk now in flight was requested
 
@@ -496,8 +499,31 @@ __global__ __launch_bounds__(64 * SP_WAVES, SP_WAVES / 4) void k_sp_xres(const S
         };
         constexpr bool PF = KST <= 8 && SP_WAVES <= 8;  // register room for the next block's fragments next to the epilogue's temporaries
         if constexpr (PF) load_blk(0);
+        u32x4 hv[4];  // GATE: pre-activations of the block (pair) about to be produced, loaded before its MFMAs
+        (void)hv;
         for (int nb = 0; nb < nbn; ++nb) {
             if constexpr (!PF) load_blk(nb);
+            if constexpr (GATE) {
+                if constexpr (STG) {
+                    if (!(nb & 1)) {  // first block of a pair: the 4 x (8 rows x 128 bytes) the flush will store
+                        const int c16 = lane & 7, col = (nb0 + nb) * 32 + c16 * 8;
+                        const bool colok = col < n_cols && (c16 < 4 || nb + 1 < nbn);
+                        const uint32_t o0 = ((uint32_t)slab * 32u + (uint32_t)(lane >> 3)) * ldo2 + (uint32_t)col * 2u;
+#pragma unroll
+                        for (int it = 0; it < 4; ++it)
+                            hv[it] = __builtin_amdgcn_raw_buffer_load_b128(grsrc, (int)(colok ? o0 + (uint32_t)(it * 8) * ldo2 : 0xFFFFFFFFu), 0, 0);
+                        st_since += 4;
+                    }
+                } else {
+                    const uint32_t rowoff = (uint32_t)m * ldo2;
+#pragma unroll
+                    for (int q = 0; q < 4; q += 2) {
+                        const int col = (nb0 + nb) * 32 + 8 * q + 8 * h;
+                        hv[q >> 1] = __builtin_amdgcn_raw_buffer_load_b128(grsrc, (int)(col < n_cols ? rowoff + (uint32_t)col * 2u : 0xFFFFFFFFu), 0, 0);
+                    }
+                    st_since += 2;
+                }
+            }
             f32x16 acc;
 #pragma unroll
             for (int q = 0; q < 4; ++q)
@@ -545,6 +571,12 @@ __global__ __launch_bounds__(64 * SP_WAVES, SP_WAVES / 4) void k_sp_xres(const S
 #pragma unroll
                     for (int it = 0; it < 4; ++it) {
                         const uint32_t off = (colok && !(dbg & 1)) ? o0 + (uint32_t)(it * 8) * ldo2 : 0xFFFFFFFFu;
+                        if constexpr (GATE) {  // the rounded gradient times gelu'(pre-activation), rounded once (as ATen does)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                v[it][e] = mtl_pk2<T>(mtl_lo2<T>(v[it][e]) * gelu_grad(mtl_lo2<T>(hv[it][e])),
+                                                      mtl_hi2<T>(v[it][e]) * gelu_grad(mtl_hi2<T>(hv[it][e])));
+                        }
                         sp_bstore(v[it], orsrc, off);
                         if constexpr (ACT) {
                             u32x4 av;
@@ -564,6 +596,11 @@ __global__ __launch_bounds__(64 * SP_WAVES, SP_WAVES / 4) void k_sp_xres(const S
                     sp_pack_pair<T>(acc, q, h, v);
                     const int col = col0 + 8 * q + 8 * h;
                     const uint32_t off = (col < n_cols && !(dbg & 1)) ? rowoff + (uint32_t)col * 2u : 0xFFFFFFFFu;
+                    if constexpr (GATE) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            v[e] = mtl_pk2<T>(mtl_lo2<T>(v[e]) * gelu_grad(mtl_lo2<T>(hv[q >> 1][e])), mtl_hi2<T>(v[e]) * gelu_grad(mtl_hi2<T>(hv[q >> 1][e])));
+                    }
                     sp_bstore(v, orsrc, off);
                     if constexpr (ACT) {
                         u32x4 av;

@@ -43,7 +43,7 @@ _factor_stream: Optional["torch.cuda.Stream"] = None
 # layers with fewer rows than this keep their factor gradients on the main stream: the fork / join costs ~30 us of host time per
 # layer and only pays while the kernels are long enough for the GPU to be the bottleneck (C1 at batch 2, M <= 6272 everywhere,
 # ran 35 % SLOWER with the side stream: 18.7 vs 13.8 ms / step)
-_FACTOR_MIN_M = int(os.environ.get("MTLORA_FACTOR_MIN_M", "16384"))
+_FACTOR_MIN_M = int(os.environ.get("MTLORA_FACTOR_MIN_M", "8192"))
 
 
 # parameters whose factor gradient is being written on the side stream in the backward now running (ids): a second use of the

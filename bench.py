@@ -168,8 +168,8 @@ def roofline(step_fn, steps):
         except Exception:
             continue
     return {"bound": "hbm" if hbm_frac >= mfma_frac else "mfma",
-            "kernel": "MTLoRALinear hot-path launches: fused forward / dX (k_sp_xres / k_sp_ares wave-streaming, k_nt / k_ntl tiled) "
-                      "and the low-rank P / Q passes that remain (k_sp_proj / k_nt)",
+            "kernel": "MTLoRALinear hot-path launches: fused forward / dX (k_sp_xres / k_sp_ares wave-streaming, k_nt / k_ntl / k_ntd tiled) "
+                      "and the low-rank P / Q passes that remain (k_sp_proj / k_sp_projsum / k_sp_projk / k_nt)",
             "achieved": round(ach8, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hbm_frac, 4),
             "frac_achievable": round(ach8 / HBM_ACHIEVABLE_GBS, 4),
             "definition": "SURVEY 8(d) bytes of these launches / their HIP-event time / 8 TB/s (frac_achievable: / 6.29 TB/s)",
@@ -179,7 +179,7 @@ def roofline(step_fn, steps):
             "launched": {"achieved": round(achl, 1), "frac": round(achl / HBM_PEAK_GBS, 4),
                          "what": "same launches, fused GELU write / GELU' gate read counted as useful bytes"},
             "mfma": {"achieved": round(tfl, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(mfma_frac, 4)},
-            "linear_path": {"what": "k_nt + k_tn + k_pack + k_tn_reduce + k_sum vs the whole 8(d) MTLoRALinear bytes",
+            "linear_path": {"what": "hot-path launches + factor gradients (k_sp_tn / k_tn) + k_pack + reduce + k_sum vs the whole 8(d) MTLoRALinear bytes",
                             "ms_per_step": round(lms / steps, 3), "s8d_GB_per_step": round(lb8 / steps / 1e9, 3),
                             "GBps": round(gbs(lb8, lms), 1), "frac": round(gbs(lb8, lms) / HBM_PEAK_GBS, 4),
                             "TFLOPs": round((lfl / 1e12) / (lms / 1e3), 1) if lms > 0 else None},

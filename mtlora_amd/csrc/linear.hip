@@ -1351,7 +1351,7 @@ static void launch_nt(const NtParams& P_in, hipStream_t s, int kind, double alg_
             const int ksteps = (seg + ND_KE - 1) / ND_KE + (kk + ND_KE - 1) / ND_KE;
             const int64_t tiles = mtl_ceil_div(P.M, ND_TM) * mtl_ceil_div(P.n_rows, ND_TN);
             const int64_t lim = ((int64_t)1 << 32) - 4096;
-            const bool fits = P.M * P.ld_act * 2 < lim && P.M * P.ldL * 2 < lim && (int64_t)P.n_rows * P.ld_wgt * 2 < lim &&
+            const bool fits = P.M * P.ld_out * 2 < lim && P.M * P.ld_act * 2 < lim && P.M * P.ldL * 2 < lim && (int64_t)P.n_rows * P.ld_wgt * 2 < lim &&
                               (int64_t)P.n_rows * P.ldR * 2 < lim && P.K % 8 == 0 && seg % 8 == 0 && (P.ld_act % 8) == 0 && (P.ld_wgt % 8) == 0 &&
                               (P.ldL % 8) == 0 && (P.ldR % 8) == 0 && (P.L == nullptr || (P.out[0].seg_lo % 8) == 0);
             // where it wins (tools/ntd_ab.sh): a reduction of >= 6 k-tiles, residency rounds (one workgroup per CU) at least 70 % full or

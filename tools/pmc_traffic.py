@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """profiles/rNN_pmc_traffic[_cfg].json from the two PMC passes of tools/pmc.sh (FETCH_SIZE and WRITE_SIZE, KB, summed per kernel):
     python tools/pmc_traffic.py gpurun_out/pmc_fetch.csv gpurun_out/pmc_write.csv [steps=2] [fetch.csv write.csv names to cite] > profiles/...json
-"k_nt" = every MTLoRALinear GEMM launch: the tiled kernels (k_nt / k_ntl) AND the wave-streaming ones (k_sp_*).
+"k_nt" = every MTLoRALinear GEMM launch: the tiled kernels (k_nt / k_ntl / k_ntd) AND the wave-streaming ones (k_sp_proj / xres / ares /
+projsum / projk); "k_tn" = the factor gradients (k_tn and k_sp_tn).
 FETCH_SIZE is doubled (gfx950 note in MI355X_MICROARCH.md, HBM section: wide coalesced reads are tallied at half their bytes)."""
 import csv, json, sys
 
@@ -25,9 +26,12 @@ def main():
            "files": sys.argv[4:6] if len(sys.argv) > 5 else ["profiles/r03_pmc_fetch.csv", "profiles/r03_pmc_write.csv"]}
     for g, key in GROUPS.items():
         def match(n):
+            tn = "k_tn" in n or "k_sp_tn" in n  # factor-gradient kernels (tiled / wave-streaming) and their reduce kernels
             if g == "k_nt":
-                return "k_nt" in n or "k_sp_" in n
-            return key in n and not (g == "k_tn" and "k_tn_reduce" in n)
+                return ("k_nt" in n or "k_sp_" in n) and not tn
+            if g == "k_tn":
+                return tn and "reduce" not in n
+            return key in n
         d = sum(v[0] for n, v in fetch.items() if match(n))
         if d == 0:
             continue

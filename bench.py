@@ -355,11 +355,11 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(row)
     if default and world == 1 and not args.no_other_configs and not args.batch:
-        # the other single-GPU BASELINE configs, short legs (5 steps, no baselines): Swin-B r=128 and the 8-task r=4 sweep point
+        # the other single-GPU BASELINE configs, short legs (8 steps after 3 warm-up steps, no baselines): Swin-B r=128 and the 8-task r=4 sweep point
         others = {}
         for name in ("c4", "c5:4"):
             try:
-                _, Bo, _, f = run_config(args, name, rank, world, dev, 5, 2, not args.no_roofline)
+                _, Bo, _, f = run_config(args, name, rank, world, dev, 8, 3, not args.no_roofline)
                 o = {"value": f["value"], "unit": "images/sec", "ms_per_step": f["ms_per_step"], "per_gpu_batch": Bo,
                      "workload": f["config"]["workload"], "host_issue_ms_per_step": f["config"]["host_issue_ms_per_step"]}
                 if "roofline" in f:

@@ -1283,6 +1283,82 @@ __global__ __launch_bounds__(256) void k_sum(SumParams P, T* out) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_rank_out : the task outputs of a dX launch,  dX_t = Q_t A_t  [.* gelu'(h_t)],  for SMALL task ranks (rp <= 16).
+// They share nothing with the base GEMM (no dY W term), and with r_t = 4 the "GEMM" is 8 multiply-adds per element: in the tiled
+// multi-output kernel each of them costs a full tile pass (rank k-tile staging, MFMA on a mostly-zero k-tile, LDS transposition) --
+// the T = 4 fc2 dX spent ~180 us per task output at stage 0.  Here it is a streaming elementwise kernel: a thread owns ONE 16-byte
+// column chunk (its rp x 8 factor values live in registers) and walks the rows, 4 in flight; rounding as the tiled epilogue
+// (fp32 sum -> T, then T * gelu'(h) -> T).
+// ------------------------------------------------------------------------------------------------
+struct RankOutParams {
+    const void* Q;      // (M x ldq)
+    const void* Acat;   // (R x K) row-major, unscaled (Q carries alpha)
+    int64_t ldq, M;
+    int K, n_t;
+    int seg[MAXO], rp[MAXO];
+    void* out[MAXO];
+    const void* gate[MAXO];
+};
+template <typename T, bool GATE, int RP>
+__global__ __launch_bounds__(256) void k_rank_out(const RankOutParams P) {
+    constexpr int UNR = 4;
+    const int t = blockIdx.y;
+    const int nchunk = P.K >> 3;
+    const int rpb = 256 / nchunk;  // rows per block sweep (nchunk <= 256)
+    const int tid = threadIdx.x;
+    if (tid >= rpb * nchunk) return;
+    const int chunk = tid % nchunk, r0 = tid / nchunk;
+    const int seg = P.seg[t];
+    float a[RP][8];
+#pragma unroll
+    for (int j = 0; j < RP; ++j) {
+        const u32x4 v = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(P.Acat) + (int64_t)(seg + j) * P.K + chunk * 8);
+        VOps<T>::unpack(v, a[j]);
+    }
+    const T* q = reinterpret_cast<const T*>(P.Q) + seg;
+    T* out = reinterpret_cast<T*>(P.out[t]);
+    const T* gate = reinterpret_cast<const T*>(P.gate[t]);
+    const int64_t step = (int64_t)gridDim.x * rpb;
+    for (int64_t row = (int64_t)blockIdx.x * rpb + r0; row < P.M; row += UNR * step) {
+        u32x4 qv[UNR][RP / 8], hv[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int64_t m = row + u * step;
+            const int64_t mc = m < P.M ? m : P.M - 1;
+#pragma unroll
+            for (int w = 0; w < RP / 8; ++w) qv[u][w] = *reinterpret_cast<const u32x4*>(q + mc * P.ldq + w * 8);
+            if constexpr (GATE) hv[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(gate + mc * P.K + chunk * 8));
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int64_t m = row + u * step;
+            float acc[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+#pragma unroll
+            for (int w = 0; w < RP / 8; ++w) {
+                float qf[8];
+                VOps<T>::unpack(qv[u][w], qf);
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc[e] += qf[j] * a[w * 8 + j][e];
+            }
+            u32x4 o = VOps<T>::pack(acc);
+            if constexpr (GATE) {
+                float of[8], hf[8];
+                VOps<T>::unpack(o, of);
+                VOps<T>::unpack(hv[u], hf);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) of[e] *= gelu_grad(hf[e]);
+                o = VOps<T>::pack(of);
+            }
+            if (m < P.M) __builtin_nontemporal_store(o, reinterpret_cast<u32x4*>(out + m * P.K + chunk * 8));
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
 static int check_desc(const mtlora_linear_desc* d) {
@@ -2425,6 +2501,9 @@ static int bwd_impl(const mtlora_linear_desc* d, const void* x, const void* cons
     // dX = G W + keep .* (Q_s A_s [+ sum_t Q_t A_t]),  dX_t = Q_t A_t
     if (do_dx && !sp_dx_done) {
         NtParams m = {};
+        RankOutParams rank_out = {};
+        int rank_out_rp = 8;
+        bool rank_out_gated = false;
         if (presum && have_g) {
             m.n_act = 1;
             m.act[0] = Gm;
@@ -2453,7 +2532,40 @@ static int bwd_impl(const mtlora_linear_desc* d, const void* x, const void* cons
         if (d->T > 0 && d->has_x_tasks) {
             O.seg_lo = sg.off[0];
             O.seg_hi = sg.off[0] + sg.rp[0];
-            for (int t = 0; t < d->T; ++t) {
+            // small task ranks: the task outputs are a streaming elementwise kernel of their own (k_rank_out), not tile passes
+            if constexpr (sizeof(T) == 2) {
+                static const int ro_mode = [] { const char* e = getenv("MTLORA_RANK_OUT"); return e ? atoi(e) : 1; }();
+                bool ok = sp_mode() != 0 && ro_mode != 0 && dx_t != nullptr && d->K % 8 == 0 && d->K / 8 <= 256 && d->M > 0;
+                int rpm = 0, gates = 0, outs = 0;
+                for (int t = 0; t < d->T; ++t) {
+                    if (!dx_t || !dx_t[t]) continue;
+                    ++outs;
+                    rpm = sg.rp[t + 1] > rpm ? sg.rp[t + 1] : rpm;
+                    gates += (gate_t && gate_t[t]) ? 1 : 0;
+                    ok = ok && sg.rp[t + 1] > 0 && !misaligned(dx_t[t]) && !(gate_t && gate_t[t] && misaligned(gate_t[t]));
+                }
+                for (int t = 0; t < d->T; ++t)
+                    if (dx_t && dx_t[t]) ok = ok && sg.rp[t + 1] == rpm;  // one register geometry per launch
+                ok = ok && outs > 0 && rpm <= 16 && (gates == 0 || gates == outs) && !misaligned(Qm) && (sg.R % 8) == 0;
+                if (ok) {
+                    rank_out.Q = Qm;
+                    rank_out.Acat = pk + L.a_cat;
+                    rank_out.ldq = sg.R;
+                    rank_out.M = d->M;
+                    rank_out.K = (int)d->K;
+                    for (int t = 0; t < d->T; ++t) {
+                        if (!dx_t[t]) continue;
+                        const int i = rank_out.n_t++;
+                        rank_out.seg[i] = sg.off[t + 1];
+                        rank_out.rp[i] = sg.rp[t + 1];
+                        rank_out.out[i] = dx_t[t];
+                        rank_out.gate[i] = gate_t ? gate_t[t] : nullptr;
+                    }
+                    rank_out_rp = rpm <= 8 ? 8 : 16;
+                    rank_out_gated = gates > 0;
+                }
+            }
+            for (int t = 0; t < d->T && rank_out.n_t == 0; ++t) {
                 if (!dx_t || !dx_t[t]) continue;
                 NtOut& Ot = m.out[m.n_out++];
                 Ot.ptr = dx_t[t];
@@ -2471,7 +2583,8 @@ static int bwd_impl(const mtlora_linear_desc* d, const void* x, const void* cons
         if (dx) {
             int n_gate = 0;  // the fused GELU backward reads the pre-activation of every gated output (algorithmic: gelu'(h) needs h)
             for (int o = 0; o < m.n_out; ++o) n_gate += m.out[o].gate ? 1 : 0;
-            const double b8d = (double)sizeof(T) * d->M * ((double)n_dy * d->N + (double)(1 + (d->has_x_tasks ? d->T : 0)) * d->K);
+            const int n_xt = rank_out.n_t > 0 ? 0 : (d->has_x_tasks ? d->T : 0);  // task outputs written by THIS launch
+            const double b8d = (double)sizeof(T) * d->M * ((double)n_dy * d->N + (double)(1 + n_xt) * d->K);
             double rsum = 0.0;
             for (int o = 0; o < sg.n; ++o)
                 if (sg.rp[o] > 0 && dyo[o]) rsum += sg.r[o];
@@ -2479,6 +2592,26 @@ static int bwd_impl(const mtlora_linear_desc* d, const void* x, const void* cons
             const bool plain = sg.R == 0;
             launch_nt<T>(m, s, plain ? PK_NT_PLAIN_DX : PK_NT_BWD_DX, b8d + (double)sizeof(T) * d->M * (double)n_gate * d->K,
                          plain ? 0.0 : b8d, fl);
+        }
+        if constexpr (sizeof(T) == 2) {
+            if (rank_out.n_t > 0) {
+                const double ob = (double)sizeof(T) * d->M * (double)rank_out.n_t * d->K;
+                mtl_prof_tag("rank_out M%lld K%lld nt%d rp%d gate%d", (long long)d->M, (long long)d->K, rank_out.n_t, rank_out_rp, rank_out_gated ? 1 : 0);
+                MtlProfScope prof(PK_NT_BWD_DX, ob * (rank_out_gated ? 2.0 : 1.0), s, ob, 0.0);
+                const int nchunk = (int)(d->K / 8), rpb = 256 / nchunk;
+                int64_t bx = mtl_ceil_div(d->M, (int64_t)rpb * 4);
+                const int64_t cap = (int64_t)sp_num_cu() * 8 / rank_out.n_t > 0 ? (int64_t)sp_num_cu() * 8 / rank_out.n_t : 1;
+                if (bx > cap) bx = cap;
+                const dim3 g((unsigned)bx, (unsigned)rank_out.n_t);
+                if (rank_out_gated && rank_out_rp == 8)
+                    hipLaunchKernelGGL((k_rank_out<T, true, 8>), g, dim3(256), 0, s, rank_out);
+                else if (rank_out_gated)
+                    hipLaunchKernelGGL((k_rank_out<T, true, 16>), g, dim3(256), 0, s, rank_out);
+                else if (rank_out_rp == 8)
+                    hipLaunchKernelGGL((k_rank_out<T, false, 8>), g, dim3(256), 0, s, rank_out);
+                else
+                    hipLaunchKernelGGL((k_rank_out<T, false, 16>), g, dim3(256), 0, s, rank_out);
+            }
         }
     }
 

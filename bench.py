@@ -350,11 +350,8 @@ def main():
     }
     if "roofline" in fields:
         result["roofline"] = fields["roofline"]
-    if rank == 0 and world == 1 and not args.no_eager_gpu:
-        result["eager_gpu"] = eager_gpu(row, B, dev, ips)
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(row)
     if default and world == 1 and not args.no_other_configs and not args.batch:
+        # (before the eager / CPU baseline legs: the CPU leg's thread pools keep spinning and cost the host-heavy c4 step 15 %)
         # the other single-GPU BASELINE configs, short legs (8 steps after 3 warm-up steps, no baselines): Swin-B r=128 and the 8-task r=4 sweep point
         others = {}
         for name in ("c4", "c5:4"):
@@ -371,6 +368,10 @@ def main():
             except Exception as e:  # noqa: BLE001  (a failing side leg must not lose the headline line)
                 others[name] = {"error": f"{type(e).__name__}: {str(e)[:120]}"}
         result["other_configs"] = others
+    if rank == 0 and world == 1 and not args.no_eager_gpu:
+        result["eager_gpu"] = eager_gpu(row, B, dev, ips)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(row)
     if world > 1:
         barrier(world)
         import torch.distributed as dist

@@ -2,7 +2,7 @@
 """profiles/rNN_pmc_traffic[_cfg].json from the two PMC passes of tools/pmc.sh (FETCH_SIZE and WRITE_SIZE, KB, summed per kernel):
     python tools/pmc_traffic.py gpurun_out/pmc_fetch.csv gpurun_out/pmc_write.csv [steps=2] [fetch.csv write.csv names to cite] > profiles/...json
 "k_nt" = every MTLoRALinear GEMM launch: the tiled kernels (k_nt / k_ntl / k_ntd) AND the wave-streaming ones (k_sp_proj / xres / ares /
-projsum / projk); "k_tn" = the factor gradients (k_tn and k_sp_tn).
+projsum / projk) and k_rank_out; "k_tn" = the factor gradients (k_tn and k_sp_tn).
 FETCH_SIZE is doubled (gfx950 note in MI355X_MICROARCH.md, HBM section: wide coalesced reads are tallied at half their bytes)."""
 import csv, json, sys
 
@@ -28,7 +28,7 @@ def main():
         def match(n):
             tn = "k_tn" in n or "k_sp_tn" in n  # factor-gradient kernels (tiled / wave-streaming) and their reduce kernels
             if g == "k_nt":
-                return ("k_nt" in n or "k_sp_" in n) and not tn
+                return ("k_nt" in n or "k_sp_" in n or "k_rank_out" in n) and not tn
             if g == "k_tn":
                 return tn and "reduce" not in n
             return key in n

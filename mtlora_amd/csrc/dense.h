@@ -23,7 +23,11 @@
 // Measured and dropped: a contiguous run of tiles per workgroup (see tile_coords); register double-buffering of the fragments across
 // k-tiles (+5 %: 240 VGPRs, no gain -- the k loop is bound by the latency of the stage loads, two stages = 96 KB in flight per CU,
 // not by LDS / MFMA overlap); 4-byte "touch" loads two k-tiles ahead to warm the L2 (1.5x SLOWER: they double the number of line
-// requests in the CU's miss queue and, returning in order, sit in front of the stage loads).
+// requests in the CU's miss queue and, returning in order, sit in front of the stage loads); full-width warm-up DMAs into a scratch KB two
+// k-tiles ahead (1.25x slower); the operands staged through three register sets instead of LDS-DMA -- THREE stages = 144 KB in flight
+// per CU on the ordinary vector-load path (correct, 7-10 % slower).  More bytes in flight do not help and more requests hurt: the
+// limit is how fast the XCD's L2 serves 32 CUs that ask for 48 KB each per k-tile (1.5 MB per XCD and k-tile, the 12 workgroups of a
+// row block hitting the same lines at once), i.e. bytes per flop -- a 256 x 256 tile with stream-K balancing is the next step.
 #pragma once
 
 constexpr int ND_TM = 256, ND_TN = 128, ND_KE = 64;
@@ -311,3 +315,4 @@ __global__ __launch_bounds__(512, 2) void k_ntd(const NlParams P) {
         }
     }
 }
+

@@ -28,6 +28,8 @@
 // per CU on the ordinary vector-load path (correct, 7-10 % slower).  More bytes in flight do not help and more requests hurt: the
 // limit is how fast the XCD's L2 serves 32 CUs that ask for 48 KB each per k-tile (1.5 MB per XCD and k-tile, the 12 workgroups of a
 // row block hitting the same lines at once), i.e. bytes per flop -- a 256 x 256 tile with stream-K balancing is the next step.
+// (Starting each column tile's base k loop at a different k-tile, so that the workgroups of a row block do not ask for the same lines
+// at once: +-0.)
 #pragma once
 
 constexpr int ND_TM = 256, ND_TN = 128, ND_KE = 64;

@@ -8,7 +8,13 @@
 //              factors b_frag / at_frag of the wave-streaming kernels;   R = sum_o rp(o), every rank padded to 8 columns
 //   k_sp_*   (stream.h) WAVE-STREAMING kernels, the default wherever a launch is eligible (16-bit types, stationary operands
 //            fit in LDS): k_sp_xres / k_sp_ares = ONE launch per T = 0 layer and direction (projection kept in registers, no
-//            P / Q pass, no re-read of X / dY), k_sp_proj = the P / Q passes of every other layer
+//            P / Q pass, no re-read of X / dY; k_sp_xres also carries the GELU second output and the GELU' gate), k_sp_proj =
+//            the P / Q passes of every other layer, k_sp_projsum = Q of all outputs + G = sum of the gradients in one pass
+//            (T <= 4), k_sp_projk = P / Q with projection rows too large for LDS (single-round launches), k_sp_tn = the
+//            factor gradients dA / dB with transposed LDS reads (large row counts)
+//   k_ntd    (dense.h) single-output launches with a long reduction and well-filled residency rounds: 256 x 128 x 64 tiles,
+//            global -> LDS ring of three stages running across the tiles of a persistent workgroup
+//   k_rank_out  the task outputs of a dX launch with small task ranks (dX_t = Q_t A_t [.* gelu'(h_t)]) as a streaming kernel
 //   k_nt     "NT" tile GEMM  D[n][m] = sum_k Wgt[n][k] * Act[m][k]  (128 x 128 tile, 4 or 8 waves per workgroup) run
 //            as ONE software-pipelined stream of k-tiles over the base GEMM and every output's rank segment, with
 //              - multi-source activation (sum of up to 1+T tensors formed while staging: G = dY_s + sum dY_t)
@@ -25,9 +31,10 @@
 //            (ds_read_b64_tr_b16) for bf16; per-split partials (deterministic) + k_tn_reduce.
 //   k_sum    G = sum of the output gradients (matrixv2 factors; pre-summed dX operand of wide outputs).
 //
-// Forward  = k_pack, then  k_sp_xres (T = 0, K <= 192)                       |  k_sp_proj / k_nt (P), k_nt (all 1+T outputs).
-// Backward = [k_sum], then k_sp_ares (T = 0, narrow input: Q + dX together)  |  k_sp_proj / k_nt (Q), k_nt (dX [+ dX_t]);
-//            k_tn + k_tn_reduce for dA / dB.
+// Forward  = k_pack, then  k_sp_xres (T = 0, K <= 192)  |  k_sp_proj / k_sp_projk / k_nt (P), k_ntd / k_ntl / k_nt (all 1+T outputs).
+// Backward = T = 0: k_sp_ares (narrow input) / k_sp_xres (wide input, short reduction, gate): Q + dX together
+//            | else k_sp_projsum (Q + G, T <= 4) / [k_sum] k_sp_proj / k_sp_projk / k_nt (Q), then k_ntd / k_ntl / k_nt (dX) [+ k_rank_out (dX_t)];
+//            k_sp_tn / k_tn + reduce for dA / dB.
 // DESIGN.md section 4.1 / 4.3 has the measurements and the experiments that were tried and dropped.
 #include <stdlib.h>
 #include <algorithm>

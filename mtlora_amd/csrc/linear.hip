@@ -2355,7 +2355,8 @@ static int bwd_impl(const mtlora_linear_desc* d, const void* x, const void* cons
     // tensors forms Q (all segments) AND G = sum_o dY_o (k_sp_projsum, stream.h); the dX launch then reads G alone
     bool q_done = false;
     if constexpr (sizeof(T) == 2) {
-        if (d->T >= 1 && d->T <= SP_PS_MAXT && d->mode == 0 && do_dx && dx && n_dy == 1 + d->T && sg.rp[0] > 0 && sg.rp[0] <= 64) {
+        static const int ps_maxt = [] { const char* e = getenv("MTLORA_PS_MAXT"); return e ? atoi(e) : MTLORA_MAX_TASKS; }();  // (A/B switch)
+        if (d->T >= 1 && d->T <= ps_maxt && d->mode == 0 && do_dx && dx && n_dy == 1 + d->T && sg.rp[0] > 0 && sg.rp[0] <= 64) {
             SpProjParams sp = {};
             sp.wproj = pk + L.bt_proj;
             sp.out = Qm;
@@ -2376,6 +2377,7 @@ static int bwd_impl(const mtlora_linear_desc* d, const void* x, const void* cons
                 ss.mask = 0;
                 if (o > 0 && ss.n_blk != 1) ok = false;
             }
+            if (ok && sp.src[sp.n_src - 1].blk_lo - sp.src[1].blk_lo + 1 > SP_PS_MAXT) ok = false;  // task segments span too many blocks
             int ch = 0;
             const int ns = ok ? sp_proj_plan<T>(sp, ch) : 0;
             if (ns > 0 && d->M * d->N * 2 < ((int64_t)1 << 32) - 64) {

@@ -843,9 +843,10 @@ __global__ __launch_bounds__(64 * SP_WAVES, SP_WAVES / 4) void k_sp_ares(const S
 // kernel, and the Q pass); with G written next to Q the dX launch becomes single-source (dX = G W + keep .* (Q_s A_s), dX_t =
 // Q_t A_t) and k_sum disappears.  Work item = slab of 32 rows; per reduction chunk the wave walks the sources (one DMA chunk
 // each, same slot ring as k_sp_proj), adds the fragments into the chunk's fp32 sum and feeds that source's projection blocks
-// (shared: <= 2 blocks of 32 rank rows, every task: 1 block).  Layers with more than 4 task outputs keep the two-pass form.
+// (shared: <= 2 blocks of 32 rank rows; the task segments lie in <= 4 blocks, the tasks of one block sharing its accumulator through
+// row-masked projection fragments).  Any number of task outputs up to MTLORA_MAX_TASKS.
 // ------------------------------------------------------------------------------------------------
-constexpr int SP_PS_MAXT = 4;
+constexpr int SP_PS_MAXT = 4;  // 32-row blocks the task segments may span (the tasks of a block share one accumulator)
 template <typename T, int CH, int NS>
 __global__ __launch_bounds__(64 * SP_WAVES, SP_WAVES / 4) void k_sp_projsum(const SpProjParams Pv, T* __restrict__ gsum) {
     typedef SpGeom<CH> G;
@@ -881,6 +882,9 @@ __global__ __launch_bounds__(64 * SP_WAVES, SP_WAVES / 4) void k_sp_projsum(cons
     SP_WAIT_VM(0);
     __syncthreads();
 
+    // task sources 1 .. n_src - 1: consecutive rank segments, each inside ONE 32-row block; blocks tblk0 .. tblk0 + n_tblk - 1
+    const int tblk0 = n_src > 1 ? P->src[1].blk_lo : 0, n_tblk = n_src > 1 ? P->src[n_src - 1].blk_lo - tblk0 + 1 : 0;
+    const int t_lo = n_src > 1 ? P->src[1].col_lo : 0, t_hi = n_src > 1 ? P->src[n_src - 1].col_hi : 0;
     const int n_waves = gridDim.x * SP_WAVES;
     const int w_gid = blockIdx.x * SP_WAVES + wave;
     // loader cursor over (slab, chunk, source)
@@ -930,9 +934,8 @@ __global__ __launch_bounds__(64 * SP_WAVES, SP_WAVES / 4) void k_sp_projsum(cons
             for (int ks = 0; ks < G::KS; ++ks)
 #pragma unroll
                 for (int e = 0; e < 8; ++e) gs[ks][e] = 0.f;
-#pragma unroll
-            for (int s = 0; s < 1 + SP_PS_MAXT; ++s) {
-                if (s < n_src) {
+            for (int s = 0; s < n_src; ++s) {
+                {
                     sp_wait_chunk<G::NDMA>(ahead - 1);
                     const unsigned char* sl = slots + slot * G::SLOT;
                     u32x4 xf[G::KS];
@@ -959,9 +962,18 @@ __global__ __launch_bounds__(64 * SP_WAVES, SP_WAVES / 4) void k_sp_projsum(cons
                             if (nb > 1) sp_mma1<T>(*reinterpret_cast<const u32x4*>(wb + ((size_t)KST + ks) * 1024), xf[ks], accS[1]);
                         }
                     } else {
+                        // the tasks of one 32-row block share ONE accumulator: this task's projection rows only (the other rows of
+                        // the fragment are zeroed), so its product lands in its own rank rows and nowhere else
+                        const int tb = blk_lo - tblk0;
+                        const bool mine = blk_lo * 32 + rl >= P->src[s].col_lo && blk_lo * 32 + rl < P->src[s].col_hi;
 #pragma unroll
-                        for (int ks = 0; ks < G::KS; ++ks)
-                            sp_mma1<T>(*reinterpret_cast<const u32x4*>(wb + (size_t)ks * 1024), xf[ks], accT[s - 1]);
+                        for (int ks = 0; ks < G::KS; ++ks) {
+                            u32x4 wf = *reinterpret_cast<const u32x4*>(wb + (size_t)ks * 1024);
+                            wf = mine ? wf : u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+                            for (int b = 0; b < SP_PS_MAXT; ++b)
+                                if (b == tb) sp_mma1<T>(wf, xf[ks], accT[b]);
+                        }
                     }
                 }
             }
@@ -974,23 +986,32 @@ __global__ __launch_bounds__(64 * SP_WAVES, SP_WAVES / 4) void k_sp_projsum(cons
                 sp_bstore(v, grsrc, m * (uint32_t)(K * 2) + (uint32_t)(ch * CH + ks * 16 + 8 * h) * 2u);
             }
         }
-        // Q segments
+        // Q segments: the shared one from accS, the task blocks from accT (columns of the task range only)
         const uint32_t rowoff = m * (uint32_t)(P->ld_out * 2);
+        {
+            const int col_lo = P->src[0].col_lo, col_hi = P->src[0].col_hi, blk_lo = P->src[0].blk_lo;
 #pragma unroll
-        for (int s = 0; s < 1 + SP_PS_MAXT; ++s) {
-            if (s < n_src) {
-                const int col_lo = P->src[s].col_lo, col_hi = P->src[s].col_hi, blk_lo = P->src[s].blk_lo;
+            for (int b = 0; b < 2; ++b) {
+                if (b == 0 || P->src[0].n_blk > 1) {
 #pragma unroll
-                for (int b = 0; b < 2; ++b) {
-                    if (b == 0 || (s == 0 && P->src[0].n_blk > 1)) {
-#pragma unroll
-                        for (int q = 0; q < 4; q += 2) {
-                            u32x4 v;
-                            sp_pack_pair<T>(s == 0 ? accS[b] : accT[s == 0 ? 0 : s - 1], q, h, v);
-                            const int col = (blk_lo + b) * 32 + 8 * q + 8 * h;
-                            sp_bstore(v, orsrc, (col >= col_lo && col < col_hi) ? rowoff + (uint32_t)col * 2u : 0xFFFFFFFFu);
-                        }
+                    for (int q = 0; q < 4; q += 2) {
+                        u32x4 v;
+                        sp_pack_pair<T>(accS[b], q, h, v);
+                        const int col = (blk_lo + b) * 32 + 8 * q + 8 * h;
+                        sp_bstore(v, orsrc, (col >= col_lo && col < col_hi) ? rowoff + (uint32_t)col * 2u : 0xFFFFFFFFu);
                     }
+                }
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < SP_PS_MAXT; ++b) {
+            if (b < n_tblk) {
+#pragma unroll
+                for (int q = 0; q < 4; q += 2) {
+                    u32x4 v;
+                    sp_pack_pair<T>(accT[b], q, h, v);
+                    const int col = (tblk0 + b) * 32 + 8 * q + 8 * h;
+                    sp_bstore(v, orsrc, (col >= t_lo && col < t_hi) ? rowoff + (uint32_t)col * 2u : 0xFFFFFFFFu);
                 }
             }
         }

@@ -7,7 +7,11 @@
  *     no torch / ATen / pybind types anywhere;
  *   - the CALLER owns every buffer (inputs, outputs, ctx, scratch); the library never
  *     allocates, frees, retains a pointer or synchronises; every launch goes on `stream`;
- *   - re-entrant, no global mutable state (safe from the autograd thread and across DDP ranks);
+ *   - re-entrant (safe from the autograd thread and across DDP ranks): nothing a call computes depends on state left by
+ *     another call.  The only process-wide state is a per-device cache of device facts (CU count, "dynamic LDS limit raised"
+ *     marks) and the opt-in profiler of mtlora_prof_begin/end; kernel selection is a function of the descriptor alone
+ *     (ABI v6: no environment variable influences what the library computes or which kernel it picks; the
+ *     opt-in profiler alone reads MTLORA_PROF_DUMP, a file name for its record dump, in mtlora_prof_end);
  *   - every function returns MTLORA_OK (0) or a negative mtlora_status; the Python shim
  *     (mtlora_amd/_lib.py) turns a non-zero status into RuntimeError -- the same observable
  *     behaviour as the reference's AT_ASSERTM -> RuntimeError (swin_window_process.cpp:64-66).
@@ -23,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MTLORA_ABI_VERSION 5
+#define MTLORA_ABI_VERSION 6
 #define MTLORA_MAX_TASKS 8
 
 typedef enum mtlora_dtype {
@@ -105,6 +109,16 @@ typedef struct mtlora_linear_desc {
                             put them on a second stream next to the rest of the backward chain: call phase 1 on stream s1,
                             order s2 after it (event), call phase 2 with the SAME arguments on s2, and join s2 before the
                             gradients are read.  Nothing but dA / dB depends on phase 2. */
+    /* ---- kernel selection (ABI v6; all 0 = the library's own choice).  Results are the same whatever is selected (the
+     * kernel families are bit-compatible up to fp32 summation order); tests pin every family against the oracle by forcing
+     * it on shapes far below the sizes at which the library would pick it, and A/B timing uses the same switches. */
+    int32_t sel_stream;  /* wave-streaming kernels (csrc/stream.h): 0 wherever eligible, 1 never (tiled kernels only) */
+    int32_t sel_dense;   /* k_ntd (csrc/dense.h), single-output MFMA-dense launches: 0 by shape heuristics, 1 never, 2 whenever eligible */
+    int32_t sel_tn;      /* k_sp_tn, streaming factor gradients: 0 when every wave gets >= 8 slabs, 1 never, 2 whenever eligible */
+    int32_t sel_projk;   /* k_sp_projk, P / Q passes with large K R: 0 single-round launches only, 1 never, 2 whenever eligible */
+    int32_t max_cu;      /* 0: size persistent grids for the whole device; n > 0: as if the device had n CUs -- every wave /
+                            workgroup of a persistent kernel then owns MANY work items even at test sizes (the steady state
+                            of the slot rings and the vmcnt accounting, reached otherwise only at benchmark sizes) */
 } mtlora_linear_desc;
 
 /* bytes of the context buffer written by fwd and read by bwd (packed low-rank factors + P). */

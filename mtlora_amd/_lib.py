@@ -12,7 +12,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int6
 import torch
 
 MAX_TASKS = 8
-ABI_VERSION = 5
+ABI_VERSION = 6
 F32, BF16, F16 = 0, 1, 2
 _DT = {torch.float32: F32, torch.bfloat16: BF16, torch.float16: F16}
 
@@ -24,7 +24,10 @@ class LinearDesc(Structure):
     _fields_ = [("M", c_int64), ("K", c_int64), ("N", c_int64), ("dtype", c_int32), ("mode", c_int32),
                 ("T", c_int32), ("r_s", c_int32), ("r_t", c_int32 * MAX_TASKS), ("scale_s", c_float),
                 ("scale_t", c_float * MAX_TASKS), ("has_x_tasks", c_int32), ("dropout_p", c_float),
-                ("seed", c_uint64), ("seed_offset", c_void_p), ("bwd_phase", c_int32)]
+                ("seed", c_uint64), ("seed_offset", c_void_p), ("bwd_phase", c_int32),
+                # kernel selection (ABI v6): 0 = the library's own choice; see include/mtlora_hip.h
+                ("sel_stream", c_int32), ("sel_dense", c_int32), ("sel_tn", c_int32), ("sel_projk", c_int32),
+                ("max_cu", c_int32)]
 
 
 class AttnDesc(Structure):

@@ -38,6 +38,7 @@
 // DESIGN.md section 4.1 / 4.3 has the measurements and the experiments that were tried and dropped.
 #include <stdlib.h>
 #include <algorithm>
+#include <atomic>
 #include <type_traits>
 
 #include "common.h"
@@ -1380,21 +1381,89 @@ static int check_desc(const mtlora_linear_desc* d) {
         if (d->r_t[t] <= 0) return MTLORA_ERR_SHAPE;
     if (d->mode != 0 && d->mode != 1) return MTLORA_ERR_UNSUPPORTED;
     if (d->bwd_phase < 0 || d->bwd_phase > 2) return MTLORA_ERR_UNSUPPORTED;
+    if (d->sel_stream < 0 || d->sel_stream > 1 || d->sel_dense < 0 || d->sel_dense > 2 || d->sel_tn < 0 || d->sel_tn > 2 || d->sel_projk < 0 ||
+        d->sel_projk > 2 || d->max_cu < 0)
+        return MTLORA_ERR_UNSUPPORTED;
     if (d->dropout_p < 0.f || d->dropout_p >= 1.f) return MTLORA_ERR_SHAPE;
     return MTLORA_OK;
 }
 
 static bool misaligned(const void* p) { return ((uintptr_t)p & 15u) != 0; }
 
-static int sp_num_cu();
+// kernel selection of one call: a function of the descriptor alone (mtlora_linear_desc.sel_* / max_cu, ABI v6) -- the library reads
+// no environment variables.  sp: wave-streaming family on; ntd / tn / projk: 0 never, 1 by heuristics, 2 whenever eligible.
+struct Tune {
+    int sp, ntd, tn, projk, max_cu;
+};
+static Tune make_tune(const mtlora_linear_desc* d) {
+    auto tri = [](int v) { return v == 1 ? 0 : (v == 2 ? 2 : 1); };
+    Tune t;
+    t.sp = d->sel_stream == 1 ? 0 : 1;
+    t.ntd = tri(d->sel_dense);
+    t.tn = tri(d->sel_tn);
+    t.projk = tri(d->sel_projk);
+    t.max_cu = d->max_cu > 0 ? d->max_cu : 0;
+    return t;
+}
+// per-device facts, cached (the only process-wide state next to the opt-in profiler): CU count and which kernels already had
+// their dynamic-LDS limit raised on which device (hipFuncSetAttribute is per device)
+constexpr int MTL_MAX_DEV = 64;
+static int cur_dev() {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    return dev >= 0 && dev < MTL_MAX_DEV ? dev : 0;
+}
+static int dev_num_cu() {
+    static std::atomic<int> cache[MTL_MAX_DEV];
+    const int dev = cur_dev();
+    int cu = cache[dev].load(std::memory_order_relaxed);
+    if (cu == 0) {
+        cu = 256;
+        (void)hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev);
+        if (cu <= 0) cu = 256;
+        cache[dev].store(cu, std::memory_order_relaxed);
+    }
+    return cu;
+}
+static int num_cu(const Tune& tu) {
+    const int cu = dev_num_cu();
+    return tu.max_cu > 0 && tu.max_cu < cu ? tu.max_cu : cu;
+}
+// raise the dynamic-LDS limit of `fn` to `bytes` once per device; false when the runtime refuses (the caller falls back / reports)
+static bool raise_lds(std::atomic<unsigned long long>& done, const void* fn, int bytes) {
+    const int dev = cur_dev();
+    if ((done.load(std::memory_order_relaxed) >> dev) & 1ull) return true;
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    done.fetch_or(1ull << dev, std::memory_order_relaxed);
+    return true;
+}
+// (a refusal is not an error here: the launch that follows fails with an invalid-configuration error, which the entry point's
+// MTL_CHECK_LAUNCH reports as MTLORA_ERR_HIP)
+#define MTL_RAISE_LDS(KERNEL, BYTES)                                        \
+    do {                                                                    \
+        static std::atomic<unsigned long long> done__{0};                   \
+        (void)raise_lds(done__, (const void*)(KERNEL), (int)(BYTES));       \
+    } while (0)
+
+// developer ablation bits (tools/nt_ablate.sh, tools/sp_ablate.sh): read from the environment ONLY in a -DMTL_NT_ABLATE=1 build
+// (MTLORA_ABLATE=1 python -m mtlora_amd.csrc.build --force); the shipped library has neither the getenv nor the kernel branches
+static int ablate_bits(const char* name) {
+#if MTL_NT_ABLATE
+    const char* e = getenv(name);
+    return e ? atoi(e) : 0;
+#else
+    (void)name;
+    return 0;
+#endif
+}
 
 template <typename T>
-static void launch_nt(const NtParams& P_in, hipStream_t s, int kind, double alg_bytes, double s8d_bytes = 0.0, double flops = 0.0) {
+static void launch_nt(const Tune& tu, const NtParams& P_in, hipStream_t s, int kind, double alg_bytes, double s8d_bytes = 0.0, double flops = 0.0) {
     NtParams P = P_in;
-    {
-        const char* e = getenv("MTLORA_NT_DBG");  // ablation timing only (tools/bench_linear.py); results are wrong with any bit set
-        P.dbg = e ? atoi(e) : 0;
-    }
+    P.dbg = ablate_bits("MTLORA_NT_DBG");
     mtl_prof_tag("M%lld K%d N%d ldL%lld no%d na%d nz%d", (long long)P.M, P.K, P.n_rows, (long long)P.ldL, P.n_out, P.n_act, P.nz);
     MtlProfScope prof(kind, alg_bytes, s, s8d_bytes, flops);
     int max_rows = P.n_rows;
@@ -1425,7 +1494,7 @@ static void launch_nt(const NtParams& P_in, hipStream_t s, int kind, double alg_
         // lean single-output bf16 launches (forward outputs, P / Q passes, rank-0 GEMMs, and the dX of layers without task
         // outputs -- masked rank part): the straight-line kernel
         // MFMA-dense launches (long reduction, enough tiles): k_ntd (dense.h).  MTLORA_NTD: 0 never, 2 whenever the shape allows
-        const int ntd_mode = [] { const char* e = getenv("MTLORA_NTD"); return e ? atoi(e) : 1; }();  // (read per call: the "[dense]" test variants)
+        const int ntd_mode = tu.ntd;  // 0 never, 1 by the heuristics below, 2 whenever the shape allows (the "[dense]" test variants)
         bool dense = false;
         if (variant == 2 && P.n_out == 1 && P.nz == 0 && ntd_mode != 0 && P.act_mask == 0 && P.n_rows % 8 == 0 && P.n_rows >= 64 &&
             P.M < (int64_t)0x7FFFFF00 && P.out[0].ptr != nullptr && !(P.out[0].gate && P.out[0].act)) {
@@ -1439,7 +1508,7 @@ static void launch_nt(const NtParams& P_in, hipStream_t s, int kind, double alg_
                               (P.ldL % 8) == 0 && (P.ldR % 8) == 0 && (P.L == nullptr || (P.out[0].seg_lo % 8) == 0);
             // where it wins (tools/ntd_ab.sh): a reduction of >= 6 k-tiles, residency rounds (one workgroup per CU) at least 70 % full or
             // a single round on at least half of the CUs, and no half-empty column tile
-            const int64_t slots = sp_num_cu();
+            const int64_t slots = num_cu(tu);
             const double eff = (double)tiles / (double)(mtl_ceil_div(tiles, slots) * slots);
             dense = fits && ksteps >= 1 &&
                     (ntd_mode == 2 || (ksteps >= 6 && (eff >= 0.7 || (tiles <= slots && tiles >= slots / 2)) && (P.n_rows % ND_TN == 0 || P.n_rows > 2 * ND_TN)));
@@ -1477,15 +1546,11 @@ static void launch_nt(const NtParams& P_in, hipStream_t s, int kind, double alg_
             q.pad_ = 0;
             q.drop = P.drop;
             const bool ml0 = P.out[0].mask_lr != 0 && P.drop.enabled() && q.seg_hi > q.seg_lo;
-            const uint32_t grid = nwg < (uint32_t)sp_num_cu() ? nwg : (uint32_t)sp_num_cu();
-#define MTL_NTD_GO(AC, ML, GA)                                                                                               \
-    do {                                                                                                                     \
-        static bool raised = false;                                                                                          \
-        if (!raised) {                                                                                                       \
-            (void)hipFuncSetAttribute((const void*)k_ntd<AC, ML, GA>, hipFuncAttributeMaxDynamicSharedMemorySize, SP_LDS_MAX); \
-            raised = true;                                                                                                   \
-        }                                                                                                                    \
-        hipLaunchKernelGGL((k_ntd<AC, ML, GA>), dim3(grid), dim3(512), (size_t)ND_LDS, s, q);                                \
+            const uint32_t grid = nwg < (uint32_t)num_cu(tu) ? nwg : (uint32_t)num_cu(tu);
+#define MTL_NTD_GO(AC, ML, GA)                                                                \
+    do {                                                                                      \
+        MTL_RAISE_LDS((k_ntd<AC, ML, GA>), SP_LDS_MAX);                                       \
+        hipLaunchKernelGGL((k_ntd<AC, ML, GA>), dim3(grid), dim3(512), (size_t)ND_LDS, s, q); \
     } while (0)
             if (q.act2)
                 MTL_NTD_GO(true, false, false);
@@ -1525,7 +1590,7 @@ static void launch_nt(const NtParams& P_in, hipStream_t s, int kind, double alg_
             // tile width: 128 columns, or 192 when that saves residency rounds (512 workgroup slots at 128 columns, 2 per CU either way;
             // a 192-wide tile is 1.5x the work)
             const int64_t t128 = m_tiles * mtl_ceil_div(P.n_rows, 128), t192 = m_tiles * mtl_ceil_div(P.n_rows, 192);
-            const int64_t slots = 2 * (int64_t)sp_num_cu();
+            const int64_t slots = 2 * (int64_t)dev_num_cu();
             const double c128 = (double)mtl_ceil_div(t128, slots), c192 = 1.5 * (double)mtl_ceil_div(t192, slots);
             const bool wide = !q.act2 && P.n_rows >= 192 && c192 < c128 - 0.01;
             const int64_t nt = wide ? mtl_ceil_div(P.n_rows, 192) : n_tiles;
@@ -1542,14 +1607,10 @@ static void launch_nt(const NtParams& P_in, hipStream_t s, int kind, double alg_
             if (q.out == nullptr) return;
             const bool ml0 = P.out[0].mask_lr != 0 && P.drop.enabled() && q.seg_hi > q.seg_lo;
             constexpr size_t LDS192 = (size_t)(192 + 128) * LDSB;
-#define MTL_NTL_GO(AC, ML, SNV, LDSV)                                                                                     \
-    do {                                                                                                                  \
-        static bool raised = false;                                                                                       \
-        if ((LDSV) > 64 * 1024 && !raised) {                                                                              \
-            (void)hipFuncSetAttribute((const void*)k_ntl<AC, ML, SNV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512); \
-            raised = true;                                                                                                \
-        }                                                                                                                 \
-        hipLaunchKernelGGL((k_ntl<AC, ML, SNV>), dim3(nwg), dim3(512), (size_t)(LDSV), s, q);                             \
+#define MTL_NTL_GO(AC, ML, SNV, LDSV)                                                         \
+    do {                                                                                      \
+        if ((LDSV) > 64 * 1024) MTL_RAISE_LDS((k_ntl<AC, ML, SNV>), 160 * 1024 - 512);        \
+        hipLaunchKernelGGL((k_ntl<AC, ML, SNV>), dim3(nwg), dim3(512), (size_t)(LDSV), s, q); \
     } while (0)
             if (q.act2)
                 MTL_NTL_GO(true, false, 2, STAGE_BYTES);
@@ -1597,22 +1658,10 @@ static void launch_nt(const NtParams& P_in, hipStream_t s, int kind, double alg_
 }
 
 // ---- wave-streaming projection (k_sp_proj, stream.h): the P = alpha D(X) A^T / Q = alpha dY B passes
-static int sp_mode() {  // MTLORA_SP=0 keeps every launch on the tiled kernels (read per call: the "[tiled]" test variants, A/B timing)
-    const char* e = getenv("MTLORA_SP");
-    return e ? atoi(e) : 1;
-}
-static int sp_num_cu() {
-    static const int n_cu = [] {
-        int dev = 0, cu = 256;
-        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev);
-        return cu > 0 ? cu : 256;
-    }();
-    return n_cu;
-}
 // fills q.n_blk_total / n_slabs / n_items and returns the ring depth (0: not eligible).  Sources must be set.
 template <typename T>
-static int sp_proj_plan(SpProjParams& q, int& ch) {
-    if (sizeof(T) != 2 || sp_mode() == 0 || q.M <= 0 || q.n_src <= 0) return 0;
+static int sp_proj_plan(const Tune& tu, SpProjParams& q, int& ch) {
+    if (sizeof(T) != 2 || tu.sp == 0 || q.M <= 0 || q.n_src <= 0) return 0;
     ch = q.K % 96 == 0 ? 96 : (q.K % 64 == 0 ? 64 : 0);
     if (ch == 0 || q.M >= ((int64_t)1 << 31) - 64) return 0;
     q.n_blk_total = (q.Rw + 31) / 32;
@@ -1632,21 +1681,17 @@ static int sp_proj_plan(SpProjParams& q, int& ch) {
     return 0;
 }
 template <typename T>
-static void launch_sp_proj(const SpProjParams& q, int ch, int ns, hipStream_t s, int kind, double alg_bytes, double s8d, double flops) {
+static void launch_sp_proj(const Tune& tu, const SpProjParams& q, int ch, int ns, hipStream_t s, int kind, double alg_bytes, double s8d, double flops) {
     mtl_prof_tag("sp_proj M%lld K%d R%d src%d ch%d ns%d", (long long)q.M, q.K, q.Rw, q.n_src, ch, ns);
     MtlProfScope prof(kind, alg_bytes, s, s8d, flops);
     const size_t lds = (size_t)q.n_blk_total * 32 * q.K * 2 + (size_t)SP_WAVES * ns * 32 * ch * 2;
     const int per_cu = lds * 2 <= (size_t)SP_LDS_MAX ? 2 : 1;
     int64_t wgs = mtl_ceil_div(q.n_items, SP_WAVES);
-    if (wgs > (int64_t)sp_num_cu() * per_cu) wgs = (int64_t)sp_num_cu() * per_cu;
-#define MTL_SP_PROJ(CHV, NSV)                                                                                              \
-    do {                                                                                                                    \
-        static bool raised = false;                                                                                         \
-        if (!raised) {                                                                                                      \
-            (void)hipFuncSetAttribute((const void*)k_sp_proj<T, CHV, NSV>, hipFuncAttributeMaxDynamicSharedMemorySize, SP_LDS_MAX); \
-            raised = true;                                                                                                  \
-        }                                                                                                                   \
-        hipLaunchKernelGGL((k_sp_proj<T, CHV, NSV>), dim3((unsigned)wgs), dim3(64 * SP_WAVES), lds, s, q);                  \
+    if (wgs > (int64_t)num_cu(tu) * per_cu) wgs = (int64_t)num_cu(tu) * per_cu;
+#define MTL_SP_PROJ(CHV, NSV)                                                                              \
+    do {                                                                                                   \
+        MTL_RAISE_LDS((k_sp_proj<T, CHV, NSV>), SP_LDS_MAX);                                               \
+        hipLaunchKernelGGL((k_sp_proj<T, CHV, NSV>), dim3((unsigned)wgs), dim3(64 * SP_WAVES), lds, s, q); \
     } while (0)
     if constexpr (sizeof(T) == 2) {
         if (ch == 96) {
@@ -1665,9 +1710,9 @@ static void launch_sp_proj(const SpProjParams& q, int ch, int ns, hipStream_t s,
 // ---- k_sp_projk (stream.h): the P / Q passes whose projection rows do not fit in LDS, for small row counts (one work item per
 // workgroup, reduction split over its waves).  Same parameter block as k_sp_proj; returns false when the shape is not eligible.
 template <typename T>
-static bool sp_projk_plan(SpProjParams& q, int& ch) {
-    if (sizeof(T) != 2 || sp_mode() == 0 || q.M <= 0 || q.n_src <= 0) return false;
-    const int mode = [] { const char* e = getenv("MTLORA_SP_PROJK"); return e ? atoi(e) : 1; }();
+static bool sp_projk_plan(const Tune& tu, SpProjParams& q, int& ch) {
+    if (sizeof(T) != 2 || tu.sp == 0 || q.M <= 0 || q.n_src <= 0) return false;
+    const int mode = tu.projk;
     if (mode == 0) return false;
     ch = q.K % 96 == 0 ? 96 : (q.K % 64 == 0 ? 64 : 0);
     if (ch == 0 || q.M >= ((int64_t)1 << 31) - 64) return false;
@@ -1682,24 +1727,20 @@ static bool sp_projk_plan(SpProjParams& q, int& ch) {
     q.n_items = q.n_slabs * q.n_src;
     // every item re-reads the projection rows from L2 and pays three barriers: it wins while the whole launch is ONE residency round
     // (stage 3: 196 slabs; 42 - 62 us -> 20 - 24 us), ties at two to three rounds and loses beyond (tools/projk_ab.sh)
-    return mode == 2 || ((int64_t)q.n_items <= (int64_t)sp_num_cu() && q.K / ch >= SP_WAVES);
+    return mode == 2 || ((int64_t)q.n_items <= (int64_t)num_cu(tu) && q.K / ch >= SP_WAVES);
 }
 template <typename T>
-static void launch_sp_projk(const SpProjParams& q, int ch, hipStream_t s, int kind, double alg_bytes, double s8d, double flops) {
+static void launch_sp_projk(const Tune& tu, const SpProjParams& q, int ch, hipStream_t s, int kind, double alg_bytes, double s8d, double flops) {
     mtl_prof_tag("sp_projk M%lld K%d R%d src%d ch%d", (long long)q.M, q.K, q.Rw, q.n_src, ch);
     MtlProfScope prof(kind, alg_bytes, s, s8d, flops);
     int64_t wgs = q.n_items;
-    if (wgs > (int64_t)sp_num_cu()) wgs = sp_num_cu();
-#define MTL_SP_PROJK(CHV, NSLV)                                                                                                 \
-    do {                                                                                                                         \
-        constexpr size_t slots = (size_t)SP_WAVES * NSLV * 32 * CHV * 2, red = (size_t)SP_WAVES * SP_MAXB * 4096;                \
-        constexpr size_t lds = slots > red ? slots : red;                                                                        \
-        static bool raised = false;                                                                                              \
-        if (!raised) {                                                                                                           \
-            (void)hipFuncSetAttribute((const void*)k_sp_projk<T, CHV, NSLV>, hipFuncAttributeMaxDynamicSharedMemorySize, SP_LDS_MAX); \
-            raised = true;                                                                                                       \
-        }                                                                                                                        \
-        hipLaunchKernelGGL((k_sp_projk<T, CHV, NSLV>), dim3((unsigned)wgs), dim3(64 * SP_WAVES), lds, s, q);                     \
+    if (wgs > (int64_t)num_cu(tu)) wgs = num_cu(tu);
+#define MTL_SP_PROJK(CHV, NSLV)                                                                                   \
+    do {                                                                                                          \
+        constexpr size_t slots = (size_t)SP_WAVES * NSLV * 32 * CHV * 2, red = (size_t)SP_WAVES * SP_MAXB * 4096; \
+        constexpr size_t lds = slots > red ? slots : red;                                                         \
+        MTL_RAISE_LDS((k_sp_projk<T, CHV, NSLV>), SP_LDS_MAX);                                                    \
+        hipLaunchKernelGGL((k_sp_projk<T, CHV, NSLV>), dim3((unsigned)wgs), dim3(64 * SP_WAVES), lds, s, q);      \
     } while (0)
     if constexpr (sizeof(T) == 2) {
         if (ch == 96)
@@ -1711,21 +1752,17 @@ static void launch_sp_projk(const SpProjParams& q, int ch, hipStream_t s, int ki
 }
 
 template <typename T>
-static void launch_sp_projsum(const SpProjParams& q, int ch, int ns, T* gsum, hipStream_t s, int kind, double alg_bytes, double s8d,
-                              double flops) {
+static void launch_sp_projsum(const Tune& tu, const SpProjParams& q, int ch, int ns, T* gsum, hipStream_t s, int kind, double alg_bytes,
+                              double s8d, double flops) {
     mtl_prof_tag("sp_projsum M%lld K%d R%d src%d ch%d ns%d", (long long)q.M, q.K, q.Rw, q.n_src, ch, ns);
     MtlProfScope prof(kind, alg_bytes, s, s8d, flops);
     const size_t lds = (size_t)q.n_blk_total * 32 * q.K * 2 + (size_t)SP_WAVES * ns * 32 * ch * 2;
     int64_t wgs = mtl_ceil_div(q.n_slabs, SP_WAVES);
-    if (wgs > (int64_t)sp_num_cu()) wgs = sp_num_cu();
-#define MTL_SP_PS(CHV, NSV)                                                                                                    \
-    do {                                                                                                                        \
-        static bool raised = false;                                                                                             \
-        if (!raised) {                                                                                                          \
-            (void)hipFuncSetAttribute((const void*)k_sp_projsum<T, CHV, NSV>, hipFuncAttributeMaxDynamicSharedMemorySize, SP_LDS_MAX); \
-            raised = true;                                                                                                      \
-        }                                                                                                                       \
-        hipLaunchKernelGGL((k_sp_projsum<T, CHV, NSV>), dim3((unsigned)wgs), dim3(64 * SP_WAVES), lds, s, q, gsum);             \
+    if (wgs > (int64_t)num_cu(tu)) wgs = num_cu(tu);
+#define MTL_SP_PS(CHV, NSV)                                                                                         \
+    do {                                                                                                            \
+        MTL_RAISE_LDS((k_sp_projsum<T, CHV, NSV>), SP_LDS_MAX);                                                     \
+        hipLaunchKernelGGL((k_sp_projsum<T, CHV, NSV>), dim3((unsigned)wgs), dim3(64 * SP_WAVES), lds, s, q, gsum); \
     } while (0)
     if constexpr (sizeof(T) == 2) {
         if (ch == 96) {
@@ -1747,13 +1784,35 @@ struct SpXresPlan {
     unsigned grid;
     size_t lds;
 };
-static int sp_stg_mode() {  // developer switch: MTLORA_SP_STG=0 direct row-per-lane stores, 1 staged stores whenever they fit, unset: auto
+// persistent grid of a fused wave-streaming launch: `parts` column parts x slab groups.  Normally the parts of one slab group sit on
+// one XCD (blockIdx b -> XCD b % 8), so the groups come in eights (xsh = 3).  With fewer than 8 * parts CUs to use (desc.max_cu: the
+// "[persist]" tests) the eight-fold grouping is dropped (xsh = 0): part = b % parts, group = b / parts.
+static unsigned sp_lin_grid(const Tune& tu, int parts, int n_slabs, int& xsh) {
+    const int64_t cu = num_cu(tu);
+    const int64_t by_slabs = mtl_ceil_div(n_slabs, SP_WAVES);
+    if (cu >= 8 * (int64_t)parts) {
+        xsh = 3;
+        int64_t g8 = mtl_ceil_div(by_slabs, 8);
+        const int64_t g8_max = cu / (8 * parts);
+        if (g8 > g8_max) g8 = g8_max;
+        return (unsigned)(8 * parts * g8);
+    }
+    xsh = 0;
+    int64_t g = cu / parts > 0 ? cu / parts : 1;
+    if (g > by_slabs) g = by_slabs;
+    return (unsigned)(parts * g);
+}
+static int sp_stg_mode() {  // developer switch (ablation builds only): MTLORA_SP_STG=0 direct row-per-lane stores, 1 staged stores whenever they fit
+#if MTL_NT_ABLATE
     static const int m = [] { const char* e = getenv("MTLORA_SP_STG"); return e ? atoi(e) : -1; }();
     return m;
+#else
+    return -1;
+#endif
 }
 template <typename T>
-static bool sp_xres_plan(SpLinParams& q, int K, SpXresPlan& pl) {
-    if (sizeof(T) != 2 || sp_mode() == 0 || q.M <= 0 || q.M >= ((int64_t)1 << 31) - 64) return false;
+static bool sp_xres_plan(const Tune& tu, SpLinParams& q, int K, SpXresPlan& pl) {
+    if (sizeof(T) != 2 || tu.sp == 0 || q.M <= 0 || q.M >= ((int64_t)1 << 31) - 64) return false;
     if (K == 96 || K == 192) {
         pl.ch = 96;
         pl.nkc = K / 96;
@@ -1800,15 +1859,9 @@ static bool sp_xres_plan(SpLinParams& q, int K, SpXresPlan& pl) {
     q.blk_per_part = stg ? bpp_s : bpp_d;
     pl.lds = stg ? lds_s : lds_d;
     q.n_parts = parts;
-    {
-        const char* e = getenv("MTLORA_SP_DBG");  // ablation timing only (tools/): results are wrong with any bit set
-        q.dbg = e ? atoi(e) : 0;
-    }
+    q.dbg = ablate_bits("MTLORA_SP_DBG");
     q.n_slabs = (int)mtl_ceil_div(q.M, 32);
-    const int64_t g8_max = sp_num_cu() / (8 * parts) > 0 ? sp_num_cu() / (8 * parts) : 1;
-    int64_t g8 = mtl_ceil_div(mtl_ceil_div(q.n_slabs, SP_WAVES), 8);
-    if (g8 > g8_max) g8 = g8_max;
-    pl.grid = (unsigned)(8 * parts * g8);
+    pl.grid = sp_lin_grid(tu, parts, q.n_slabs, q.xsh);
     return true;
 }
 template <typename T>
@@ -1816,15 +1869,10 @@ static void launch_sp_xres(const SpLinParams& q, const SpXresPlan& pl, bool act,
                            double flops, bool gate = false) {
     mtl_prof_tag("sp_xres M%lld K%d N%d R%d parts%d stg%d", (long long)q.M, pl.ch * pl.nkc, q.n_cols, q.R, q.n_parts, pl.stg ? 1 : 0);
     MtlProfScope prof(kind, alg_bytes, s, s8d, flops);
-#define MTL_SP_X1(CHV, NKCV, NRBV, ACTV, STGV, GAV)                                                                                     \
-    do {                                                                                                                                \
-        static bool raised = false;                                                                                                     \
-        if (!raised) {                                                                                                                  \
-            (void)hipFuncSetAttribute((const void*)k_sp_xres<T, CHV, NKCV, NRBV, ACTV, STGV, GAV>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                      SP_LDS_MAX);                                                                                      \
-            raised = true;                                                                                                              \
-        }                                                                                                                               \
-        hipLaunchKernelGGL((k_sp_xres<T, CHV, NKCV, NRBV, ACTV, STGV, GAV>), dim3(pl.grid), dim3(64 * SP_WAVES), pl.lds, s, q);         \
+#define MTL_SP_X1(CHV, NKCV, NRBV, ACTV, STGV, GAV)                                                                             \
+    do {                                                                                                                        \
+        MTL_RAISE_LDS((k_sp_xres<T, CHV, NKCV, NRBV, ACTV, STGV, GAV>), SP_LDS_MAX);                                            \
+        hipLaunchKernelGGL((k_sp_xres<T, CHV, NKCV, NRBV, ACTV, STGV, GAV>), dim3(pl.grid), dim3(64 * SP_WAVES), pl.lds, s, q); \
     } while (0)
 #define MTL_SP_X(CHV, NKCV, NRBV, ACTV, STGV)                                    \
     do {                                                                         \
@@ -1867,8 +1915,8 @@ struct SpAresPlan {
     size_t lds;
 };
 template <typename T>
-static bool sp_ares_plan(SpLinParams& q, int Kred, SpAresPlan& pl) {
-    if (sizeof(T) != 2 || sp_mode() == 0 || q.M <= 0 || q.M >= ((int64_t)1 << 31) - 64) return false;
+static bool sp_ares_plan(const Tune& tu, SpLinParams& q, int Kred, SpAresPlan& pl) {
+    if (sizeof(T) != 2 || tu.sp == 0 || q.M <= 0 || q.M >= ((int64_t)1 << 31) - 64) return false;
     pl.ch = Kred % 96 == 0 ? 96 : (Kred % 64 == 0 ? 64 : 0);
     if (pl.ch == 0) return false;
     pl.nob = pl.ch == 96 ? 3 : 4;
@@ -1891,29 +1939,19 @@ static bool sp_ares_plan(SpLinParams& q, int Kred, SpAresPlan& pl) {
     pl.lds = (size_t)need;
     q.n_parts = parts;
     q.blk_per_part = pl.nob;
-    {
-        const char* e = getenv("MTLORA_SP_DBG");
-        q.dbg = e ? atoi(e) : 0;
-    }
+    q.dbg = ablate_bits("MTLORA_SP_DBG");
     q.n_slabs = (int)mtl_ceil_div(q.M, 32);
-    const int64_t g8_max = sp_num_cu() / (8 * parts) > 0 ? sp_num_cu() / (8 * parts) : 1;
-    int64_t g8 = mtl_ceil_div(mtl_ceil_div(q.n_slabs, SP_WAVES), 8);
-    if (g8 > g8_max) g8 = g8_max;
-    pl.grid = (unsigned)(8 * parts * g8);
+    pl.grid = sp_lin_grid(tu, parts, q.n_slabs, q.xsh);
     return true;
 }
 template <typename T>
 static void launch_sp_ares(const SpLinParams& q, const SpAresPlan& pl, hipStream_t s, int kind, double alg_bytes, double s8d, double flops) {
     mtl_prof_tag("sp_ares M%lld Kred%d N%d R%d parts%d", (long long)q.M, q.estep2, q.n_cols, q.R, q.n_parts);
     MtlProfScope prof(kind, alg_bytes, s, s8d, flops);
-#define MTL_SP_A(CHV, NOBV, NRBV)                                                                                                  \
-    do {                                                                                                                            \
-        static bool raised = false;                                                                                                 \
-        if (!raised) {                                                                                                              \
-            (void)hipFuncSetAttribute((const void*)k_sp_ares<T, CHV, NOBV, NRBV>, hipFuncAttributeMaxDynamicSharedMemorySize, SP_LDS_MAX); \
-            raised = true;                                                                                                          \
-        }                                                                                                                           \
-        hipLaunchKernelGGL((k_sp_ares<T, CHV, NOBV, NRBV>), dim3(pl.grid), dim3(64 * SP_WAVES), pl.lds, s, q);                      \
+#define MTL_SP_A(CHV, NOBV, NRBV)                                                                              \
+    do {                                                                                                       \
+        MTL_RAISE_LDS((k_sp_ares<T, CHV, NOBV, NRBV>), SP_LDS_MAX);                                            \
+        hipLaunchKernelGGL((k_sp_ares<T, CHV, NOBV, NRBV>), dim3(pl.grid), dim3(64 * SP_WAVES), pl.lds, s, q); \
     } while (0)
     if constexpr (sizeof(T) == 2) {
         if (pl.ch == 96) {
@@ -1939,8 +1977,12 @@ static int sp_tn_nb(const mtlora_linear_desc* d) {
     if (d->K % 96 == 0 && d->N % 96 == 0) return 3;
     return 0;
 }
-static int sp_tn_groups(int n_pp, int64_t M) {
+static int sp_tn_groups(const Tune& tu, int n_pp, int64_t M) {
     int G = SP_TN_WGS / (n_pp > 0 ? n_pp : 1);  // one resident round of workgroups, every workgroup the same number of rows
+    if (tu.max_cu > 0) {  // (tests: as if the device had max_cu CUs -- fewer row groups, more slabs per wave)
+        const int cap = tu.max_cu / (n_pp > 0 ? n_pp : 1);
+        G = G < cap ? G : (cap > 0 ? cap : 1);
+    }
     const int64_t by_rows = mtl_ceil_div(mtl_ceil_div(M, 32), SP_WAVES);  // no more waves than slabs
     if (G > by_rows) G = (int)by_rows;
     return G < 1 ? 1 : G;
@@ -2026,12 +2068,8 @@ static unsigned sp_tn_map(SpTnParams& q) {
     q.G = g_fine > 0 ? g_fine : G0;
     return sp_tn_map_units(q, false, mx);
 }
-// developer switch MTLORA_SP_TN: 0 tiled k_tn only, 2 streaming whenever the shape allows, unset / 1: streaming when every wave gets
+// Tune.tn (desc.sel_tn): 0 tiled k_tn only, 2 streaming whenever the shape allows, 1 (default): streaming when every wave gets
 // >= 8 slabs (below that the launch is latency-bound and the tiled kernel's 64-row chunks win: measured on the stage-2 / 3 shapes)
-static int sp_tn_mode() {
-    const char* e = getenv("MTLORA_SP_TN");
-    return e ? atoi(e) : 1;
-}
 static int64_t sp_tn_part_bytes(const mtlora_linear_desc* d, const Segs& sg) {
     const int nb = sp_tn_nb(d);
     if (nb == 0) return 0;
@@ -2049,21 +2087,14 @@ static void launch_sp_tn(SpTnParams& q, int nb, hipStream_t s, double xb, double
         {
             mtl_prof_tag("sp_tn %s np%d pp%d G%d nb%d", tag, q.n_prob, q.n_pp, q.G, nb);
             MtlProfScope prof(PK_TN, xb, s, xb, fl);
-#define MTL_SP_TN(NBV, NSV)                                                                                                     \
-    do {                                                                                                                         \
-        constexpr size_t lds = (size_t)SP_WAVES * NSV * (SP_TN_NARROW + 32 * NBV * 64);                                          \
-        static bool raised = false;                                                                                              \
-        if (!raised) {                                                                                                           \
-            (void)hipFuncSetAttribute((const void*)k_sp_tn<T, NBV, NSV>, hipFuncAttributeMaxDynamicSharedMemorySize, SP_LDS_MAX); \
-            raised = true;                                                                                                       \
-        }                                                                                                                        \
-        hipLaunchKernelGGL((k_sp_tn<T, NBV, NSV>), dim3(grid), dim3(64 * SP_WAVES), lds, s, q);                                  \
+#define MTL_SP_TN(NBV, NSV)                                                                     \
+    do {                                                                                        \
+        constexpr size_t lds = (size_t)SP_WAVES * NSV * (SP_TN_NARROW + 32 * NBV * 64);         \
+        MTL_RAISE_LDS((k_sp_tn<T, NBV, NSV>), SP_LDS_MAX);                                      \
+        hipLaunchKernelGGL((k_sp_tn<T, NBV, NSV>), dim3(grid), dim3(64 * SP_WAVES), lds, s, q); \
     } while (0)
-            static const int force_ns = [] { const char* e = getenv("MTLORA_SP_TN_NS"); return e ? atoi(e) : 0; }();
             if (nb == 4)
                 MTL_SP_TN(4, 1);
-            else if (force_ns == 1)
-                MTL_SP_TN(3, 1);
             else
                 MTL_SP_TN(3, 2);
 #undef MTL_SP_TN
@@ -2113,6 +2144,7 @@ static int fwd_impl(const mtlora_linear_desc* d, const void* x, const void* cons
                     const float* const* B_t, void* y_s, void* const* y_t, void* ctx, hipStream_t s, void* a_s = nullptr,
                     void* const* a_t = nullptr) {
     const Segs sg = make_segs(d);
+    const Tune tu = make_tune(d);
     const CtxLayout L = ctx_layout(d, sg);
     unsigned char* c = reinterpret_cast<unsigned char*>(ctx);
     unsigned char* pk = c;
@@ -2149,7 +2181,7 @@ static int fwd_impl(const mtlora_linear_desc* d, const void* x, const void* cons
             q.mask_lr = 0;
             q.drop = dc;
             SpXresPlan pl;
-            if (sp_xres_plan<T>(q, (int)d->K, pl)) {
+            if (sp_xres_plan<T>(tu, q, (int)d->K, pl)) {
                 const double b8d = (double)sizeof(T) * d->M * (d->K + (double)d->N);
                 const double fl = 2.0 * d->M * (double)d->K * d->N + 2.0 * d->M * (double)sg.r[0] * (d->K + d->N);
                 launch_sp_xres<T>(q, pl, a_s != nullptr, s, PK_NT_FWD_MAIN, b8d + (a_s ? (double)sizeof(T) * d->M * d->N : 0.0), b8d, fl);
@@ -2214,13 +2246,13 @@ static int fwd_impl(const mtlora_linear_desc* d, const void* x, const void* cons
                     ss.mask = (o == 0) ? 1 : 0;
                 }
                 int ch = 0;
-                const int ns = sp_proj_plan<T>(sp, ch);
+                const int ns = sp_proj_plan<T>(tu, sp, ch);
                 if (ns > 0)
-                    launch_sp_proj<T>(sp, ch, ns, s, PK_NT_FWD_P, xb, xb, 2.0 * d->M * d->K * rsum);
-                else if (sp_projk_plan<T>(sp, ch))
-                    launch_sp_projk<T>(sp, ch, s, PK_NT_FWD_P, xb, xb, 2.0 * d->M * d->K * rsum);
+                    launch_sp_proj<T>(tu, sp, ch, ns, s, PK_NT_FWD_P, xb, xb, 2.0 * d->M * d->K * rsum);
+                else if (sp_projk_plan<T>(tu, sp, ch))
+                    launch_sp_projk<T>(tu, sp, ch, s, PK_NT_FWD_P, xb, xb, 2.0 * d->M * d->K * rsum);
                 else
-                    launch_nt<T>(q, s, PK_NT_FWD_P, xb, xb, 2.0 * d->M * d->K * rsum);
+                    launch_nt<T>(tu, q, s, PK_NT_FWD_P, xb, xb, 2.0 * d->M * d->K * rsum);
             }
         }
     }
@@ -2261,7 +2293,7 @@ static int fwd_impl(const mtlora_linear_desc* d, const void* x, const void* cons
         for (int o = 0; o < sg.n; ++o) rsum += sg.r[o];
         const double fl = 2.0 * d->M * d->K * d->N + 2.0 * d->M * d->N * rsum;
         const bool plain = sg.R == 0;
-        launch_nt<T>(m, s, plain ? PK_NT_PLAIN_FWD : PK_NT_FWD_MAIN, b8d + (double)sizeof(T) * d->M * (double)n_actout * d->N,
+        launch_nt<T>(tu, m, s, plain ? PK_NT_PLAIN_FWD : PK_NT_FWD_MAIN, b8d + (double)sizeof(T) * d->M * (double)n_actout * d->N,
                      plain ? 0.0 : b8d, fl);
     }
     return MTLORA_OK;
@@ -2318,6 +2350,7 @@ static int bwd_impl(const mtlora_linear_desc* d, const void* x, const void* cons
                     float* dA_s, float* dB_s, float* const* dA_t, float* const* dB_t, void* scratch, hipStream_t s,
                     const void* gate_s = nullptr, const void* const* gate_t = nullptr) {
     const Segs sg = make_segs(d);
+    const Tune tu = make_tune(d);
     const CtxLayout L = ctx_layout(d, sg);
     const BwdScratch S = bwd_scratch(d, sg);
     const unsigned char* c = reinterpret_cast<const unsigned char*>(ctx);
@@ -2355,8 +2388,7 @@ static int bwd_impl(const mtlora_linear_desc* d, const void* x, const void* cons
     // tensors forms Q (all segments) AND G = sum_o dY_o (k_sp_projsum, stream.h); the dX launch then reads G alone
     bool q_done = false;
     if constexpr (sizeof(T) == 2) {
-        static const int ps_maxt = [] { const char* e = getenv("MTLORA_PS_MAXT"); return e ? atoi(e) : MTLORA_MAX_TASKS; }();  // (A/B switch)
-        if (d->T >= 1 && d->T <= ps_maxt && d->mode == 0 && do_dx && dx && n_dy == 1 + d->T && sg.rp[0] > 0 && sg.rp[0] <= 64) {
+        if (d->T >= 1 && d->mode == 0 && do_dx && dx && n_dy == 1 + d->T && sg.rp[0] > 0 && sg.rp[0] <= 64) {
             SpProjParams sp = {};
             sp.wproj = pk + L.bt_proj;
             sp.out = Qm;
@@ -2379,11 +2411,11 @@ static int bwd_impl(const mtlora_linear_desc* d, const void* x, const void* cons
             }
             if (ok && sp.src[sp.n_src - 1].blk_lo - sp.src[1].blk_lo + 1 > SP_PS_MAXT) ok = false;  // task segments span too many blocks
             int ch = 0;
-            const int ns = ok ? sp_proj_plan<T>(sp, ch) : 0;
+            const int ns = ok ? sp_proj_plan<T>(tu, sp, ch) : 0;
             if (ns > 0 && d->M * d->N * 2 < ((int64_t)1 << 32) - 64) {
                 double rsum = 0.0;
                 for (int o = 0; o < sg.n; ++o) rsum += sg.r[o];
-                launch_sp_projsum<T>(sp, ch, ns, Gm, s, PK_NT_BWD_Q, 0.0, 0.0, 2.0 * d->M * d->N * rsum);
+                launch_sp_projsum<T>(tu, sp, ch, ns, Gm, s, PK_NT_BWD_Q, 0.0, 0.0, 2.0 * d->M * d->N * rsum);
                 q_done = true;
                 presum = true;
                 have_g = true;
@@ -2431,14 +2463,14 @@ static int bwd_impl(const mtlora_linear_desc* d, const void* x, const void* cons
         const double fl = 2.0 * d->M * (double)d->N * d->K + 2.0 * d->M * (double)sg.r[0] * (d->K + d->N);
         SpAresPlan pl;
         SpXresPlan px;
-        if (!gate_s && sp_ares_plan<T>(q, (int)d->N, pl)) {
+        if (!gate_s && sp_ares_plan<T>(tu, q, (int)d->N, pl)) {
             launch_sp_ares<T>(q, pl, s, PK_NT_BWD_DX, b8d, b8d, fl);
             sp_dx_done = true;
         } else {
             // wide input, short reduction (the Mlp's fc2: dX has 4 C columns, the reduction C <= 192): the activation-resident form,
             // with the GELU' gate of the fused Mlp in its epilogue
             q.gate = gate_s;
-            if (sp_xres_plan<T>(q, (int)d->N, px)) {
+            if (sp_xres_plan<T>(tu, q, (int)d->N, px)) {
                 launch_sp_xres<T>(q, px, false, s, PK_NT_BWD_DX, b8d + (gate_s ? (double)sizeof(T) * d->M * d->K : 0.0), b8d, fl, gate_s != nullptr);
                 sp_dx_done = true;
             }
@@ -2497,13 +2529,13 @@ static int bwd_impl(const mtlora_linear_desc* d, const void* x, const void* cons
                 ss.mask = 0;
             }
             int ch = 0;
-            const int ns = sp_proj_plan<T>(sp, ch);
+            const int ns = sp_proj_plan<T>(tu, sp, ch);
             if (ns > 0)
-                launch_sp_proj<T>(sp, ch, ns, s, PK_NT_BWD_Q, 0.0, 0.0, 2.0 * d->M * d->N * rsum);
-            else if (sp_projk_plan<T>(sp, ch))
-                launch_sp_projk<T>(sp, ch, s, PK_NT_BWD_Q, 0.0, 0.0, 2.0 * d->M * d->N * rsum);
+                launch_sp_proj<T>(tu, sp, ch, ns, s, PK_NT_BWD_Q, 0.0, 0.0, 2.0 * d->M * d->N * rsum);
+            else if (sp_projk_plan<T>(tu, sp, ch))
+                launch_sp_projk<T>(tu, sp, ch, s, PK_NT_BWD_Q, 0.0, 0.0, 2.0 * d->M * d->N * rsum);
             else
-                launch_nt<T>(q, s, PK_NT_BWD_Q, 0.0, 0.0, 2.0 * d->M * d->N * rsum);
+                launch_nt<T>(tu, q, s, PK_NT_BWD_Q, 0.0, 0.0, 2.0 * d->M * d->N * rsum);
         }
     }
 
@@ -2543,8 +2575,7 @@ static int bwd_impl(const mtlora_linear_desc* d, const void* x, const void* cons
             O.seg_hi = sg.off[0] + sg.rp[0];
             // small task ranks: the task outputs are a streaming elementwise kernel of their own (k_rank_out), not tile passes
             if constexpr (sizeof(T) == 2) {
-                static const int ro_mode = [] { const char* e = getenv("MTLORA_RANK_OUT"); return e ? atoi(e) : 1; }();
-                bool ok = sp_mode() != 0 && ro_mode != 0 && dx_t != nullptr && d->K % 8 == 0 && d->K / 8 <= 256 && d->M > 0;
+                bool ok = tu.sp != 0 && dx_t != nullptr && d->K % 8 == 0 && d->K / 8 <= 256 && d->M > 0;
                 int rpm = 0, gates = 0, outs = 0;
                 for (int t = 0; t < d->T; ++t) {
                     if (!dx_t || !dx_t[t]) continue;
@@ -2599,7 +2630,7 @@ static int bwd_impl(const mtlora_linear_desc* d, const void* x, const void* cons
                 if (sg.rp[o] > 0 && dyo[o]) rsum += sg.r[o];
             const double fl = (n_dy > 0 ? 2.0 * d->M * d->N * d->K : 0.0) + 2.0 * d->M * d->K * rsum;
             const bool plain = sg.R == 0;
-            launch_nt<T>(m, s, plain ? PK_NT_PLAIN_DX : PK_NT_BWD_DX, b8d + (double)sizeof(T) * d->M * (double)n_gate * d->K,
+            launch_nt<T>(tu, m, s, plain ? PK_NT_PLAIN_DX : PK_NT_BWD_DX, b8d + (double)sizeof(T) * d->M * (double)n_gate * d->K,
                          plain ? 0.0 : b8d, fl);
         }
         if constexpr (sizeof(T) == 2) {
@@ -2609,7 +2640,7 @@ static int bwd_impl(const mtlora_linear_desc* d, const void* x, const void* cons
                 MtlProfScope prof(PK_NT_BWD_DX, ob * (rank_out_gated ? 2.0 : 1.0), s, ob, 0.0);
                 const int nchunk = (int)(d->K / 8), rpb = 256 / nchunk;
                 int64_t bx = mtl_ceil_div(d->M, (int64_t)rpb * 4);
-                const int64_t cap = (int64_t)sp_num_cu() * 8 / rank_out.n_t > 0 ? (int64_t)sp_num_cu() * 8 / rank_out.n_t : 1;
+                const int64_t cap = (int64_t)num_cu(tu) * 8 / rank_out.n_t > 0 ? (int64_t)num_cu(tu) * 8 / rank_out.n_t : 1;
                 if (bx > cap) bx = cap;
                 const dim3 g((unsigned)bx, (unsigned)rank_out.n_t);
                 if (rank_out_gated && rank_out_rp == 8)
@@ -2685,7 +2716,7 @@ static int bwd_impl(const mtlora_linear_desc* d, const void* x, const void* cons
         }
         bool tn_done = false;
         if constexpr (sizeof(T) == 2) {
-            const int nb = (sp_mode() != 0 && sp_tn_mode() != 0) ? sp_tn_nb(d) : 0;
+            const int nb = (tu.sp != 0 && tu.tn != 0) ? sp_tn_nb(d) : 0;
             bool ok = nb != 0 && tp.n_prob > 0;
             SpTnParams q = {};
             for (int i = 0; ok && i < tp.n_prob; ++i) {
@@ -2712,9 +2743,9 @@ static int bwd_impl(const mtlora_linear_desc* d, const void* x, const void* cons
                 q.n_pp += r.tiles_a * r.parts;
             }
             if (ok) {
-                const int mode = sp_tn_mode();
+                const int mode = tu.tn;
                 q.n_prob = tp.n_prob;
-                q.G = sp_tn_groups(q.n_pp, d->M);
+                q.G = sp_tn_groups(tu, q.n_pp, d->M);
                 ok = q.n_pp <= SP_TN_WGS && q.G < 65536 && (mode == 2 || (mode == 1 && mtl_ceil_div(d->M, 32) >= (int64_t)8 * q.G * SP_WAVES));
                 if (ok) {
                     SpTnParams probe = q;

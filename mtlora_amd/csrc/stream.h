@@ -294,8 +294,10 @@ struct SpLinParams {
     void* pout;          // (M x ldp) projection image for the factor gradients, nullable
     int64_t ld_out, ldp, M;
     int n_cols, R, n_parts, blk_per_part;
-    int n_slabs, mask_act, mask_lr, dbg;  // dbg: developer ablation bits (MTLORA_SP_DBG): 1 no output stores, 2 no slab loads, 4 no block MFMAs, 8 no P store
+    int n_slabs, mask_act, mask_lr, dbg;  // dbg: developer ablation bits (MTLORA_SP_DBG, -DMTL_NT_ABLATE=1 builds only): 1 no output stores, 2 no slab loads, 4 no block MFMAs, 8 no P store
     int estep, estep2;   // rank steps per block in `expand` (2 * ceil(R / 32)); k_sp_ares: the reduction length K
+    int xsh, pad_;       // blockIdx -> (part, slab group): part = (b >> xsh) % n_parts, group = (b & (2^xsh - 1)) + ((b / (n_parts << xsh)) << xsh);
+                         // xsh = 3: the parts of a group share an XCD (b % 8); xsh = 0: grids smaller than 8 * n_parts (desc.max_cu)
     DropoutCfg drop;
 };
 typedef const __attribute__((address_space(4))) SpLinParams* SpLinPtr;
@@ -336,9 +338,9 @@ __global__ __launch_bounds__(64 * SP_WAVES, SP_WAVES / 4) void k_sp_xres(const S
     const int n_cols = P->n_cols;
     // (part, slab group) of this workgroup: b, b + 8, b + 16, ... (one XCD) are the parts of one group
     const int n_parts = P->n_parts;
-    const int b = blockIdx.x;
-    const int part = (b >> 3) % n_parts;
-    const int grp = (b & 7) + 8 * (b / (8 * n_parts));
+    const int b = blockIdx.x, xsh = P->xsh;
+    const int part = (b >> xsh) % n_parts;
+    const int grp = (b & ((1 << xsh) - 1)) + ((b / (n_parts << xsh)) << xsh);
     const int n_grp = gridDim.x / n_parts;
     const int nb_all = (n_cols + 31) >> 5;
     const int bpp = P->blk_per_part;
@@ -359,7 +361,7 @@ __global__ __launch_bounds__(64 * SP_WAVES, SP_WAVES / 4) void k_sp_xres(const S
     drop.off = P->drop.off;
     mtl_dropout_resolve(drop);
     const bool mask_act = P->mask_act != 0 && drop.thr16 != 0, mask_lr = P->mask_lr != 0 && drop.thr16 != 0;
-    const int dbg = P->dbg;
+    const int dbg = P->dbg & NT_DBG_MASK;  // (0 at compile time unless -DMTL_NT_ABLATE=1)
 
     {   // stationary operands
         const T* wp = reinterpret_cast<const T*>(P->w);
@@ -639,9 +641,9 @@ __global__ __launch_bounds__(64 * SP_WAVES, SP_WAVES / 4) void k_sp_ares(const S
     const int K = P->estep2;              // reduction length (elements), a multiple of CH
     const int KST = K >> 4, NCH = K / CH;
     const int n_parts = P->n_parts;
-    const int b = blockIdx.x;
-    const int part = (b >> 3) % n_parts;
-    const int grp = (b & 7) + 8 * (b / (8 * n_parts));
+    const int b = blockIdx.x, xsh = P->xsh;
+    const int part = (b >> xsh) % n_parts;
+    const int grp = (b & ((1 << xsh) - 1)) + ((b / (n_parts << xsh)) << xsh);
     const int n_grp = gridDim.x / n_parts;
     const int nb_all = (n_cols + 31) >> 5;
     constexpr int bpp = NOB;              // blocks per part (blocks past the last column have zero weights and are not stored)
@@ -660,7 +662,7 @@ __global__ __launch_bounds__(64 * SP_WAVES, SP_WAVES / 4) void k_sp_ares(const S
     drop.off = P->drop.off;
     mtl_dropout_resolve(drop);
     const bool mask_act = P->mask_act != 0 && drop.thr16 != 0, mask_lr = P->mask_lr != 0 && drop.thr16 != 0;
-    const int dbg = P->dbg;
+    const int dbg = P->dbg & NT_DBG_MASK;  // (0 at compile time unless -DMTL_NT_ABLATE=1)
 
     {   // stationary operands
         const T* wp = reinterpret_cast<const T*>(P->w);

@@ -7,6 +7,7 @@ from __future__ import annotations
 
 import ctypes
 import os
+import weakref
 from dataclasses import dataclass, field
 from typing import List, Optional, Sequence, Tuple
 
@@ -46,16 +47,26 @@ _factor_stream: Optional["torch.cuda.Stream"] = None
 _FACTOR_MIN_M = int(os.environ.get("MTLORA_FACTOR_MIN_M", "8192"))
 
 
-# parameters whose factor gradient is being written on the side stream in the backward now running (ids): a second use of the
-# same layer in one graph, or an accumulating backward racing it, must not touch that .grad on the main stream meanwhile
-_side_inflight: set = set()
+# factor parameters whose gradient was written on the side stream by an earlier backward call -> that stream.  A later use of the
+# same layer (twice in one graph, or a second backward accumulating into the .grad before the caller joined the side stream) makes
+# its own stream WAIT for the side stream before anything touches the gradient; afterwards the side stream may be used again.
+# Weak keys: a freed Parameter leaves no entry behind (raw ids can be reused by other objects).  A caller that joins the side stream
+# (train_step, GradReducer) says so with ``factor_stream_joined()``; one that installs the stream once and never says anything still
+# gets correct results and keeps the side stream (the former id set was only cleared on install, which silently
+# disabled the side stream from the second backward on).
+_side_pending: "weakref.WeakKeyDictionary" = weakref.WeakKeyDictionary()
+
+
+def factor_stream_joined() -> None:
+    """the caller made its stream wait for the side stream: nothing written there is pending any more"""
+    _side_pending.clear()
 
 
 def set_factor_stream(stream: Optional["torch.cuda.Stream"]) -> None:
-    """install (or, with None, remove) the side stream; (re)installing it starts a new backward: nothing is in flight"""
+    """install (or, with None, remove) the side stream for the factor gradients (see above)"""
     global _factor_stream
     _factor_stream = stream
-    _side_inflight.clear()
+    _side_pending.clear()  # (a caller (re)installs the stream at a point where it has joined the previous one)
 
 
 def factor_stream() -> Optional["torch.cuda.Stream"]:
@@ -135,6 +146,39 @@ def droppath_scale(n: int, B: int, keep: float, device) -> torch.Tensor:
     return _droppath_pool.scale(n, B, keep, device)
 
 
+# ----------------------------------------------------------------------------------------------
+# kernel selection (mtlora_linear_desc.sel_* / max_cu, ABI v6).  The LIBRARY reads no environment variables; this module reads
+# the developer switches once at import and hands them to every call through the descriptor.  ``set_tuning`` overrides them in
+# process (tests: the "[tiled]" / "[dense]" / "[persist]" families of tests/conftest.py; tools/bench_linear.py A/B runs).
+#   MTLORA_SP=0        -> stream=1  (tiled kernels only)         MTLORA_NTD=0 / 2      -> dense=1 / 2 (k_ntd never / whenever)
+#   MTLORA_SP_TN=0 / 2 -> tn=1 / 2  (k_sp_tn never / whenever)   MTLORA_SP_PROJK=0 / 2 -> projk=1 / 2
+#   MTLORA_MAX_CU=n    -> max_cu=n  (persistent grids sized as if the device had n CUs)
+# ----------------------------------------------------------------------------------------------
+def _env_tri(name: str) -> int:
+    v = os.environ.get(name)
+    return 0 if v is None or v == "1" else (1 if v == "0" else 2)
+
+
+_TUNING_DEFAULT = {"stream": 1 if os.environ.get("MTLORA_SP") == "0" else 0, "dense": _env_tri("MTLORA_NTD"),
+                   "tn": _env_tri("MTLORA_SP_TN"), "projk": _env_tri("MTLORA_SP_PROJK"),
+                   "max_cu": int(os.environ.get("MTLORA_MAX_CU", "0"))}
+_tuning = dict(_TUNING_DEFAULT)
+
+
+def set_tuning(**kw) -> dict:
+    """override kernel-selection switches for the calls that follow (keys: stream, dense, tn, projk, max_cu; values as in
+    include/mtlora_hip.h: 0 = library default); ``set_tuning()`` with no arguments restores the import-time values.
+    Returns the previous settings."""
+    prev = dict(_tuning)
+    if not kw:
+        _tuning.update(_TUNING_DEFAULT)
+    for k, v in kw.items():
+        if k not in _tuning:
+            raise KeyError(f"mtlora_amd: unknown tuning key {k!r} (have {sorted(_tuning)})")
+        _tuning[k] = int(v)
+    return prev
+
+
 def next_seed() -> int:
     global _seed_counter
     _seed_counter += 1
@@ -208,6 +252,8 @@ class LinearMeta:
         d.dropout_p = self.dropout_p
         d.seed = self.seed
         d.seed_offset = 0 if _seed_offset is None else _seed_offset.data_ptr()
+        tu = _tuning
+        d.sel_stream, d.sel_dense, d.sel_tn, d.sel_projk, d.max_cu = tu["stream"], tu["dense"], tu["tn"], tu["projk"], tu["max_cu"]
         return d
 
 
@@ -354,13 +400,15 @@ class MTLoRALinearFn(torch.autograd.Function):
         use_side = (side is not None and fgrads and not ctx.has_scale_s and meta.n_scale_t == 0
                     and side.device == dev and M >= _FACTOR_MIN_M
                     and all(p is None or p.grad is None for p in ctx.factor_params))
-        if side is not None and any(p is not None and id(p) in _side_inflight for p in ctx.factor_params):
-            # the same layer was applied twice in this graph (or a second backward accumulates into it): its first factor
-            # gradient is still being written on the side stream -- join before anything here accumulates into that .grad
-            torch.cuda.current_stream(dev).wait_stream(side)
-            use_side = False
+        if _side_pending:
+            # an earlier backward call wrote this layer's factor gradients on the side stream and nobody joined it since: order
+            # everything below (and autograd's accumulation into those .grad tensors) behind that stream
+            pend = {id(st): st for st in (_side_pending.pop(p, None) for p in ctx.factor_params if p is not None) if st is not None}
+            for st in pend.values():
+                torch.cuda.current_stream(dev).wait_stream(st)
+            if pend:  # this call's gradients are summed with the earlier ones by the autograd engine on THIS stream: keep them here
+                use_side = False
         if use_side:
-            _side_inflight.update(id(p) for p in ctx.factor_params if p is not None)
             d.bwd_phase = 1
             launch(L.stream_ptr())
             ev = torch.cuda.Event()
@@ -368,6 +416,9 @@ class MTLoRALinearFn(torch.autograd.Function):
             side.wait_event(ev)
             d.bwd_phase = 2
             launch(ctypes.c_void_p(side.cuda_stream))
+            for p in ctx.factor_params:
+                if p is not None:
+                    _side_pending[p] = side
             for t in [x2, ctxbuf, scratch, *xt2, *fgrads] + [g for g in g2 if g is not None]:
                 t.record_stream(side)  # allocated on this stream, still in use on the side stream when freed here
         else:

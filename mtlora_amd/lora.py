@@ -140,6 +140,8 @@ class MTLoRALinear(LoRALayer):
         hit = self._wcache.get(key)
         if w.requires_grad or (b is not None and b.requires_grad):
             hit = None  # trained by an optimizer every step: never serve a cached copy
+        if hit is not None and hit[1].is_inference() and not torch.is_inference_mode_enabled():
+            hit = None  # copies made under torch.inference_mode() (an eval pass) cannot be saved for backward or refreshed in place
         if hit is None or hit[0] != ver:
             with torch.no_grad():
                 if hit is not None and hit[1].shape == w.shape and (b is None) == (hit[3] is None):
@@ -154,7 +156,9 @@ class MTLoRALinear(LoRALayer):
                     wt = w.detach().t().to(dtype).contiguous()
                     bf = None if b is None else b.detach().float().contiguous()
             hit = (ver, wc, wt, bf)
-            self._wcache = {key: hit}
+            # one entry per (dtype, device), none evicted: an fp32 eval between bf16 graphed steps must not free the copies whose
+            # addresses a captured HIP graph holds (52 MB per extra dtype at C2: irrelevant against 288 GB)
+            self._wcache[key] = hit
         return hit[1], hit[2], hit[3]
 
     def invalidate_weight_cache(self) -> None:
@@ -173,7 +177,14 @@ class MTLoRALinear(LoRALayer):
         # a state dict always holds the UN-merged pretrained weight (see state_dict below): whatever is loaded replaces a merged
         # weight, so the flag goes back to "not merged" (loading into a merged module used to leave the flag set: the shared update
         # was then skipped, and the next train() subtracted a delta the loaded weight never contained)
-        self.merged = False
+        # -- unless the dict is PARTIAL (strict=False: LoRA factors only, checkpoint.load_state): then linear.weight still holds
+        # W + s B A of the OLD factors, and clearing the flag would make the next forward add the shared update a second time while
+        # train() / unmerge() no longer subtracted it: un-merge with the old factors first, then load.
+        if self.merged:
+            if (prefix + "linear.weight") in state_dict:
+                self.merged = False
+            else:
+                self.unmerge()
         self.invalidate_weight_cache()
         return super()._load_from_state_dict(state_dict, prefix, *a, **k)
 

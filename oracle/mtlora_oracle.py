@@ -77,6 +77,30 @@ def dropout_keep_mask(seed: int, stream: int, rows: int, cols: int, p: float) ->
     return torch.from_numpy(bits >= thr)
 
 
+def dropout_keep_mask_t(seed: int, stream: int, rows: int, cols: int, p: float, device="cpu", row0: int = 0) -> Tensor:
+    """:func:`dropout_keep_mask` restated with torch int64 arithmetic (any device; rows ``row0 .. row0 + rows``): the full-size
+    GPU parity tests need the mask of 4e5 x 384 activations, which the numpy form builds in minutes.  Pinned to the numpy
+    form element for element by tests/test_oracle_golden.py."""
+    if p <= 0.0:
+        return torch.ones(rows, cols, dtype=torch.bool, device=device)
+    M32 = 0xFFFFFFFF
+
+    def mix(x):  # x in [0, 2^32): int64 products wrap mod 2^64, the low 32 bits are exact
+        x = x ^ (x >> 16)
+        x = (x * 0x7FEB352D) & M32
+        x = x ^ (x >> 15)
+        x = (x * 0x846CA68B) & M32
+        return x ^ (x >> 16)
+
+    seed_lo, seed_hi = seed & M32, (seed >> 32) & M32
+    m = torch.arange(row0, row0 + rows, dtype=torch.int64, device=device)[:, None]
+    k = torch.arange(cols, dtype=torch.int64, device=device)[None, :]
+    rh = mix((m * 0x9E3779B1 + seed_lo + stream * 0x85EBCA77) & M32)
+    h = mix(rh ^ (((k >> 1) + seed_hi * 0x27D4EB2F) & M32))
+    bits = torch.where((k & 1) == 1, h >> 16, h & 0xFFFF)
+    return bits >= min(int(p * 65536.0), 65535)
+
+
 # --------------------------------------------------------------------------
 # a2/a3/a4  MTLoRALinear  (models/lora.py:159-284)
 # --------------------------------------------------------------------------

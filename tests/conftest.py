@@ -28,41 +28,44 @@ def golden():
     return load
 
 
-# ---- two kernel families serve the MTLoRALinear launches: the wave-streaming kernels (csrc/stream.h: fused T = 0 forward / dX,
-# P / Q passes -- the default wherever a shape is eligible) and the tiled kernels (k_nt / k_ntl: everything else).  Every GPU
-# test that runs an MTLoRALinear in a 16-bit type is ALSO run with the streaming family switched off ("[tiled]" variants:
-# MTLORA_SP=0, read by the library at every call), so the golden / oracle cases pin both the default path and the fallback.
+# ---- kernel families.  The MTLoRALinear launches are served by the wave-streaming kernels (csrc/stream.h: fused T = 0 forward /
+# dX, P / Q passes -- the default wherever a shape is eligible), the tiled kernels (k_nt / k_ntl: everything else) and the
+# shape-selected ones (k_ntd, k_sp_tn, k_sp_projk).  Every GPU test that runs an MTLoRALinear in a 16-bit type is ALSO run
+#   [tiled]    with the streaming family switched off (the fallback path),
+#   [dense]    with every shape-selected kernel taken wherever it is ELIGIBLE, whatever the size heuristics say (the test shapes are
+#              far below the sizes at which the library picks them on its own),
+#   [persist]  like [dense] with the persistent grids sized as if the device had ONE CU (mtlora_linear_desc.max_cu): every wave of
+#              k_sp_xres / k_sp_ares / k_sp_proj / k_sp_projsum / k_sp_tn then owns several slabs and every k_ntd workgroup several
+#              tiles -- the steady state of the slot rings, of the "next slab's DMA under this slab's MFMAs" overlap and of the
+#              hand-counted vmcnt waits, which at test sizes on 256 CUs is never reached,
+# so the golden / oracle cases pin every path.  The switches travel in the descriptor (functional.set_tuning): the library reads no
+# environment variables.
 _TILED_TESTS = ("linear", "mlp", "swin_block", "backbone", "config_model", "module_golden", "c1_reference", "task_streams",
                 "reducer_on_the_real_model")
-
-
-# "dense": every launch that is ELIGIBLE for one of the shape-selected kernels takes it, whatever the size heuristics say (k_ntd for
-# the single-output GEMMs, k_sp_tn for the factor gradients, k_sp_projk for the P / Q passes with large K R): the test shapes are
-# far below the sizes at which the library picks them on its own
 _DENSE_TESTS = ("linear", "mlp", "swin_block")
+_PERSIST_TESTS = ("linear", "mlp", "swin_block", "backbone")
+_FAMILIES = {"tiled": (_TILED_TESTS, dict(stream=1, dense=1)),
+             "dense": (_DENSE_TESTS, dict(dense=2, tn=2, projk=2)),
+             "persist": (_PERSIST_TESTS, dict(dense=2, tn=2, projk=2, max_cu=1))}
 
 
-@pytest.fixture(autouse=True, params=["auto", "tiled", "dense"])
-def _kernel_family(request, monkeypatch):
-    for k in ("MTLORA_SP", "MTLORA_NTD", "MTLORA_SP_TN", "MTLORA_SP_PROJK"):
-        monkeypatch.delenv(k, raising=False)
-    if request.param == "tiled":
-        monkeypatch.setenv("MTLORA_SP", "0")
-        monkeypatch.setenv("MTLORA_NTD", "0")
-    elif request.param == "dense":
-        monkeypatch.setenv("MTLORA_NTD", "2")
-        monkeypatch.setenv("MTLORA_SP_TN", "2")
-        monkeypatch.setenv("MTLORA_SP_PROJK", "2")
+@pytest.fixture(autouse=True, params=["auto", "tiled", "dense", "persist"])
+def _kernel_family(request):
+    from mtlora_amd import functional as Fn
+    prev = Fn.set_tuning(stream=0, dense=0, tn=0, projk=0, max_cu=0)
+    if request.param != "auto":
+        Fn.set_tuning(**_FAMILIES[request.param][1])
     yield
+    Fn.set_tuning(**prev)
 
 
 def pytest_collection_modifyitems(config, items):
     keep = []
     for it in items:
-        variant = next((v for v in ("tiled", "dense") if f"[{v}" in it.name or f"-{v}]" in it.name), None)
+        variant = next((v for v in _FAMILIES if f"[{v}" in it.name or f"-{v}]" in it.name), None)
         if variant:
             is_gpu = it.get_closest_marker("gpu") is not None
-            wants = any(k in it.name for k in (_TILED_TESTS if variant == "tiled" else _DENSE_TESTS))
+            wants = any(k in it.name for k in _FAMILIES[variant][0])
             import torch
             vals = list(getattr(getattr(it, "callspec", None), "params", {}).values())
             fp32_only = ("fp32" in it.name) or (torch.float32 in vals and torch.bfloat16 not in vals and torch.float16 not in vals)

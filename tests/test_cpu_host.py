@@ -91,6 +91,66 @@ def test_size_queries_and_validation(built_lib):
     assert L.mtlora_roll_and_window_partition_forward(ctypes.c_void_p(16), ctypes.c_void_p(32), 1, 14, 14, 8, -3, 5, 0, None) == -2
 
 
+def test_descriptor_selection_fields_are_validated(built_lib):
+    """ABI v6: kernel selection travels in the descriptor (no environment reads in the library); out-of-range values are rejected
+    by the size queries like any other invalid field, and the Python side fills them from functional.set_tuning."""
+    import ctypes
+    from mtlora_amd import _lib
+    from mtlora_amd import functional as Fn
+    L = _lib.lib()
+    d = _lib.LinearDesc()
+    d.M, d.K, d.N, d.dtype, d.T, d.r_s = 1000, 96, 384, _lib.BF16, 0, 64
+    base = L.mtlora_linear_ctx_bytes(ctypes.byref(d))
+    assert base > 0
+    for field, bad in (("sel_stream", 2), ("sel_dense", 3), ("sel_tn", -1), ("sel_projk", 7), ("max_cu", -1)):
+        setattr(d, field, bad)
+        assert L.mtlora_linear_ctx_bytes(ctypes.byref(d)) < 0, field
+        setattr(d, field, 0)
+    d.sel_dense, d.sel_tn, d.sel_projk, d.max_cu = 2, 2, 2, 1
+    assert L.mtlora_linear_ctx_bytes(ctypes.byref(d)) == base  # workspace sizes do not depend on the selection
+    prev = Fn.set_tuning(stream=1, dense=2, max_cu=3)
+    try:
+        meta = Fn.LinearMeta(K=96, N=96, r_s=8, r_t=(), scale_s=1.0, scale_t=(), mode=0, has_x_tasks=False, dropout_p=0.0, seed=0,
+                             dtype=torch.bfloat16)
+        dd = meta.desc(64)
+        assert (dd.sel_stream, dd.sel_dense, dd.sel_tn, dd.sel_projk, dd.max_cu) == (1, 2, prev["tn"], prev["projk"], 3)
+        with pytest.raises(KeyError):
+            Fn.set_tuning(nonsense=1)
+    finally:
+        Fn.set_tuning(**prev)
+    # the shipped library does not read the environment for kernel selection / debugging
+    blob = open(_lib.LIB_PATH, "rb").read()
+    for name in (b"MTLORA_SP\0", b"MTLORA_NTD", b"MTLORA_SP_TN", b"MTLORA_SP_PROJK", b"MTLORA_NT_DBG", b"MTLORA_SP_DBG", b"MTLORA_SP_STG",
+                 b"MTLORA_PS_MAXT", b"MTLORA_RANK_OUT"):
+        assert name not in blob, name
+
+
+def test_partial_state_dict_into_merged_layer_unmerges_first():
+    """loading a LoRA-only (strict=False) dict into a MERGED layer must not leave W + s B_old A_old behind with the
+    merged flag cleared (the shared update would be added twice; a later unmerge would subtract the wrong delta)."""
+    from mtlora_amd.lora import MTLoRALinear
+    torch.manual_seed(0)
+    m = MTLoRALinear(16, 24, r=4, lora_shared_scale=2.0)
+    with torch.no_grad():
+        m.lora_shared_B.normal_()
+    w0 = m.linear.weight.detach().clone()
+    m.eval()
+    assert m.merge() and m.merged
+    assert not torch.allclose(m.linear.weight, w0)
+    new = {"lora_shared_A": torch.randn(4, 16), "lora_shared_B": torch.randn(24, 4)}
+    missing, unexpected = m.load_state_dict(new, strict=False)
+    assert "linear.weight" in missing and not unexpected
+    assert not m.merged
+    assert torch.allclose(m.linear.weight, w0, atol=1e-6)      # the OLD delta was taken out before the factors changed
+    assert torch.equal(m.lora_shared_A, new["lora_shared_A"])
+    # a full dict into a merged layer: the loaded weight is un-merged by definition
+    m.merge()
+    full = {k: v.clone() for k, v in m.state_dict().items()}
+    assert torch.allclose(full["linear.weight"], w0, atol=1e-6)  # state_dict of a merged layer saves the un-merged weight
+    m.load_state_dict(full)
+    assert not m.merged and torch.allclose(m.linear.weight, w0, atol=1e-6)
+
+
 def test_no_cpu_fallback():
     from mtlora_amd.lora import MTLoRALinear
     from mtlora_amd import window_process as WP

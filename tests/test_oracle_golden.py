@@ -278,3 +278,16 @@ def test_c1_model(golden):
         assert torch.allclose(g[cs["idx"]], ref, rtol=2e-3, atol=2e-6 * max(1e-12, ref.abs().max().item()) + 1e-9), n
     none = sorted(k for k, v in P.items() if v.requires_grad and v.grad is None)
     assert none == c["grad_is_none"]
+
+
+def test_dropout_mask_torch_restatement_equals_numpy_form():
+    """oracle.dropout_keep_mask_t (torch int64, any device, row offset) == oracle.dropout_keep_mask (numpy uint64), the
+    definition mirrored from csrc/common.h: seeds with high bits set, odd sizes, a row offset."""
+    for seed, stream, rows, cols, p in [(0x9E3779B97F4A7C15, 0, 257, 96, 0.25), (12345, 3, 64, 384, 0.05),
+                                        (0xFFFFFFFFFFFFFFFF, 1, 33, 7, 0.5), (1 << 32, 0, 5, 1536, 0.999)]:
+        a = O.dropout_keep_mask(seed, stream, rows, cols, p)
+        b = O.dropout_keep_mask_t(seed, stream, rows, cols, p)
+        assert torch.equal(a, b), (seed, stream, rows, cols, p)
+        c = O.dropout_keep_mask_t(seed, stream, rows - rows // 2, cols, p, row0=rows // 2)
+        assert torch.equal(a[rows // 2:], c)
+    assert O.dropout_keep_mask_t(1, 0, 4, 8, 0.0).all()

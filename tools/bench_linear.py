@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-layer kernel time of the MTLoRALinear forward / backward on the C2 shapes (B=32): default path (wave-streaming kernels
-where eligible) vs the tiled kernels only (MTLORA_SP=0, read by the library per call).
+where eligible) vs the tiled kernels only (functional.set_tuning(stream=1) / MTLORA_SP=0 at import).
     python tools/bench_linear.py [--shapes s0.qkv ...] [--iters 5] [--kinds] [--knt-only: default path only]"""
 import argparse, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -53,10 +53,8 @@ def run(name, iters):
     xts = {t: torch.randn(M, K, device=dev, dtype=torch.bfloat16, requires_grad=True) for t in TASKS} if xt else None
     res = {}
     for mode, env in ((("k_nt", "0"),) if not KNT_ONLY else ()) + (("panel", None),):  # "k_nt": tiled only; "panel": default path
-        if env is None:
-            os.environ.pop("MTLORA_SP", None)
-        else:
-            os.environ["MTLORA_SP"] = env
+        from mtlora_amd import functional as Fn
+        Fn.set_tuning(stream=0 if env is None else 1)  # the switches travel in the descriptor (the library reads no environment)
         with torch.autocast("cuda", dtype=torch.bfloat16):
             y, yt = m(x, xts)
         outs = [y] + ([yt[t] for t in TASKS] if yt else [])

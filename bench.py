@@ -55,6 +55,7 @@ def parse():
     ap.add_argument("--config", default="c2", help="c1 | c2 (default, the BASELINE metric) | c4 | c5:<r>")
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the config's)")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--roofline-steps", type=int, default=0, help="steps of the profiled leg (default: min(max(steps, 2), 5); tools/pmc.sh uses 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-eager-gpu", action="store_true")
     ap.add_argument("--graph", action="store_true",
@@ -113,7 +114,33 @@ def time_steps(step_fn, steps, warmup, world):
     return dt, t_issue
 
 
-def roofline(step_fn, steps):
+def _static_traffic(cfg_name, n_hot, n_all):
+    """PMC-measured HBM bytes of the committed profile of this config (separate `--pmc FETCH_SIZE` / `WRITE_SIZE` passes cannot be
+    collected from inside the timed process): STATIC, quoted only when the launch structure matches the profiled run.  r04 profiles
+    attribute the counters per launch kind (tools/pmc_traffic.py: hot-path launches only); older ones cover every launch of the GEMM
+    kernels, i.e. the callers' rank-0 GEMMs too -- labelled as such."""
+    suffix = "" if cfg_name == "c2" else "_" + cfg_name.replace(":", "_")
+    for rnd in ("r04", "r03", "r02", "r01"):
+        fn = f"{rnd}_pmc_traffic{suffix}.json"
+        try:
+            pm = json.load(open(os.path.join(ROOT, "profiles", fn)))
+        except Exception:
+            continue
+        hp = pm.get("hot_path")
+        if hp and abs(hp["launches_per_step"] - n_hot) < 0.5:
+            lp = pm.get("linear_path", {})
+            return {"traffic": round(hp["traffic_bytes_per_launch"]), "traffic_ratio": round(hp["traffic_ratio"], 3),
+                    "traffic_source": f"static: profiles/{fn} (hot-path launches only, per-kind attribution)",
+                    "linear_traffic_GB": round(lp.get("traffic_bytes_per_step", 0.0) / 1e9, 2) or None,
+                    "linear_traffic_ratio": round(lp["traffic_ratio"], 3) if lp.get("traffic_ratio") else None}
+        if "k_nt" in pm and abs(pm["k_nt"]["launches_per_step"] - n_all) < 0.5:
+            return {"traffic": round(pm["k_nt"]["traffic_bytes_per_launch"]), "traffic_ratio": None,
+                    "traffic_source": f"static: profiles/{fn} (ALL launches of the GEMM kernels incl. the callers' rank-0 GEMMs: "
+                                      "not comparable with alg_bytes_per_launch)", "linear_traffic_GB": None, "linear_traffic_ratio": None}
+    return {"traffic": None, "traffic_ratio": None, "traffic_source": None, "linear_traffic_GB": None, "linear_traffic_ratio": None}
+
+
+def roofline(step_fn, steps, cfg_name="c2"):
     """HIP-event timing of every library launch over `steps` extra steps (same stream as the launches)."""
     import ctypes
     from mtlora_amd import _lib as L
@@ -156,24 +183,14 @@ def roofline(step_fn, steps):
     ach8, achl = gbs(b8, ms), gbs(by, ms)
     tfl = (fl / 1e12) / (ms / 1e3) if ms > 0 else 0.0
     hbm_frac, mfma_frac = ach8 / HBM_PEAK_GBS, tfl / MFMA_PEAK_TFLOPS
-    # HBM bytes per launch from the committed PMC passes of this same workload (separate `--pmc` runs cannot be collected
-    # from inside the timed process): STATIC, and only quoted when the launch structure matches the profiled run
-    traffic, traffic_src = None, None
-    for fn in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
-        try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", fn)))
-            if abs(pm["k_nt"]["launches_per_step"] - agg(nt + ["k_nt:plain_fwd", "k_nt:plain_dX"])[0] / steps) < 0.5:
-                traffic, traffic_src = round(pm["k_nt"]["traffic_bytes_per_launch"]), f"static: profiles/{fn} (all k_nt launches)"
-                break
-        except Exception:
-            continue
+    tr = _static_traffic(cfg_name, n / steps, agg(nt + ["k_nt:plain_fwd", "k_nt:plain_dX"])[0] / steps)
     return {"bound": "hbm" if hbm_frac >= mfma_frac else "mfma",
             "kernel": "MTLoRALinear hot-path launches: fused forward / dX (k_sp_xres / k_sp_ares wave-streaming, k_nt / k_ntl / k_ntd tiled) "
                       "and the low-rank P / Q passes that remain (k_sp_proj / k_sp_projsum / k_sp_projk / k_nt)",
             "achieved": round(ach8, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hbm_frac, 4),
             "frac_achievable": round(ach8 / HBM_ACHIEVABLE_GBS, 4),
             "definition": "SURVEY 8(d) bytes of these launches / their HIP-event time / 8 TB/s (frac_achievable: / 6.29 TB/s)",
-            "traffic": traffic, "traffic_source": traffic_src,
+            "traffic": tr["traffic"], "traffic_ratio": tr["traffic_ratio"], "traffic_source": tr["traffic_source"],
             "launches_per_step": n / steps, "avg_launch_us": round(1e3 * ms / max(n, 1), 2),
             "alg_bytes_per_launch": round(b8 / max(n, 1)), "kernel_ms_per_step": round(ms / steps, 3),
             "launched": {"achieved": round(achl, 1), "frac": round(achl / HBM_PEAK_GBS, 4),
@@ -182,6 +199,7 @@ def roofline(step_fn, steps):
             "linear_path": {"what": "hot-path launches + factor gradients (k_sp_tn / k_tn) + k_pack + reduce + k_sum vs the whole 8(d) MTLoRALinear bytes",
                             "ms_per_step": round(lms / steps, 3), "s8d_GB_per_step": round(lb8 / steps / 1e9, 3),
                             "GBps": round(gbs(lb8, lms), 1), "frac": round(gbs(lb8, lms) / HBM_PEAK_GBS, 4),
+                            "traffic_GB": tr["linear_traffic_GB"], "traffic_ratio": tr["linear_traffic_ratio"],
                             "TFLOPs": round((lfl / 1e12) / (lms / 1e3), 1) if lms > 0 else None},
             "all_kernels": kinds}
 
@@ -317,9 +335,9 @@ def run_config(args, name, rank, world, dev, steps, warmup, want_roofline, batch
     }
     if rank == 0 and want_roofline:
         # profiled EAGERLY: the library's HIP-event brackets are recorded at launch time (same kernels as the graph)
-        fields["roofline"] = roofline(eager_step, max(2, min(steps, 5)))
+        fields["roofline"] = roofline(eager_step, args.roofline_steps or max(2, min(steps, 5)), name)
     elif want_roofline and world > 1:
-        for _ in range(1 + max(2, min(steps, 5))):  # keep ranks in lock-step with rank 0's profiled steps
+        for _ in range(1 + (args.roofline_steps or max(2, min(steps, 5)))):  # keep ranks in lock-step with rank 0's profiled steps
             eager_step()
     del model, opt
     torch.cuda.empty_cache()
@@ -362,7 +380,7 @@ def main():
                 if "roofline" in f:
                     r = f["roofline"]
                     o["roofline"] = {k: r[k] for k in ("bound", "achieved", "peak", "unit", "frac", "frac_achievable", "kernel_ms_per_step",
-                                                         "launches_per_step", "traffic") if k in r}
+                                                         "launches_per_step", "alg_bytes_per_launch", "traffic", "traffic_ratio") if k in r}
                     o["roofline"]["mfma_frac"] = r["mfma"]["frac"]
                 others[name] = o
             except Exception as e:  # noqa: BLE001  (a failing side leg must not lose the headline line)

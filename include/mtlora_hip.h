@@ -119,10 +119,34 @@ typedef struct mtlora_linear_desc {
     int32_t max_cu;      /* 0: size persistent grids for the whole device; n > 0: as if the device had n CUs -- every wave /
                             workgroup of a persistent kernel then owns MANY work items even at test sizes (the steady state
                             of the slot rings and the vmcnt accounting, reached otherwise only at benchmark sizes) */
+    const void* packed;  /* ABI v6, optional DEVICE pointer (null = none): the layer's packed low-rank factors, written earlier by
+                            mtlora_linear_pack / mtlora_linear_pack_table from the SAME masters, scales, dropout_p and has_x_tasks.
+                            fwd then skips its own packing launch and ctx only holds P; bwd must get the same pointer.  The masters
+                            change once per optimizer step, so a trainer packs every layer in ONE launch per step instead of one
+                            launch per layer and call. */
 } mtlora_linear_desc;
 
-/* bytes of the context buffer written by fwd and read by bwd (packed low-rank factors + P). */
+/* bytes of the context buffer written by fwd and read by bwd (packed low-rank factors + P; P alone when d->packed is set). */
 int64_t mtlora_linear_ctx_bytes(const mtlora_linear_desc* d);
+
+/* ---- packing the low-rank factors ahead of time (ABI v6).  fwd needs the fp32 masters A_* (r,K), B_* (N,r) of
+ * models/lora.py:196-215 in the compute dtype and in several layouts (row-major, transposed, alpha-scaled projection rows,
+ * fragment-major expansion factors): a small kernel per layer and call when done inside fwd.  The factors only change when the
+ * optimizer steps, so a caller may keep one `packed` buffer per layer (mtlora_linear_packed_bytes) and refresh ALL of them with
+ * one launch per step:
+ *   mtlora_linear_pack            one layer, one launch (same arguments as fwd takes);
+ *   mtlora_linear_pack_entry      writes one entry (mtlora_linear_pack_entry_bytes) of a HOST table describing a layer: master
+ *                                 pointers, scales, geometry, destination; the caller copies the table to the device once (the
+ *                                 pointers stay valid while parameters are updated in place);
+ *   mtlora_linear_pack_table      ONE launch that packs every layer of a DEVICE table (entries of one dtype).
+ * d->M is ignored by all of them; d->dropout_p / has_x_tasks / scales enter the alpha-scaled copies (train and eval differ). */
+int64_t mtlora_linear_packed_bytes(const mtlora_linear_desc* d);
+int mtlora_linear_pack(const mtlora_linear_desc* d, const float* A_s, const float* B_s, const float* const* A_t,
+                       const float* const* B_t, void* packed, int64_t packed_bytes, void* stream);
+int64_t mtlora_linear_pack_entry_bytes(void);
+int mtlora_linear_pack_entry(const mtlora_linear_desc* d, const float* A_s, const float* B_s, const float* const* A_t,
+                             const float* const* B_t, void* packed, int64_t packed_bytes, void* entry_host);
+int mtlora_linear_pack_table(const void* table_dev, int n_entries, int dtype, void* stream);
 /* bytes of the backward scratch buffer. */
 int64_t mtlora_linear_bwd_scratch_bytes(const mtlora_linear_desc* d);
 

@@ -27,7 +27,7 @@ class LinearDesc(Structure):
                 ("seed", c_uint64), ("seed_offset", c_void_p), ("bwd_phase", c_int32),
                 # kernel selection (ABI v6): 0 = the library's own choice; see include/mtlora_hip.h
                 ("sel_stream", c_int32), ("sel_dense", c_int32), ("sel_tn", c_int32), ("sel_projk", c_int32),
-                ("max_cu", c_int32)]
+                ("max_cu", c_int32), ("packed", c_void_p)]
 
 
 class AttnDesc(Structure):
@@ -57,6 +57,13 @@ _SIGS = {
     "mtlora_window_merge_and_roll_backward": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int, c_int, c_int, c_void_p]),
     "mtlora_linear_ctx_bytes": (c_int64, [POINTER(LinearDesc)]),
     "mtlora_linear_bwd_scratch_bytes": (c_int64, [POINTER(LinearDesc)]),
+    "mtlora_linear_packed_bytes": (c_int64, [POINTER(LinearDesc)]),
+    "mtlora_linear_pack": (c_int, [POINTER(LinearDesc), c_void_p, c_void_p, POINTER(c_void_p), POINTER(c_void_p), c_void_p, c_int64,
+                                   c_void_p]),
+    "mtlora_linear_pack_entry_bytes": (c_int64, []),
+    "mtlora_linear_pack_entry": (c_int, [POINTER(LinearDesc), c_void_p, c_void_p, POINTER(c_void_p), POINTER(c_void_p), c_void_p, c_int64,
+                                         c_void_p]),
+    "mtlora_linear_pack_table": (c_int, [c_void_p, c_int, c_int, c_void_p]),
     "mtlora_linear_fwd": (c_int, [POINTER(LinearDesc), c_void_p, POINTER(c_void_p), c_void_p, c_void_p, c_void_p, c_void_p,
                                   POINTER(c_void_p), POINTER(c_void_p), c_void_p, POINTER(c_void_p), c_void_p, c_int64,
                                   c_void_p]),

@@ -37,6 +37,7 @@
 //            k_sp_tn / k_tn + reduce for dA / dB.
 // DESIGN.md section 4.1 / 4.3 has the measurements and the experiments that were tried and dropped.
 #include <stdlib.h>
+#include <string.h>
 #include <algorithm>
 #include <atomic>
 #include <type_traits>
@@ -93,8 +94,10 @@ static Segs make_segs(const mtlora_linear_desc* d) {
     return s;
 }
 
+// packed factors (offsets relative to the pack base: the head of the ctx buffer, or the caller's persistent d->packed buffer) and
+// P (offset relative to the ctx base)
 struct CtxLayout {
-    int64_t a_cat, b_cat, at_cat, bt_cat, alpha, a_proj, bt_proj, b_frag, at_frag, p, total;
+    int64_t a_cat, b_cat, at_cat, bt_cat, alpha, a_proj, bt_proj, b_frag, at_frag, pack_total, p, total;
 };
 static CtxLayout ctx_layout(const mtlora_linear_desc* d, const Segs& s) {
     const int es = mtl_elem_size(d->dtype);
@@ -118,6 +121,8 @@ static CtxLayout ctx_layout(const mtlora_linear_desc* d, const Segs& s) {
     // (rank steps padded to whole 32-row projection blocks: 2 * ceil(R / 32) steps per block, zero past the segments)
     L.b_frag = take(mtl_round_up(d->N, 32) * mtl_round_up(s.R, 32) * es);   // rows = output columns n:  B_cat[n][r]
     L.at_frag = take(mtl_round_up(d->K, 32) * mtl_round_up(s.R, 32) * es);  // rows = input columns k:   A_cat[r][k]
+    L.pack_total = o;
+    if (d->packed) o = 0;  // the factors live in the caller's buffer: ctx holds P alone
     L.p = take(d->M * s.R * es);
     L.total = o;
     return L;
@@ -134,14 +139,14 @@ struct PackParams {
     int K, N;
 };
 
-template <typename T>
-__global__ __launch_bounds__(256) void k_pack(PackParams p, T* a_cat, T* b_cat, T* at_cat, T* bt_cat, float* alpha, T* a_proj,
-                                              T* bt_proj, T* b_frag, T* at_frag) {
+template <typename T, typename PP>
+__device__ __forceinline__ void pack_body(const PP& p, T* a_cat, T* b_cat, T* at_cat, T* bt_cat, float* alpha, T* a_proj, T* bt_proj, T* b_frag,
+                                          T* at_frag, int bid, int nblk) {
     const int R = p.s.R;
     {   // fragment-major expansion factors (16-bit types only: the wave-streaming kernels)
         const int N32 = (p.N + 31) & ~31, K32 = (p.K + 31) & ~31, R16 = ((R + 31) >> 5) << 1, R32 = R16 << 4;
         const int64_t nbf = sizeof(T) == 2 ? (int64_t)N32 * R32 : 0, naf = sizeof(T) == 2 ? (int64_t)K32 * R32 : 0;
-        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nbf + naf; i += (int64_t)gridDim.x * 256) {
+        for (int64_t i = (int64_t)bid * 256 + threadIdx.x; i < nbf + naf; i += (int64_t)nblk * 256) {
             const bool isb = i < nbf;
             const int64_t j = isb ? i : i - nbf;
             const int sidx = (int)(j & 7), ln = (int)((j >> 3) & 63);
@@ -166,7 +171,7 @@ __global__ __launch_bounds__(256) void k_pack(PackParams p, T* a_cat, T* b_cat, 
         }
     }
     const int64_t na = (int64_t)R * p.K, nb = (int64_t)R * p.N;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < na + nb + R; i += (int64_t)gridDim.x * 256) {
+    for (int64_t i = (int64_t)bid * 256 + threadIdx.x; i < na + nb + R; i += (int64_t)nblk * 256) {
         int64_t j = i < na ? i : (i < na + nb ? i - na : i - na - nb);
         const int dim = i < na ? p.K : p.N;
         int rr = (i < na + nb) ? (int)(j / dim) : (int)j;
@@ -191,6 +196,30 @@ __global__ __launch_bounds__(256) void k_pack(PackParams p, T* a_cat, T* b_cat, 
             alpha[rr] = p.alpha[o];
         }
     }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_pack(PackParams p, T* a_cat, T* b_cat, T* at_cat, T* bt_cat, float* alpha, T* a_proj,
+                                              T* bt_proj, T* b_frag, T* at_frag) {
+    pack_body<T>(p, a_cat, b_cat, at_cat, bt_cat, alpha, a_proj, bt_proj, b_frag, at_frag, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// one launch for EVERY layer of a model (mtlora_linear_pack_table): blockIdx.y = table entry.  The factors change once per optimizer
+// step, so a trainer refreshes all the packed buffers here instead of paying one k_pack launch per layer and forward call
+// (48 launches per step at C2, 96 at C4).
+struct PackEntry {
+    PackParams pp;
+    unsigned char* dst;  // the layer's packed buffer (device)
+    int64_t off[9];      // a_cat, b_cat, at_cat, bt_cat, alpha, a_proj, bt_proj, b_frag, at_frag
+};
+template <typename T>
+__global__ __launch_bounds__(256) void k_pack_table(const PackEntry* __restrict__ table) {
+    const PackEntry& e = table[blockIdx.y];
+    unsigned char* d = e.dst;
+    pack_body<T>(e.pp, reinterpret_cast<T*>(d + e.off[0]), reinterpret_cast<T*>(d + e.off[1]), reinterpret_cast<T*>(d + e.off[2]),
+                 reinterpret_cast<T*>(d + e.off[3]), reinterpret_cast<float*>(d + e.off[4]), reinterpret_cast<T*>(d + e.off[5]),
+                 reinterpret_cast<T*>(d + e.off[6]), reinterpret_cast<T*>(d + e.off[7]), reinterpret_cast<T*>(d + e.off[8]), (int)blockIdx.x,
+                 (int)gridDim.x);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2107,9 +2136,8 @@ static void launch_sp_tn(SpTnParams& q, int nb, hipStream_t s, double xb, double
     }
 }
 
-template <typename T>
-static void launch_pack(const mtlora_linear_desc* d, const Segs& sg, const CtxLayout& L, unsigned char* pk, const float* A_s,
-                        const float* B_s, const float* const* A_t, const float* const* B_t, hipStream_t s) {
+static PackParams make_pack_params(const mtlora_linear_desc* d, const Segs& sg, const float* A_s, const float* B_s, const float* const* A_t,
+                                   const float* const* B_t) {
     const float keep_scale = mtl_make_dropout(d->dropout_p, 0).enabled() ? 1.f / (1.f - d->dropout_p) : 1.f;
     PackParams pp;
     pp.s = sg;
@@ -2128,11 +2156,20 @@ static void launch_pack(const mtlora_linear_desc* d, const Segs& sg, const CtxLa
         pp.B[t + 1] = B_t[t];
         pp.alpha[t + 1] = d->scale_t[t] * (d->has_x_tasks ? 1.f : keep_scale);
     }
+    return pp;
+}
+static unsigned pack_blocks(const mtlora_linear_desc* d, const Segs& sg) {
     const int64_t work = (int64_t)sg.R * (d->K + d->N + 1);
     int64_t blocks = mtl_ceil_div(work, 256);
     if (blocks > 2048) blocks = 2048;
+    return (unsigned)(blocks > 0 ? blocks : 1);
+}
+template <typename T>
+static void launch_pack(const mtlora_linear_desc* d, const Segs& sg, const CtxLayout& L, unsigned char* pk, const float* A_s,
+                        const float* B_s, const float* const* A_t, const float* const* B_t, hipStream_t s) {
+    const PackParams pp = make_pack_params(d, sg, A_s, B_s, A_t, B_t);
     MtlProfScope prof(PK_PACK, 0.0, s);
-    hipLaunchKernelGGL(k_pack<T>, dim3((unsigned)blocks), dim3(256), 0, s, pp, reinterpret_cast<T*>(pk + L.a_cat),
+    hipLaunchKernelGGL(k_pack<T>, dim3(pack_blocks(d, sg)), dim3(256), 0, s, pp, reinterpret_cast<T*>(pk + L.a_cat),
                        reinterpret_cast<T*>(pk + L.b_cat), reinterpret_cast<T*>(pk + L.at_cat), reinterpret_cast<T*>(pk + L.bt_cat),
                        reinterpret_cast<float*>(pk + L.alpha), reinterpret_cast<T*>(pk + L.a_proj),
                        reinterpret_cast<T*>(pk + L.bt_proj), reinterpret_cast<T*>(pk + L.b_frag), reinterpret_cast<T*>(pk + L.at_frag));
@@ -2147,7 +2184,7 @@ static int fwd_impl(const mtlora_linear_desc* d, const void* x, const void* cons
     const Tune tu = make_tune(d);
     const CtxLayout L = ctx_layout(d, sg);
     unsigned char* c = reinterpret_cast<unsigned char*>(ctx);
-    unsigned char* pk = c;
+    unsigned char* pk = d->packed ? const_cast<unsigned char*>(reinterpret_cast<const unsigned char*>(d->packed)) : c;
     T* a_cat = reinterpret_cast<T*>(pk + L.a_cat);
     T* b_cat = reinterpret_cast<T*>(pk + L.b_cat);
     T* at_cat = reinterpret_cast<T*>(pk + L.at_cat);
@@ -2159,7 +2196,7 @@ static int fwd_impl(const mtlora_linear_desc* d, const void* x, const void* cons
     const DropoutCfg dc = mtl_make_dropout(d->dropout_p, d->seed, d->seed_offset);
 
     if (sg.R > 0) {
-        launch_pack<T>(d, sg, L, pk, A_s, B_s, A_t, B_t, s);
+        if (!d->packed) launch_pack<T>(d, sg, L, pk, A_s, B_s, A_t, B_t, s);
 
         // T = 0 layers with a short reduction: ONE wave-streaming launch (projection in registers, stream.h)
         if (d->T == 0 && d->mode == 0) {
@@ -2354,7 +2391,7 @@ static int bwd_impl(const mtlora_linear_desc* d, const void* x, const void* cons
     const CtxLayout L = ctx_layout(d, sg);
     const BwdScratch S = bwd_scratch(d, sg);
     const unsigned char* c = reinterpret_cast<const unsigned char*>(ctx);
-    const unsigned char* pk = c;
+    const unsigned char* pk = d->packed ? reinterpret_cast<const unsigned char*>(d->packed) : c;
     const T* at_cat = reinterpret_cast<const T*>(pk + L.at_cat);
     const T* bt_cat = reinterpret_cast<const T*>(pk + L.bt_cat);
     const float* alpha = reinterpret_cast<const float*>(pk + L.alpha);
@@ -2801,6 +2838,85 @@ int64_t mtlora_linear_bwd_scratch_bytes(const mtlora_linear_desc* d) {
     return bwd_scratch(d, sg).total + 256;
 }
 
+int64_t mtlora_linear_packed_bytes(const mtlora_linear_desc* d) {
+    if (check_desc(d) != MTLORA_OK) return -1;
+    const Segs sg = make_segs(d);
+    return ctx_layout(d, sg).pack_total + 256;
+}
+
+static int pack_check(const mtlora_linear_desc* d, const float* A_s, const float* B_s, const float* const* A_t, const float* const* B_t,
+                      const void* packed, int64_t packed_bytes) {
+    const int st = check_desc(d);
+    if (st != MTLORA_OK) return st;
+    if (!packed) return MTLORA_ERR_NULL;
+    if (misaligned(packed)) return MTLORA_ERR_ALIGN;
+    if (d->r_s > 0 && (!A_s || !B_s)) return MTLORA_ERR_NULL;
+    for (int t = 0; t < d->T; ++t)
+        if (!A_t || !B_t || !A_t[t] || !B_t[t]) return MTLORA_ERR_NULL;
+    const Segs sg = make_segs(d);
+    if (packed_bytes < ctx_layout(d, sg).pack_total) return MTLORA_ERR_WORKSPACE;
+    return MTLORA_OK;
+}
+
+int mtlora_linear_pack(const mtlora_linear_desc* d, const float* A_s, const float* B_s, const float* const* A_t,
+                       const float* const* B_t, void* packed, int64_t packed_bytes, void* stream) {
+    const int st = pack_check(d, A_s, B_s, A_t, B_t, packed, packed_bytes);
+    if (st != MTLORA_OK) return st;
+    const Segs sg = make_segs(d);
+    if (sg.R == 0) return MTLORA_OK;
+    const CtxLayout L = ctx_layout(d, sg);
+    unsigned char* pk = reinterpret_cast<unsigned char*>(packed);
+    hipStream_t s = (hipStream_t)stream;
+    if (d->dtype == MTLORA_F32)
+        launch_pack<float>(d, sg, L, pk, A_s, B_s, A_t, B_t, s);
+    else if (d->dtype == MTLORA_F16)
+        launch_pack<f16>(d, sg, L, pk, A_s, B_s, A_t, B_t, s);
+    else
+        launch_pack<bf16>(d, sg, L, pk, A_s, B_s, A_t, B_t, s);
+    MTL_CHECK_LAUNCH();
+    return MTLORA_OK;
+}
+
+int64_t mtlora_linear_pack_entry_bytes(void) { return (int64_t)sizeof(PackEntry); }
+
+int mtlora_linear_pack_entry(const mtlora_linear_desc* d, const float* A_s, const float* B_s, const float* const* A_t,
+                             const float* const* B_t, void* packed, int64_t packed_bytes, void* entry_host) {
+    const int st = pack_check(d, A_s, B_s, A_t, B_t, packed, packed_bytes);
+    if (st != MTLORA_OK) return st;
+    if (!entry_host) return MTLORA_ERR_NULL;
+    const Segs sg = make_segs(d);
+    if (sg.R == 0) return MTLORA_ERR_SHAPE;  // nothing to pack: such a layer does not belong in a table
+    const CtxLayout L = ctx_layout(d, sg);
+    PackEntry e;
+    memset(&e, 0, sizeof(e));
+    e.pp = make_pack_params(d, sg, A_s, B_s, A_t, B_t);
+    e.dst = reinterpret_cast<unsigned char*>(packed);
+    const int64_t off[9] = {L.a_cat, L.b_cat, L.at_cat, L.bt_cat, L.alpha, L.a_proj, L.bt_proj, L.b_frag, L.at_frag};
+    for (int i = 0; i < 9; ++i) e.off[i] = off[i];
+    memcpy(entry_host, &e, sizeof(e));
+    return MTLORA_OK;
+}
+
+int mtlora_linear_pack_table(const void* table_dev, int n_entries, int dtype, void* stream) {
+    if (dtype != MTLORA_F32 && dtype != MTLORA_BF16 && dtype != MTLORA_F16) return MTLORA_ERR_DTYPE;
+    if (n_entries < 0 || n_entries > 65535) return MTLORA_ERR_SHAPE;
+    if (n_entries == 0) return MTLORA_OK;
+    if (!table_dev) return MTLORA_ERR_NULL;
+    if (((uintptr_t)table_dev & 7u) != 0) return MTLORA_ERR_ALIGN;
+    hipStream_t s = (hipStream_t)stream;
+    const PackEntry* tb = reinterpret_cast<const PackEntry*>(table_dev);
+    MtlProfScope prof(PK_PACK, 0.0, s);
+    const dim3 g(48, (unsigned)n_entries);  // 48 workgroups per layer walk its 0.1 - 1 M elements
+    if (dtype == MTLORA_F32)
+        hipLaunchKernelGGL(k_pack_table<float>, g, dim3(256), 0, s, tb);
+    else if (dtype == MTLORA_F16)
+        hipLaunchKernelGGL(k_pack_table<f16>, g, dim3(256), 0, s, tb);
+    else
+        hipLaunchKernelGGL(k_pack_table<bf16>, g, dim3(256), 0, s, tb);
+    MTL_CHECK_LAUNCH();
+    return MTLORA_OK;
+}
+
 static int linear_fwd_entry(const mtlora_linear_desc* d, const void* x, const void* const* x_t, const void* W,
                             const float* bias, const float* A_s, const float* B_s, const float* const* A_t,
                             const float* const* B_t, void* y_s, void* const* y_t, void* a_s, void* const* a_t, void* ctx,
@@ -2808,10 +2924,11 @@ static int linear_fwd_entry(const mtlora_linear_desc* d, const void* x, const vo
     int st = check_desc(d);
     if (st != MTLORA_OK) return st;
     if (!x || !W || !y_s) return MTLORA_ERR_NULL;
-    if (d->r_s > 0 && (!A_s || !B_s)) return MTLORA_ERR_NULL;
-    if (misaligned(x) || misaligned(W) || misaligned(y_s) || misaligned(bias)) return MTLORA_ERR_ALIGN;
+    if (d->r_s > 0 && !d->packed && (!A_s || !B_s)) return MTLORA_ERR_NULL;
+    if (misaligned(x) || misaligned(W) || misaligned(y_s) || misaligned(bias) || misaligned(d->packed)) return MTLORA_ERR_ALIGN;
     for (int t = 0; t < d->T; ++t) {
-        if (!A_t || !B_t || !y_t || !A_t[t] || !B_t[t] || !y_t[t]) return MTLORA_ERR_NULL;
+        if (!y_t || !y_t[t]) return MTLORA_ERR_NULL;
+        if (!d->packed && (!A_t || !B_t || !A_t[t] || !B_t[t])) return MTLORA_ERR_NULL;
         if (misaligned(y_t[t])) return MTLORA_ERR_ALIGN;
         if (d->has_x_tasks && (!x_t || !x_t[t])) return MTLORA_ERR_NULL;
         if (d->has_x_tasks && misaligned(x_t[t])) return MTLORA_ERR_ALIGN;

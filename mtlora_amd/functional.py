@@ -234,6 +234,7 @@ class LinearMeta:
     n_scale_t: int = 0        # >0: per-task scales are trainable Parameters passed after B_t
     n_gate: int = 0           # >0: x (and x_t) = gelu(gate): the LAST n_gate args are the pre-activations; dx *= gelu'(gate)
     gelu_out: bool = False    # also return gelu(y) for every output (fc1 of the Mlp): outputs = (y_s, *y_t, a_s, *a_t)
+    packed: Optional[torch.Tensor] = None  # the layer's factors packed ahead of time (PackTable / mtlora_linear_pack): fwd skips k_pack
 
     @property
     def T(self) -> int:
@@ -254,6 +255,7 @@ class LinearMeta:
         d.seed_offset = 0 if _seed_offset is None else _seed_offset.data_ptr()
         tu = _tuning
         d.sel_stream, d.sel_dense, d.sel_tn, d.sel_projk, d.max_cu = tu["stream"], tu["dense"], tu["tn"], tu["projk"], tu["max_cu"]
+        d.packed = 0 if self.packed is None else self.packed.data_ptr()
         return d
 
 
@@ -275,12 +277,49 @@ _bytes_cache: dict = {}  # (kind, M, K, N, r_s, r_t, T-independent fields ...) -
 
 
 def _desc_bytes(kind: str, fn, meta: "LinearMeta", M: int, d) -> int:
-    key = (kind, M, meta.K, meta.N, meta.r_s, meta.r_t, meta.has_x_tasks, meta.dtype, meta.mode)
+    key = (kind, M, meta.K, meta.N, meta.r_s, meta.r_t, meta.has_x_tasks, meta.dtype, meta.mode, meta.packed is not None)
     v = _bytes_cache.get(key)
     if v is None:
         v = fn(ctypes.byref(d))
         _bytes_cache[key] = v
     return v
+
+
+class PackTable:
+    """ONE launch per optimizer step that packs the low-rank factors of many MTLoRALinear layers (``mtlora_linear_pack_table``).
+
+    ``entries``: list of (meta, A_s, B_s, A_t list, B_t list, packed uint8 tensor) -- ``meta`` a LinearMeta carrying the scales,
+    dropout_p and has_x_tasks the layer is CALLED with (they enter the alpha-scaled copies).  The table holds raw device pointers of
+    the masters and the destinations: valid while those tensors live and are only updated in place (``nn.Parameter``s under an
+    optimizer; the packed buffers are owned by the layers)."""
+
+    def __init__(self, entries, device, dtype: torch.dtype):
+        lib = L.lib()
+        eb = lib.mtlora_linear_pack_entry_bytes()
+        host = (ctypes.c_ubyte * (eb * max(len(entries), 1)))()
+        self.keep = entries  # (keeps every tensor whose address is in the table alive)
+        for i, (meta, A_s, B_s, A_t, B_t, packed) in enumerate(entries):
+            d = meta.desc(1)
+            d.packed = 0
+            st = lib.mtlora_linear_pack_entry(ctypes.byref(d), L.ptr(A_s), L.ptr(B_s), L.ptr_array(A_t), L.ptr_array(B_t), L.ptr(packed),
+                                              packed.numel(), ctypes.byref(host, i * eb))
+            L.check(st, "mtlora_linear_pack_entry")
+        self.n = len(entries)
+        self.dtype_code = _DT_CODE[dtype]
+        self.table = torch.frombuffer(host, dtype=torch.uint8).clone().to(device)
+
+    def pack(self) -> None:
+        if self.n:
+            L.check(L.lib().mtlora_linear_pack_table(L.ptr(self.table), self.n, self.dtype_code, L.stream_ptr()), "mtlora_linear_pack_table")
+
+
+def packed_bytes(meta: "LinearMeta") -> int:
+    d = meta.desc(1)
+    d.packed = 0
+    n = L.lib().mtlora_linear_packed_bytes(ctypes.byref(d))
+    if n < 0:
+        raise RuntimeError("mtlora_amd: invalid MTLoRALinear shape for mtlora_linear_packed_bytes")
+    return n
 
 
 class MTLoRALinearFn(torch.autograd.Function):
@@ -337,6 +376,7 @@ class MTLoRALinearFn(torch.autograd.Function):
                 raise RuntimeError("mtlora_amd: gelu gates must be contiguous pre-activations of x / x_t in the compute dtype")
         ctx.save_for_backward(x2, Wt_c, ctxbuf, *xt2, *gates)
         ctx.keep = (A_s_c, B_s_c, A_t_c, B_t_c)  # fp32 factor views (also used for the trainable-scale gradients)
+        # (meta.packed keeps the packed-factor buffer alive until backward; a trainer overwrites it only after the step's backward)
         ctx.factor_params = (A_s, B_s, *A_t, *B_t)  # the Parameters themselves: backward looks at their .grad (side stream)
         ctx.has_scale_s = scale_s_param is not None
         outs = [ys.reshape(*lead, meta.N)] + [y.reshape(*lead, meta.N) for y in yt] + [a.reshape(*lead, meta.N) for a in acts]

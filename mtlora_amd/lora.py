@@ -85,6 +85,19 @@ class MTLoRALinear(LoRALayer):
                 self.lora_shared_scale = lora_shared_scale
             self.reset_parameters()
         self._wcache: Dict[Any, Any] = {}
+        # factors packed ahead of time by a FactorPacker (one launch per optimizer step for the whole model instead of one k_pack per
+        # layer and forward): the buffer, what it was packed for (call signature + parameter versions), and the last call's signature
+        self._packed: Optional[torch.Tensor] = None
+        self._packed_sig = None
+        self._call_sig = None
+
+    def _factor_params(self):
+        ps = []
+        if hasattr(self, "lora_shared_A"):
+            ps += [self.lora_shared_A, self.lora_shared_B]
+        if hasattr(self, "lora_tasks_A"):
+            ps += [self.lora_tasks_A[t] for t in self.tasks] + [self.lora_tasks_B[t] for t in self.tasks]
+        return ps
 
     def reset_parameters(self):
         """A ~ kaiming_uniform(a=sqrt 5), B = 0 (reference lora.py:236-247)."""
@@ -230,6 +243,12 @@ class MTLoRALinear(LoRALayer):
             dtype=dtype, weight_requires_grad=self.linear.weight.requires_grad or (
                 self.linear.bias is not None and self.linear.bias.requires_grad),
             n_scale_t=len(tasks) if (tasks and isinstance(st[0], nn.Parameter)) else 0)
+        if has_lora:
+            # (what the packed factors depend on besides the masters: the alpha-scaled copies carry the scales and the dropout scale)
+            sig = (dtype, meta.r_s, meta.r_t, meta.scale_s, meta.scale_t, meta.mode, meta.has_x_tasks, p, str(x.device))
+            self._call_sig = sig
+            if self._packed is not None and self._packed_sig == (sig, tuple(q._version for q in self._factor_params())):
+                meta.packed = self._packed
         if gelu_out:
             if self.shared_mode == "addition":
                 raise RuntimeError("mtlora_amd: gelu_out is not available with shared_mode='addition'")
@@ -260,6 +279,58 @@ class MTLoRALinear(LoRALayer):
             y = y + nn.functional.layer_norm(tot, (tot.shape[-1],), self.lora_norm.weight.float(),
                                              self.lora_norm.bias.float(), self.lora_norm.eps).to(y.dtype)
         return y, y_tasks
+
+
+class FactorPacker:
+    """Packs the low-rank factors of every MTLoRALinear of ``model`` in ONE kernel launch (``mtlora_linear_pack_table``) instead of one
+    ``k_pack`` launch per layer and forward call (48 per Swin-T step, 96 per Swin-B step).  The factors change when the optimizer
+    steps; a trainer calls ``refresh()`` once per step before the forward (``mtl_harness.train_step`` does).  A layer uses its packed
+    buffer only while it is provably current: same call signature (dtype, ranks, scales, dropout p, x_tasks or not) and unchanged
+    ``_version`` of every factor Parameter -- anything else (first step, eval, a state-dict load, hand edits) falls back to packing
+    inside the forward call.  Layers with trainable scales (1-element Parameters that move every step) are left out."""
+
+    def __init__(self, model: nn.Module):
+        self.layers = [m for m in model.modules() if isinstance(m, MTLoRALinear) and m.r > 0]
+        self._table = None
+        self._table_key = None
+
+    def _eligible(self, m: "MTLoRALinear") -> bool:
+        if m._call_sig is None or m.merged:
+            return False
+        if isinstance(m.lora_shared_scale, torch.Tensor):
+            return False
+        if m.tasks is not None and isinstance(m.lora_task_scale, nn.ParameterDict):
+            return False
+        return all(q.dtype == torch.float32 and q.is_contiguous() and q.is_cuda for q in m._factor_params())
+
+    def refresh(self) -> int:
+        """(re)pack every eligible layer for the signature of its LAST forward call; returns the number of layers packed."""
+        todo = [m for m in self.layers if self._eligible(m)]
+        if not todo:
+            return 0
+        key = tuple((id(m), m._call_sig) + tuple(q.data_ptr() for q in m._factor_params()) for m in todo)
+        if key != self._table_key:
+            by_dtype = {}
+            for m in todo:
+                dtype, r_s, r_t, scale_s, scale_t, mode, has_xt, p, _dev = m._call_sig
+                meta = Fn.LinearMeta(K=m.linear.in_features, N=m.linear.out_features, r_s=r_s, r_t=r_t, scale_s=scale_s, scale_t=scale_t,
+                                     mode=mode, has_x_tasks=has_xt, dropout_p=p, seed=0, dtype=dtype)
+                dev = m._factor_params()[0].device
+                need = Fn.packed_bytes(meta)
+                if m._packed is None or m._packed.numel() < need or m._packed.device != dev:
+                    m._packed = torch.empty(need, dtype=torch.uint8, device=dev)
+                shared = r_s > 0
+                tasks = list(m.tasks) if (m.tasks is not None and len(r_t) > 0) else []
+                ent = (meta, m.lora_shared_A if shared else None, m.lora_shared_B if shared else None,
+                       [m.lora_tasks_A[t] for t in tasks], [m.lora_tasks_B[t] for t in tasks], m._packed)
+                by_dtype.setdefault((dtype, str(dev)), []).append(ent)
+            self._table = [Fn.PackTable(ents, ents[0][5].device, dt) for (dt, _), ents in by_dtype.items()]
+            self._table_key = key
+        for tb in self._table:
+            tb.pack()
+        for m in todo:
+            m._packed_sig = (m._call_sig, tuple(q._version for q in m._factor_params()))
+        return len(todo)
 
 
 def mark_only_lora_as_trainable(model: nn.Module, bias: str = "none", freeze_patch_embed: bool = False,

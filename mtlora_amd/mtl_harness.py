@@ -419,6 +419,24 @@ def _factor_side_stream(device):
     return _factor_streams[key]
 
 
+_PACK_ONCE = os.environ.get("MTLORA_PACK_ONCE", "1") != "0"
+
+
+class _NoPacker:
+    def refresh(self):
+        return 0
+
+
+def _factor_packer(model):
+    """the model's lora.FactorPacker (created on first use; MTLORA_PACK_ONCE=0: every forward packs its own factors)"""
+    pk = getattr(model, "_mtlora_factor_packer", None)
+    if pk is None:
+        from .lora import FactorPacker
+        pk = FactorPacker(model) if _PACK_ONCE else _NoPacker()
+        object.__setattr__(model, "_mtlora_factor_packer", pk)
+    return pk
+
+
 def train_step(model, criterion, optimizer, images, targets, clip_grad: float = 5.0, reducer=None,
                amp_dtype: Optional[torch.dtype] = torch.bfloat16, fused_loss: bool = True):
     """one reference train step (main.py:329-354): autocast fwd + weighted multi-task loss, backward,
@@ -434,6 +452,7 @@ def train_step(model, criterion, optimizer, images, targets, clip_grad: float = 
 
     if images.is_cuda:
         Fn.droppath_begin_step(images.device)  # DropPath factors of the whole step from one draw (functional._DropPathPool)
+        _factor_packer(model).refresh()        # the low-rank factors of every MTLoRALinear packed by ONE launch (lora.FactorPacker)
     try:
         if amp_dtype is not None:
             with torch.autocast("cuda", dtype=amp_dtype):
@@ -558,6 +577,8 @@ class GraphedTrainStep:
     # -- pieces of the step (shared by the eager fallback and the capture)
     def _forward_backward(self):
         self.seed.add_(self.SEED_STEP)
+        if self.images.is_cuda:
+            _factor_packer(self.model).refresh()  # (inside a capture: one graph node; the table and the masters keep their addresses)
         ctx = (torch.autocast("cuda", dtype=self.amp_dtype, cache_enabled=False) if self.amp_dtype is not None
                else contextlib.nullcontext())
         with ctx:

@@ -404,6 +404,59 @@ def test_factor_gradient_stream_is_bit_identical():
         assert torch.equal(runs[0][1][n], runs[1][1][n]), n
 
 
+def test_factor_packer_one_launch_per_step_is_bit_identical():
+    """lora.FactorPacker: the low-rank factors of every MTLoRALinear packed by ONE launch per step (mtlora_linear_pack_table, from the
+    second step on: the first records each layer's call signature) instead of one k_pack per layer and forward -- four train steps must
+    leave loss and every parameter bit-identical to the run that packs inside every forward call, the library's launch profile must
+    show exactly one packing launch per step, and a parameter edited behind the packer's back must fall back to per-call packing."""
+    import ctypes
+    from mtlora_amd import _lib as L
+    from mtlora_amd import functional as Fn
+    from mtlora_amd import mtl_harness as H
+    from mtlora_amd.lora import MTLoRALinear
+    tasks = ["semseg", "normals", "sal", "human_parts"]
+    img, tg = H.synthetic_batch(2, 224, tasks, seed=13, device=dev())
+    runs, packs = [], []
+    keep = H._PACK_ONCE
+    try:
+        for on in (False, True):
+            H._PACK_ONCE = on
+            torch.manual_seed(5)
+            Fn._seed_counter = 0
+            Fn.droppath_reset()
+            model = H.build_model(img_size=224, tasks=tasks, depths=(2, 2, 2, 2), r_shared=16, r_task=4, seed=3).to(dev()).train()
+            crit, opt = H.MultiTaskLoss(tasks), H.build_optimizer(model, lr=1e-3)
+            losses = [H.train_step(model, crit, opt, img, tg)[0].clone() for _ in range(3)]
+            torch.cuda.synchronize()
+            L.check(L.lib().mtlora_prof_begin(100000), "prof_begin")
+            losses.append(H.train_step(model, crit, opt, img, tg)[0].clone())
+            torch.cuda.synchronize()
+            s = L.ProfSummary()
+            L.check(L.lib().mtlora_prof_end(ctypes.byref(s)), "prof_end")
+            names = {L.lib().mtlora_prof_kind_name(k).decode(): s.count[k] for k in range(L.PROF_KINDS) if s.count[k]}
+            packs.append(names.get("k_pack", 0))
+            runs.append((losses, {n: p.detach().clone() for n, p in model.named_parameters()}))
+            if on:  # a hand edit (no version bump through .data): the packer cannot see it, so callers must invalidate -- but an
+                # in-place op that DOES bump the version makes the layer fall back on its own
+                lin = next(m for m in model.modules() if isinstance(m, MTLoRALinear) and m.r > 0)
+                assert lin._packed is not None and lin._packed_sig is not None
+                with torch.no_grad():
+                    lin.lora_shared_B.mul_(1.0)
+                x = torch.randn(4, 49, lin.linear.in_features, device=dev())
+                sig_before = lin._packed_sig
+                with torch.autocast("cuda", dtype=torch.bfloat16):
+                    lin(x)
+                assert lin._packed_sig == sig_before and lin._packed_sig[1] != tuple(q._version for q in lin._factor_params())
+    finally:
+        H._PACK_ONCE = keep
+    n_layers = sum(1 for m in model.modules() if isinstance(m, MTLoRALinear) and m.r > 0)
+    assert packs[0] == n_layers and packs[1] == 1, (packs, n_layers)
+    for a, b in zip(runs[0][0], runs[1][0]):
+        assert torch.equal(a, b), (a.item(), b.item())
+    for n in runs[0][1]:
+        assert torch.equal(runs[0][1][n], runs[1][1][n]), n
+
+
 @pytest.mark.gpu
 def test_graphed_train_step_replays_the_eager_step():
     """The whole train step (autocast forward, fused losses, backward with the per-task and factor-gradient side streams, clip,

@@ -25,6 +25,12 @@
 
 namespace {
 
+#ifndef MTL_ATTN_FWD_WPS
+#define MTL_ATTN_FWD_WPS 2  // waves per SIMD the forward kernel is compiled for
+#endif
+#ifndef MTL_ATTN_BWD_WPS
+#define MTL_ATTN_BWD_WPS 1  // waves per SIMD the backward kernel is compiled for (register budget 512 / WPS; at 2 it spills 254 VGPRs)
+#endif
 constexpr int AN = 64;  // padded tokens per window
 constexpr int HD = 32;  // head_dim
 
@@ -91,12 +97,15 @@ __device__ __forceinline__ int pack_tyx(const AttnParams& p, int t) {
     const int ty = t / p.ws;
     return (ty << 8) | (t - ty * p.ws);
 }
-__device__ __forceinline__ int64_t token_at(const AttnParams& p, const WinPos& q, int t, int tyx) {
-    if (!p.image_layout) return q.base + t;
+// index of token t of the window RELATIVE to q.base (the window's first token / the image's first token): 32 bits, so that every
+// per-lane address is [wave-uniform 64-bit base] + [32-bit offset] (the host checks H * W * 3C * elem_size < 2^31) -- 64-bit
+// multiplies per row and output vector were a tenth of the kernels' VALU instructions
+__device__ __forceinline__ int token_at(const AttnParams& p, const WinPos& q, int t, int tyx) {
+    if (!p.image_layout) return t;
     int y = q.y0 + (tyx >> 8), x = q.x0 + (tyx & 255);
     y = y >= p.H ? y - p.H : y;
     x = x >= p.W ? x - p.W : x;
-    return q.base + (int64_t)y * p.W + x;
+    return y * p.W + x;
 }
 
 // The LDS image of a (window, head) operand holds its N token rows plus ONE shared zero row (index N): every
@@ -124,24 +133,6 @@ __device__ __forceinline__ void av_map(int it, int lane, int& row, int& vec) {
     }
 }
 
-// copy N rows of 32 elements (row r at base + tok[r]*stride) into the image, row N zeroed
-template <typename T>
-__device__ __forceinline__ void stage_rows(unsigned char* s, const T* base, int64_t stride, const int* tok, int n,
-                                           int lane) {
-    constexpr int VPR = AC<T>::VPR, VEC = ET<T>::VEC, RS = AC<T>::RS;
-    const int rows = img_rows(n);
-#pragma unroll
-    for (int it = 0; it < VPR; ++it) {
-        int row, vec;
-        av_map<T>(it, lane, row, vec);
-        if (row < rows) {
-            u32x4 v = u32x4{0u, 0u, 0u, 0u};
-            if (row < n) v = *reinterpret_cast<const u32x4*>(base + (int64_t)tok[row] * stride + vec * VEC);
-            *reinterpret_cast<u32x4*>(s + row * RS + vec * 16) = v;
-        }
-    }
-}
-
 // the same copy split in two, for the software pipeline of the persistent kernels: the next window's rows are loaded
 // into registers while the current window is being multiplied, and written to the images at the next iteration
 template <typename T>
@@ -165,23 +156,25 @@ __device__ __forceinline__ RowIds<T> row_ids(const AttnParams& p, int lane) {
     }
     return r;
 }
+// off[it]: ELEMENT offset (token index * stride + the lane's vector) of the row this lane copies in iteration it, relative to the
+// window's base pointer; -1 = none
 template <typename T>
-__device__ __forceinline__ void row_offsets(int64_t (&off)[AC<T>::VPR], const AttnParams& p, const WinPos& q,
-                                            const RowIds<T>& ids) {
+__device__ __forceinline__ void row_offsets(int (&off)[AC<T>::VPR], const AttnParams& p, const WinPos& q, const RowIds<T>& ids,
+                                            int stride, int lane) {
 #pragma unroll
-    for (int it = 0; it < AC<T>::VPR; ++it) off[it] = ids.t[it] >= 0 ? token_at(p, q, ids.t[it], ids.tyx[it]) : -1;
-}
-template <typename T>
-__device__ __forceinline__ void load_rows(RowRegs<T>& r, const T* base, int64_t stride, const int64_t (&off)[AC<T>::VPR],
-                                          int lane) {
-    constexpr int VPR = AC<T>::VPR, VEC = ET<T>::VEC;
-#pragma unroll
-    for (int it = 0; it < VPR; ++it) {
+    for (int it = 0; it < AC<T>::VPR; ++it) {
         int row, vec;
         av_map<T>(it, lane, row, vec);
         (void)row;
-        r.v[it] = off[it] >= 0 ? *reinterpret_cast<const u32x4*>(base + off[it] * stride + vec * VEC) : u32x4{0u, 0u, 0u, 0u};
+        off[it] = ids.t[it] >= 0 ? token_at(p, q, ids.t[it], ids.tyx[it]) * stride + vec * ET<T>::VEC : -1;
     }
+}
+// base: wave-uniform pointer (tensor + window base + head / q-k-v slice)
+template <typename T>
+__device__ __forceinline__ void load_rows(RowRegs<T>& r, const T* base, const int (&off)[AC<T>::VPR]) {
+#pragma unroll
+    for (int it = 0; it < AC<T>::VPR; ++it)
+        r.v[it] = off[it] >= 0 ? *reinterpret_cast<const u32x4*>(base + (uint32_t)off[it]) : u32x4{0u, 0u, 0u, 0u};
 }
 template <typename T>
 __device__ __forceinline__ void store_rows(unsigned char* s, const RowRegs<T>& r, int n, int lane) {
@@ -251,6 +244,8 @@ __device__ __forceinline__ Frag<float> colfrag(const unsigned char* s, int kt, i
     return f;
 }
 
+constexpr float NEG_BIG = -1.0e30f;
+
 // P / dS hand-over images of the backward ([32 query rows][64 keys], row stride IMG_RS): the accumulators hold them
 // query-per-lane; dK / dV need them key-per-lane with the queries along k, i.e. transposed -- written row-wise, read back
 // with the transposing load exactly like colfrag (same slot <-> row order as the Q / dO operand they are paired with)
@@ -284,7 +279,7 @@ __device__ __forceinline__ void img_store(unsigned char* img, const f32x16 (&a)[
                     f32x4{a[sj][4 * q], a[sj][4 * q + 1], a[sj][4 * q + 2], a[sj][4 * q + 3]};
             } else {
                 *reinterpret_cast<u32x2*>(img + il * IMG<bf16>::RS + j0 * 2) =
-                    u32x2{mtl_pack2<T>(a[sj][4 * q], a[sj][4 * q + 1]), mtl_pack2<T>(a[sj][4 * q + 2], a[sj][4 * q + 3])};
+                    u32x2{mtl_pk2<T>(a[sj][4 * q], a[sj][4 * q + 1]), mtl_pk2<T>(a[sj][4 * q + 2], a[sj][4 * q + 3])};
             }
         }
 }
@@ -329,22 +324,18 @@ __device__ __forceinline__ Frag<float> imgfrag(const unsigned char* s, int col0,
 }
 
 // operand fed from accumulator registers: acc[0..1] are the two 32-row subtiles along the k axis
-__device__ __forceinline__ uint32_t pack_bf16(float a, float b) {
-    bf16 x = (bf16)a, y = (bf16)b;
-    return (uint32_t)__builtin_bit_cast(uint16_t, x) | ((uint32_t)__builtin_bit_cast(uint16_t, y) << 16);
-}
 __device__ __forceinline__ Frag<bf16> regfrag(const f32x16 (&acc)[2], int kt, bf16*) {
     Frag<bf16> f;
     const f32x16& a = acc[kt];
-    f.v[0] = u32x4{pack_bf16(a[0], a[1]), pack_bf16(a[2], a[3]), pack_bf16(a[4], a[5]), pack_bf16(a[6], a[7])};
-    f.v[1] = u32x4{pack_bf16(a[8], a[9]), pack_bf16(a[10], a[11]), pack_bf16(a[12], a[13]), pack_bf16(a[14], a[15])};
+    f.v[0] = u32x4{mtl_pk2<bf16>(a[0], a[1]), mtl_pk2<bf16>(a[2], a[3]), mtl_pk2<bf16>(a[4], a[5]), mtl_pk2<bf16>(a[6], a[7])};
+    f.v[1] = u32x4{mtl_pk2<bf16>(a[8], a[9]), mtl_pk2<bf16>(a[10], a[11]), mtl_pk2<bf16>(a[12], a[13]), mtl_pk2<bf16>(a[14], a[15])};
     return f;
 }
 __device__ __forceinline__ Frag<f16> regfrag(const f32x16 (&acc)[2], int kt, f16*) {
     Frag<f16> f;
     const f32x16& a = acc[kt];
-    f.v[0] = u32x4{mtl_pack_f16(a[0], a[1]), mtl_pack_f16(a[2], a[3]), mtl_pack_f16(a[4], a[5]), mtl_pack_f16(a[6], a[7])};
-    f.v[1] = u32x4{mtl_pack_f16(a[8], a[9]), mtl_pack_f16(a[10], a[11]), mtl_pack_f16(a[12], a[13]), mtl_pack_f16(a[14], a[15])};
+    f.v[0] = u32x4{mtl_pk2<f16>(a[0], a[1]), mtl_pk2<f16>(a[2], a[3]), mtl_pk2<f16>(a[4], a[5]), mtl_pk2<f16>(a[6], a[7])};
+    f.v[1] = u32x4{mtl_pk2<f16>(a[8], a[9]), mtl_pk2<f16>(a[10], a[11]), mtl_pk2<f16>(a[12], a[13]), mtl_pk2<f16>(a[14], a[15])};
     return f;
 }
 __device__ __forceinline__ Frag<float> regfrag(const f32x16 (&acc)[2], int kt, float*) {
@@ -361,41 +352,141 @@ __device__ __forceinline__ void zero(f32x16& a) {
     for (int r = 0; r < 16; ++r) a[r] = 0.f;
 }
 
-// store a [d][token] accumulator subtile: lane owns token row `tok_off` (element offset of that token's
-// 32-wide head slice), registers 4q..4q+3 are d = 8q + 4h + 0..3
+// store a [d][token] accumulator subtile (lane owns token i = lane & 31, registers 4q..4q+3 are d = 8q + 4h + 0..3) through a per-wave LDS image: the accumulator subtile holds [d][token] with a lane owning ONE token and 4-element
+// runs of d, so a direct store writes 8-byte pieces of 32 different rows per instruction (16-byte pieces per token with its h
+// partner) -- partial-sector writes that the memory system serves at half the rate of whole 64-byte row segments (ablation
+// tools/ab: the forward's loads + stores alone took 79 of its 92 us at stage 0).  Here the subtile is written to the image
+// token-major, read back 16 bytes per lane (4 lanes = one token's 32-element head slice) and stored with whole row segments per
+// 4 lanes.  `tokrow`: LDS table of the 32 tokens' element offsets; rows >= n_rows are padding.
 template <typename T>
-__device__ __forceinline__ void store_dt(T* base, int64_t tok_off, const f32x16& a, float mul, int lane) {
-    const int h = lane >> 5;
+struct STG {
+    static constexpr int RB = 32 * (int)sizeof(T);  // bytes of a token's head slice
+    static constexpr int RS = RB + 16;              // image row stride
+    static constexpr int BYTES = 32 * RS;
+    static constexpr int PPR = RB / 16;             // 16-byte pieces per row
+};
+template <typename T>
+__device__ __forceinline__ void store_dt_lds(unsigned char* stg, T* base, const int* tokrow, int n_rows, const f32x16& a, float mul,
+                                             int lane) {
+    const int il = lane & 31, h = lane >> 5;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        T* dst = base + tok_off + 8 * q + 4 * h;
-        if constexpr (sizeof(T) == 4) {
+        unsigned char* dst = stg + il * STG<T>::RS + (8 * q + 4 * h) * (int)sizeof(T);
+        if constexpr (sizeof(T) == 4)
             *reinterpret_cast<f32x4*>(dst) = f32x4{a[4 * q] * mul, a[4 * q + 1] * mul, a[4 * q + 2] * mul, a[4 * q + 3] * mul};
-        } else {
-            const u32x2 pk = {mtl_pack2<T>(a[4 * q] * mul, a[4 * q + 1] * mul), mtl_pack2<T>(a[4 * q + 2] * mul, a[4 * q + 3] * mul)};
-            *reinterpret_cast<u32x2*>(dst) = pk;
+        else
+            *reinterpret_cast<u32x2*>(dst) = u32x2{mtl_pk2<T>(a[4 * q] * mul, a[4 * q + 1] * mul), mtl_pk2<T>(a[4 * q + 2] * mul, a[4 * q + 3] * mul)};
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the image is private to this wave
+    __builtin_amdgcn_wave_barrier();
+    constexpr int PPR = STG<T>::PPR, IT = 32 * PPR / 64;
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        const int idx = it * 64 + lane, row = idx / PPR, pc = idx % PPR;
+        const u32x4 v = *reinterpret_cast<const u32x4*>(stg + row * STG<T>::RS + pc * 16);
+        const int off = tokrow[row];
+        if (row < n_rows) *reinterpret_cast<u32x4*>(base + (uint32_t)(off + pc * (16 / (int)sizeof(T)))) = v;
+    }
+    __builtin_amdgcn_wave_barrier();  // (the next user of the image writes it only after these reads have been issued in order)
+}
+
+// ---- the relative-position bias of the wave's head.  A wave serves ONE head for all of its windows, and the (key, query) pair behind
+// accumulator element (sj, r) of lane l is the same for every window.
+//  * 16-bit types: the bias enters through the MATRIX pipe.  scores' = K Q^T + I . (bias / scale)^T -- an identity A operand times a B
+//    operand holding bias / scale in the compute type (32 VGPRs per wave for the whole launch, loaded once): 8 extra MFMAs per window
+//    and head on a pipe that is 90 % idle here, and the per-element section of round 1-3 (an LDS read of the bias image, a select for the
+//    padded keys, an FMA: ~450 VALU + 64 LDS instructions per window and head in a VALU-issue-bound kernel) disappears; the softmax
+//    runs on scores' with the multiplier scale * log2(e) folded into its exponent FMA.  Padded KEYS (j >= N) carry PAD_BIG in the bias
+//    operand, padded QUERIES (never stored) 0.  bias / scale is rounded to the compute type: |bias| 2^-9 ~ 2e-4 absolute on a logit
+//    (the reference adds the fp32 bias to a bf16-ROUNDED q k^T, swin_transformer_mtlora.py:200-207: its own error there is 30x larger).
+//    The 9.6 KB bias image per workgroup is gone from LDS as well.
+//  * fp32: exact path as before -- an LDS image of bias[head] with an odd row stride, one read + FMA + select per element.
+constexpr int bias_stride_c(int N) { return (N & 1) ? N : N + 1; }
+__device__ __forceinline__ int bias_stride(int N) { return (N & 1) ? N : N + 1; }
+
+template <typename T>
+struct BiasSrc {  // 16-bit
+    Frag<T> idf;        // identity: lane (j = lane & 31, h), k-slot (t, e) <-> k = 16 t + 8 h + e:  1 where k == j
+    Frag<T> bf[2][2];   // [si][sj]: lane (i = lane & 31, h), k-slot (t, e):  bias[32 si + i][32 sj + 16 t + 8 h + e] / scale
+    float c;            // softmax multiplier on scores': scale * log2(e)
+    float maskv;        // shift-mask value in the scores' domain: mask_value / scale
+};
+template <>
+struct BiasSrc<float> {
+    const float* sBias;  // LDS image [N][bias_stride(N)]
+    float c;             // log2(e)
+    float maskv;
+};
+
+template <typename T>
+__device__ __forceinline__ float pad_big() {
+    if constexpr (__is_same(T, f16))
+        return -3.0e4f;   // (fp16 range; times scale * log2 e it is still far below any real score)
+    else
+        return -1.0e30f;
+}
+
+template <typename T>
+__device__ __forceinline__ void bias_init(BiasSrc<T>& B, const AttnParams& p, int head, float* sBias, int lane) {
+    const float* src = p.bias + (int64_t)head * p.N * p.N;
+    if constexpr (sizeof(T) == 4) {
+        const int bs = bias_stride(p.N);
+        for (int idx = lane; idx < p.N * p.N; idx += 64) sBias[(idx / p.N) * bs + (idx % p.N)] = src[idx];
+        B.sBias = sBias;
+        B.c = 1.4426950408889634f;
+        B.maskv = p.mask_value;
+    } else {
+        (void)sBias;
+        const float inv = 1.f / p.scale;
+        const int rl = lane & 31, h = lane >> 5;
+        uint32_t one;
+        if constexpr (__is_same(T, f16))
+            one = 0x3C00u;
+        else
+            one = 0x3F80u;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            uint32_t w[4];
+#pragma unroll
+            for (int e2 = 0; e2 < 4; ++e2) {
+                const int k0 = 16 * t + 8 * h + 2 * e2;
+                w[e2] = (k0 == rl ? one : 0u) | (k0 + 1 == rl ? one << 16 : 0u);
+            }
+            B.idf.v[t] = u32x4{w[0], w[1], w[2], w[3]};
         }
+#pragma unroll
+        for (int si = 0; si < 2; ++si) {
+            const int i = si * 32 + rl;
+#pragma unroll
+            for (int sj = 0; sj < 2; ++sj)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    float f[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const int j = sj * 32 + 16 * t + 8 * h + e;
+                        f[e] = j < p.N ? (i < p.N ? src[i * p.N + j] * inv : 0.f) : pad_big<T>();
+                    }
+                    B.bf[si][sj].v[t] = u32x4{mtl_pk2<T>(f[0], f[1]), mtl_pk2<T>(f[2], f[3]), mtl_pk2<T>(f[4], f[5]), mtl_pk2<T>(f[6], f[7])};
+                }
+        }
+        B.c = p.scale * 1.4426950408889634f;
+        B.maskv = p.mask_value * inv;
     }
 }
 
-constexpr float NEG_BIG = -1.0e30f;
-
-__device__ __forceinline__ int bias_stride(int N) { return (N & 1) ? N : N + 1; }
-
-// stage bias[head] (N x N fp32) into LDS with an odd row stride: lane-over-i and lane-over-j reads are both
-// conflict-free, so ONE image serves the query-owned and the key-owned pass
-__device__ __forceinline__ void stage_bias(float* sBias, const float* bias, int head, int N, int lane) {
-    const float* src = bias + (int64_t)head * N * N;
-    const int bs = bias_stride(N);
-    for (int idx = lane; idx < N * N; idx += 64) sBias[(idx / N) * bs + (idx % N)] = src[idx];
-}
-
-// scores for query half `si` in the query-owned orientation: st[sj][r] = S^T[key][query]
+// scores for query half `si` in the query-owned orientation: st[sj][r] = S^T[key][query] (16-bit types: in the scores' = S / scale
+// domain, see BiasSrc).  `masked` is wave-uniform: only the windows that straddle the shift boundary carry a mask (the last window row /
+// column of an image: 31 of 256 at stage 0, and no window of an unshifted block) -- all the others skip the per-element mask section.
 template <typename T, bool DENSE>
 __device__ __forceinline__ void scores_t(f32x16 (&st)[2], const unsigned char* sK, const unsigned char* sQ, int si,
-                                         const AttnParams& p, const float* sBias, const int* srid, int wm, int lane) {
+                                         const AttnParams& p, const BiasSrc<T>& B, const int* srid, bool masked, int wm, int lane) {
     zero(st[0]);
     zero(st[1]);
+    if constexpr (sizeof(T) == 2) {
+#pragma unroll
+        for (int sj = 0; sj < 2; ++sj) mtl_mma(B.idf, B.bf[si][sj], st[sj]);
+    }
 #pragma unroll
     for (int kt = 0; kt < AC<T>::KT_D; ++kt) {
         Frag<T> fq = rowfrag<T>(sQ, si, kt, lane, p.N);
@@ -405,59 +496,89 @@ __device__ __forceinline__ void scores_t(f32x16 (&st)[2], const unsigned char* s
             mtl_mma(fk, fq, st[sj]);
         }
     }
-    // bias + mask, branch-free: clamped indices + selects, so the 32 LDS reads of a lane are issued back to back
-    // (per-element branches made every read its own wait -- the kernel spent its time in exposed LDS latency)
     const int i = si * 32 + (lane & 31);
     const bool iv = i < p.N;
     const int ic = iv ? i : p.N - 1;
-    const float* brow = sBias + ic * bias_stride(p.N);
-    const int rid_i = srid[ic];  // 0 everywhere when there is no region-id mask
-    const float* mrow = DENSE ? p.mask + ((int64_t)wm * p.N + ic) * p.N : nullptr;  // dense additive mask: slow path
     const int h4 = 4 * (lane >> 5);
+    if constexpr (sizeof(T) == 4) {
+        // bias (+ mask), branch-free: clamped indices + selects, so the LDS reads of a lane are issued back to back
+        const float* brow = B.sBias + ic * bias_stride(p.N);
+        const int rid_i = srid[ic];  // 0 everywhere when there is no region-id mask
+        const float* mrow = DENSE ? p.mask + ((int64_t)wm * p.N + ic) * p.N : nullptr;  // dense additive mask: slow path
 #pragma unroll
-    for (int sj = 0; sj < 2; ++sj) {
-        __builtin_amdgcn_sched_barrier(0);  // 16 elements' LDS reads in flight at a time, not 64 (register pressure)
+        for (int sj = 0; sj < 2; ++sj) {
+            __builtin_amdgcn_sched_barrier(0);  // 16 elements' LDS reads in flight at a time, not 32 (register pressure)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int j = sj * 32 + (r & 3) + 8 * (r >> 2) + h4;
-            const int jc = j < p.N ? j : p.N - 1;
-            float add = brow[jc];
-            if constexpr (DENSE)
-                add += mrow[jc];
-            else  // region ids are all 0 when there is no mask: the compare is then never true (no per-element branch)
-                add += srid[jc] != rid_i ? p.mask_value : 0.f;
-            const float v = st[sj][r] * p.scale + (iv ? add : 0.f);
-            st[sj][r] = j < p.N ? v : NEG_BIG;
+            for (int r = 0; r < 16; ++r) {
+                const int j = sj * 32 + (r & 3) + 8 * (r >> 2) + h4;
+                const int jc = j < p.N ? j : p.N - 1;
+                float add = brow[jc];
+                if constexpr (DENSE)
+                    add += mrow[jc];
+                else
+                    add += srid[jc] != rid_i ? B.maskv : 0.f;
+                const float v = st[sj][r] * p.scale + (iv ? add : 0.f);
+                st[sj][r] = j < p.N ? v : NEG_BIG;
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        (void)masked;
+    } else {
+        if (DENSE || masked) {
+            const int rid_i = srid[ic];
+            const float* mrow = DENSE ? p.mask + ((int64_t)wm * p.N + ic) * p.N : nullptr;
+            const float inv = DENSE ? 1.f / p.scale : 0.f;
+#pragma unroll
+            for (int sj = 0; sj < 2; ++sj) {
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int j = sj * 32 + (r & 3) + 8 * (r >> 2) + h4;
+                    const int jc = j < p.N ? j : p.N - 1;
+                    float add;
+                    if constexpr (DENSE)
+                        add = mrow[jc] * inv;
+                    else
+                        add = srid[jc] != rid_i ? B.maskv : 0.f;
+                    st[sj][r] += (iv && j < p.N) ? add : 0.f;
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
-    __builtin_amdgcn_sched_barrier(0);
 }
 
-// in-place softmax over the 64 keys of a query column (32 in this lane, 32 in lane^32)
-__device__ __forceinline__ void softmax_t(f32x16 (&st)[2], float& m_out, float& inv_l_out) {
-    float m = NEG_BIG;
+// in-place softmax numerators over the 64 keys of a query column (32 in this lane, 32 in lane^32): st <- exp2((st - max) * c),
+// returns 1 / sum.  NORM: also multiply the numerators by it (the backward needs P itself; the 16-bit forward scales its 16 outputs
+// instead).  EXACT (fp32 kernels): exp2((st - max) * c), the difference formed first -- the arithmetic of rounds 1-3 (__expf(st - max));
+// the 16-bit kernels fold the subtraction into one FMA, st * c - max * c (relative error 2^-24 |st c| on the exponent: 1e-6).
+template <bool NORM, bool EXACT>
+__device__ __forceinline__ float softmax_t(f32x16 (&st)[2], float c) {
+    float m = -3.0e38f;
 #pragma unroll
     for (int sj = 0; sj < 2; ++sj)
 #pragma unroll
         for (int r = 0; r < 16; ++r) m = fmaxf(m, st[sj][r]);
     m = fmaxf(m, __shfl_xor(m, 32));
+    const float mc = -m * c;
     float l = 0.f;
 #pragma unroll
     for (int sj = 0; sj < 2; ++sj)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const float e = __expf(st[sj][r] - m);
+            const float e = EXACT ? __builtin_amdgcn_exp2f((st[sj][r] - m) * c) : __builtin_amdgcn_exp2f(st[sj][r] * c + mc);
             st[sj][r] = e;
             l += e;
         }
     l += __shfl_xor(l, 32);
     const float inv = 1.f / l;
+    if constexpr (NORM) {
 #pragma unroll
-    for (int sj = 0; sj < 2; ++sj)
+        for (int sj = 0; sj < 2; ++sj)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) st[sj][r] *= inv;
-    m_out = m;
-    inv_l_out = inv;
+            for (int r = 0; r < 16; ++r) st[sj][r] *= inv;
+    }
+    return inv;
 }
 
 __device__ __forceinline__ int64_t xcd_remap(int64_t b, int64_t n) {
@@ -466,7 +587,7 @@ __device__ __forceinline__ int64_t xcd_remap(int64_t b, int64_t n) {
 }
 
 template <typename T, bool DENSE>
-__global__ __launch_bounds__(64, 2) void k_attn_fwd(const AttnParams p) {
+__global__ __launch_bounds__(64, MTL_ATTN_FWD_WPS) void k_attn_fwd(const AttnParams p) {
     constexpr int RS = AC<T>::RS;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int IB = ((img_rows(p.N) * RS + 15) / 16) * 16;  // bytes per image
@@ -475,48 +596,54 @@ __global__ __launch_bounds__(64, 2) void k_attn_fwd(const AttnParams p) {
     unsigned char* sV = smem + 2 * IB;
     int* tok = reinterpret_cast<int*>(smem + 3 * IB);
     int* srid = tok + AN;
-    float* sBias = reinterpret_cast<float*>(srid + AN);
     const int lane = threadIdx.x;
     const int64_t L = xcd_remap(blockIdx.x, gridDim.x);
     const int head = (int)(L % p.nH);
     const int g = (int)(L / p.nH);
     const int nWimg = p.nWx * p.nWy;
-    const T* qkv = reinterpret_cast<const T*>(p.qkv);
-    T* out = reinterpret_cast<T*>(p.out);
-    const int64_t C3 = 3 * (int64_t)p.C;
-    stage_bias(sBias, p.bias, head, p.N, lane);
+    const T* qkv = reinterpret_cast<const T*>(p.qkv) + head * HD;
+    T* out = reinterpret_cast<T*>(p.out) + head * HD;
+    const int C3 = 3 * p.C;
+    unsigned char* stg = reinterpret_cast<unsigned char*>(srid + AN);  // output staging image
+    BiasSrc<T> B;
+    bias_init<T>(B, p, head, reinterpret_cast<float*>(stg + STG<T>::BYTES), lane);
     const RowIds<T> ids = row_ids<T>(p, lane);
     const int lane_tyx = pack_tyx(p, lane < p.N ? lane : 0);
     RowRegs<T> rq, rk, rv;
     int rid_next = 0;  // region id of this lane's token in the prefetched window (a load at the top of the iteration, right
                        // in front of its LDS store, exposed one L2 round trip per window of every shifted block)
     auto prefetch = [&](int64_t w) __attribute__((always_inline)) {
-        int64_t off[AC<T>::VPR];
-        row_offsets<T>(off, p, win_pos(p, w), ids);
-        load_rows<T>(rq, qkv + head * HD, C3, off, lane);
-        load_rows<T>(rk, qkv + p.C + head * HD, C3, off, lane);
-        load_rows<T>(rv, qkv + 2 * p.C + head * HD, C3, off, lane);
+        int off[AC<T>::VPR];
+        const WinPos q = win_pos(p, w);
+        row_offsets<T>(off, p, q, ids, C3, lane);
+        const T* wb = qkv + q.base * C3;  // wave-uniform
+        load_rows<T>(rq, wb, off);
+        load_rows<T>(rk, wb + p.C, off);
+        load_rows<T>(rv, wb + 2 * p.C, off);
         rid_next = (p.mask_ids && lane < p.N) ? p.mask_ids[(int)(w % nWimg) * p.N + lane] : 0;
     };
     if (g < p.n_windows) prefetch(g);
 
     for (int64_t w = g; w < p.n_windows; w += p.G) {
         const int wm = (int)(w % nWimg);
+        const WinPos wq = win_pos(p, w);
         __syncthreads();  // previous item's LDS reads are done
-        tok[lane] = lane < p.N ? (int)token_at(p, win_pos(p, w), lane, lane_tyx) : 0;
+        tok[lane] = lane < p.N ? token_at(p, wq, lane, lane_tyx) * p.C : 0;  // element offset of the token's output row
         srid[lane] = rid_next;
+        // does this window carry a shift mask at all?  (wave-uniform: region ids of its tokens differ)
+        const bool masked = __ballot(lane < p.N && rid_next != __builtin_amdgcn_readfirstlane(rid_next)) != 0ull;
         store_rows<T>(sQ, rq, p.N, lane);
         store_rows<T>(sK, rk, p.N, lane);
         store_rows<T>(sV, rv, p.N, lane);
         __syncthreads();
         if (w + p.G < p.n_windows) prefetch(w + p.G);  // next window's rows fly while this one is multiplied
-#pragma unroll 1
-        for (int si = 0; si < 2; ++si) {
-            if (si * 32 >= p.N) break;
+        T* ob = out + wq.base * p.C;  // wave-uniform
+        auto half = [&](int si) __attribute__((always_inline)) {
             f32x16 st[2];
-            scores_t<T, DENSE>(st, sK, sQ, si, p, sBias, srid, wm, lane);
-            float m, inv_l;
-            softmax_t(st, m, inv_l);
+            scores_t<T, DENSE>(st, sK, sQ, si, p, B, srid, masked, wm, lane);
+            // 16-bit: numerators only, the 16 outputs are scaled by 1 / sum instead; fp32: P itself, as in rounds 1-3
+            const float inv_raw = softmax_t<sizeof(T) == 4, sizeof(T) == 4>(st, B.c);
+            const float inv_l = sizeof(T) == 4 ? 1.f : inv_raw;
             f32x16 o;
             zero(o);
 #pragma unroll
@@ -525,8 +652,17 @@ __global__ __launch_bounds__(64, 2) void k_attn_fwd(const AttnParams p) {
                 Frag<T> fp = regfrag(st, kt, (T*)nullptr);
                 mtl_mma(fv, fp, o);
             }
-            const int i = si * 32 + (lane & 31);
-            if (i < p.N) store_dt<T>(out, (int64_t)tok[i] * p.C + head * HD, o, 1.f, lane);
+            store_dt_lds<T>(stg, ob, tok + si * 32, p.N - si * 32, o, inv_l, lane);
+        };
+        if constexpr (sizeof(T) == 2) {  // (the bias operand is indexed by the half: constant after inlining)
+            half(0);
+            if (p.N > 32) half(1);
+        } else {
+#pragma unroll 1
+            for (int si = 0; si < 2; ++si) {
+                if (si * 32 >= p.N) break;
+                half(si);
+            }
         }
     }
 }
@@ -538,7 +674,7 @@ __global__ __launch_bounds__(64, 2) void k_attn_fwd(const AttnParams p) {
 // to accumulate dK^T += Q^T dS and dV^T += dO^T P -- instead of a second, key-owned pass that recomputed S, P and dP from
 // the row statistics (16 MFMAs, 64 exps per lane and a long element-wise section per window).
 template <typename T, bool DENSE>
-__global__ __launch_bounds__(64, 1) void k_attn_bwd(const AttnParams p) {
+__global__ __launch_bounds__(64, MTL_ATTN_BWD_WPS) void k_attn_bwd(const AttnParams p) {
     constexpr int RS = AC<T>::RS;
     constexpr int KQ = 32 / (AC<T>::KT_N == 2 ? 32 : 16);  // k-tiles per 32-query half (bf16: 1, f32: 2)
     // Q, K, V, dO images + P / dS hand-over images + token table + region ids + bias[head]
@@ -552,17 +688,18 @@ __global__ __launch_bounds__(64, 1) void k_attn_bwd(const AttnParams p) {
     unsigned char* sDi = sPi + 32 * IMG<T>::RS;         // [32][64] dS
     int* tok = reinterpret_cast<int*>(sDi + 32 * IMG<T>::RS);
     int* srid = tok + AN;
-    float* sBias = reinterpret_cast<float*>(srid + AN);  // [N][bias_stride(N)]
     const int lane = threadIdx.x;
     const int64_t L = xcd_remap(blockIdx.x, gridDim.x);
     const int head = (int)(L % p.nH);
     const int g = (int)(L / p.nH);
     const int nWimg = p.nWx * p.nWy;
-    const T* qkv = reinterpret_cast<const T*>(p.qkv);
-    const T* dout = reinterpret_cast<const T*>(p.dout);
-    T* dqkv = reinterpret_cast<T*>(p.dqkv);
-    const int64_t C3 = 3 * (int64_t)p.C;
-    stage_bias(sBias, p.bias, head, p.N, lane);
+    const T* qkv = reinterpret_cast<const T*>(p.qkv) + head * HD;
+    const T* dout = reinterpret_cast<const T*>(p.dout) + head * HD;
+    T* dqkv = reinterpret_cast<T*>(p.dqkv) + head * HD;
+    const int C3 = 3 * p.C;
+    unsigned char* stg = reinterpret_cast<unsigned char*>(srid + AN);  // output staging image
+    BiasSrc<T> B;
+    bias_init<T>(B, p, head, reinterpret_cast<float*>(stg + STG<T>::BYTES), lane);
     // dbias accumulator in REGISTERS: element (sj, r) of lane l is always (key j = 32 sj + row(l, r), query i = 32 si + l % 32),
     // the same pair for every window this wave visits
     f32x16 dbacc[2][2];
@@ -577,20 +714,26 @@ __global__ __launch_bounds__(64, 1) void k_attn_bwd(const AttnParams p) {
     RowRegs<T> rq, rk, rv, ro;
     int rid_next = 0;  // (as in k_attn_fwd)
     auto prefetch = [&](int64_t w) __attribute__((always_inline)) {
-        int64_t off[AC<T>::VPR];
-        row_offsets<T>(off, p, win_pos(p, w), ids);
-        load_rows<T>(rq, qkv + head * HD, C3, off, lane);
-        load_rows<T>(rk, qkv + p.C + head * HD, C3, off, lane);
-        load_rows<T>(rv, qkv + 2 * p.C + head * HD, C3, off, lane);
-        load_rows<T>(ro, dout + head * HD, (int64_t)p.C, off, lane);
+        int off[AC<T>::VPR], offo[AC<T>::VPR];
+        const WinPos q = win_pos(p, w);
+        row_offsets<T>(off, p, q, ids, C3, lane);
+        row_offsets<T>(offo, p, q, ids, p.C, lane);
+        const T* wb = qkv + q.base * C3;  // wave-uniform
+        load_rows<T>(rq, wb, off);
+        load_rows<T>(rk, wb + p.C, off);
+        load_rows<T>(rv, wb + 2 * p.C, off);
+        load_rows<T>(ro, dout + q.base * p.C, offo);
         rid_next = (p.mask_ids && lane < p.N) ? p.mask_ids[(int)(w % nWimg) * p.N + lane] : 0;
     };
     if (g < p.n_windows) prefetch(g);
     for (int64_t w = g; w < p.n_windows; w += p.G) {
         const int wm = (int)(w % nWimg);
+        const WinPos wq = win_pos(p, w);
         __syncthreads();
-        tok[lane] = lane < p.N ? (int)token_at(p, win_pos(p, w), lane, lane_tyx) : 0;
+        tok[lane] = lane < p.N ? token_at(p, wq, lane, lane_tyx) * C3 : 0;  // element offset of the token's dqkv row
         srid[lane] = rid_next;
+        const bool masked = __ballot(lane < p.N && rid_next != __builtin_amdgcn_readfirstlane(rid_next)) != 0ull;  // (as in k_attn_fwd)
+        T* gb = dqkv + wq.base * C3;  // wave-uniform
         store_rows<T>(sQ, rq, p.N, lane);
         store_rows<T>(sK, rk, p.N, lane);
         store_rows<T>(sV, rv, p.N, lane);
@@ -607,9 +750,8 @@ __global__ __launch_bounds__(64, 1) void k_attn_bwd(const AttnParams p) {
         for (int si = 0; si < 2; ++si) {
             if (si * 32 >= p.N) break;
             f32x16 pt[2];
-            scores_t<T, DENSE>(pt, sK, sQ, si, p, sBias, srid, wm, lane);
-            float m, inv_l;
-            softmax_t(pt, m, inv_l);
+            scores_t<T, DENSE>(pt, sK, sQ, si, p, B, srid, masked, wm, lane);
+            (void)softmax_t<true, sizeof(T) == 4>(pt, B.c);
             // dP^T[j][i] = sum_d V[j][d] dO[i][d]
             f32x16 dp[2];
             zero(dp[0]);
@@ -652,8 +794,7 @@ __global__ __launch_bounds__(64, 1) void k_attn_bwd(const AttnParams p) {
                 Frag<T> fs = regfrag(dp, kt, (T*)nullptr);
                 mtl_mma(fk, fs, dq);
             }
-            const int i = si * 32 + (lane & 31);
-            if (i < p.N) store_dt<T>(dqkv, (int64_t)tok[i] * C3 + head * HD, dq, p.scale, lane);
+            store_dt_lds<T>(stg, gb, tok + si * 32, p.N - si * 32, dq, p.scale, lane);
             __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the image stores have landed (single wave: no barrier needed)
             __builtin_amdgcn_wave_barrier();
             // dK^T[d][j] += sum_{i in half} Q[i][d] dS[i][j],  dV^T[d][j] += sum_i dO[i][d] P[i][j]
@@ -673,10 +814,9 @@ __global__ __launch_bounds__(64, 1) void k_attn_bwd(const AttnParams p) {
         }
 #pragma unroll
         for (int sj = 0; sj < 2; ++sj) {
-            const int j = sj * 32 + (lane & 31);
-            if (j < p.N) {
-                store_dt<T>(dqkv, (int64_t)tok[j] * C3 + p.C + head * HD, dk[sj], p.scale, lane);
-                store_dt<T>(dqkv, (int64_t)tok[j] * C3 + 2 * p.C + head * HD, dv[sj], 1.f, lane);
+            if (sj * 32 < p.N) {
+                store_dt_lds<T>(stg, gb + p.C, tok + sj * 32, p.N - sj * 32, dk[sj], p.scale, lane);
+                store_dt_lds<T>(stg, gb + 2 * p.C, tok + sj * 32, p.N - sj * 32, dv[sj], 1.f, lane);
             }
         }
     }
@@ -725,10 +865,9 @@ int check(const mtlora_attn_desc* d) {
     if (d->H % d->window_size || d->W % d->window_size) return MTLORA_ERR_SHAPE;
     if (d->shift < 0 || d->shift >= d->window_size) return MTLORA_ERR_SHAPE;
     if (d->B * d->H * d->W >= ((int64_t)1 << 31)) return MTLORA_ERR_SHAPE;
+    if ((int64_t)d->H * d->W * 3 * d->num_heads * d->head_dim * 4 >= ((int64_t)1 << 31)) return MTLORA_ERR_SHAPE;  // 32-bit in-image offsets
     return MTLORA_OK;
 }
-
-static int bias_stride_host(int N) { return (N & 1) ? N : N + 1; }
 
 // persistent launch: G window-groups per head such that G * nH workgroups are all resident
 // (LDS-limited workgroups per CU, capped by `cap`), never more groups than windows
@@ -747,13 +886,13 @@ static size_t bwd_lds_bytes(const mtlora_attn_desc* d) {
     const int rs = d->dtype == MTLORA_F32 ? AC<float>::RS : AC<bf16>::RS;
     const size_t ib = (size_t)((img_rows_h(N) * rs + 15) / 16) * 16;
     const size_t img = d->dtype == MTLORA_F32 ? IMG<float>::RS : IMG<bf16>::RS;  // P / dS hand-over images
-    return 4 * ib + 2 * 32 * img + 2 * AN * 4 + (size_t)N * bias_stride_host(N) * 4;
+    return 4 * ib + 2 * 32 * img + 2 * AN * 4 + (d->dtype == MTLORA_F32 ? STG<float>::BYTES : STG<bf16>::BYTES) + (d->dtype == MTLORA_F32 ? (size_t)N * bias_stride_c(N) * 4 : 0);  // (fp32: bias image)
 }
 
 int bwd_groups(const mtlora_attn_desc* d) {
     const int64_t nwin = d->B * (d->H / d->window_size) * (d->W / d->window_size);
-    // one single-wave workgroup per SIMD (the kernel is compiled for the full register file): 4 per CU
-    return groups_for(bwd_lds_bytes(d), 4, d->num_heads, nwin);
+    // MTL_ATTN_BWD_WPS single-wave workgroups per SIMD (the register budget the kernel is compiled for), LDS permitting
+    return groups_for(bwd_lds_bytes(d), 4 * MTL_ATTN_BWD_WPS, d->num_heads, nwin);
 }
 
 AttnParams make_params(const mtlora_attn_desc* d) {
@@ -799,8 +938,8 @@ int mtlora_window_attn_fwd(const mtlora_attn_desc* d, const void* qkv, const flo
     p.out = out;
     const int rs = d->dtype == MTLORA_F32 ? AC<float>::RS : AC<bf16>::RS;
     const size_t ib = (size_t)((img_rows_h(p.N) * rs + 15) / 16) * 16;
-    const size_t lds = 3 * ib + 2 * AN * 4 + (size_t)p.N * bias_stride_host(p.N) * 4;
-    p.G = groups_for(lds, 8, p.nH, p.n_windows);  // persistent grid: exactly the resident workgroups
+    const size_t lds = 3 * ib + 2 * AN * 4 + (d->dtype == MTLORA_F32 ? STG<float>::BYTES : STG<bf16>::BYTES) + (d->dtype == MTLORA_F32 ? (size_t)p.N * bias_stride_c(p.N) * 4 : 0);  // (fp32: bias image)
+    p.G = groups_for(lds, 4 * MTL_ATTN_FWD_WPS, p.nH, p.n_windows);  // persistent grid: exactly the resident workgroups
     const unsigned grid = (unsigned)(p.G * p.nH);
     hipStream_t s = (hipStream_t)stream;
     const double ab = 4.0 * mtl_elem_size(d->dtype) * (double)p.n_windows * p.N * p.C;

@@ -63,6 +63,7 @@ __global__ __launch_bounds__(512, 2) void k_ntd(const NlParams P) {
     const int use_base = P.use_base;
     DropoutCfg drop = P.drop;
     mtl_dropout_resolve(drop);
+    const int dbg = P.dbg & NT_DBG_MASK;  // developer ablation bits (0 at compile time unless -DMTL_NT_ABLATE=1): 1 no stores, 2 no stage loads, 4 no MFMA, 8 no epilogue
     const __amdgpu_buffer_rsrc_t orsrc = sp_rsrc(P.out, (int64_t)M * P.ld_out * 2);
     const __amdgpu_buffer_rsrc_t arsrc = sp_rsrc(P.act2, ACT ? (int64_t)M * P.ld_out * 2 : 0);
     const __amdgpu_buffer_rsrc_t grsrc = sp_rsrc(const_cast<bf16*>(P.gate), GATE ? (int64_t)M * P.ld_out * 2 : 0);
@@ -112,6 +113,7 @@ __global__ __launch_bounds__(512, 2) void k_ntd(const NlParams P) {
         }
     };
     auto issue = [&](int i, int slot) __attribute__((always_inline)) {  // k-tile i of the tile whose rows are in rowc -> ring slot
+        if (dbg & 2) return;
         const bool lr = i < n1;
         const int k0 = lr ? seg_lo + i * ND_KE : (i - n1) * ND_KE;
         const int khi = lr ? seg_hi : Kb;
@@ -207,12 +209,14 @@ __global__ __launch_bounds__(512, 2) void k_ntd(const NlParams P) {
                     fw[ks][bq] = *reinterpret_cast<const u32x4*>(sw + bq * 32 * 128 + co[ks]);
                     fa[ks][bq] = *reinterpret_cast<const u32x4*>(sa + bq * 32 * 128 + co[ks]);
                 }
+            if (!(dbg & 4)) {
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks)
+                for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-                for (int sn = 0; sn < 2; ++sn)
+                    for (int sn = 0; sn < 2; ++sn)
 #pragma unroll
-                    for (int sm = 0; sm < 2; ++sm) sp_mma1<bf16>(fw[ks][sn], fa[ks][sm], acc[sn][sm]);
+                        for (int sm = 0; sm < 2; ++sm) sp_mma1<bf16>(fw[ks][sn], fa[ks][sm], acc[sn][sm]);
+            }
             if constexpr (MLR) {
                 if (i + 1 == n1 && drop.thr16 != 0) {  // the rank part is complete: acc *= keep(m, n)
 #pragma unroll
@@ -272,7 +276,7 @@ __global__ __launch_bounds__(512, 2) void k_ntd(const NlParams P) {
         // ---- epilogue: the wave's 64 (m) x 64 (n) tile, 32 rows at a time, through a private image in the ring slot of the last
         // k-tile (free once every wave has left the k loop); then whole 128-byte row segments per 8 lanes.  EPI_OPS operations.
         __syncthreads();
-        {
+        if (!(dbg & 8)) {
             unsigned char* img = smem + img_slot * ND_STAGE + wave * (32 * ND_ORS);
             const int c16 = lane & 7;
             const int n = n0c + wn * 64 + c16 * 8;
@@ -294,7 +298,7 @@ __global__ __launch_bounds__(512, 2) void k_ntd(const NlParams P) {
                     const int ml = it * 8 + (lane >> 3);
                     const int m = m0c + wm * 64 + sm * 32 + ml;
                     u32x4 v = *reinterpret_cast<const u32x4*>(img + ml * ND_ORS + c16 * 16);
-                    const uint32_t off = (m < M && n < n_rows) ? (uint32_t)m * ldo2 + (uint32_t)n * 2u : 0xFFFFFFFFu;
+                    const uint32_t off = (m < M && n < n_rows && !(dbg & 1)) ? (uint32_t)m * ldo2 + (uint32_t)n * 2u : 0xFFFFFFFFu;
                     if constexpr (GATE) {  // the bf16-rounded gradient times gelu'(pre-activation), rounded once (as ATen does)
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {

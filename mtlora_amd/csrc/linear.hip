@@ -1571,7 +1571,7 @@ static void launch_nt(const Tune& tu, const NtParams& P_in, hipStream_t s, int k
             q.r8 = nwg % 8u;
             q.act_mask = 0;
             q.use_base = P.out[0].use_base;
-            q.dbg = 0;
+            q.dbg = P.dbg;
             q.pad_ = 0;
             q.drop = P.drop;
             const bool ml0 = P.out[0].mask_lr != 0 && P.drop.enabled() && q.seg_hi > q.seg_lo;

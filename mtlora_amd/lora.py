@@ -92,12 +92,23 @@ class MTLoRALinear(LoRALayer):
         self._call_sig = None
 
     def _factor_params(self):
-        ps = []
-        if hasattr(self, "lora_shared_A"):
-            ps += [self.lora_shared_A, self.lora_shared_B]
-        if hasattr(self, "lora_tasks_A"):
-            ps += [self.lora_tasks_A[t] for t in self.tasks] + [self.lora_tasks_B[t] for t in self.tasks]
+        """the layer's low-rank factor Parameters (shared A, B, then the tasks' A..., B...); the tuple is built once -- Parameters are
+        registered at construction and keep their identity through .to() / load_state_dict (both work in place)"""
+        ps = self.__dict__.get("_fp_cache")
+        if ps is None:
+            ps = []
+            if hasattr(self, "lora_shared_A"):
+                ps += [self.lora_shared_A, self.lora_shared_B]
+            if hasattr(self, "lora_tasks_A"):
+                ps += [self.lora_tasks_A[t] for t in self.tasks] + [self.lora_tasks_B[t] for t in self.tasks]
+            ps = tuple(ps)
+            self.__dict__["_fp_cache"] = ps
         return ps
+
+    def __setattr__(self, name, value):
+        if name.startswith("lora_"):  # a factor (container) is being (re)assigned: the cached tuple of _factor_params is stale
+            self.__dict__.pop("_fp_cache", None)
+        super().__setattr__(name, value)
 
     def reset_parameters(self):
         """A ~ kaiming_uniform(a=sqrt 5), B = 0 (reference lora.py:236-247)."""
@@ -305,6 +316,8 @@ class FactorPacker:
 
     def refresh(self) -> int:
         """(re)pack every eligible layer for the signature of its LAST forward call; returns the number of layers packed."""
+        for m in self.layers:  # (an entry of a ParameterDict replaced behind the module's back is picked up here)
+            m.__dict__.pop("_fp_cache", None)
         todo = [m for m in self.layers if self._eligible(m)]
         if not todo:
             return 0

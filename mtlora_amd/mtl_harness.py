@@ -625,7 +625,7 @@ class GraphedTrainStep:
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):  # allocator / autotune / lazy-init warm-up off the capture stream
-            for _ in range(max(1, warmup)):
+            for _ in range(max(2, warmup)):  # (two: the FactorPacker builds its table -- a host-to-device copy -- at the SECOND step)
                 self._eager()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()

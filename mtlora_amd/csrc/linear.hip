@@ -1940,6 +1940,7 @@ static void launch_sp_xres(const SpLinParams& q, const SpXresPlan& pl, bool act,
 // ---- fused wave-streaming launch, accumulator-resident form (k_sp_ares, stream.h): few output columns, any reduction length
 struct SpAresPlan {
     int ch, nob, nrb;
+    bool expg;  // expansion fragments from global memory instead of LDS (k_sp_ares<..., EXPG>)
     unsigned grid;
     size_t lds;
 };
@@ -1949,6 +1950,7 @@ static bool sp_ares_plan(const Tune& tu, SpLinParams& q, int Kred, SpAresPlan& p
     pl.ch = Kred % 96 == 0 ? 96 : (Kred % 64 == 0 ? 64 : 0);
     if (pl.ch == 0) return false;
     pl.nob = pl.ch == 96 ? 3 : 4;
+    pl.expg = false;
     if (q.R <= 0 || q.R > 128 || (q.R % 16) != 0) return false;
     pl.nrb = q.R <= 64 ? 2 : 4;
     q.estep = 2 * ((q.R + 31) / 32);
@@ -1962,8 +1964,16 @@ static bool sp_ares_plan(const Tune& tu, SpLinParams& q, int Kred, SpAresPlan& p
     const int parts = (nb_all + pl.nob - 1) / pl.nob;
     if (parts > 2) return false;  // every part re-reads the activation: only worth it for narrow outputs
     const int64_t kst = Kred / 16;
-    const int64_t need = (int64_t)pl.nob * kst * 1024 + (int64_t)pl.nrb * kst * 1024 + (int64_t)pl.nob * 2 * pl.nrb * 1024 + pl.nob * 128 +
-                         (int64_t)SP_WAVES * 32 * pl.ch * 2;
+    int64_t need = (int64_t)pl.nob * kst * 1024 + (int64_t)pl.nrb * kst * 1024 + (int64_t)pl.nob * 2 * pl.nrb * 1024 + pl.nob * 128 +
+                   (int64_t)SP_WAVES * 32 * pl.ch * 2;
+    if (need > SP_LDS_MAX && nb_all <= 3 && Kred % 64 == 0 && pl.nrb == 2) {
+        // a long reduction with a 64-wide rank (stage-0 fc2 forward / fc1 dX: 384 -> 96): 64-wide slots, three output blocks and the
+        // expansion fragments left in global memory (k_sp_ares<T, 64, 3, 2, EXPG>)
+        pl.ch = 64;
+        pl.nob = 3;
+        pl.expg = true;
+        need = (int64_t)pl.nob * kst * 1024 + (int64_t)pl.nrb * kst * 1024 + pl.nob * 128 + (int64_t)SP_WAVES * 32 * pl.ch * 2;
+    }
     if (need > SP_LDS_MAX) return false;
     pl.lds = (size_t)need;
     q.n_parts = parts;
@@ -1983,7 +1993,10 @@ static void launch_sp_ares(const SpLinParams& q, const SpAresPlan& pl, hipStream
         hipLaunchKernelGGL((k_sp_ares<T, CHV, NOBV, NRBV>), dim3(pl.grid), dim3(64 * SP_WAVES), pl.lds, s, q); \
     } while (0)
     if constexpr (sizeof(T) == 2) {
-        if (pl.ch == 96) {
+        if (pl.expg) {
+            MTL_RAISE_LDS((k_sp_ares<T, 64, 3, 2, true>), SP_LDS_MAX);
+            hipLaunchKernelGGL((k_sp_ares<T, 64, 3, 2, true>), dim3(pl.grid), dim3(64 * SP_WAVES), pl.lds, s, q);
+        } else if (pl.ch == 96) {
             if (pl.nrb == 2) MTL_SP_A(96, 3, 2);
             else MTL_SP_A(96, 3, 4);
         } else {
@@ -2218,10 +2231,18 @@ static int fwd_impl(const mtlora_linear_desc* d, const void* x, const void* cons
             q.mask_lr = 0;
             q.drop = dc;
             SpXresPlan pl;
+            const double b8d = (double)sizeof(T) * d->M * (d->K + (double)d->N);
+            const double fl = 2.0 * d->M * (double)d->K * d->N + 2.0 * d->M * (double)sg.r[0] * (d->K + d->N);
             if (sp_xres_plan<T>(tu, q, (int)d->K, pl)) {
-                const double b8d = (double)sizeof(T) * d->M * (d->K + (double)d->N);
-                const double fl = 2.0 * d->M * (double)d->K * d->N + 2.0 * d->M * (double)sg.r[0] * (d->K + d->N);
                 launch_sp_xres<T>(q, pl, a_s != nullptr, s, PK_NT_FWD_MAIN, b8d + (a_s ? (double)sizeof(T) * d->M * d->N : 0.0), b8d, fl);
+                return MTLORA_OK;
+            }
+            // a long reduction into few output columns (the Mlp's fc2 at stage 0: 384 -> 96): the accumulator-resident form, whose
+            // projection sees the dropout-masked activation -- the P pass and its re-read of X disappear here too
+            SpAresPlan pa;
+            q.estep = q.estep2 = 0;
+            if (a_s == nullptr && sp_ares_plan<T>(tu, q, (int)d->K, pa)) {
+                launch_sp_ares<T>(q, pa, s, PK_NT_FWD_MAIN, b8d, b8d, fl);
                 return MTLORA_OK;
             }
         }

@@ -627,7 +627,10 @@ __global__ __launch_bounds__(64 * SP_WAVES, SP_WAVES / 4) void k_sp_xres(const S
 // output block is formed in a scratch accumulator, masked, added, and the block is stored.  [mask_act: the projection sees
 // the dropout-masked activation -- the forward of a narrow layer, Y = X W^T + b + Bp (alpha A D(X)^T).]
 // ------------------------------------------------------------------------------------------------
-template <typename T, int CH, int NOB, int NRB>
+// EXPG: the expansion-factor fragments are read from global memory (L2-resident: <= 12 KB shared by every workgroup) instead of LDS,
+// the block after next being requested while the current one is multiplied -- frees the 12 KB that let a reduction of 384 with a
+// 64-wide rank (stage-0 fc2 forward / fc1 dX: 72 KB of weight fragments + 48 KB of projection fragments) fit next to the slots.
+template <typename T, int CH, int NOB, int NRB, bool EXPG = false>
 __global__ __launch_bounds__(64 * SP_WAVES, SP_WAVES / 4) void k_sp_ares(const SpLinParams Pv) {
     typedef SpGeom<CH> G;
     constexpr int RST = 2 * NRB;
@@ -649,11 +652,11 @@ __global__ __launch_bounds__(64 * SP_WAVES, SP_WAVES / 4) void k_sp_ares(const S
     constexpr int bpp = NOB;              // blocks per part (blocks past the last column have zero weights and are not stored)
     const int nb0 = part * bpp;
     (void)nb_all;
-    // LDS: [w frags bpp*KST][proj frags NRB*KST][expand frags bpp*RST][bias 32*bpp floats][slots]
+    // LDS: [w frags bpp*KST][proj frags NRB*KST][expand frags bpp*RST (not with EXPG)][bias 32*bpp floats][slots]
     unsigned char* wl = smem;
     unsigned char* pl = wl + (size_t)bpp * KST * 1024;
     unsigned char* el = pl + (size_t)NRB * KST * 1024;
-    float* bl = reinterpret_cast<float*>(el + (size_t)bpp * RST * 1024);
+    float* bl = reinterpret_cast<float*>(el + (EXPG ? (size_t)0 : (size_t)bpp * RST * 1024));
     unsigned char* slots = reinterpret_cast<unsigned char*>(bl + bpp * 32) + (size_t)wave * G::SLOT;
     DropoutCfg drop;
     drop.seed_lo = P->drop.seed_lo;
@@ -681,7 +684,7 @@ __global__ __launch_bounds__(64 * SP_WAVES, SP_WAVES / 4) void k_sp_ares(const S
         }
         const unsigned char* ep = reinterpret_cast<const unsigned char*>(P->expand);
         const int estep = P->estep;
-        for (int f = wave; f < bpp * RST; f += SP_WAVES) {
+        for (int f = wave; !EXPG && f < bpp * RST; f += SP_WAVES) {
             const int blk = f / RST, t = f - blk * RST;
             const void* g = (t < estep && (nb0 + blk) * 32 < n_cols) ? (const void*)(ep + ((size_t)(nb0 + blk) * estep + t) * 1024 + lane * 16) : (const void*)g_zero16;
             sp_dma16(g, el + (size_t)f * 1024);
@@ -800,17 +803,46 @@ __global__ __launch_bounds__(64 * SP_WAVES, SP_WAVES / 4) void k_sp_ares(const S
             st_since += 2 * NRB;
         }
         const uint32_t rowoff = (uint32_t)m * ldo2;
+        u32x4 ef[RST], efn[RST];  // expansion fragments of the current / the next block
+        auto load_ef = [&](u32x4 (&e)[RST], int ob) __attribute__((always_inline)) {
+            if constexpr (EXPG) {
+                const unsigned char* ep = reinterpret_cast<const unsigned char*>(P->expand);
+                const int estep = P->estep;
+                const bool live = (nb0 + ob) * 32 < n_cols;
+#pragma unroll
+                for (int t = 0; t < RST; ++t)
+                    e[t] = (live && t < estep) ? *reinterpret_cast<const u32x4*>(ep + ((size_t)(nb0 + ob) * estep + t) * 1024 + lane * 16)
+                                               : u32x4{0u, 0u, 0u, 0u};
+            } else {
+                const unsigned char* eb = el + (size_t)ob * RST * 1024 + lane * 16;
+#pragma unroll
+                for (int t = 0; t < RST; ++t) e[t] = *reinterpret_cast<const u32x4*>(eb + t * 1024);
+            }
+        };
+        if constexpr (EXPG) {
+            load_ef(efn, 0);
+            st_since += RST;  // (vector-memory operations behind the chunk in flight: an under-count would only wait longer)
+        }
 #pragma unroll
         for (int ob = 0; ob < NOB; ++ob) {
             {
                 const int col0 = (nb0 + ob) * 32;
-                const unsigned char* eb = el + (size_t)ob * RST * 1024 + lane * 16;
+                if constexpr (EXPG) {
+#pragma unroll
+                    for (int t = 0; t < RST; ++t) ef[t] = efn[t];
+                    if (ob + 1 < NOB) {
+                        load_ef(efn, ob + 1);
+                        st_since += RST;
+                    }
+                } else {
+                    load_ef(ef, ob);
+                }
                 if (mask_lr) {
                     f32x16 lr;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) lr[r] = 0.f;
 #pragma unroll
-                    for (int t = 0; t < RST; ++t) sp_mma1<T>(*reinterpret_cast<const u32x4*>(eb + t * 1024), pf[t], lr);
+                    for (int t = 0; t < RST; ++t) sp_mma1<T>(ef[t], pf[t], lr);
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const int n = col0 + 8 * q + 4 * h;
@@ -823,7 +855,7 @@ __global__ __launch_bounds__(64 * SP_WAVES, SP_WAVES / 4) void k_sp_ares(const S
                     }
                 } else {
 #pragma unroll
-                    for (int t = 0; t < RST; ++t) sp_mma1<T>(*reinterpret_cast<const u32x4*>(eb + t * 1024), pf[t], acc[ob]);
+                    for (int t = 0; t < RST; ++t) sp_mma1<T>(ef[t], pf[t], acc[ob]);
                 }
 #pragma unroll
                 for (int q = 0; q < 4; q += 2) {

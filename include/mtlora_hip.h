@@ -113,7 +113,8 @@ typedef struct mtlora_linear_desc {
      * kernel families are bit-compatible up to fp32 summation order); tests pin every family against the oracle by forcing
      * it on shapes far below the sizes at which the library would pick it, and A/B timing uses the same switches. */
     int32_t sel_stream;  /* wave-streaming kernels (csrc/stream.h): 0 wherever eligible, 1 never (tiled kernels only) */
-    int32_t sel_dense;   /* k_ntd (csrc/dense.h), single-output MFMA-dense launches: 0 by shape heuristics, 1 never, 2 whenever eligible */
+    int32_t sel_dense;   /* k_ntd / k_nte (csrc/dense.h), single-output MFMA-dense launches: 0 by shape heuristics, 1 never, 2 k_ntd whenever
+                            eligible, 3 k_nte (two 4-wave workgroups per CU) whenever eligible, 4 heuristics without k_nte (A/B) */
     int32_t sel_tn;      /* k_sp_tn, streaming factor gradients: 0 when every wave gets >= 8 slabs, 1 never, 2 whenever eligible */
     int32_t sel_projk;   /* k_sp_projk, P / Q passes with large K R: 0 single-round launches only, 1 never, 2 whenever eligible */
     int32_t max_cu;      /* 0: size persistent grids for the whole device; n > 0: as if the device had n CUs -- every wave /

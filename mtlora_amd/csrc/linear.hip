@@ -1410,7 +1410,7 @@ static int check_desc(const mtlora_linear_desc* d) {
         if (d->r_t[t] <= 0) return MTLORA_ERR_SHAPE;
     if (d->mode != 0 && d->mode != 1) return MTLORA_ERR_UNSUPPORTED;
     if (d->bwd_phase < 0 || d->bwd_phase > 2) return MTLORA_ERR_UNSUPPORTED;
-    if (d->sel_stream < 0 || d->sel_stream > 1 || d->sel_dense < 0 || d->sel_dense > 2 || d->sel_tn < 0 || d->sel_tn > 2 || d->sel_projk < 0 ||
+    if (d->sel_stream < 0 || d->sel_stream > 1 || d->sel_dense < 0 || d->sel_dense > 4 || d->sel_tn < 0 || d->sel_tn > 2 || d->sel_projk < 0 ||
         d->sel_projk > 2 || d->max_cu < 0)
         return MTLORA_ERR_UNSUPPORTED;
     if (d->dropout_p < 0.f || d->dropout_p >= 1.f) return MTLORA_ERR_SHAPE;
@@ -1428,7 +1428,7 @@ static Tune make_tune(const mtlora_linear_desc* d) {
     auto tri = [](int v) { return v == 1 ? 0 : (v == 2 ? 2 : 1); };
     Tune t;
     t.sp = d->sel_stream == 1 ? 0 : 1;
-    t.ntd = tri(d->sel_dense);
+    t.ntd = d->sel_dense >= 3 ? d->sel_dense : tri(d->sel_dense);  // (3: k_nte whenever eligible, 4: heuristics without k_nte)
     t.tn = tri(d->sel_tn);
     t.projk = tri(d->sel_projk);
     t.max_cu = d->max_cu > 0 ? d->max_cu : 0;
@@ -1489,6 +1489,15 @@ static int ablate_bits(const char* name) {
 #endif
 }
 
+// k_nte (two 4-wave workgroups per CU) instead of k_ntd / k_ntl?  Measured per shape (tools/ntd_ab.sh, profiles/r04_ntd_ab.txt): it wins
+// where a tile spends a large share of its life outside the k loop -- short reductions (<= 12 k-steps of 64) with at least 1.5 tiles per
+// CU -- and where k_ntd's one-workgroup-per-CU rounds are badly filled (< 70 %) while every CU still gets a tile; it loses on long
+// reductions with few tiles (stage 3 dX: half the waves per CU).
+static bool nte_prefer(int64_t tiles, int ksteps, int64_t cus) {
+    const double eff_d = (double)tiles / (double)(mtl_ceil_div(tiles, cus) * cus);
+    return (ksteps >= 4 && ksteps <= 12 && tiles * 2 >= 3 * cus) || (ksteps >= 6 && eff_d < 0.7 && tiles >= cus);
+}
+
 template <typename T>
 static void launch_nt(const Tune& tu, const NtParams& P_in, hipStream_t s, int kind, double alg_bytes, double s8d_bytes = 0.0, double flops = 0.0) {
     NtParams P = P_in;
@@ -1524,12 +1533,13 @@ static void launch_nt(const Tune& tu, const NtParams& P_in, hipStream_t s, int k
         // outputs -- masked rank part): the straight-line kernel
         // MFMA-dense launches (long reduction, enough tiles): k_ntd (dense.h).  MTLORA_NTD: 0 never, 2 whenever the shape allows
         const int ntd_mode = tu.ntd;  // 0 never, 1 by the heuristics below, 2 whenever the shape allows (the "[dense]" test variants)
-        bool dense = false;
+        bool dense = false, use_e = false;
+        int ksteps = 0;
         if (variant == 2 && P.n_out == 1 && P.nz == 0 && ntd_mode != 0 && P.act_mask == 0 && P.n_rows % 8 == 0 && P.n_rows >= 64 &&
             P.M < (int64_t)0x7FFFFF00 && P.out[0].ptr != nullptr && !(P.out[0].gate && P.out[0].act)) {
             const int seg = P.L ? P.out[0].seg_hi - P.out[0].seg_lo : 0;
             const int kk = (P.act[0] && P.out[0].use_base ? P.K : 0);
-            const int ksteps = (seg + ND_KE - 1) / ND_KE + (kk + ND_KE - 1) / ND_KE;
+            ksteps = (seg + ND_KE - 1) / ND_KE + (kk + ND_KE - 1) / ND_KE;
             const int64_t tiles = mtl_ceil_div(P.M, ND_TM) * mtl_ceil_div(P.n_rows, ND_TN);
             const int64_t lim = ((int64_t)1 << 32) - 4096;
             const bool fits = P.M * P.ld_out * 2 < lim && P.M * P.ld_act * 2 < lim && P.M * P.ldL * 2 < lim && (int64_t)P.n_rows * P.ld_wgt * 2 < lim &&
@@ -1539,8 +1549,10 @@ static void launch_nt(const Tune& tu, const NtParams& P_in, hipStream_t s, int k
             // a single round on at least half of the CUs, and no half-empty column tile
             const int64_t slots = num_cu(tu);
             const double eff = (double)tiles / (double)(mtl_ceil_div(tiles, slots) * slots);
+            use_e = ntd_mode == 3 || (ntd_mode == 1 && nte_prefer(tiles, ksteps, slots) && (P.n_rows % ND_TN == 0 || P.n_rows > 2 * ND_TN));
             dense = fits && ksteps >= 1 &&
-                    (ntd_mode == 2 || (ksteps >= 6 && (eff >= 0.7 || (tiles <= slots && tiles >= slots / 2)) && (P.n_rows % ND_TN == 0 || P.n_rows > 2 * ND_TN)));
+                    (ntd_mode == 2 || ntd_mode == 3 || use_e ||
+                     (ksteps >= 6 && (eff >= 0.7 || (tiles <= slots && tiles >= slots / 2)) && (P.n_rows % ND_TN == 0 || P.n_rows > 2 * ND_TN)));
         }
         if (dense) {
             NlParams q;
@@ -1581,6 +1593,27 @@ static void launch_nt(const Tune& tu, const NtParams& P_in, hipStream_t s, int k
         MTL_RAISE_LDS((k_ntd<AC, ML, GA>), SP_LDS_MAX);                                       \
         hipLaunchKernelGGL((k_ntd<AC, ML, GA>), dim3(grid), dim3(512), (size_t)ND_LDS, s, q); \
     } while (0)
+            // k_nte: the same tile with two 4-wave workgroups per CU (dense.h); ntd_mode 3 forces it, 2 forces k_ntd
+            if (use_e) {
+                const uint32_t ge = nwg < 2u * (uint32_t)num_cu(tu) ? nwg : 2u * (uint32_t)num_cu(tu);
+#define MTL_NTE_GO(AC, ML, GA)                                                                \
+    do {                                                                                      \
+        MTL_RAISE_LDS((k_nte<AC, ML, GA>), SP_LDS_MAX);                                       \
+        hipLaunchKernelGGL((k_nte<AC, ML, GA>), dim3(ge), dim3(256), (size_t)NE_LDS, s, q);   \
+    } while (0)
+                if (q.act2)
+                    MTL_NTE_GO(true, false, false);
+                else if (q.gate && ml0)
+                    MTL_NTE_GO(false, true, true);
+                else if (q.gate)
+                    MTL_NTE_GO(false, false, true);
+                else if (ml0)
+                    MTL_NTE_GO(false, true, false);
+                else
+                    MTL_NTE_GO(false, false, false);
+#undef MTL_NTE_GO
+                return;
+            }
             if (q.act2)
                 MTL_NTD_GO(true, false, false);
             else if (q.gate && ml0)

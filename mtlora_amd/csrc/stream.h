@@ -177,8 +177,6 @@ __global__ __launch_bounds__(64 * SP_WAVES, SP_WAVES / 4) void k_sp_proj(const S
 #pragma unroll
     for (int ks = 0; ks < G::KS; ++ks) fo[ks] = rl * G::ROWB + G::phys(rl, 2 * ks + h) * 16;
 
-    SP_WAIT_VM(0);
-    __syncthreads();
 
     const int n_waves = gridDim.x * SP_WAVES;
     const int w_gid = blockIdx.x * SP_WAVES + wave;
@@ -209,6 +207,9 @@ __global__ __launch_bounds__(64 * SP_WAVES, SP_WAVES / 4) void k_sp_proj(const S
     int ahead = 0;  // chunks in flight
 #pragma unroll
     for (int i = 0; i < NS; ++i) ahead += issue(i) ? 1 : 0;
+    // (the first slab requests above are in flight together with the stationary operands: one latency, not two)
+    SP_WAIT_VM(0);
+    __syncthreads();
 
     f32x16 acc[SP_MAXB];
     int slot = 0;
@@ -399,8 +400,6 @@ __global__ __launch_bounds__(64 * SP_WAVES, SP_WAVES / 4) void k_sp_xres(const S
     }
 #pragma unroll
     for (int ks = 0; ks < G::KS; ++ks) fo[ks] = rl * G::ROWB + G::phys(rl, 2 * ks + h) * 16;
-    SP_WAIT_VM(0);
-    __syncthreads();
 
     const int n_slabs = P->n_slabs;
     const int stride = n_grp * SP_WAVES;
@@ -428,6 +427,9 @@ __global__ __launch_bounds__(64 * SP_WAVES, SP_WAVES / 4) void k_sp_xres(const S
         return true;
     };
     issue();
+    // (the first slab requests above are in flight together with the stationary operands: one latency, not two)
+    SP_WAIT_VM(0);
+    __syncthreads();
     const __amdgpu_buffer_rsrc_t orsrc = sp_rsrc(P->out, M * P->ld_out * 2), o2rsrc = sp_rsrc(P->out2, P->out2 ? M * P->ld_out * 2 : 0),
                                  prsrc = sp_rsrc(P->pout, P->pout ? M * P->ldp * 2 : 0);
     (void)o2rsrc;
@@ -703,8 +705,6 @@ __global__ __launch_bounds__(64 * SP_WAVES, SP_WAVES / 4) void k_sp_ares(const S
     }
 #pragma unroll
     for (int ks = 0; ks < G::KS; ++ks) fo[ks] = rl * G::ROWB + G::phys(rl, 2 * ks + h) * 16;
-    SP_WAIT_VM(0);
-    __syncthreads();
 
     const int n_slabs = P->n_slabs;
     const int stride = n_grp * SP_WAVES;
@@ -731,6 +731,9 @@ __global__ __launch_bounds__(64 * SP_WAVES, SP_WAVES / 4) void k_sp_ares(const S
         return true;
     };
     issue();
+    // (the first slab requests above are in flight together with the stationary operands: one latency, not two)
+    SP_WAIT_VM(0);
+    __syncthreads();
     const __amdgpu_buffer_rsrc_t orsrc = sp_rsrc(P->out, M * P->ld_out * 2), prsrc = sp_rsrc(P->pout, P->pout ? M * P->ldp * 2 : 0);
     const uint32_t ldo2 = (uint32_t)(P->ld_out * 2);
     int st_since = 0;
@@ -913,8 +916,6 @@ __global__ __launch_bounds__(64 * SP_WAVES, SP_WAVES / 4) void k_sp_projsum(cons
     }
 #pragma unroll
     for (int ks = 0; ks < G::KS; ++ks) fo[ks] = rl * G::ROWB + G::phys(rl, 2 * ks + h) * 16;
-    SP_WAIT_VM(0);
-    __syncthreads();
 
     // task sources 1 .. n_src - 1: consecutive rank segments, each inside ONE 32-row block; blocks tblk0 .. tblk0 + n_tblk - 1
     const int tblk0 = n_src > 1 ? P->src[1].blk_lo : 0, n_tblk = n_src > 1 ? P->src[n_src - 1].blk_lo - tblk0 + 1 : 0;
@@ -950,6 +951,9 @@ __global__ __launch_bounds__(64 * SP_WAVES, SP_WAVES / 4) void k_sp_projsum(cons
     int ahead = 0;
 #pragma unroll
     for (int i = 0; i < NS; ++i) ahead += issue(i) ? 1 : 0;
+    // (the first slab requests above are in flight together with the stationary operands: one latency, not two)
+    SP_WAIT_VM(0);
+    __syncthreads();
     const __amdgpu_buffer_rsrc_t orsrc = sp_rsrc(P->out, M * P->ld_out * 2), grsrc = sp_rsrc(gsum, M * (int64_t)K * 2);
 
     int slot = 0;

@@ -156,7 +156,7 @@ def droppath_scale(n: int, B: int, keep: float, device) -> torch.Tensor:
 # ----------------------------------------------------------------------------------------------
 def _env_tri(name: str) -> int:
     v = os.environ.get(name)
-    return 0 if v is None or v == "1" else (1 if v == "0" else 2)
+    return 0 if v is None or v == "1" else (1 if v == "0" else int(v))
 
 
 _TUNING_DEFAULT = {"stream": 1 if os.environ.get("MTLORA_SP") == "0" else 0, "dense": _env_tri("MTLORA_NTD"),

@@ -46,10 +46,14 @@ _DENSE_TESTS = ("linear", "mlp", "swin_block")
 _PERSIST_TESTS = ("linear", "mlp", "swin_block", "backbone")
 _FAMILIES = {"tiled": (_TILED_TESTS, dict(stream=1, dense=1)),
              "dense": (_DENSE_TESTS, dict(dense=2, tn=2, projk=2)),
-             "persist": (_PERSIST_TESTS, dict(dense=2, tn=2, projk=2, max_cu=1))}
+             "persist": (_PERSIST_TESTS, dict(dense=2, tn=2, projk=2, max_cu=1)),
+             # k_nte (two 4-wave workgroups per CU on the dense tiles) forced wherever eligible, once on the whole device and once on
+             # ONE CU (two workgroups walk every tile: the ring across tiles, the epilogue under the next tile's first stages)
+             "nte": (_DENSE_TESTS, dict(dense=3)),
+             "ntepersist": (_DENSE_TESTS, dict(dense=3, max_cu=1))}
 
 
-@pytest.fixture(autouse=True, params=["auto", "tiled", "dense", "persist"])
+@pytest.fixture(autouse=True, params=["auto", "tiled", "dense", "persist", "nte", "ntepersist"])
 def _kernel_family(request):
     from mtlora_amd import functional as Fn
     prev = Fn.set_tuning(stream=0, dense=0, tn=0, projk=0, max_cu=0)

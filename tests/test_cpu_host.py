@@ -102,7 +102,7 @@ def test_descriptor_selection_fields_are_validated(built_lib):
     d.M, d.K, d.N, d.dtype, d.T, d.r_s = 1000, 96, 384, _lib.BF16, 0, 64
     base = L.mtlora_linear_ctx_bytes(ctypes.byref(d))
     assert base > 0
-    for field, bad in (("sel_stream", 2), ("sel_dense", 3), ("sel_tn", -1), ("sel_projk", 7), ("max_cu", -1)):
+    for field, bad in (("sel_stream", 2), ("sel_dense", 5), ("sel_tn", -1), ("sel_projk", 7), ("max_cu", -1)):
         setattr(d, field, bad)
         assert L.mtlora_linear_ctx_bytes(ctypes.byref(d)) < 0, field
         setattr(d, field, 0)

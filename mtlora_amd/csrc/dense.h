@@ -608,3 +608,4 @@ __global__ __launch_bounds__(256, 2) void k_nte(const NlParams P) {
         }
     }
 }
+

@@ -139,62 +139,120 @@ struct PackParams {
     int K, N;
 };
 
+// The packing walks 64 x 64 TILES of the two concatenated factor matrices -- A_cat (R x K, rows = rank columns rr) and B_cat (N x R) -- one
+// tile per workgroup pass: the fp32 masters are read along their contiguous axis (K for A, the segment's rank for B), the same-orientation
+// copies (a_cat / a_proj, b_cat) are stored from registers, and the tile goes through LDS once for everything that is transposed or
+// permuted (at_cat, bt_cat / bt_proj, the fragment-major at_frag / b_frag): every global access of the launch is a coalesced row segment.
+// (Round 3's element-wise walk scattered 2-byte stores with a stride of R for the transposed copies and divided 64-bit indices per
+// element: 1.07 ms for the 72 layers of Swin-B at rank 128, 30 x the time of the bytes it moves.)
+constexpr int PK_T = 64;
+
+template <typename PP>
+__device__ __forceinline__ int pack_seg_of(const PP& p, int rr) {
+    int o = 0;
+#pragma unroll
+    for (int q = 1; q < MAXO; ++q)
+        if (q < p.s.n && rr >= p.s.off[q]) o = q;
+    return o;
+}
+
 template <typename T, typename PP>
 __device__ __forceinline__ void pack_body(const PP& p, T* a_cat, T* b_cat, T* at_cat, T* bt_cat, float* alpha, T* a_proj, T* bt_proj, T* b_frag,
                                           T* at_frag, int bid, int nblk) {
-    const int R = p.s.R;
-    {   // fragment-major expansion factors (16-bit types only: the wave-streaming kernels)
-        const int N32 = (p.N + 31) & ~31, K32 = (p.K + 31) & ~31, R16 = ((R + 31) >> 5) << 1, R32 = R16 << 4;
-        const int64_t nbf = sizeof(T) == 2 ? (int64_t)N32 * R32 : 0, naf = sizeof(T) == 2 ? (int64_t)K32 * R32 : 0;
-        for (int64_t i = (int64_t)bid * 256 + threadIdx.x; i < nbf + naf; i += (int64_t)nblk * 256) {
-            const bool isb = i < nbf;
-            const int64_t j = isb ? i : i - nbf;
-            const int sidx = (int)(j & 7), ln = (int)((j >> 3) & 63);
-            const int64_t f = j >> 9;  // fragment index = blk * R16 + t
-            const int blk = (int)(f / R16), t = (int)(f - (int64_t)blk * R16);
-            const int row = blk * 32 + (ln & 31);
-            const int rr = 16 * t + 8 * (sidx >> 2) + 4 * (ln >> 5) + (sidx & 3);
-            int o = 0;
+    __shared__ float tile[PK_T][PK_T + 1];
+    constexpr bool FRAG = sizeof(T) == 2;  // fragment-major expansion factors: 16-bit types only (the wave-streaming kernels)
+    const int R = p.s.R, K = p.K, N = p.N;
+    const int tr = (R + PK_T - 1) / PK_T, tk = (K + PK_T - 1) / PK_T, tn = (N + PK_T - 1) / PK_T;
+    const int na_t = tr * tk, nb_t = tn * tr;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int R16 = ((R + 31) >> 5) << 1, K32 = (K + 31) & ~31, N32 = (N + 31) & ~31;
+    for (int job = bid; job < na_t + nb_t; job += nblk) {
+        const bool isa = job < na_t;
+        const int jb = isa ? job : job - na_t;
+        // tile origin: rows r0 / cols c0 of A_cat (rr, k), or rows n0 / cols r0 of B_cat (n, rr)
+        const int row0 = isa ? (jb / tk) * PK_T : (jb / tr) * PK_T;
+        const int col0 = isa ? (jb % tk) * PK_T : (jb % tr) * PK_T;
+        float v[PK_T / 4];  // all 16 loads of the tile are in flight before the first store (the stores may alias for all the compiler knows)
+        if (isa) {
+            const int c = col0 + tx;
+            float al[PK_T / 4];
 #pragma unroll
-            for (int q = 1; q < MAXO; ++q)
-                if (q < p.s.n && rr >= p.s.off[q]) o = q;
-            const int lr = rr - p.s.off[o];
-            float v = 0.f;
-            if (rr < R && lr < p.s.r[o]) {
-                if (isb) {
-                    if (row < p.N && p.B[o]) v = p.B[o][(int64_t)row * p.s.r[o] + lr];
-                } else {
-                    if (row < p.K && p.A[o]) v = p.A[o][(int64_t)lr * p.K + row];
+            for (int i = 0; i < PK_T / 4; ++i) {
+                const int rr = row0 + ty + 4 * i;  // (wave-uniform)
+                const int o = pack_seg_of(p, rr), lr = rr - p.s.off[o];
+                al[i] = p.alpha[o];
+                v[i] = (rr < R && lr < p.s.r[o] && c < K && p.A[o]) ? p.A[o][(int64_t)lr * K + c] : 0.f;
+            }
+#pragma unroll
+            for (int i = 0; i < PK_T / 4; ++i) {
+                const int row = ty + 4 * i, rr = row0 + row;
+                tile[row][tx] = v[i];
+                if (rr < R && c < K) {
+                    a_cat[(int64_t)rr * K + c] = mtl_from_f32<T>(v[i]);
+                    a_proj[(int64_t)rr * K + c] = mtl_from_f32<T>(v[i] * al[i]);
                 }
             }
-            (isb ? b_frag : at_frag)[j] = mtl_from_f32<T>(v);
-        }
-    }
-    const int64_t na = (int64_t)R * p.K, nb = (int64_t)R * p.N;
-    for (int64_t i = (int64_t)bid * 256 + threadIdx.x; i < na + nb + R; i += (int64_t)nblk * 256) {
-        int64_t j = i < na ? i : (i < na + nb ? i - na : i - na - nb);
-        const int dim = i < na ? p.K : p.N;
-        int rr = (i < na + nb) ? (int)(j / dim) : (int)j;
-        int c = (i < na + nb) ? (int)(j % dim) : 0;
-        int o = 0;
-#pragma unroll
-        for (int q = 1; q < MAXO; ++q)
-            if (q < p.s.n && rr >= p.s.off[q]) o = q;
-        const int lr = rr - p.s.off[o];
-        const bool valid = lr < p.s.r[o];
-        if (i < na) {  // A_o[lr][c]  (r x K)
-            float v = (valid && p.A[o]) ? p.A[o][(int64_t)lr * p.K + c] : 0.f;
-            a_cat[(int64_t)rr * p.K + c] = mtl_from_f32<T>(v);
-            at_cat[(int64_t)c * R + rr] = mtl_from_f32<T>(v);
-            a_proj[(int64_t)rr * p.K + c] = mtl_from_f32<T>(v * p.alpha[o]);
-        } else if (i < na + nb) {  // B_o[c][lr]  (N x r)
-            float v = (valid && p.B[o]) ? p.B[o][(int64_t)c * p.s.r[o] + lr] : 0.f;
-            b_cat[(int64_t)c * R + rr] = mtl_from_f32<T>(v);
-            bt_cat[(int64_t)rr * p.N + c] = mtl_from_f32<T>(v);
-            bt_proj[(int64_t)rr * p.N + c] = mtl_from_f32<T>(v * p.alpha[o]);
+            if (col0 == 0 && threadIdx.x < PK_T && row0 + tx < R) alpha[row0 + tx] = p.alpha[pack_seg_of(p, row0 + tx)];
         } else {
-            alpha[rr] = p.alpha[o];
+            const int rr = col0 + tx;
+            const int o = pack_seg_of(p, rr), lr = rr - p.s.off[o], ro = p.s.r[o];
+            const bool live = rr < R && lr < ro && p.B[o];
+            const float* __restrict__ Bo = p.B[o];
+#pragma unroll
+            for (int i = 0; i < PK_T / 4; ++i) {
+                const int n = row0 + ty + 4 * i;
+                v[i] = (live && n < N) ? Bo[(int64_t)n * ro + lr] : 0.f;
+            }
+#pragma unroll
+            for (int i = 0; i < PK_T / 4; ++i) {
+                const int row = ty + 4 * i, n = row0 + row;
+                tile[row][tx] = v[i];
+                if (rr < R && n < N) b_cat[(int64_t)n * R + rr] = mtl_from_f32<T>(v[i]);
+            }
         }
+        __syncthreads();
+        if (isa) {  // at_cat[k][rr]: lanes along rr
+            const int rr = row0 + tx;
+#pragma unroll 4
+            for (int i = 0; i < PK_T / 4; ++i) {
+                const int cl = ty + 4 * i, c = col0 + cl;
+                if (rr < R && c < K) at_cat[(int64_t)c * R + rr] = mtl_from_f32<T>(tile[tx][cl]);
+            }
+        } else {    // bt_cat / bt_proj[rr][n]: lanes along n
+            const int n = row0 + tx;
+#pragma unroll 4
+            for (int i = 0; i < PK_T / 4; ++i) {
+                const int rl = ty + 4 * i, rr = col0 + rl;  // (wave-uniform)
+                if (rr < R && n < N) {
+                    const float v = tile[tx][rl];
+                    bt_cat[(int64_t)rr * N + n] = mtl_from_f32<T>(v);
+                    bt_proj[(int64_t)rr * N + n] = mtl_from_f32<T>(v * p.alpha[pack_seg_of(p, rr)]);
+                }
+            }
+        }
+        if constexpr (FRAG) {
+            // fragment (32-row block blk of k or n, 16-wide rank step t) = 512 elements: lane l = (row blk * 32 + (l & 31), h = l >> 5)
+            // holds rank columns 16 t + 8 (s >> 2) + 4 h + (s & 3), s = 0..7.  The tile holds 2 x 4 fragments; a thread writes two
+            // (fragment, lane) groups of 8 elements = one 16-byte store each.
+            T* __restrict__ dst = isa ? at_frag : b_frag;
+            const int blk0 = (isa ? col0 : row0) >> 5, t0 = (isa ? row0 : col0) >> 4, nblk32 = (isa ? K32 : N32) >> 5;
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {
+                const int q = threadIdx.x + 256 * h2, fl = q >> 6, ln = q & 63;
+                const int bl = fl >> 2, tl = fl & 3, rl = bl * 32 + (ln & 31);
+                if (blk0 + bl < nblk32 && t0 + tl < R16) {
+                    T tmp[8];
+#pragma unroll
+                    for (int sidx = 0; sidx < 8; ++sidx) {
+                        const int kl = 16 * tl + 8 * (sidx >> 2) + 4 * (ln >> 5) + (sidx & 3);
+                        tmp[sidx] = mtl_from_f32<T>(isa ? tile[kl][rl] : tile[rl][kl]);
+                    }
+                    const int64_t f = (int64_t)(blk0 + bl) * R16 + (t0 + tl);
+                    *reinterpret_cast<uint4*>(dst + f * 512 + ln * 8) = *reinterpret_cast<const uint4*>(tmp);
+                }
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -2205,8 +2263,8 @@ static PackParams make_pack_params(const mtlora_linear_desc* d, const Segs& sg, 
     return pp;
 }
 static unsigned pack_blocks(const mtlora_linear_desc* d, const Segs& sg) {
-    const int64_t work = (int64_t)sg.R * (d->K + d->N + 1);
-    int64_t blocks = mtl_ceil_div(work, 256);
+    const int64_t tr = mtl_ceil_div(sg.R, PK_T);
+    int64_t blocks = tr * (mtl_ceil_div(d->K, PK_T) + mtl_ceil_div(d->N, PK_T));  // one 64 x 64 tile of A_cat / B_cat per workgroup
     if (blocks > 2048) blocks = 2048;
     return (unsigned)(blocks > 0 ? blocks : 1);
 }
@@ -2960,7 +3018,7 @@ int mtlora_linear_pack_table(const void* table_dev, int n_entries, int dtype, vo
     hipStream_t s = (hipStream_t)stream;
     const PackEntry* tb = reinterpret_cast<const PackEntry*>(table_dev);
     MtlProfScope prof(PK_PACK, 0.0, s);
-    const dim3 g(48, (unsigned)n_entries);  // 48 workgroups per layer walk its 0.1 - 1 M elements
+    const dim3 g(256, (unsigned)n_entries);  // up to 256 workgroups per layer walk its 20 - 800 tiles (the others leave at once)
     if (dtype == MTLORA_F32)
         hipLaunchKernelGGL(k_pack_table<float>, g, dim3(256), 0, s, tb);
     else if (dtype == MTLORA_F16)

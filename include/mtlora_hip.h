@@ -116,7 +116,8 @@ typedef struct mtlora_linear_desc {
     int32_t sel_dense;   /* k_ntd / k_nte (csrc/dense.h), single-output MFMA-dense launches: 0 by shape heuristics, 1 never, 2 k_ntd whenever
                             eligible, 3 k_nte (two 4-wave workgroups per CU) whenever eligible, 4 heuristics without k_nte (A/B) */
     int32_t sel_tn;      /* k_sp_tn, streaming factor gradients: 0 when every wave gets >= 8 slabs, 1 never, 2 whenever eligible */
-    int32_t sel_projk;   /* k_sp_projk, P / Q passes with large K R: 0 single-round launches only, 1 never, 2 whenever eligible */
+    int32_t sel_projk;   /* P / Q passes whose projection rows do not fit in LDS: 0 heuristics (k_sp_projk on single-round launches, k_pq on
+                            single-source passes, tiled otherwise), 1 tiled only, 2 k_sp_projk whenever eligible, 3 k_pq whenever eligible */
     int32_t max_cu;      /* 0: size persistent grids for the whole device; n > 0: as if the device had n CUs -- every wave /
                             workgroup of a persistent kernel then owns MANY work items even at test sizes (the steady state
                             of the slot rings and the vmcnt accounting, reached otherwise only at benchmark sizes) */

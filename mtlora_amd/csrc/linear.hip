@@ -1092,6 +1092,7 @@ __global__ __launch_bounds__(512, 4) void k_ntl(const NlParams P) {
 
 #include "stream.h"
 #include "dense.h"
+#include "pq.h"
 
 // ------------------------------------------------------------------------------------------------
 // k_tn : Out[a][b] = sum_m SrcA[m][a0 + a] * SrcB[m][b0 + b], split over m.
@@ -1469,7 +1470,7 @@ static int check_desc(const mtlora_linear_desc* d) {
     if (d->mode != 0 && d->mode != 1) return MTLORA_ERR_UNSUPPORTED;
     if (d->bwd_phase < 0 || d->bwd_phase > 2) return MTLORA_ERR_UNSUPPORTED;
     if (d->sel_stream < 0 || d->sel_stream > 1 || d->sel_dense < 0 || d->sel_dense > 4 || d->sel_tn < 0 || d->sel_tn > 2 || d->sel_projk < 0 ||
-        d->sel_projk > 2 || d->max_cu < 0)
+        d->sel_projk > 3 || d->max_cu < 0)
         return MTLORA_ERR_UNSUPPORTED;
     if (d->dropout_p < 0.f || d->dropout_p >= 1.f) return MTLORA_ERR_SHAPE;
     return MTLORA_OK;
@@ -1478,7 +1479,8 @@ static int check_desc(const mtlora_linear_desc* d) {
 static bool misaligned(const void* p) { return ((uintptr_t)p & 15u) != 0; }
 
 // kernel selection of one call: a function of the descriptor alone (mtlora_linear_desc.sel_* / max_cu, ABI v6) -- the library reads
-// no environment variables.  sp: wave-streaming family on; ntd / tn / projk: 0 never, 1 by heuristics, 2 whenever eligible.
+// no environment variables.  sp: wave-streaming family on; ntd / tn / projk: 0 never, 1 by heuristics, 2 whenever eligible (projk 3: k_pq
+// whenever eligible).
 struct Tune {
     int sp, ntd, tn, projk, max_cu;
 };
@@ -1488,7 +1490,7 @@ static Tune make_tune(const mtlora_linear_desc* d) {
     t.sp = d->sel_stream == 1 ? 0 : 1;
     t.ntd = d->sel_dense >= 3 ? d->sel_dense : tri(d->sel_dense);  // (3: k_nte whenever eligible, 4: heuristics without k_nte)
     t.tn = tri(d->sel_tn);
-    t.projk = tri(d->sel_projk);
+    t.projk = d->sel_projk == 3 ? 3 : tri(d->sel_projk);  // (3: k_pq whenever eligible)
     t.max_cu = d->max_cu > 0 ? d->max_cu : 0;
     return t;
 }
@@ -1827,6 +1829,54 @@ static void launch_sp_proj(const Tune& tu, const SpProjParams& q, int ch, int ns
 #undef MTL_SP_PROJ
 }
 
+// ---- k_pq (pq.h): the P / Q passes of single-source launches whose projection rows do not fit in LDS: 64- or 128-row tiles with a deep
+// LDS-DMA ring.  Fills `pq`, returns the row blocks per wave (1: 64-row tiles, 2: 128-row tiles; 0: not eligible).
+template <typename T>
+static int pq_plan(const Tune& tu, const SpProjParams& q, PqParams& pq) {
+    if (sizeof(T) != 2 || tu.sp == 0 || tu.projk == 0 || tu.projk == 2 || q.M <= 0 || q.n_src != 1) return 0;
+    const SpSrc& s0 = q.src[0];
+    if (s0.col_lo != 0 || s0.col_hi + 15 < q.Rw) return 0;  // one source that owns every column (padding columns get zeros)
+    if (q.Rw > 128 || q.Rw % 8 != 0 || q.K % 8 != 0 || q.K < 32 || (q.ld_out % 8) != 0) return 0;
+    if ((((uintptr_t)s0.act | (uintptr_t)q.wproj | (uintptr_t)q.out) & 15u) != 0) return 0;
+    if (q.M >= ((int64_t)1 << 31) - 256 || q.M * q.ld_out * 2 >= ((int64_t)1 << 32) - 64) return 0;
+    pq.act = s0.act;
+    pq.wproj = q.wproj;
+    pq.out = q.out;
+    pq.ld_out = q.ld_out;
+    pq.M = (int)q.M;
+    pq.K = q.K;
+    pq.R = q.Rw;
+    pq.mask = s0.mask;
+    pq.drop = q.drop;
+    // 64-row tiles while they are about one residency round (a workgroup per CU), 128-row tiles beyond
+    return mtl_ceil_div(q.M, 64) * 4 <= (int64_t)num_cu(tu) * 5 ? 1 : 2;
+}
+static bool pq_one_round(const Tune& tu, const PqParams& pq, int mb) {
+    return mtl_ceil_div(pq.M, 64 * mb) * 4 <= (int64_t)num_cu(tu) * 5;
+}
+template <typename T>
+static void launch_pq(const PqParams& pq, int mb, hipStream_t s, int kind, double alg_bytes, double s8d, double flops) {
+    mtl_prof_tag("pq M%d K%d R%d mb%d mask%d", pq.M, pq.K, pq.R, mb, pq.mask);
+    MtlProfScope prof(kind, alg_bytes, s, s8d, flops);
+    const unsigned grid = (unsigned)mtl_ceil_div(pq.M, 64 * mb);
+#define MTL_PQ(WMV, NBV, NSTV, KSV)                                                                               \
+    do {                                                                                                          \
+        constexpr size_t lds = (size_t)NSTV * (32 * WMV + 32 * NBV) * 64;                                         \
+        MTL_RAISE_LDS((k_pq<T, WMV, NBV, NSTV, KSV>), SP_LDS_MAX);                                                \
+        hipLaunchKernelGGL((k_pq<T, WMV, NBV, NSTV, KSV>), dim3(grid), dim3(256), lds, s, pq);                    \
+    } while (0)
+    if constexpr (sizeof(T) == 2) {
+        const bool wide = pq.R > 64, ksp = pq.mask != 0 && pq.drop.enabled();  // (masked: every activation fragment hashed by one wave)
+        if (mb == 1 && wide && ksp) MTL_PQ(2, 4, 6, true);   // 64 x 128: 12 KB stages, 60 KB in flight
+        else if (mb == 1 && wide) MTL_PQ(2, 4, 6, false);
+        else if (mb == 1 && ksp) MTL_PQ(2, 2, 8, true);      // 64 x 64:   8 KB stages, 56 KB in flight
+        else if (mb == 1) MTL_PQ(2, 2, 8, false);
+        else if (wide) MTL_PQ(4, 4, 5, false);               // 128 x 128: 16 KB stages, 64 KB in flight
+        else MTL_PQ(4, 2, 6, false);                         // 128 x 64: 12 KB stages, 60 KB in flight
+    }
+#undef MTL_PQ
+}
+
 // ---- k_sp_projk (stream.h): the P / Q passes whose projection rows do not fit in LDS, for small row counts (one work item per
 // workgroup, reduction split over its waves).  Same parameter block as k_sp_proj; returns false when the shape is not eligible.
 template <typename T>
@@ -1847,7 +1897,7 @@ static bool sp_projk_plan(const Tune& tu, SpProjParams& q, int& ch) {
     q.n_items = q.n_slabs * q.n_src;
     // every item re-reads the projection rows from L2 and pays three barriers: it wins while the whole launch is ONE residency round
     // (stage 3: 196 slabs; 42 - 62 us -> 20 - 24 us), ties at two to three rounds and loses beyond (tools/projk_ab.sh)
-    return mode == 2 || ((int64_t)q.n_items <= (int64_t)num_cu(tu) && q.K / ch >= SP_WAVES);
+    return mode == 2 || (mode == 1 && (int64_t)q.n_items <= (int64_t)num_cu(tu) && q.K / ch >= SP_WAVES);
 }
 template <typename T>
 static void launch_sp_projk(const Tune& tu, const SpProjParams& q, int ch, hipStream_t s, int kind, double alg_bytes, double s8d, double flops) {
@@ -2396,10 +2446,18 @@ static int fwd_impl(const mtlora_linear_desc* d, const void* x, const void* cons
                 }
                 int ch = 0;
                 const int ns = sp_proj_plan<T>(tu, sp, ch);
-                if (ns > 0)
+                PqParams pq = {};
+                const int mb = pq_plan<T>(tu, sp, pq);
+                // k_pq first: forced (3: the "[pq]" test family), instead of a one-slot k_sp_proj ring (which cannot overlap its loads), and
+                // for launches of about one residency round (tools/pq_times.py: stage 2 of Swin-T 13 vs 16 us, Swin-B 14 vs 21 us)
+                if (mb > 0 && (tu.projk == 3 || ns == 1 || pq_one_round(tu, pq, mb)))
+                    launch_pq<T>(pq, mb, s, PK_NT_FWD_P, xb, xb, 2.0 * d->M * d->K * rsum);
+                else if (ns > 0)
                     launch_sp_proj<T>(tu, sp, ch, ns, s, PK_NT_FWD_P, xb, xb, 2.0 * d->M * d->K * rsum);
                 else if (sp_projk_plan<T>(tu, sp, ch))
                     launch_sp_projk<T>(tu, sp, ch, s, PK_NT_FWD_P, xb, xb, 2.0 * d->M * d->K * rsum);
+                else if (mb > 0)
+                    launch_pq<T>(pq, mb, s, PK_NT_FWD_P, xb, xb, 2.0 * d->M * d->K * rsum);
                 else
                     launch_nt<T>(tu, q, s, PK_NT_FWD_P, xb, xb, 2.0 * d->M * d->K * rsum);
             }
@@ -2679,10 +2737,16 @@ static int bwd_impl(const mtlora_linear_desc* d, const void* x, const void* cons
             }
             int ch = 0;
             const int ns = sp_proj_plan<T>(tu, sp, ch);
-            if (ns > 0)
+            PqParams pq = {};
+            const int mb = pq_plan<T>(tu, sp, pq);
+            if (mb > 0 && (tu.projk == 3 || ns == 1 || pq_one_round(tu, pq, mb)))
+                launch_pq<T>(pq, mb, s, PK_NT_BWD_Q, 0.0, 0.0, 2.0 * d->M * d->N * rsum);
+            else if (ns > 0)
                 launch_sp_proj<T>(tu, sp, ch, ns, s, PK_NT_BWD_Q, 0.0, 0.0, 2.0 * d->M * d->N * rsum);
             else if (sp_projk_plan<T>(tu, sp, ch))
                 launch_sp_projk<T>(tu, sp, ch, s, PK_NT_BWD_Q, 0.0, 0.0, 2.0 * d->M * d->N * rsum);
+            else if (mb > 0)
+                launch_pq<T>(pq, mb, s, PK_NT_BWD_Q, 0.0, 0.0, 2.0 * d->M * d->N * rsum);
             else
                 launch_nt<T>(tu, q, s, PK_NT_BWD_Q, 0.0, 0.0, 2.0 * d->M * d->N * rsum);
         }

@@ -50,10 +50,12 @@ _FAMILIES = {"tiled": (_TILED_TESTS, dict(stream=1, dense=1)),
              # k_nte (two 4-wave workgroups per CU on the dense tiles) forced wherever eligible, once on the whole device and once on
              # ONE CU (two workgroups walk every tile: the ring across tiles, the epilogue under the next tile's first stages)
              "nte": (_DENSE_TESTS, dict(dense=3)),
-             "ntepersist": (_DENSE_TESTS, dict(dense=3, max_cu=1))}
+             "ntepersist": (_DENSE_TESTS, dict(dense=3, max_cu=1)),
+             # k_pq (64 / 128-row tiles with a deep LDS-DMA ring) for every single-source P / Q pass
+             "pq": (_DENSE_TESTS, dict(projk=3))}
 
 
-@pytest.fixture(autouse=True, params=["auto", "tiled", "dense", "persist", "nte", "ntepersist"])
+@pytest.fixture(autouse=True, params=["auto", "tiled", "dense", "persist", "nte", "ntepersist", "pq"])
 def _kernel_family(request):
     from mtlora_amd import functional as Fn
     prev = Fn.set_tuning(stream=0, dense=0, tn=0, projk=0, max_cu=0)

@@ -64,7 +64,41 @@ def timed(f, n):
     return e0.elapsed_time(e1) / n
 
 
+def heads_only():
+    """heads + losses forward and backward from DETACHED stage outputs (the backbone is run once, outside the timed region)"""
+    main = torch.cuda.current_stream(dev)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        feats_in = [(x.detach(), {t: v.detach().requires_grad_(True) for t, v in tl.items()}) for x, tl in STAGES]
+        streams = model.task_streams(dev)
+        per = {}
+        for t, st in zip(tasks, streams):
+            st.wait_stream(main)
+            with torch.cuda.stream(st):
+                lo = model.decoders({t: model.downsampler[t]([tl[t] for _, tl in feats_in])}, upsample=False, tasks=[t])[t]
+                per[t] = crit.task_low(t, lo, tg[t])
+        for st in streams:
+            main.wait_stream(st)
+        loss = crit.combine(per)[0]
+    return loss, feats_in
+
+
+def heads_fwd():
+    heads_only()
+
+
+def heads_fwd_bwd():
+    loss, _ = heads_only()
+    loss.backward()
+    for p in model.parameters():
+        p.grad = None
+
+
 for _ in range(5):
     full()
+with torch.no_grad():
+    STAGES = backbone()
+STAGES = [(x.detach(), {t: v.detach() for t, v in tl.items()}) for x, tl in STAGES]
+thf, thfb = timed(heads_fwd, a.steps), timed(heads_fwd_bwd, a.steps)
+print(f"heads + losses alone (4 task streams, detached stage outputs): forward {thf:.2f} ms, forward + backward {thfb:.2f} ms")
 tb, tf, tfb, tfull = timed(backbone, a.steps), timed(fwd, a.steps), timed(fwd_bwd, a.steps), timed(full, a.steps)
 print(f"{a.config} B={B}: backbone fwd {tb:.2f} ms | + heads & losses fwd {tf - tb:.2f} | backward {tfb - tf:.2f} | clip + AdamW {tfull - tfb:.2f} | step {tfull:.2f} ms")

@@ -7,7 +7,7 @@ mkdir -p $OUT
 cd $REPO
 PART=${1:-1}
 if [ "$PART" = "1" ]; then
-  timeout 1500 python -m pytest tests -q -m gpu > $OUT/pytest.txt 2>&1; grep -E "passed|failed" $OUT/pytest.txt | tail -1
+  timeout 2400 python -m pytest tests -q -m gpu > $OUT/pytest.txt 2>&1; grep -E "passed|failed" $OUT/pytest.txt | tail -1
   cp gpurun_out/model_parity.jsonl $OUT/model_parity.jsonl 2>/dev/null
   python bench.py > $OUT/bench_default.json 2>/dev/null; cut -c1-160 $OUT/bench_default.json
   for c in c1 c4 c5:4 c5:16 c5:64 c5:256; do
@@ -33,6 +33,9 @@ else
   bash tools/tn_ab.sh > $OUT/tn_ab.txt 2>&1
   bash tools/ntd_ab.sh > $OUT/ntd_ab.txt 2>&1
   bash tools/projk_ab.sh > $OUT/projk_ab.txt 2>&1
+  python tools/pq_times.py > $OUT/pq_times.txt 2>&1
+  python tools/phase_times.py > $OUT/phase_times.txt 2>&1
+  python tools/host_breakdown.py > $OUT/host_breakdown.txt 2>&1
   tools/probe/wprobe > $OUT/wprobe.txt 2>&1
   python tools/bw_probe.py > $OUT/bw_probe.txt 2>&1
   ls -la $OUT

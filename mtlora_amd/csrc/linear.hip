@@ -2449,8 +2449,9 @@ static int fwd_impl(const mtlora_linear_desc* d, const void* x, const void* cons
                 PqParams pq = {};
                 const int mb = pq_plan<T>(tu, sp, pq);
                 // k_pq first: forced (3: the "[pq]" test family), instead of a one-slot k_sp_proj ring (which cannot overlap its loads), and
-                // for launches of about one residency round (tools/pq_times.py: stage 2 of Swin-T 13 vs 16 us, Swin-B 14 vs 21 us)
-                if (mb > 0 && (tu.projk == 3 || ns == 1 || pq_one_round(tu, pq, mb)))
+                // instead of k_sp_proj for launches of about one residency round (tools/pq_times.py: stage 2 of Swin-T 13 vs 16 us, Swin-B 14
+                // vs 21 us); where k_sp_proj does not fit at all, k_sp_projk's single-round rule comes first (stage 3: 15 vs 21 us)
+                if (mb > 0 && (tu.projk == 3 || ns == 1 || (ns > 1 && pq_one_round(tu, pq, mb))))
                     launch_pq<T>(pq, mb, s, PK_NT_FWD_P, xb, xb, 2.0 * d->M * d->K * rsum);
                 else if (ns > 0)
                     launch_sp_proj<T>(tu, sp, ch, ns, s, PK_NT_FWD_P, xb, xb, 2.0 * d->M * d->K * rsum);
@@ -2739,7 +2740,7 @@ static int bwd_impl(const mtlora_linear_desc* d, const void* x, const void* cons
             const int ns = sp_proj_plan<T>(tu, sp, ch);
             PqParams pq = {};
             const int mb = pq_plan<T>(tu, sp, pq);
-            if (mb > 0 && (tu.projk == 3 || ns == 1 || pq_one_round(tu, pq, mb)))
+            if (mb > 0 && (tu.projk == 3 || ns == 1 || (ns > 1 && pq_one_round(tu, pq, mb))))
                 launch_pq<T>(pq, mb, s, PK_NT_BWD_Q, 0.0, 0.0, 2.0 * d->M * d->N * rsum);
             else if (ns > 0)
                 launch_sp_proj<T>(tu, sp, ch, ns, s, PK_NT_BWD_Q, 0.0, 0.0, 2.0 * d->M * d->N * rsum);

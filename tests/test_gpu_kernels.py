@@ -1246,7 +1246,12 @@ FULL_T0 = {  # BASELINE configs[1] layers without tasks, full M: name -> (M, K, 
     "s0.qkv": (_M0, 96, 288, None), "s0.proj": (_M0, 96, 96, None), "s0.fc1": (_M0, 96, 384, "gelu_out"),
     "s0.fc2": (_M0, 384, 96, "gate"), "s1.qkv": (_M1, 192, 576, None), "s1.fc1": (_M1, 192, 768, "gelu_out"),
     "s1.fc2": (_M1, 768, 192, "gate"), "s2.qkv": (_M2, 384, 1152, None), "s2.fc1": (_M2, 384, 1536, "gelu_out"),
-    "s2.fc2": (_M2, 1536, 384, "gate"),
+    "s2.fc2": (_M2, 1536, 384, "gate"), "s3.qkv": (32 * 14 * 14, 768, 2304, None), "s3.fc2": (32 * 14 * 14, 3072, 768, "gate"),
+    # BASELINE configs[3] (Swin-B / 448, B = 16, rank 128), stage 2 -- the shapes k_pq exists for (64-row tiles, masked P with the
+    # k-split wave grid, unmasked Q with the column-split one), and stage 1 (128-row tiles)
+    "b2.qkv": (16 * 28 * 28, 512, 1536, None, 128), "b2.proj": (16 * 28 * 28, 512, 512, None, 128),
+    "b2.fc1": (16 * 28 * 28, 512, 2048, "gelu_out", 128), "b2.fc2": (16 * 28 * 28, 2048, 512, "gate", 128),
+    "b1.fc2": (16 * 56 * 56, 1024, 256, "gate", 128),
 }
 
 
@@ -1257,10 +1262,10 @@ def test_full_size_linear_t0_train_vs_oracle(name):
     reduced over the FULL M against the fp64 oracle (ATen fp64 on the GPU).  This is the only place where the persistent kernels
     run in the regime the benchmark times: a wave of k_sp_xres / k_sp_ares / k_sp_tn owns 6 - 49 slabs, a k_ntd workgroup walks
     several tiles with its ring running across them, k_ntl takes its 192-wide tile."""
-    M, K, N, kind = FULL_T0[name]
+    M, K, N, kind, *rank = FULL_T0[name]
     dtype, p = torch.bfloat16, 0.05
     torch.manual_seed(len(name) + K + N)
-    m = _t0_layer(K, N, 64, dtype, p, scale=4.0)
+    m = _t0_layer(K, N, rank[0] if rank else 64, dtype, p, scale=4.0)
     got, ref, keep = _t0_train_case(m, M, dtype, p, kind, dev(), in_scale=0.5)
     assert abs(keep.float().mean().item() - 0.95) < 0.002
     assert_close(got["y"], ref["y"], dtype, f"{name} y")

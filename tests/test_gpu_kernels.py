@@ -1241,6 +1241,34 @@ def test_full_size_linear_rows_vs_oracle():
         assert ((lhs - rhs).abs().max() / rhs.abs().max()).item() < 2e-2
 
 
+@pytest.mark.parametrize("geom", [
+    # (M, K, N, rank, dtype, p): k_pq forced (sel_projk = 3) on shapes off its tile grid
+    (1000, 40, 72, 8, torch.bfloat16, 0.25),      # ragged last k-tile (K = 40: one full + one quarter), R = 8 (16-column stride), ragged M
+    (777, 104, 200, 24, torch.bfloat16, 0.25),    # K = 3.25 k-tiles, R = 24 -> R stride 32: the 64-column tile is half empty
+    (4097, 200, 104, 72, torch.float16, 0.1),     # R = 72 -> 128-column tile 62 % full, one row past a tile boundary, fp16
+    (130, 520, 136, 128, torch.bfloat16, 0.0),    # unmasked (column-split wave grid), K = 16.25 k-tiles (> ring depth), R = 128
+    (130, 520, 136, 128, torch.bfloat16, 0.5),    # the same masked (k-split wave grid)
+    (24000, 96, 96, 64, torch.bfloat16, 0.05),    # > 1.25 residency rounds of 64-row tiles: the 128-row form (4 x 1 wave grid)
+])
+def test_pq_kernel_off_grid_shapes(geom):
+    """k_pq (csrc/pq.h) on shapes that do not line up with its tiles: ragged M, K not a multiple of the 32-wide k-tile (zero-page
+    chunks), rank strides of 16 - 128 (half-empty column tiles, clamped projection rows), more k-tiles than ring stages, both wave grids
+    and both tile heights -- forward, dX and both factor gradients against the fp64 oracle with the specified dropout mask."""
+    from mtlora_amd import functional as Fn
+    M, K, N, r, dtype, p = geom
+    torch.manual_seed(M + K)
+    m = _t0_layer(K, N, r, dtype, p, scale=2.0)
+    prev = Fn.set_tuning(projk=3)
+    try:
+        got, ref, keep = _t0_train_case(m, M, dtype, p, None, torch.device("cpu") if M < 5000 else dev())
+    finally:
+        Fn.set_tuning(**prev)
+    assert_close(got["y"], ref["y"], dtype, "y")
+    assert_close(got["dx"], ref["dx"], dtype, "dx", mult=2)
+    assert_close(got["dA"], ref["dA"], dtype, "dA", mult=3)
+    assert_close(got["dB"], ref["dB"], dtype, "dB", mult=3)
+
+
 _M0, _M1, _M2 = 32 * 112 * 112, 32 * 56 * 56, 32 * 28 * 28
 FULL_T0 = {  # BASELINE configs[1] layers without tasks, full M: name -> (M, K, N, kind)
     "s0.qkv": (_M0, 96, 288, None), "s0.proj": (_M0, 96, 96, None), "s0.fc1": (_M0, 96, 384, "gelu_out"),

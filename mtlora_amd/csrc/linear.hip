@@ -1829,44 +1829,61 @@ static void launch_sp_proj(const Tune& tu, const SpProjParams& q, int ch, int ns
 #undef MTL_SP_PROJ
 }
 
-// ---- k_pq (pq.h): the P / Q passes of single-source launches whose projection rows do not fit in LDS: 64- or 128-row tiles with a deep
-// LDS-DMA ring.  Fills `pq`, returns the row blocks per wave (1: 64-row tiles, 2: 128-row tiles; 0: not eligible).
+// ---- k_pq (pq.h): the P / Q passes whose projection rows do not fit in LDS: 64- or 128-row tiles with a deep LDS-DMA ring, one grid
+// slice (blockIdx.z) per source with its column segment.  Fills `pq`, returns the row blocks per wave (1: 64-row tiles, 2: 128-row
+// tiles; 0: not eligible).
 template <typename T>
 static int pq_plan(const Tune& tu, const SpProjParams& q, PqParams& pq) {
-    if (sizeof(T) != 2 || tu.sp == 0 || tu.projk == 0 || tu.projk == 2 || q.M <= 0 || q.n_src != 1) return 0;
-    const SpSrc& s0 = q.src[0];
-    if (s0.col_lo != 0 || s0.col_hi + 15 < q.Rw) return 0;  // one source that owns every column (padding columns get zeros)
-    if (q.Rw > 128 || q.Rw % 8 != 0 || q.K % 8 != 0 || q.K < 32 || (q.ld_out % 8) != 0) return 0;
-    if ((((uintptr_t)s0.act | (uintptr_t)q.wproj | (uintptr_t)q.out) & 15u) != 0) return 0;
+    if (sizeof(T) != 2 || tu.sp == 0 || tu.projk == 0 || tu.projk == 2 || q.M <= 0 || q.n_src < 1 || q.n_src > MAXO) return 0;
+    if (q.Rw % 8 != 0 || q.K % 8 != 0 || q.K < 32 || (q.ld_out % 8) != 0) return 0;
+    if ((((uintptr_t)q.wproj | (uintptr_t)q.out) & 15u) != 0) return 0;
     if (q.M >= ((int64_t)1 << 31) - 256 || q.M * q.ld_out * 2 >= ((int64_t)1 << 32) - 64) return 0;
-    pq.act = s0.act;
+    int wmax = 0;
+    for (int s = 0; s < q.n_src; ++s) {
+        const SpSrc& ss = q.src[s];
+        if (((uintptr_t)ss.act & 15u) != 0 || ss.col_lo % 8 != 0 || ss.col_hi % 8 != 0 || ss.col_hi <= ss.col_lo || ss.col_hi > q.Rw) return 0;
+        if (ss.col_hi - ss.col_lo > 1024) return 0;  // (<= 8 column tiles per source)
+        pq.src[s].act = ss.act;
+        pq.src[s].col_lo = ss.col_lo;
+        pq.src[s].col_hi = ss.col_hi;
+        pq.src[s].mask = ss.mask;
+        pq.src[s].pad_ = 0;
+        wmax = ss.col_hi - ss.col_lo > wmax ? ss.col_hi - ss.col_lo : wmax;
+    }
+    pq.n_src = q.n_src;
     pq.wproj = q.wproj;
     pq.out = q.out;
     pq.ld_out = q.ld_out;
     pq.M = (int)q.M;
     pq.K = q.K;
     pq.R = q.Rw;
-    pq.mask = s0.mask;
     pq.drop = q.drop;
-    // 64-row tiles while they are about one residency round (a workgroup per CU), 128-row tiles beyond
-    return mtl_ceil_div(q.M, 64) * 4 <= (int64_t)num_cu(tu) * 5 ? 1 : 2;
+    // 64-row tiles while the launch is about one residency round (a workgroup per CU), 128-row tiles beyond
+    const int64_t per_row_tile = (int64_t)q.n_src * mtl_ceil_div(wmax, wmax > 64 ? 128 : 64);
+    return mtl_ceil_div(q.M, 64) * per_row_tile * 4 <= (int64_t)num_cu(tu) * 5 ? 1 : 2;
 }
 static bool pq_one_round(const Tune& tu, const PqParams& pq, int mb) {
-    return mtl_ceil_div(pq.M, 64 * mb) * 4 <= (int64_t)num_cu(tu) * 5;
+    return pq.n_src == 1 && mtl_ceil_div(pq.M, 64 * mb) * 4 <= (int64_t)num_cu(tu) * 5;
 }
 template <typename T>
 static void launch_pq(const PqParams& pq, int mb, hipStream_t s, int kind, double alg_bytes, double s8d, double flops) {
-    mtl_prof_tag("pq M%d K%d R%d mb%d mask%d", pq.M, pq.K, pq.R, mb, pq.mask);
+    int wmax = 0, any_mask = 0;
+    for (int i = 0; i < pq.n_src; ++i) {
+        wmax = pq.src[i].col_hi - pq.src[i].col_lo > wmax ? pq.src[i].col_hi - pq.src[i].col_lo : wmax;
+        any_mask |= pq.src[i].mask;
+    }
+    mtl_prof_tag("pq M%d K%d R%d src%d w%d mb%d mask%d", pq.M, pq.K, pq.R, pq.n_src, wmax, mb, any_mask);
     MtlProfScope prof(kind, alg_bytes, s, s8d, flops);
-    const unsigned grid = (unsigned)mtl_ceil_div(pq.M, 64 * mb);
+    const bool wide = wmax > 64;
+    const dim3 grid((unsigned)mtl_ceil_div(pq.M, 64 * mb), (unsigned)mtl_ceil_div(wmax, wide ? 128 : 64), (unsigned)pq.n_src);
 #define MTL_PQ(WMV, NBV, NSTV, KSV)                                                                               \
     do {                                                                                                          \
         constexpr size_t lds = (size_t)NSTV * (32 * WMV + 32 * NBV) * 64;                                         \
         MTL_RAISE_LDS((k_pq<T, WMV, NBV, NSTV, KSV>), SP_LDS_MAX);                                                \
-        hipLaunchKernelGGL((k_pq<T, WMV, NBV, NSTV, KSV>), dim3(grid), dim3(256), lds, s, pq);                    \
+        hipLaunchKernelGGL((k_pq<T, WMV, NBV, NSTV, KSV>), grid, dim3(256), lds, s, pq);                          \
     } while (0)
     if constexpr (sizeof(T) == 2) {
-        const bool wide = pq.R > 64, ksp = pq.mask != 0 && pq.drop.enabled();  // (masked: every activation fragment hashed by one wave)
+        const bool ksp = any_mask != 0 && pq.drop.enabled();  // (masked: every activation fragment hashed by one wave)
         if (mb == 1 && wide && ksp) MTL_PQ(2, 4, 6, true);   // 64 x 128: 12 KB stages, 60 KB in flight
         else if (mb == 1 && wide) MTL_PQ(2, 4, 6, false);
         else if (mb == 1 && ksp) MTL_PQ(2, 2, 8, true);      // 64 x 64:   8 KB stages, 56 KB in flight

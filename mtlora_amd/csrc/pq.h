@@ -13,13 +13,18 @@
 // (layers without task inputs; the Q pass of layers without task outputs).
 #pragma once
 
+struct PqSrc {
+    const void* act;     // (M x K) contiguous rows
+    int col_lo, col_hi;  // columns of Out (= rows of wproj) this source owns (multiples of 8)
+    int mask, pad_;      // mask: dropout keep-mask on the activation (keyed by (m, k))
+};
 struct PqParams {
-    const void* act;    // (M x K) contiguous rows
     const void* wproj;  // (R x K) alpha-scaled projection rows
     void* out;          // (M x ld_out)
     int64_t ld_out;
-    int M, K, R, mask;  // mask: dropout keep-mask on the activation (keyed by (m, k))
+    int M, K, R, n_src;
     DropoutCfg drop;
+    PqSrc src[MAXO];    // blockIdx.z = source (P: x and the tasks' own inputs; Q: the outputs' gradients)
 };
 
 template <int N>
@@ -55,12 +60,15 @@ __global__ __launch_bounds__(256) void k_pq(const PqParams P) {
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave % WM, wk = KSPLIT ? wave / WM : 0, wn = SPLITN ? wave / WM : 0, h = lane >> 5, rl = lane & 31;
     const int M = P.M, K = P.K, R = P.R;
-    const int m0 = (int)blockIdx.x * TM;
+    const PqSrc& S = P.src[blockIdx.z];
+    const int c_hi = S.col_hi;
+    const int m0 = (int)blockIdx.x * TM, n0 = S.col_lo + (int)blockIdx.y * TN;  // (blockIdx.y: column tile of a segment wider than TN)
+    if (n0 >= c_hi) return;  // (uniform: the whole workgroup leaves before any barrier)
     const unsigned char* const wgt = reinterpret_cast<const unsigned char*>(P.wproj);
-    const unsigned char* const act = reinterpret_cast<const unsigned char*>(P.act);
+    const unsigned char* const act = reinterpret_cast<const unsigned char*>(S.act);
     DropoutCfg drop = P.drop;
     mtl_dropout_resolve(drop);
-    const bool masked = P.mask != 0 && drop.thr16 != 0;
+    const bool masked = S.mask != 0 && drop.thr16 != 0;
     const int total = (K + KE - 1) / KE;
 
     // loader: wave w issues the DMA instructions j = w + 4 t (t < DPW) of a stage; instruction j covers stage rows 16 j .. 16 j + 15
@@ -74,7 +82,7 @@ __global__ __launch_bounds__(256) void k_pq(const PqParams P) {
         q8[t] = (p ^ ((row >> 2) & 3)) * 8;  // logical k offset (elements) of this lane's 16 bytes
         isw[t] = 16 * j < TN;
         if (isw[t]) {
-            const int wr = row < R ? row : R - 1;
+            const int wr = n0 + row < R ? n0 + row : R - 1;
             src[t] = (int64_t)wr * K + q8[t];
         } else {
             const int ar = m0 + row - TN;
@@ -172,8 +180,8 @@ __global__ __launch_bounds__(256) void k_pq(const PqParams P) {
 #pragma unroll
     for (int it = 0; it < CPR / 2; ++it) {
         const int idx = it * 64 + lane, ml = idx / CPR, c16 = idx - ml * CPR;
-        const int m = m0 + wm * 32 + ml, n = wn * (NBW * 32) + c16 * 8;
+        const int m = m0 + wm * 32 + ml, n = n0 + wn * (NBW * 32) + c16 * 8;
         const u32x4 v = *reinterpret_cast<const u32x4*>(img + ml * ORS + c16 * 16);
-        sp_bstore(v, orsrc, (m < M && n < R) ? (uint32_t)m * ldo2 + (uint32_t)n * 2u : 0xFFFFFFFFu);
+        sp_bstore(v, orsrc, (m < M && n < c_hi) ? (uint32_t)m * ldo2 + (uint32_t)n * 2u : 0xFFFFFFFFu);
     }
 }

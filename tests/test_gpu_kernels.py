@@ -1249,6 +1249,8 @@ def test_full_size_linear_rows_vs_oracle():
     (130, 520, 136, 128, torch.bfloat16, 0.0),    # unmasked (column-split wave grid), K = 16.25 k-tiles (> ring depth), R = 128
     (130, 520, 136, 128, torch.bfloat16, 0.5),    # the same masked (k-split wave grid)
     (24000, 96, 96, 64, torch.bfloat16, 0.05),    # > 1.25 residency rounds of 64-row tiles: the 128-row form (4 x 1 wave grid)
+    (700, 384, 200, 256, torch.bfloat16, 0.1),    # rank stride 256: two 128-column tiles (blockIdx.y)
+    (300, 136, 72, 328, torch.float16, 0.0),      # rank stride 336: three column tiles, the last one 62 % full
 ])
 def test_pq_kernel_off_grid_shapes(geom):
     """k_pq (csrc/pq.h) on shapes that do not line up with its tiles: ragged M, K not a multiple of the 32-wide k-tile (zero-page

@@ -10,6 +10,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--config", default="c2")
 ap.add_argument("--batch", type=int, default=2)
 ap.add_argument("--top", type=int, default=60)
+ap.add_argument("--views", action="store_true", help="list the view-type ops instead (each one is an autograd node when its input requires grad)")
 a = ap.parse_args()
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 VIEWS = ("view", "reshape", "permute", "transpose", "t.default", "expand", "slice", "select", "unsqueeze", "squeeze", "detach", "alias",
@@ -23,7 +24,8 @@ class Sites(TorchDispatchMode):
 
     def __torch_dispatch__(self, func, types, args=(), kwargs=None):
         name = str(func)
-        if not any(v in name for v in VIEWS):
+        isview = any(v in name for v in VIEWS) and not any(v in name for v in ("empty", "_local_scalar", "is_", "size", "stride", "record_stream", "detach"))
+        if (isview if a.views else not any(v in name for v in VIEWS)):
             site = "?"
             for fr in reversed(traceback.extract_stack(limit=40)):
                 if fr.filename.startswith(REPO) and "tools/" not in fr.filename:
@@ -46,6 +48,6 @@ torch.cuda.synchronize()
 with Sites() as m:
     step()
 torch.cuda.synchronize()
-print(f"{sum(m.n.values())} non-view ATen ops in one step ({a.config}, B = {a.batch})")
+print(f"{sum(m.n.values())} {'view-type' if a.views else 'non-view'} ATen ops in one step ({a.config}, B = {a.batch})")
 for (op, site), k in m.n.most_common(a.top):
     print(f"  {k:4d}  {op:34s} {site}")

@@ -198,7 +198,15 @@ def ptr(t) -> c_void_p:
     return c_void_p(0 if t is None else t.data_ptr())
 
 
+_NO_PTRS = None
+
+
 def ptr_array(ts) -> "PtrArr":
+    global _NO_PTRS
+    if not ts:  # (the T = 0 layers pass four empty lists per call: one shared all-null array, never written)
+        if _NO_PTRS is None:
+            _NO_PTRS = PtrArr()
+        return _NO_PTRS
     a = PtrArr()
     for i in range(MAX_TASKS):
         a[i] = 0 if (ts is None or i >= len(ts) or ts[i] is None) else ts[i].data_ptr()

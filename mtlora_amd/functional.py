@@ -266,6 +266,14 @@ def _as2d(t: torch.Tensor, cols: int, dtype: torch.dtype) -> torch.Tensor:
     return t.reshape(-1, cols).to(dtype).contiguous()
 
 
+def _flat(t: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    """t itself when it is already contiguous in ``dtype`` (the kernels take a pointer and a row count: no 2-D view object is needed --
+    each ``.view`` costs ~1.5 us of dispatch, 10 of them per MTLoRALinear call), else a contiguous copy in ``dtype``"""
+    if t.dtype == dtype and t.is_contiguous():
+        return t
+    return t.to(dtype).contiguous()
+
+
 def _f32c(p):
     """fp32 contiguous view of a factor (Parameters already are: used as they come, autograd is off inside Function.forward)."""
     if p is None or (p.dtype == torch.float32 and p.is_contiguous()):
@@ -340,9 +348,11 @@ class MTLoRALinearFn(torch.autograd.Function):
         x_t, A_t, B_t = list(rest[:nx]), list(rest[nx:nx + T]), list(rest[nx + T:nx + 2 * T])
         L.require_gpu(x, W_c, *x_t)
         lead = x.shape[:-1]
-        x2 = _as2d(x, meta.K, meta.dtype)
-        xt2 = [_as2d(t, meta.K, meta.dtype) for t in x_t]
-        M = x2.shape[0]
+        x2 = _flat(x, meta.dtype)              # (M x K) row-major whatever the leading shape
+        xt2 = [_flat(t, meta.dtype) for t in x_t]
+        M = x2.numel() // meta.K
+        if x2.shape[-1] != meta.K or any(t.shape != x2.shape for t in xt2):
+            raise RuntimeError(f"mtlora_amd: MTLoRALinear input of shape {tuple(x.shape)} for in_features = {meta.K}")
         d = meta.desc(M)
         lib = L.lib()
         ctx_bytes = _desc_bytes("ctx", lib.mtlora_linear_ctx_bytes, meta, M, d)
@@ -350,13 +360,14 @@ class MTLoRALinearFn(torch.autograd.Function):
             raise RuntimeError(f"mtlora_amd: invalid MTLoRALinear shape M={M} K={meta.K} N={meta.N} (K, N must be "
                                "multiples of 8)")
         ctxbuf = torch.empty(ctx_bytes, dtype=torch.uint8, device=x.device)
-        ys = torch.empty((M, meta.N), dtype=meta.dtype, device=x.device)
-        yt = [torch.empty((M, meta.N), dtype=meta.dtype, device=x.device) for _ in range(T)]
+        oshape = (*lead, meta.N)
+        ys = torch.empty(oshape, dtype=meta.dtype, device=x.device)
+        yt = [torch.empty(oshape, dtype=meta.dtype, device=x.device) for _ in range(T)]
         A_s_c, B_s_c = _f32c(A_s), _f32c(B_s)
         A_t_c, B_t_c = [_f32c(a) for a in A_t], [_f32c(b) for b in B_t]
         acts = []
         if meta.gelu_out:  # second outputs gelu(y) written by the same epilogue (mtlora_linear_fwd_gelu)
-            acts = [torch.empty((M, meta.N), dtype=meta.dtype, device=x.device) for _ in range(1 + T)]
+            acts = [torch.empty(oshape, dtype=meta.dtype, device=x.device) for _ in range(1 + T)]
             st = lib.mtlora_linear_fwd_gelu(ctypes.byref(d), L.ptr(x2), L.ptr_array(xt2), L.ptr(W_c), L.ptr(bias_f32),
                                             L.ptr(A_s_c), L.ptr(B_s_c), L.ptr_array(A_t_c), L.ptr_array(B_t_c), L.ptr(ys),
                                             L.ptr_array(yt), L.ptr(acts[0]), L.ptr_array(acts[1:]), L.ptr(ctxbuf), ctx_bytes,
@@ -371,16 +382,17 @@ class MTLoRALinearFn(torch.autograd.Function):
         ctx.in_dtypes = [x.dtype] + [t.dtype for t in x_t]
         gates = []
         if meta.n_gate:
-            gates = [g.reshape(-1, meta.K) for g in rest[len(rest) - meta.n_gate:]]
-            if len(gates) != 1 + nx or any(g.dtype != meta.dtype or not g.is_contiguous() or g.shape != x2.shape for g in gates):
+            gates = list(rest[len(rest) - meta.n_gate:])
+            if len(gates) != 1 + nx or any(g.dtype != meta.dtype or not g.is_contiguous() or g.numel() != x2.numel() or g.shape[-1] != meta.K
+                                           for g in gates):
                 raise RuntimeError("mtlora_amd: gelu gates must be contiguous pre-activations of x / x_t in the compute dtype")
         ctx.save_for_backward(x2, Wt_c, ctxbuf, *xt2, *gates)
         ctx.keep = (A_s_c, B_s_c, A_t_c, B_t_c)  # fp32 factor views (also used for the trainable-scale gradients)
         # (meta.packed keeps the packed-factor buffer alive until backward; a trainer overwrites it only after the step's backward)
         ctx.factor_params = (A_s, B_s, *A_t, *B_t)  # the Parameters themselves: backward looks at their .grad (side stream)
         ctx.has_scale_s = scale_s_param is not None
-        outs = [ys.reshape(*lead, meta.N)] + [y.reshape(*lead, meta.N) for y in yt] + [a.reshape(*lead, meta.N) for a in acts]
-        return tuple(outs)
+        ctx.M = M
+        return (ys, *yt, *acts)
 
     @staticmethod
     def backward(ctx, *grads):
@@ -397,17 +409,18 @@ class MTLoRALinearFn(torch.autograd.Function):
         gates = []
         if meta.n_gate:
             xt2, gates = xt2[:nx], xt2[nx:]
-        M = x2.shape[0]
+        M = ctx.M
         dev = x2.device
-        g2 = [None if g is None else _as2d(g, meta.N, meta.dtype) for g in grads]
+        g2 = [None if g is None else _flat(g, meta.dtype) for g in grads]
         dy_s, dy_t = g2[0], g2[1:1 + T]
         d = meta.desc(M)
         lib = L.lib()
         scratch_bytes = _desc_bytes("bwd", lib.mtlora_linear_bwd_scratch_bytes, meta, M, d)
         scratch = torch.empty(scratch_bytes, dtype=torch.uint8, device=dev)
         need = ctx.needs_input_grad  # (meta, x, W_c, Wt_c, bias_f32, W_master, bias_master, A_s, B_s, scale_s, *rest)
-        dx = torch.empty((M, meta.K), dtype=meta.dtype, device=dev)
-        dxt = [torch.empty((M, meta.K), dtype=meta.dtype, device=dev) for _ in range(nx)]
+        ishape = (*ctx.lead, meta.K)
+        dx = torch.empty(ishape, dtype=meta.dtype, device=dev)
+        dxt = [torch.empty(ishape, dtype=meta.dtype, device=dev) for _ in range(nx)]
         has_s = meta.r_s > 0 and (dy_s is not None or (meta.mode == 1 and any(g is not None for g in dy_t)))
         dA_s = torch.empty((meta.r_s, meta.K), dtype=torch.float32, device=dev) if has_s else None
         dB_s = torch.empty((meta.N, meta.r_s), dtype=torch.float32, device=dev) if has_s else None
@@ -471,14 +484,14 @@ class MTLoRALinearFn(torch.autograd.Function):
             G = None
             for g in g2:
                 if g is not None:
-                    G = g.float() if G is None else G + g.float()
+                    G = g.reshape(M, meta.N).float() if G is None else G + g.reshape(M, meta.N).float()
             if G is not None:
                 if need[5]:
-                    dW = G.t() @ x2.float()
+                    dW = G.t() @ x2.reshape(M, meta.K).float()
                 if need[6]:
                     dbias = G.sum(0)
-        dxo = dx.reshape(*ctx.lead, meta.K).to(ctx.in_dtypes[0])
-        dxto = [dxt[t].reshape(*ctx.lead, meta.K).to(ctx.in_dtypes[1 + t]) for t in range(nx)]
+        dxo = dx if ctx.in_dtypes[0] == meta.dtype else dx.to(ctx.in_dtypes[0])
+        dxto = [dxt[t] if ctx.in_dtypes[1 + t] == meta.dtype else dxt[t].to(ctx.in_dtypes[1 + t]) for t in range(nx)]
         _, B_s_c, _, B_t_c = ctx.keep
         d_ss = None
         if ctx.has_scale_s and dB_s is not None and meta.scale_s != 0.0:

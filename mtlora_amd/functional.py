@@ -1292,7 +1292,7 @@ class PlainLinearFn(torch.autograd.Function):
                           dtype=cdtype)
         d = meta.desc(M)
         lib = L.lib()
-        ctx_bytes = lib.mtlora_linear_ctx_bytes(ctypes.byref(d))
+        ctx_bytes = _desc_bytes("ctx", lib.mtlora_linear_ctx_bytes, meta, M, d)
         if ctx_bytes < 0:
             raise RuntimeError(f"mtlora_amd: invalid plain-linear shape M={M} K={K} N={N}")
         ctxbuf = torch.empty(max(ctx_bytes, 16), dtype=torch.uint8, device=x.device)
@@ -1319,7 +1319,7 @@ class PlainLinearFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             d = ctx.meta.desc(M)
             lib = L.lib()
-            sb = lib.mtlora_linear_bwd_scratch_bytes(ctypes.byref(d))
+            sb = _desc_bytes("bwd", lib.mtlora_linear_bwd_scratch_bytes, ctx.meta, M, d)
             scratch = torch.empty(max(sb, 16), dtype=torch.uint8, device=x.device)
             wt = w.t().contiguous()
             dx = torch.empty((M, K), dtype=x.dtype, device=x.device)

@@ -1241,6 +1241,51 @@ def test_full_size_linear_rows_vs_oracle():
         assert ((lhs - rhs).abs().max() / rhs.abs().max()).item() < 2e-2
 
 
+def test_linear_accepts_strided_and_wider_inputs():
+    """MTLoRALinear takes what nn.Linear takes: a NON-contiguous input (a transposed view), a 4-D input, an fp32 input under bf16
+    autocast (cast inside) and a 1-D input; outputs keep the leading shape, gradients come back in the input's dtype and shape
+    (the Function passes tensors to the kernels as they come and only copies what is not contiguous in the compute dtype)."""
+    from mtlora_amd.lora import MTLoRALinear
+    torch.manual_seed(5)
+    tasks = ["a", "b"]
+    m = MTLoRALinear(64, 96, r={"shared": 16, "a": 8, "b": 8}, lora_shared_scale=2.0, lora_task_scale={"a": 1.5, "b": 0.5}, tasks=tasks).to(dev())
+    with torch.no_grad():
+        for n_, q in m.named_parameters():
+            q.copy_(torch.randn_like(q) * (0.1 if "lora" in n_ else 0.05))
+    m.eval()
+    P = {k: v.detach().double() for k, v in m.named_parameters()}
+
+    def ref(x64):
+        y, yt = O.mtlora_linear(x64, P["linear.weight"], P["linear.bias"], P["lora_shared_A"], P["lora_shared_B"], m.lora_shared_scale,
+                                tasks=tasks, A_t={t: P["lora_tasks_A." + t] for t in tasks}, B_t={t: P["lora_tasks_B." + t] for t in tasks},
+                                scale_t=m.lora_task_scale)
+        return y, yt
+
+    base = torch.randn(3, 64, 10, device=dev())                       # (B, K, L)
+    for name, x in (("transposed view", base.transpose(1, 2)),         # (B, L, K), stride (640, 1, 10)
+                    ("4-D", torch.randn(2, 3, 5, 64, device=dev())),
+                    ("1-D", torch.randn(64, device=dev()))):
+        x = x.detach().requires_grad_(True)
+        y, yt = m(x)
+        assert y.shape == (*x.shape[:-1], 96) and all(yt[t].shape == y.shape for t in tasks), name
+        (y.sum() + 2.0 * yt["a"].sum() - yt["b"].sum()).backward()
+        xo = x.detach().double().requires_grad_(True)
+        yo, yto = ref(xo)
+        (yo.sum() + 2.0 * yto["a"].sum() - yto["b"].sum()).backward()
+        assert_close(y, yo.detach(), torch.float32, f"{name} y")
+        assert_close(yt["b"], yto["b"].detach(), torch.float32, f"{name} y_b")
+        assert x.grad.shape == x.shape and x.grad.dtype == x.dtype, name
+        assert_close(x.grad, xo.grad, torch.float32, f"{name} dx")
+    x = torch.randn(4, 7, 64, device=dev(), requires_grad=True)       # fp32 in, bf16 compute
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y, yt = m(x)
+    assert y.dtype == torch.bfloat16 and y.shape == (4, 7, 96)
+    y.float().sum().backward()
+    assert x.grad.dtype == torch.float32 and x.grad.shape == x.shape
+    yo, _ = ref(x.detach().double())
+    assert_close(y, yo, torch.bfloat16, "autocast y")
+
+
 @pytest.mark.parametrize("geom", [
     # (M, K, N, rank, dtype, p): k_pq forced (sel_projk = 3) on shapes off its tile grid
     (1000, 40, 72, 8, torch.bfloat16, 0.25),      # ragged last k-tile (K = 40: one full + one quarter), R = 8 (16-column stride), ragged M

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MTLORA_ABI_VERSION 6
+#define MTLORA_ABI_VERSION 7
 #define MTLORA_MAX_TASKS 8
 
 typedef enum mtlora_dtype {
@@ -378,6 +378,76 @@ int mtlora_upsample_cl_fwd(const void* coarse, void* fine, int64_t B, int h, int
                            int dtype, void* stream);
 int mtlora_upsample_cl_bwd(const void* grad_fine, void* grad_coarse, int64_t B, int h, int w, int C, int scale,
                            int64_t ld_fine, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * One whole SwinTransformerBlock WITHOUT task outputs, forward and backward, as ONE call each (ABI v7) -- replaces the
+ * tasks-free path of SwinTransformerBlock.forward, models/swin_transformer_mtlora.py:326-408 (norm1 :331, shift / partition
+ * :336-350, WindowAttention :353 = :186-227, merge / reverse shift :365-377, residual + DropPath :389, norm2 + Mlp :395-396
+ * = :68-81, residual :398) with the four MTLoRALinear layers of lora.py:253-284 inside.  Nothing new is computed: the call
+ * issues the launches of the entry points above in the block's order (LayerNorm -> qkv -> window attention -> proj ->
+ * residual + DropPath + norm2 -> fc1 (+ GELU) -> fc2 -> residual + DropPath + the NEXT block's norm1), so its results are bit
+ * identical to calling them one by one; what it removes is the caller's per-launch work (one host crossing and one autograd
+ * node per block and direction instead of ~10: the train step of the reference's Swin-B config was bound by exactly that).
+ * Every stage of a Swin backbone is `depth - 1` such blocks followed by one task-enabled block (:523-531), so a block of
+ * this kind always hands over to another block: x_out AND normed_out = LayerNorm_next(x_out) are produced together.
+ *
+ * Tensors (M = B*H*W rows, token order (B, H*W) as everywhere in this library):
+ *   x (M,C) x_dtype: the residual stream entering the block;  normed (M,C) dtype: norm1(x) when has_norm1 == 0 (it came out of
+ *   the previous block's call), ignored otherwise;  x_out (M,C) x_dtype, normed_out (M,C) dtype.
+ *   save: ONE caller-owned buffer of mtlora_block_save_bytes() that fwd fills and bwd reads (normalised tensors, qkv, attention
+ *   output, the linears' ctx = P, the mid-block residual stream, fc1's pre-activation and activation, LayerNorm statistics);
+ *   tmp: scratch of mtlora_block_fwd_tmp_bytes(), dead when fwd returns (stream-ordered).
+ * bwd: g_x_out (M,C) x_dtype and g_normed_out (M,C) dtype are the gradients of the two outputs (g_x_out may be NULL);
+ *   it writes g_x (x_dtype) and, when has_norm1 == 0, g_normed (dtype), the LayerNorm gradients, the eight factor gradients
+ *   (fp32, shapes of the masters) and dbias (num_heads, N, N) fp32.  phase as mtlora_linear_desc.bwd_phase: 0 everything on
+ *   `stream`; 1 everything but the factor gradients; 2 the factor gradients only (same arguments, a second stream ordered
+ *   behind phase 1).  scratch: mtlora_block_bwd_scratch_bytes(), must stay valid until phase 2 has run.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct mtlora_block_desc {
+    int64_t B;
+    int32_t H, W, C, hidden;   /* token map, channels, Mlp hidden width */
+    int32_t num_heads, window_size, shift;
+    int32_t dtype;             /* compute dtype: the linears, the normalised tensors, attention */
+    int32_t x_dtype;           /* dtype of the residual stream (fp32 under autocast) */
+    int32_t has_norm1;         /* 1: the call applies norm1 itself (first block of a stage); 0: `normed` is an input */
+    float eps1, eps2, eps_next;
+    float attn_scale, mask_value;
+    mtlora_linear_desc lin[4]; /* qkv (C -> 3C), proj (C -> C), fc1 (C -> hidden, + GELU), fc2 (hidden -> C); T = 0, M = B*H*W;
+                                  seed / dropout_p / packed / sel_* as for a stand-alone call (bwd_phase is set by the block call) */
+} mtlora_block_desc;
+
+typedef struct mtlora_block_params {   /* device pointers, caller-owned; fp32 unless noted */
+    const float *norm1_g, *norm1_b;    /* has_norm1 only */
+    const float *norm2_g, *norm2_b, *next_g, *next_b;
+    const void* W[4];                  /* (N,K) dtype */
+    const void* Wt[4];                 /* (K,N) dtype (bwd) */
+    const float* bias[4];              /* (N) or NULL */
+    const float* A[4];                 /* (r,K) masters */
+    const float* Bf[4];                /* (N,r) masters */
+    const float* attn_bias;            /* dense (num_heads, N, N) */
+    const int32_t* mask_ids;           /* (nW, N) region ids of SW-MSA or NULL */
+    const float* mask;                 /* general dense mask or NULL (ignored when mask_ids is given) */
+    const float *scale1, *scale2;      /* DropPath mask / keep of the two residuals, (B) each, or NULL (= 1) */
+} mtlora_block_params;
+
+typedef struct mtlora_block_grads {    /* outputs of bwd, fp32 unless noted, all overwritten */
+    void* g_x;                         /* (M,C) x_dtype */
+    void* g_normed;                    /* (M,C) dtype; has_norm1 == 0 only */
+    float *d_norm1_g, *d_norm1_b;      /* has_norm1 only */
+    float *d_norm2_g, *d_norm2_b, *d_next_g, *d_next_b;
+    float* dA[4];
+    float* dB[4];
+    float* dbias;                      /* (num_heads, N, N) */
+} mtlora_block_grads;
+
+int64_t mtlora_block_save_bytes(const mtlora_block_desc* d);
+int64_t mtlora_block_fwd_tmp_bytes(const mtlora_block_desc* d);
+int64_t mtlora_block_bwd_scratch_bytes(const mtlora_block_desc* d);
+int mtlora_block_fwd(const mtlora_block_desc* d, const mtlora_block_params* p, const void* x, const void* normed, void* x_out,
+                     void* normed_out, void* save, int64_t save_bytes, void* tmp, int64_t tmp_bytes, void* stream);
+int mtlora_block_bwd(const mtlora_block_desc* d, const mtlora_block_params* p, const void* x, const void* normed,
+                     const void* x_out, const void* g_x_out, const void* g_normed_out, const void* save, int64_t save_bytes,
+                     const mtlora_block_grads* g, void* scratch, int64_t scratch_bytes, int phase, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Hardware self-test: writes the lane->element maps of the MFMA / LDS-transpose primitives the

@@ -12,7 +12,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int6
 import torch
 
 MAX_TASKS = 8
-ABI_VERSION = 6
+ABI_VERSION = 7
 F32, BF16, F16 = 0, 1, 2
 _DT = {torch.float32: F32, torch.bfloat16: BF16, torch.float16: F16}
 
@@ -34,6 +34,27 @@ class AttnDesc(Structure):
     _fields_ = [("B", c_int64), ("H", c_int32), ("W", c_int32), ("window_size", c_int32), ("shift", c_int32),
                 ("num_heads", c_int32), ("head_dim", c_int32), ("image_layout", c_int32), ("dtype", c_int32),
                 ("scale", c_float), ("mask_value", c_float)]
+
+
+class BlockDesc(Structure):
+    """mtlora_block_desc (ABI v7): one SwinTransformerBlock without task outputs"""
+    _fields_ = [("B", c_int64), ("H", c_int32), ("W", c_int32), ("C", c_int32), ("hidden", c_int32), ("num_heads", c_int32),
+                ("window_size", c_int32), ("shift", c_int32), ("dtype", c_int32), ("x_dtype", c_int32), ("has_norm1", c_int32),
+                ("eps1", c_float), ("eps2", c_float), ("eps_next", c_float), ("attn_scale", c_float), ("mask_value", c_float),
+                ("lin", LinearDesc * 4)]
+
+
+class BlockParams(Structure):
+    _fields_ = [("norm1_g", c_void_p), ("norm1_b", c_void_p), ("norm2_g", c_void_p), ("norm2_b", c_void_p), ("next_g", c_void_p),
+                ("next_b", c_void_p), ("W", c_void_p * 4), ("Wt", c_void_p * 4), ("bias", c_void_p * 4), ("A", c_void_p * 4),
+                ("Bf", c_void_p * 4), ("attn_bias", c_void_p), ("mask_ids", c_void_p), ("mask", c_void_p), ("scale1", c_void_p),
+                ("scale2", c_void_p)]
+
+
+class BlockGrads(Structure):
+    _fields_ = [("g_x", c_void_p), ("g_normed", c_void_p), ("d_norm1_g", c_void_p), ("d_norm1_b", c_void_p), ("d_norm2_g", c_void_p),
+                ("d_norm2_b", c_void_p), ("d_next_g", c_void_p), ("d_next_b", c_void_p), ("dA", c_void_p * 4), ("dB", c_void_p * 4),
+                ("dbias", c_void_p)]
 
 
 PROF_KINDS = 24
@@ -133,6 +154,13 @@ _SIGS = {
                                      c_int, c_int, ctypes.c_float, c_void_p]),
     "mtlora_upsample_cl_fwd": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int64, c_int, c_void_p]),
     "mtlora_upsample_cl_bwd": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int64, c_int, c_void_p]),
+    "mtlora_block_save_bytes": (c_int64, [POINTER(BlockDesc)]),
+    "mtlora_block_fwd_tmp_bytes": (c_int64, [POINTER(BlockDesc)]),
+    "mtlora_block_bwd_scratch_bytes": (c_int64, [POINTER(BlockDesc)]),
+    "mtlora_block_fwd": (c_int, [POINTER(BlockDesc), POINTER(BlockParams), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
+                                 c_void_p, c_int64, c_void_p]),
+    "mtlora_block_bwd": (c_int, [POINTER(BlockDesc), POINTER(BlockParams), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                 c_int64, POINTER(BlockGrads), c_void_p, c_int64, c_int, c_void_p]),
     "mtlora_selftest_layouts": (c_int, [c_void_p, c_void_p]),
     "mtlora_prof_begin": (c_int, [c_int]),
     "mtlora_prof_end": (c_int, [POINTER(ProfSummary)]),

@@ -7,7 +7,6 @@ from __future__ import annotations
 
 import ctypes
 import os
-import weakref
 from dataclasses import dataclass, field
 from typing import List, Optional, Sequence, Tuple
 
@@ -47,14 +46,21 @@ _factor_stream: Optional["torch.cuda.Stream"] = None
 _FACTOR_MIN_M = int(os.environ.get("MTLORA_FACTOR_MIN_M", "8192"))
 
 
-# factor parameters whose gradient was written on the side stream by an earlier backward call -> that stream.  A later use of the
-# same layer (twice in one graph, or a second backward accumulating into the .grad before the caller joined the side stream) makes
-# its own stream WAIT for the side stream before anything touches the gradient; afterwards the side stream may be used again.
-# Weak keys: a freed Parameter leaves no entry behind (raw ids can be reused by other objects).  A caller that joins the side stream
-# (train_step, GradReducer) says so with ``factor_stream_joined()``; one that installs the stream once and never says anything still
-# gets correct results and keeps the side stream (the former id set was only cleared on install, which silently
-# disabled the side stream from the second backward on).
-_side_pending: "weakref.WeakKeyDictionary" = weakref.WeakKeyDictionary()
+# factor parameters whose gradient was written on the side stream by an earlier backward call -> (that stream, the autograd graph
+# task it happened in).  A later use of the same layer makes its own stream WAIT for the side stream before anything touches the
+# gradient; whether the side stream may be used again depends on WHEN the entry was written:
+#   * in the CURRENT backward pass (the layer is applied twice in one graph): the autograd engine sums the two gradients of a factor
+#     on the stream of the forward call, so the second gradient stays on that stream;
+#   * in an EARLIER pass that nobody joined: once waited for, the side stream is free again (unless the factor's .grad exists, in
+#     which case autograd accumulates into it on this stream -- ``use_side`` checks that separately).
+# Keys are compared by IDENTITY (a WeakKeyDictionary compares its referents with ``==``, which is element-wise for
+# tensors -- looking up a present key raised "Boolean value of Tensor ... is ambiguous"); weak, so a freed Parameter leaves no
+# entry behind (raw ids can be reused by other objects).  A caller that joins the side stream AFTER the backward pass (train_step,
+# GraphedTrainStep) says so with ``factor_stream_joined()``; the GradReducer's mid-pass waits do not (the same-pass rule above
+# must keep holding for the rest of the pass).
+from torch.utils.weak import WeakIdKeyDictionary  # noqa: E402
+
+_side_pending: "WeakIdKeyDictionary" = WeakIdKeyDictionary()
 
 
 def factor_stream_joined() -> None:
@@ -63,10 +69,41 @@ def factor_stream_joined() -> None:
 
 
 def set_factor_stream(stream: Optional["torch.cuda.Stream"]) -> None:
-    """install (or, with None, remove) the side stream for the factor gradients (see above)"""
+    """install (or, with None, remove) the side stream for the factor gradients (see above).  Entries of ``_side_pending`` stay:
+    whoever installs / removes the stream has not necessarily joined the previous one (``factor_stream_joined`` says that)."""
     global _factor_stream
     _factor_stream = stream
-    _side_pending.clear()  # (a caller (re)installs the stream at a point where it has joined the previous one)
+
+
+def _graph_task_id() -> int:
+    return torch._C._current_graph_task_id()
+
+
+def _side_join_pending(params, dev) -> bool:
+    """make the current stream wait for every side stream that still holds a gradient of ``params`` (the layer's factor
+    Parameters) from an earlier backward call.  Returns True when one of those entries was written in the CURRENT backward pass
+    (same layer twice in one graph): this call's factor gradients must then stay on the current stream."""
+    if not _side_pending:
+        return False
+    same_pass, streams, task = False, {}, _graph_task_id()
+    for p in params:
+        if p is None:
+            continue
+        ent = _side_pending.pop(p, None)
+        if ent is not None:
+            streams[id(ent[0])] = ent[0]
+            same_pass = same_pass or ent[1] == task
+    cur = torch.cuda.current_stream(dev) if streams else None
+    for st in streams.values():
+        cur.wait_stream(st)
+    return same_pass
+
+
+def _side_mark_pending(params, side) -> None:
+    task = _graph_task_id()
+    for p in params:
+        if p is not None:
+            _side_pending[p] = (side, task)
 
 
 def factor_stream() -> Optional["torch.cuda.Stream"]:
@@ -306,7 +343,7 @@ class PackTable:
         eb = lib.mtlora_linear_pack_entry_bytes()
         host = (ctypes.c_ubyte * (eb * max(len(entries), 1)))()
         self.keep = entries  # (keeps every tensor whose address is in the table alive)
-        for i, (meta, A_s, B_s, A_t, B_t, packed) in enumerate(entries):
+        for i, (meta, A_s, B_s, A_t, B_t, packed, *_owner) in enumerate(entries):
             d = meta.desc(1)
             d.packed = 0
             st = lib.mtlora_linear_pack_entry(ctypes.byref(d), L.ptr(A_s), L.ptr(B_s), L.ptr_array(A_t), L.ptr_array(B_t), L.ptr(packed),
@@ -453,14 +490,8 @@ class MTLoRALinearFn(torch.autograd.Function):
         use_side = (side is not None and fgrads and not ctx.has_scale_s and meta.n_scale_t == 0
                     and side.device == dev and M >= _FACTOR_MIN_M
                     and all(p is None or p.grad is None for p in ctx.factor_params))
-        if _side_pending:
-            # an earlier backward call wrote this layer's factor gradients on the side stream and nobody joined it since: order
-            # everything below (and autograd's accumulation into those .grad tensors) behind that stream
-            pend = {id(st): st for st in (_side_pending.pop(p, None) for p in ctx.factor_params if p is not None) if st is not None}
-            for st in pend.values():
-                torch.cuda.current_stream(dev).wait_stream(st)
-            if pend:  # this call's gradients are summed with the earlier ones by the autograd engine on THIS stream: keep them here
-                use_side = False
+        if _side_join_pending(ctx.factor_params, dev):
+            use_side = False  # same layer earlier in THIS backward pass: autograd sums the two gradients on this stream
         if use_side:
             d.bwd_phase = 1
             launch(L.stream_ptr())
@@ -469,9 +500,7 @@ class MTLoRALinearFn(torch.autograd.Function):
             side.wait_event(ev)
             d.bwd_phase = 2
             launch(ctypes.c_void_p(side.cuda_stream))
-            for p in ctx.factor_params:
-                if p is not None:
-                    _side_pending[p] = side
+            _side_mark_pending(ctx.factor_params, side)
             for t in [x2, ctxbuf, scratch, *xt2, *fgrads] + [g for g in g2 if g is not None]:
                 t.record_stream(side)  # allocated on this stream, still in use on the side stream when freed here
         else:
@@ -1464,3 +1493,181 @@ class ConcatUpsampleFn(torch.autograd.Function):
             L.check(st, "mtlora_upsample_cl_bwd")
             grads.append(d)
         return tuple(grads)
+
+
+# ----------------------------------------------------------------------------------------------
+# a run of SwinTransformerBlocks without task outputs: ONE autograd node, one library call per block and direction
+# (mtlora_block_fwd / mtlora_block_bwd, ABI v7)
+# ----------------------------------------------------------------------------------------------
+class BlockCall:
+    """what one block of a ``SwinBlockRunFn`` call needs besides its tensors: the four linears' metas (seeds drawn, packed factors
+    looked up), their frozen-weight copies, the attention geometry.  Built per call by ``SwinTransformerBlock._block_call``."""
+    __slots__ = ("has_norm1", "metas", "weights", "mask", "mask_ids", "H", "W", "num_heads", "window_size", "shift", "hidden",
+                 "eps", "attn_scale", "mask_value", "factor_params", "desc", "params", "n_flat")
+
+    def __init__(self, has_norm1, metas, weights, mask, mask_ids, H, W, num_heads, window_size, shift, hidden, eps, attn_scale,
+                 factor_params, mask_value=-100.0):
+        self.has_norm1, self.metas, self.weights, self.mask, self.mask_ids = has_norm1, metas, weights, mask, mask_ids
+        self.H, self.W, self.num_heads, self.window_size, self.shift, self.hidden = H, W, num_heads, window_size, shift, hidden
+        self.eps, self.attn_scale, self.mask_value, self.factor_params = eps, attn_scale, mask_value, factor_params
+        self.desc = self.params = None
+        self.n_flat = 17 if has_norm1 else 15
+
+    def build_desc(self, B: int, C: int, cdtype: torch.dtype, x_dtype: torch.dtype) -> "L.BlockDesc":
+        d = L.BlockDesc()
+        d.B, d.H, d.W, d.C, d.hidden = B, self.H, self.W, C, self.hidden
+        d.num_heads, d.window_size, d.shift = self.num_heads, self.window_size, self.shift
+        d.dtype, d.x_dtype, d.has_norm1 = _DT_CODE[cdtype], _DT_CODE[x_dtype], 1 if self.has_norm1 else 0
+        d.eps1, d.eps2, d.eps_next = self.eps
+        d.attn_scale, d.mask_value = self.attn_scale, self.mask_value
+        M = B * self.H * self.W
+        for i, m in enumerate(self.metas):
+            d.lin[i] = m.desc(M)
+        self.desc = d
+        return d
+
+
+_blk_bytes_cache: dict = {}
+
+
+def _block_bytes(call: "BlockCall", d, B: int, C: int) -> Tuple[int, int, int]:
+    """(save, fwd tmp, bwd scratch) bytes of a block call -- three host calls into the library per new geometry"""
+    key = (B, call.H, call.W, C, call.hidden, call.has_norm1, d.dtype, d.x_dtype,
+           tuple((m.r_s, m.packed is not None) for m in call.metas))
+    v = _blk_bytes_cache.get(key)
+    if v is None:
+        lib = L.lib()
+        v = (lib.mtlora_block_save_bytes(ctypes.byref(d)), lib.mtlora_block_fwd_tmp_bytes(ctypes.byref(d)),
+             lib.mtlora_block_bwd_scratch_bytes(ctypes.byref(d)))
+        if min(v) < 0:
+            raise RuntimeError(f"mtlora_amd: invalid SwinTransformerBlock geometry B={B} H={call.H} W={call.W} C={C} hidden={call.hidden}")
+        _blk_bytes_cache[key] = v
+    return v
+
+
+class SwinBlockRunFn(torch.autograd.Function):
+    """(x_out, normed_out) of a run of n consecutive SwinTransformerBlocks WITHOUT task outputs (reference
+    swin_transformer_mtlora.py:326-408, tasks-free path): each block is ONE library call forward and ONE (or phase 1 + phase 2 with the
+    factor-gradient side stream) backward; the block calls issue exactly the launches of the per-layer Functions above.
+
+    args: calls (list of BlockCall), x (B, L, C) residual stream, normed (norm1(x) of the first block, or None when that block
+    applies it itself), then per block
+        bias (nH, N, N) fp32, scale1, scale2 ((B) fp32 DropPath factors or None), [norm1.weight, norm1.bias when has_norm1],
+        norm2.weight, norm2.bias, next_norm.weight, next_norm.bias, A_qkv, B_qkv, A_proj, B_proj, A_fc1, B_fc1, A_fc2, B_fc2"""
+
+    @staticmethod
+    def forward(ctx, calls, x, normed, *flat):
+        L.require_gpu(x, normed)
+        lib = L.lib()
+        B, _, C = x.shape
+        M = x.numel() // C
+        cdtype = calls[0].metas[0].dtype
+        if not x.is_contiguous() or (normed is not None and (normed.dtype != cdtype or not normed.is_contiguous())):
+            raise RuntimeError("mtlora_amd: SwinBlockRunFn needs contiguous inputs, norm1(x) in the compute dtype")
+        stream = L.stream_ptr()
+        dev = x.device
+        tmp = None
+        at = 0
+        xs, ns, saves = [x], [normed], []
+        for c in calls:
+            t = flat[at:at + c.n_flat]
+            at += c.n_flat
+            d = c.build_desc(B, C, cdtype, x.dtype)
+            sb, tb, _ = _block_bytes(c, d, B, C)
+            p = L.BlockParams()
+            k = 3
+            p.attn_bias, p.scale1, p.scale2 = t[0].data_ptr(), (0 if t[1] is None else t[1].data_ptr()), (0 if t[2] is None else t[2].data_ptr())
+            if c.has_norm1:
+                p.norm1_g, p.norm1_b = t[3].data_ptr(), t[4].data_ptr()
+                k = 5
+            p.norm2_g, p.norm2_b, p.next_g, p.next_b = t[k].data_ptr(), t[k + 1].data_ptr(), t[k + 2].data_ptr(), t[k + 3].data_ptr()
+            for i in range(4):
+                wc, wt, bf = c.weights[i]
+                p.W[i], p.Wt[i], p.bias[i] = wc.data_ptr(), wt.data_ptr(), (0 if bf is None else bf.data_ptr())
+                p.A[i], p.Bf[i] = t[k + 4 + 2 * i].data_ptr(), t[k + 5 + 2 * i].data_ptr()
+            p.mask_ids = 0 if c.mask_ids is None else c.mask_ids.data_ptr()
+            p.mask = 0 if (c.mask is None or c.mask_ids is not None) else c.mask.data_ptr()
+            c.params = p
+            if tmp is None or tmp.numel() < tb:
+                tmp = torch.empty(tb, dtype=torch.uint8, device=dev)
+            save = torch.empty(sb, dtype=torch.uint8, device=dev)
+            x_out = torch.empty_like(xs[-1])
+            n_out = torch.empty(x.shape, dtype=cdtype, device=dev)
+            st = lib.mtlora_block_fwd(ctypes.byref(d), ctypes.byref(p), xs[-1].data_ptr(), 0 if ns[-1] is None else ns[-1].data_ptr(),
+                                      x_out.data_ptr(), n_out.data_ptr(), save.data_ptr(), sb, tmp.data_ptr(), tb, stream)
+            L.check(st, "mtlora_block_fwd")
+            xs.append(x_out)
+            ns.append(n_out)
+            saves.append(save)
+        n = len(calls)
+        ctx.calls, ctx.n, ctx.has_normed = calls, n, normed is not None
+        ctx.dims = (B, M, C, cdtype)
+        # tensors whose addresses the params structs hold: inputs first (autograd tracks their versions), then the call's own buffers
+        ctx.save_for_backward(*xs, *[t for t in ns if t is not None], *saves, *[t for t in flat if t is not None])
+        ctx.flat_none = [t is None for t in flat]
+        return xs[-1], ns[-1]
+
+    @staticmethod
+    def backward(ctx, g_x, g_n):
+        calls, n = ctx.calls, ctx.n
+        B, M, C, cdtype = ctx.dims
+        sv = ctx.saved_tensors
+        xs = sv[:n + 1]
+        k = n + 1
+        ns = list(sv[k:k + n + (1 if ctx.has_normed else 0)])
+        k += len(ns)
+        if not ctx.has_normed:
+            ns = [None] + ns
+        saves = sv[k:k + n]
+        dev = xs[0].device
+        lib = L.lib()
+        g_x = g_x.contiguous() if g_x.dtype == xs[0].dtype else g_x.to(xs[0].dtype).contiguous()
+        g_n = g_n.contiguous() if g_n.dtype == cdtype else g_n.to(cdtype).contiguous()
+        side = _factor_stream
+        grads_flat = []
+        for bi in range(n - 1, -1, -1):
+            c = calls[bi]
+            d, p = c.desc, c.params
+            _, _, scb = _block_bytes(c, d, B, C)
+            scratch = torch.empty(scb, dtype=torch.uint8, device=dev)
+            nH, N = c.num_heads, c.window_size * c.window_size
+            gx = torch.empty_like(xs[bi])
+            gn = None if c.has_norm1 else torch.empty(xs[bi].shape, dtype=cdtype, device=dev)
+            lnw = torch.empty((6, C), dtype=torch.float32, device=dev)
+            dbias = torch.empty((nH, N, N), dtype=torch.float32, device=dev)
+            fg = []
+            for i, m in enumerate(c.metas):
+                fg.append(torch.empty((m.r_s, m.K), dtype=torch.float32, device=dev))
+                fg.append(torch.empty((m.N, m.r_s), dtype=torch.float32, device=dev))
+            g = L.BlockGrads()
+            g.g_x, g.g_normed = gx.data_ptr(), (0 if gn is None else gn.data_ptr())
+            g.d_norm1_g, g.d_norm1_b, g.d_norm2_g, g.d_norm2_b = lnw[0].data_ptr(), lnw[1].data_ptr(), lnw[2].data_ptr(), lnw[3].data_ptr()
+            g.d_next_g, g.d_next_b, g.dbias = lnw[4].data_ptr(), lnw[5].data_ptr(), dbias.data_ptr()
+            for i in range(4):
+                g.dA[i], g.dB[i] = fg[2 * i].data_ptr(), fg[2 * i + 1].data_ptr()
+            fparams = c.factor_params
+            use_side = (side is not None and side.device == dev and M >= _FACTOR_MIN_M
+                        and all(q.grad is None for q in fparams))
+            if _side_join_pending(fparams, dev):
+                use_side = False
+            args = (ctypes.byref(d), ctypes.byref(p), xs[bi].data_ptr(), 0 if ns[bi] is None else ns[bi].data_ptr(),
+                    xs[bi + 1].data_ptr(), g_x.data_ptr(), g_n.data_ptr(), saves[bi].data_ptr(), saves[bi].numel(), ctypes.byref(g),
+                    scratch.data_ptr(), scb)
+            if use_side:
+                L.check(lib.mtlora_block_bwd(*args, 1, L.stream_ptr()), "mtlora_block_bwd")
+                ev = torch.cuda.Event()
+                ev.record()
+                side.wait_event(ev)
+                L.check(lib.mtlora_block_bwd(*args, 2, ctypes.c_void_p(side.cuda_stream)), "mtlora_block_bwd (factor gradients)")
+                _side_mark_pending(fparams, side)
+                for t in (xs[bi], saves[bi], scratch, *fg) + (() if ns[bi] is None else (ns[bi],)):
+                    t.record_stream(side)  # allocated on this stream, still in use on the side stream when freed here
+            else:
+                L.check(lib.mtlora_block_bwd(*args, 0, L.stream_ptr()), "mtlora_block_bwd")
+            blk = [dbias, None, None]
+            if c.has_norm1:
+                blk += [lnw[0], lnw[1]]
+            blk += [lnw[2], lnw[3], lnw[4], lnw[5], *fg]
+            grads_flat = blk + grads_flat
+            g_x, g_n = gx, gn
+        return (None, g_x, g_n if ctx.has_normed else None, *grads_flat)

@@ -190,11 +190,16 @@ class MTLoRALinear(LoRALayer):
         buffers (their addresses may be baked into a captured HIP graph).  The cache keys on the tensors' version counters and
         storage, which in-place updates through ``.data`` (EMA, hand-written loaders, older optimizers) do NOT bump: call this
         after such an update.  ``load_state_dict``, ``merge`` / ``unmerge`` call it themselves; ``.to()`` / ``.cuda()`` drop the
-        copies altogether."""
+        copies altogether.  The same holds for the low-rank factors packed ahead of time by a ``FactorPacker``: an edit of
+        ``lora_*`` through ``.data`` needs this call too (it drops the "packed factors are current" mark; the next forward packs
+        inside the call until the packer refreshes)."""
         self._wcache = {k: (None,) + tuple(v[1:]) for k, v in self._wcache.items()}
+        self._packed_sig = None  # the packed low-rank factors too (freshness is judged by Parameter._version, which .data edits skip)
 
     def _apply(self, fn, *a, **k):  # .to() / .cuda(): the copies live on the old device / dtype
         self._wcache = {}
+        self._packed_sig = None
+        self.__dict__.pop("_fp_cache", None)
         return super()._apply(fn, *a, **k)
 
     def _load_from_state_dict(self, state_dict, prefix, *a, **k):
@@ -227,6 +232,20 @@ class MTLoRALinear(LoRALayer):
         if mode and self.merged:  # a merged weight cannot be trained through (loralib convention: train() un-merges)
             self.unmerge()
         return super().train(mode)  # (the cached copies stay: W did not change, and a captured graph may hold their addresses)
+
+    def meta_t0(self, dtype: torch.dtype, device) -> "Fn.LinearMeta":
+        """the LinearMeta of a call of a layer WITHOUT tasks and with a constant shared scale (``tasks is None``, shared_mode 'matrix',
+        not merged) -- what ``forward`` builds for such a layer, for callers that issue the library call themselves (the one-call
+        Swin block, swin_transformer_mtlora.SwinTransformerBlock._block_call).  Draws the call's dropout seed."""
+        p = self.dropout_p if self.training else 0.0
+        ss = float(self.lora_shared_scale)
+        meta = Fn.LinearMeta(K=self.linear.in_features, N=self.linear.out_features, r_s=self.r, r_t=(), scale_s=ss, scale_t=(), mode=0,
+                             has_x_tasks=False, dropout_p=p, seed=Fn.next_seed() if p > 0 else 0, dtype=dtype)
+        sig = (dtype, meta.r_s, (), ss, (), 0, False, p, str(device))
+        self._call_sig = sig
+        if self._packed is not None and self._packed_sig == (sig, tuple(q._version for q in self._factor_params())):
+            meta.packed = self._packed
+        return meta
 
     def forward(self, x: torch.Tensor, x_tasks: Optional[Dict[str, torch.Tensor]] = None, gelu_gate=None, gelu_out: bool = False
                 ) -> Tuple[torch.Tensor, Optional[Dict[str, torch.Tensor]]]:
@@ -304,6 +323,10 @@ class FactorPacker:
         self.layers = [m for m in model.modules() if isinstance(m, MTLoRALinear) and m.r > 0]
         self._table = None
         self._table_key = None
+        # every table ever built and every packed buffer it points to, per key: a captured HIP graph (GraphedTrainStep) has the raw
+        # device addresses of the table and of the layers' packed buffers baked into its nodes, so a change of call signature
+        # (an eval or fp32 forward between graphed steps) must not free them -- same policy as MTLoRALinear._wcache
+        self._tables = {}
 
     def _eligible(self, m: "MTLoRALinear") -> bool:
         if m._call_sig is None or m.merged:
@@ -322,7 +345,13 @@ class FactorPacker:
         if not todo:
             return 0
         key = tuple((id(m), m._call_sig) + tuple(q.data_ptr() for q in m._factor_params()) for m in todo)
-        if key != self._table_key:
+        if key != self._table_key and key in self._tables:
+            self._table = self._tables[key]
+            self._table_key = key
+            for tb in self._table:  # the layers go back to the buffers this table writes
+                for ent in tb.keep:
+                    ent[6]._packed = ent[5]
+        elif key != self._table_key:
             by_dtype = {}
             for m in todo:
                 dtype, r_s, r_t, scale_s, scale_t, mode, has_xt, p, _dev = m._call_sig
@@ -330,15 +359,16 @@ class FactorPacker:
                                      mode=mode, has_x_tasks=has_xt, dropout_p=p, seed=0, dtype=dtype)
                 dev = m._factor_params()[0].device
                 need = Fn.packed_bytes(meta)
-                if m._packed is None or m._packed.numel() < need or m._packed.device != dev:
-                    m._packed = torch.empty(need, dtype=torch.uint8, device=dev)
+                # one buffer per (layer, signature), never freed or re-used for another signature (see __init__)
+                m._packed = torch.empty(need, dtype=torch.uint8, device=dev)
                 shared = r_s > 0
                 tasks = list(m.tasks) if (m.tasks is not None and len(r_t) > 0) else []
                 ent = (meta, m.lora_shared_A if shared else None, m.lora_shared_B if shared else None,
-                       [m.lora_tasks_A[t] for t in tasks], [m.lora_tasks_B[t] for t in tasks], m._packed)
+                       [m.lora_tasks_A[t] for t in tasks], [m.lora_tasks_B[t] for t in tasks], m._packed, m)
                 by_dtype.setdefault((dtype, str(dev)), []).append(ent)
             self._table = [Fn.PackTable(ents, ents[0][5].device, dt) for (dt, _), ents in by_dtype.items()]
             self._table_key = key
+            self._tables[key] = self._table
         for tb in self._table:
             tb.pack()
         for m in todo:

@@ -473,6 +473,7 @@ def train_step(model, criterion, optimizer, images, targets, clip_grad: float = 
         Fn.set_factor_stream(None)
     if side is not None:
         torch.cuda.current_stream(images.device).wait_stream(side)  # dA / dB of every MTLoRALinear are complete from here on
+        Fn.factor_stream_joined()
     if reducer is not None:
         reducer.finish()
     params = [p for g in optimizer.param_groups for p in g["params"] if p.grad is not None]
@@ -601,6 +602,7 @@ class GraphedTrainStep:
             Fn.set_factor_stream(None)
         if side is not None:  # joins the side stream back (inside a capture: closes the graph's second branch)
             torch.cuda.current_stream(self.images.device).wait_stream(side)
+            Fn.factor_stream_joined()
         if self.reducer is not None:
             self.reducer.flush_packs()
         return loss.detach()

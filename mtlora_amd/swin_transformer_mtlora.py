@@ -28,9 +28,22 @@ import torch
 import torch.nn as nn
 from torch import Tensor
 
+import os
+
 from . import functional as Fn
 from .lora import MTLoRALinear
 from .window_process import WindowProcess, WindowProcessReverse
+
+
+# MTLORA_FUSED_BLOCKS=0: every block through the per-layer autograd Functions (A/B of the one-call path; same kernels, same results)
+_FUSED_BLOCKS = os.environ.get("MTLORA_FUSED_BLOCKS", "1") != "0"
+
+
+def set_fused_blocks(on: bool) -> bool:
+    """switch the one-call-per-block path (functional.SwinBlockRunFn) on / off; returns the previous setting"""
+    global _FUSED_BLOCKS
+    prev, _FUSED_BLOCKS = _FUSED_BLOCKS, bool(on)
+    return prev
 
 
 # -- small stand-ins for the three timm helpers the reference imports (timm is not a dependency) ----
@@ -288,6 +301,62 @@ class SwinTransformerBlock(nn.Module):
         self.fused_window_process = fused_window_process
         self.attention_layout = "image"  # "windows": reference dataflow through the window-process kernels
 
+    # -- the whole block as ONE library call per direction (functional.SwinBlockRunFn, mtlora_block_fwd / _bwd) ------------------
+    def _fusable_static(self, next_norm) -> bool:
+        """structure-only part of the eligibility test (cached per (block, next_norm) by ``BasicLayer``): the stock tasks-free block
+        of every shipped config -- four frozen-weight MTLoRALinear layers with a shared 'matrix' update and constant scales, exact
+        GELU, no dropout modules in play, plain nn.LayerNorm's, image-order attention, and NO hooks on any module inside (a hook
+        expects to see its module called: such a block takes the per-layer path)."""
+        def plain_ln(m):
+            return (type(m) is nn.LayerNorm and m.elementwise_affine and m.bias is not None and len(m.normalized_shape) == 1
+                    and m.weight.dtype == torch.float32)
+
+        def stock_linear(m):
+            return (isinstance(m, MTLoRALinear) and m.r > 0 and m.tasks is None and hasattr(m, "lora_shared_A")
+                    and m.shared_mode == "matrix" and not isinstance(m.lora_shared_scale, torch.Tensor)
+                    and not m.linear.weight.requires_grad and (m.linear.bias is None or not m.linear.bias.requires_grad)
+                    and m.lora_shared_A.dtype == torch.float32 and m.lora_shared_A.is_contiguous() and m.lora_shared_B.is_contiguous())
+
+        def hookless(m):
+            return not (m._forward_hooks or m._forward_pre_hooks or m._backward_hooks or m._backward_pre_hooks)
+
+        lin = (self.attn.qkv, self.attn.proj, self.mlp.fc1, self.mlp.fc2)
+        mods = (self, self.attn, self.mlp, self.norm1, self.norm2, next_norm, self.mlp.act, self.drop_path) + lin
+        C = self.dim
+        return (not self.lora and self.attention_layout == "image" and next_norm is not None
+                and all(stock_linear(m) for m in lin) and all(plain_ln(m) for m in (self.norm1, self.norm2, next_norm))
+                and type(self.mlp.act) is nn.GELU and getattr(self.mlp.act, "approximate", "none") == "none"
+                and self.mlp.drop.p == 0.0 and self.attn.proj_drop.p == 0.0 and self.attn.attn_drop.p == 0.0
+                and all(hookless(m) for m in mods) and C % 8 == 0 and self.mlp.fc1.linear.out_features % 8 == 0
+                and C // self.num_heads == 32 and self.window_size * self.window_size <= 64)
+
+    def _block_call(self, has_norm1: bool, next_norm, cdtype, x):
+        """(BlockCall, flat tensor list) of this block for a ``SwinBlockRunFn`` call, or None when a layer cannot run fused now
+        (merged weights, factors on another device ...).  Draws the dropout seeds and DropPath factors in the order of ``forward``."""
+        lin = (self.attn.qkv, self.attn.proj, self.mlp.fc1, self.mlp.fc2)
+        metas, weights, fparams = [], [], []
+        for m in lin:
+            if m.merged or not m.lora_shared_A.is_cuda:
+                return None
+            metas.append(m.meta_t0(cdtype, x.device))
+            weights.append(m._weights(cdtype))
+            fparams += [m.lora_shared_A, m.lora_shared_B]
+        p_dp = self.drop_path.drop_prob if isinstance(self.drop_path, DropPath) else 0.0
+        s1 = s2 = None
+        if self.training and p_dp > 0.0:
+            keep = 1.0 - p_dp
+            s1 = Fn.droppath_scale(1, x.shape[0], keep, x.device)[0]
+            s2 = Fn.droppath_scale(1, x.shape[0], keep, x.device)[0]
+        H, W = self.input_resolution
+        call = Fn.BlockCall(has_norm1, metas, weights, self.attn_mask, self._attn_mask_ids, H, W, self.num_heads, self.window_size,
+                            self.shift_size, self.mlp.fc1.linear.out_features, (self.norm1.eps, self.norm2.eps, next_norm.eps),
+                            self.attn.scale, tuple(fparams))
+        flat = [self.attn.dense_bias(), s1, s2]
+        if has_norm1:
+            flat += [self.norm1.weight, self.norm1.bias]
+        flat += [self.norm2.weight, self.norm2.bias, next_norm.weight, next_norm.bias, *fparams]
+        return call, flat
+
     # -- attention half ------------------------------------------------------------------------------
     def _attend_windows(self, xn: Tensor, B: int, H: int, W: int, C: int):
         ws, s = self.window_size, self.shift_size
@@ -425,11 +494,45 @@ class BasicLayer(nn.Module):
         self.downsample = (downsample(input_resolution, dim=dim, norm_layer=norm_layer, layer_idx=layer_idx, mtlora=mtlora)
                            if downsample is not None else None)
 
+    def _fused_run(self, x):
+        """the leading run of blocks that can go through ``Fn.SwinBlockRunFn`` (one autograd node for the run, one library call per
+        block and direction): (number of blocks consumed, x, normed) -- (0, x, None) when the first block already does not qualify."""
+        ok = (_FUSED_BLOCKS and x.is_cuda and x.dim() == 3 and x.is_contiguous() and torch.is_grad_enabled() and x.dtype in Fn._GLUE_DTYPES)
+        if not ok:
+            return 0, x, None
+        cdtype = Fn.compute_dtype(x)
+        C = x.shape[-1]
+        if C > (2048 if x.dtype == torch.float32 else 4096) or (x.dtype != torch.float32 and x.dtype != cdtype):
+            return 0, x, None
+        st = self.__dict__.get("_fusable_cache")
+        if st is None:
+            st = [blk._fusable_static(self.blocks[i + 1].norm1 if i + 1 < len(self.blocks) else None) for i, blk in enumerate(self.blocks)]
+            self.__dict__["_fusable_cache"] = st
+        calls, flat = [], []
+        for i, blk in enumerate(self.blocks):
+            if not st[i] or blk.training != self.training:
+                break
+            cf = blk._block_call(i == 0, self.blocks[i + 1].norm1, cdtype, x)
+            if cf is None:
+                break
+            calls.append(cf[0])
+            flat += cf[1]
+        if not calls:
+            return 0, x, None
+        x, normed = Fn.SwinBlockRunFn.apply(calls, x, None, *flat)
+        return len(calls), x, normed
+
+    def invalidate_fused_cache(self) -> None:
+        """forget which blocks qualify for the one-call path (after registering hooks on / swapping modules inside a block)"""
+        self.__dict__.pop("_fusable_cache", None)
+
     def forward(self, x):
         tasks_lora = None
-        normed = None
         deferred = None
+        first, x, normed = self._fused_run(x)
         for i, blk in enumerate(self.blocks):
+            if i < first:
+                continue
             # a block that ends in a single-stream residual also applies the next block's norm1 (one fused kernel)
             nxt = self.blocks[i + 1].norm1 if (i + 1 < len(self.blocks) and not blk.lora) else None
             last = i + 1 == len(self.blocks)

@@ -404,6 +404,120 @@ def test_factor_gradient_stream_is_bit_identical():
         assert torch.equal(runs[0][1][n], runs[1][1][n]), n
 
 
+@pytest.mark.parametrize("mode", ["bf16_side_stream", "bf16_one_stream", "fp32"])
+def test_block_call_matches_per_layer_calls(mode):
+    """the tasks-free blocks as ONE library call per block and direction inside ONE autograd node per run (functional.SwinBlockRunFn,
+    mtlora_block_fwd / _bwd): three train steps -- dropout, DropPath, factor packer, clip, AdamW -- must leave the losses and every
+    parameter bit-identical to the run through the per-layer autograd Functions (the block call issues the same launches in the same
+    order).  depths (3, 2, 3, 2): runs of two blocks (first one applies its own norm1, second one gets it handed over) and of one."""
+    from mtlora_amd import functional as Fn
+    from mtlora_amd import mtl_harness as H
+    from mtlora_amd import swin_transformer_mtlora as S
+    tasks = ["semseg", "normals", "sal", "human_parts"]
+    img, tg = H.synthetic_batch(2, 224, tasks, seed=13, device=dev())
+    amp = None if mode == "fp32" else torch.bfloat16
+    runs, used = [], []
+    keep, keep_m, keep_f = H._FACTOR_STREAM, Fn._FACTOR_MIN_M, S._FUSED_BLOCKS
+    calls = [0]
+    orig = Fn.SwinBlockRunFn.forward
+
+    def counting(ctx, cl, *a):
+        calls[0] += len(cl)
+        return orig(ctx, cl, *a)
+
+    Fn.SwinBlockRunFn.forward = staticmethod(counting)
+    try:
+        Fn._FACTOR_MIN_M = 0
+        H._FACTOR_STREAM = mode == "bf16_side_stream"
+        for fused in (False, True):
+            S.set_fused_blocks(fused)
+            calls[0] = 0
+            torch.manual_seed(5)
+            Fn._seed_counter = 0
+            Fn.droppath_reset()
+            model = H.build_model(img_size=224, tasks=tasks, depths=(3, 2, 3, 2), r_shared=16, r_task=4, seed=3).to(dev()).train()
+            crit, opt = H.MultiTaskLoss(tasks), H.build_optimizer(model, lr=1e-3)
+            losses = [H.train_step(model, crit, opt, img, tg, amp_dtype=amp)[0].clone() for _ in range(3)]
+            torch.cuda.synchronize()
+            used.append(calls[0])
+            runs.append((losses, {n: p.detach().clone() for n, p in model.named_parameters()}))
+    finally:
+        Fn.SwinBlockRunFn.forward = staticmethod(orig)
+        H._FACTOR_STREAM, Fn._FACTOR_MIN_M = keep, keep_m
+        S.set_fused_blocks(keep_f)
+    assert used == [0, 3 * 6], used  # 2 + 1 + 2 + 1 tasks-free blocks per forward, three steps
+    for a, b in zip(runs[0][0], runs[1][0]):
+        assert torch.isfinite(a) and torch.equal(a, b), (a.item(), b.item())
+    for n in runs[0][1]:
+        assert torch.equal(runs[0][1][n], runs[1][1][n]), n
+
+
+def test_block_call_falls_back_for_hooked_or_merged_blocks():
+    """a forward hook inside a block, a merged layer or the reference's window layout keep that block on the per-layer path (the hook
+    still fires); eval-mode forwards with gradients take the one-call path and agree with the per-layer path bit for bit."""
+    from mtlora_amd import functional as Fn
+    from mtlora_amd import mtl_harness as H
+    from mtlora_amd import swin_transformer_mtlora as S
+    tasks = ["semseg", "normals"]
+    model = H.build_model(img_size=224, tasks=tasks, depths=(3, 2), num_heads=(3, 6), r_shared=8, r_task=4, seed=3).to(dev()).eval()
+    bb = model.backbone
+    x = torch.randn(2, 3, 224, 224, device=dev())
+    n_calls = [0]
+    orig = Fn.SwinBlockRunFn.forward
+
+    def counting(ctx, cl, *a):
+        n_calls[0] += len(cl)
+        return orig(ctx, cl, *a)
+
+    def run():
+        bb.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            st = bb(x, return_stages=True)
+        sum((s.float() ** 2).sum() + sum((v.float() ** 2).sum() for v in tl.values()) for s, tl in st).backward()
+        return ([s.detach().clone() for s, _ in st],
+                {n: p.grad.detach().clone() for n, p in bb.named_parameters() if p.grad is not None})
+
+    Fn.SwinBlockRunFn.forward = staticmethod(counting)
+    try:
+        prev = S.set_fused_blocks(False)
+        ref = run()
+        S.set_fused_blocks(True)
+        got = run()
+        assert n_calls[0] == 3  # stage 0: two blocks, stage 1: one
+        for a, b in zip(ref[0], got[0]):
+            assert torch.equal(a, b)
+        assert ref[1].keys() == got[1].keys()
+        for n in ref[1]:
+            assert torch.equal(ref[1][n], got[1][n]), n
+        # a hook on the second block's fc1: the run ends in front of that block, the hook fires, results unchanged
+        seen = []
+        h = bb.layers[0].blocks[1].mlp.fc1.register_forward_hook(lambda m, i, o: seen.append(1))
+        for lyr in bb.layers:
+            lyr.invalidate_fused_cache()
+        n_calls[0] = 0
+        got = run()
+        assert n_calls[0] == 2 and seen
+        for n in ref[1]:
+            assert torch.equal(ref[1][n], got[1][n]), n
+        h.remove()
+        # merged weights (inference): no fused call for that block; with torch.no_grad() none at all
+        for lyr in bb.layers:
+            lyr.invalidate_fused_cache()
+        bb.layers[0].blocks[0].attn.qkv.merge()
+        n_calls[0] = 0
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            bb(x, return_stages=True)
+        assert n_calls[0] == 1  # only stage 1's block
+        bb.layers[0].blocks[0].attn.qkv.unmerge()
+        n_calls[0] = 0
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+            bb(x, return_stages=True)
+        assert n_calls[0] == 0
+    finally:
+        Fn.SwinBlockRunFn.forward = staticmethod(orig)
+        S.set_fused_blocks(prev)
+
+
 def test_factor_packer_one_launch_per_step_is_bit_identical():
     """lora.FactorPacker: the low-rank factors of every MTLoRALinear packed by ONE launch per step (mtlora_linear_pack_table, from the
     second step on: the first records each layer's call signature) instead of one k_pack per layer and forward -- four train steps must

@@ -9,6 +9,7 @@
 #include <stdint.h>
 
 #include "../../include/mtlora_hip.h"
+#include "internal.h"
 
 namespace {
 
@@ -31,7 +32,7 @@ struct SaveLayout {
 // ---- backward scratch ----
 struct BwdLayout {
     int64_t d_m, d_h, d_xn2, d_x1, d_y, d_a, d_qkv, d_xn, d_skip;  // activation gradients along the chain
-    int64_t ln, attn, lin[4];                                // LayerNorm partials (re-used, same stream), attention, the linears' scratch (Q)
+    int64_t ln[3], attn, lin[4];                             // LayerNorm partials (next / norm2 / norm1: kept until phase 2 reduces them), attention, the linears' scratch (Q)
     int64_t ln_bytes, attn_bytes, lin_bytes[4];
     int64_t total;
 };
@@ -112,7 +113,7 @@ int bwd_layout(const mtlora_block_desc* d, BwdLayout& L) {
     const mtlora_attn_desc a = attn_desc(d);
     L.attn_bytes = mtlora_window_attn_bwd_scratch_bytes(&a);
     if (L.ln_bytes < 0 || L.attn_bytes < 0) return MTLORA_ERR_SHAPE;
-    L.ln = take(L.ln_bytes);
+    for (int i = 0; i < 3; ++i) L.ln[i] = (i < 2 || d->has_norm1) ? take(L.ln_bytes) : -1;
     L.attn = take(L.attn_bytes > 16 ? L.attn_bytes : 16);
     for (int i = 0; i < 4; ++i) {
         L.lin_bytes[i] = mtlora_linear_bwd_scratch_bytes(&d->lin[i]);
@@ -227,35 +228,52 @@ int mtlora_block_bwd(const mtlora_block_desc* d, const mtlora_block_params* p, c
         return mtlora_linear_bwd(&ld[i], lin_x[i], kNoIn, p->Wt[i], lin_dy[i], kNoIn, at(save, L.ctx[i]), L.ctx_bytes[i], lin_dx[i],
                                  kNoOut, g->dA[i], g->dB[i], kNoG, kNoG, at(scratch, S.lin[i]), S.lin_bytes[i], stream);
     };
-    if (phase == 2) {  // the factor gradients of the four layers, in the order their inputs became available
-        for (int i = 3; i >= 0; --i) BLK_TRY(linear_bwd(i));
+    const mtlora_attn_desc ad = attn_desc(d);
+    auto ln_next = [&](int ph) -> int {      // next block's norm1 + the MLP residual: d_x1 = g_x_out + LN'(g_normed_out), d_m = scale2 * d_x1
+        return mtli_residual_layernorm_bwd(g_normed_out, x_out, p->next_g, (const float*)at(save, L.mean_n),
+                                           (const float*)at(save, L.rstd_n), at(scratch, S.d_x1), at(scratch, S.d_m), g->d_next_g,
+                                           g->d_next_b, p->scale2, d->B, M, C, d->x_dtype, d->dtype, at(scratch, S.ln[0]), S.ln_bytes,
+                                           g_x_out, ph, stream);
+    };
+    void* d_skip = d->has_norm1 ? (void*)at(scratch, S.d_skip) : g->g_x;
+    auto ln_2 = [&](int ph) -> int {         // norm2 + the attention residual: d_x (skip part) = d_x1 + LN'(d_xn2), d_y = scale1 * that
+        return mtli_residual_layernorm_bwd(at(scratch, S.d_xn2), at(save, L.x1), p->norm2_g, (const float*)at(save, L.mean2),
+                                           (const float*)at(save, L.rstd2), d_skip, at(scratch, S.d_y), g->d_norm2_g, g->d_norm2_b,
+                                           p->scale1, d->B, M, C, d->x_dtype, d->dtype, at(scratch, S.ln[1]), S.ln_bytes,
+                                           at(scratch, S.d_x1), ph, stream);
+    };
+    auto ln_1 = [&](int ph) -> int {         // g_x = d_skip + LN1'(d_xn)
+        return mtli_layernorm_bwd(at(scratch, S.d_xn), x, p->norm1_g, (const float*)at(save, L.mean1), (const float*)at(save, L.rstd1),
+                                  g->g_x, g->d_norm1_g, g->d_norm1_b, M, C, d->x_dtype, d->dtype, at(scratch, S.ln[2]), S.ln_bytes,
+                                  d_skip, ph, stream);
+    };
+    // (dbias is reduced on the chain's stream in every phase: the caller's gather table[index] -> bias has a backward of its own that
+    // reads dbias as soon as this call returns)
+    auto attn_bwd = [&]() -> int {
+        return mtlora_window_attn_bwd(&ad, at(save, L.qkv), p->attn_bias, p->mask, p->mask_ids, at(scratch, S.d_a), at(scratch, S.d_qkv),
+                                      g->dbias, at(scratch, S.attn), S.attn_bytes, stream);
+    };
+    if (!g->g_x || !g->d_norm2_g || !g->d_norm2_b || !g->d_next_g || !g->d_next_b || !g->dbias) return MTLORA_ERR_NULL;
+    if (d->has_norm1 && (!p->norm1_g || !g->d_norm1_g || !g->d_norm1_b)) return MTLORA_ERR_NULL;
+    if (phase == 2) {  // everything only the optimizer reads: the factor gradients of the four layers (in the order their inputs became
+                       // available) and the second-stage reduces of the LayerNorm gradients
+        BLK_TRY(ln_next(2));
+        BLK_TRY(linear_bwd(3));
+        BLK_TRY(linear_bwd(2));
+        BLK_TRY(ln_2(2));
+        BLK_TRY(linear_bwd(1));
+        BLK_TRY(linear_bwd(0));
+        if (d->has_norm1) BLK_TRY(ln_1(2));
         return MTLORA_OK;
     }
-    if (!g->g_x || !g->d_norm2_g || !g->d_norm2_b || !g->d_next_g || !g->d_next_b || !g->dbias) return MTLORA_ERR_NULL;
-    // next block's norm1 + the MLP residual: d_x1 = g_x_out + LN'(g_normed_out), d_m = scale2 * d_x1
-    BLK_TRY(mtlora_residual_layernorm_bwd(g_normed_out, x_out, p->next_g, (const float*)at(save, L.mean_n),
-                                          (const float*)at(save, L.rstd_n), at(scratch, S.d_x1), at(scratch, S.d_m), g->d_next_g,
-                                          g->d_next_b, p->scale2, d->B, M, C, d->x_dtype, d->dtype, at(scratch, S.ln), S.ln_bytes,
-                                          g_x_out, stream));
+    BLK_TRY(ln_next(phase));
     BLK_TRY(linear_bwd(3));  // d_h
     BLK_TRY(linear_bwd(2));  // d_xn2
-    // norm2 + the attention residual: d_x (skip part) = d_x1 + LN'(d_xn2), d_y = scale1 * that
-    void* d_skip = d->has_norm1 ? (void*)at(scratch, S.d_skip) : g->g_x;
-    BLK_TRY(mtlora_residual_layernorm_bwd(at(scratch, S.d_xn2), at(save, L.x1), p->norm2_g, (const float*)at(save, L.mean2),
-                                          (const float*)at(save, L.rstd2), d_skip, at(scratch, S.d_y), g->d_norm2_g, g->d_norm2_b,
-                                          p->scale1, d->B, M, C, d->x_dtype, d->dtype, at(scratch, S.ln), S.ln_bytes,
-                                          at(scratch, S.d_x1), stream));
+    BLK_TRY(ln_2(phase));
     BLK_TRY(linear_bwd(1));  // d_a
-    const mtlora_attn_desc ad = attn_desc(d);
-    BLK_TRY(mtlora_window_attn_bwd(&ad, at(save, L.qkv), p->attn_bias, p->mask, p->mask_ids, at(scratch, S.d_a), at(scratch, S.d_qkv),
-                                   g->dbias, at(scratch, S.attn), S.attn_bytes, stream));
+    BLK_TRY(attn_bwd());
     BLK_TRY(linear_bwd(0));  // d_xn (has_norm1) or g_normed
-    if (d->has_norm1) {      // g_x = d_skip + LN1'(d_xn)
-        if (!p->norm1_g || !g->d_norm1_g || !g->d_norm1_b) return MTLORA_ERR_NULL;
-        BLK_TRY(mtlora_layernorm_bwd(at(scratch, S.d_xn), x, p->norm1_g, (const float*)at(save, L.mean1), (const float*)at(save, L.rstd1),
-                                     g->g_x, g->d_norm1_g, g->d_norm1_b, M, C, d->x_dtype, d->dtype, at(scratch, S.ln), S.ln_bytes,
-                                     d_skip, 0, 0, stream));
-    }
+    if (d->has_norm1) BLK_TRY(ln_1(phase));
     return MTLORA_OK;
 }
 

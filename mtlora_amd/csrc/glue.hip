@@ -9,6 +9,7 @@
 //                         workgroup visits, LDS reduction over its row groups, per-workgroup partials, and a
 //                         deterministic second-stage reduce.
 #include "common.h"
+#include "internal.h"
 
 namespace {
 
@@ -915,7 +916,8 @@ int mtlora_residual_layernorm_fwd(const void* shortcut, const void* branch, cons
 static int ln_bwd_impl(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd, void* dx,
                        float* dgamma, float* dbeta, int64_t M, int64_t C, int x_dtype, int dy_dtype, void* scratch,
                        int64_t scratch_bytes, const void* dx_addend, int merge_h, int merge_w, void* d_branch,
-                       const float* scale, int64_t B, void* stream) {
+                       const float* scale, int64_t B, void* stream, int phase = 0) {
+    // phase (internal.h): 0 main kernel + reduce, 1 main kernel only, 2 reduce of the partials in `scratch` only
     int st = ln_check(M, C, x_dtype, dy_dtype);
     if (st != MTLORA_OK) return st;
     if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta || !scratch) return MTLORA_ERR_NULL;
@@ -951,7 +953,7 @@ static int ln_bwd_impl(const void* dy, const void* x, const float* gamma, const 
     const int grid = ln_grid(M, lpr);
     const size_t lds = (size_t)4 * (64 / lpr) * 2 * C * 4;
     const int es_x = mtl_elem_size(x_dtype), es_g = mtl_elem_size(dy_dtype);
-    {
+    if (phase != 2) {
         mtl_prof_tag("M%lld C%lld x%d g%d mg%d add%d", (long long)M, (long long)C, x_dtype, dy_dtype, merge_w, dx_addend ? 1 : 0);
         MtlProfScope prof(PK_LN_BWD, (double)M * C * (2 * es_x + es_g + (dx_addend ? es_x : 0) + (d_branch ? es_g : 0)), s);
 #define LN_EXTRA
@@ -974,10 +976,27 @@ static int ln_bwd_impl(const void* dy, const void* x, const float* gamma, const 
         }
 #undef LN_EXTRA
     }
-    hipLaunchKernelGGL(k_ln_reduce, dim3((unsigned)mtl_ceil_div(2 * C, 64)), dim3(64 * LN_RW), 0, s, (const float*)p.part, dgamma,
-                       dbeta, grid, (int)C);
+    if (phase != 1)
+        hipLaunchKernelGGL(k_ln_reduce, dim3((unsigned)mtl_ceil_div(2 * C, 64)), dim3(64 * LN_RW), 0, s, (const float*)p.part, dgamma,
+                           dbeta, grid, (int)C);
     MTL_CHECK_LAUNCH();
     return MTLORA_OK;
+}
+
+int mtli_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd, void* dx,
+                       float* dgamma, float* dbeta, int64_t M, int64_t C, int x_dtype, int dy_dtype, void* scratch,
+                       int64_t scratch_bytes, const void* dx_addend, int phase, void* stream) {
+    return ln_bwd_impl(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, M, C, x_dtype, dy_dtype, scratch, scratch_bytes, dx_addend, 0, 0,
+                       nullptr, nullptr, 1, stream, phase);
+}
+
+int mtli_residual_layernorm_bwd(const void* dy, const void* x_new, const float* gamma, const float* mean, const float* rstd,
+                                void* d_shortcut, void* d_branch, float* dgamma, float* dbeta, const float* scale, int64_t B,
+                                int64_t M, int64_t C, int x_dtype, int dy_dtype, void* scratch, int64_t scratch_bytes,
+                                const void* dx_addend, int phase, void* stream) {
+    if (!d_branch) return MTLORA_ERR_NULL;
+    return ln_bwd_impl(dy, x_new, gamma, mean, rstd, d_shortcut, dgamma, dbeta, M, C, x_dtype, dy_dtype, scratch, scratch_bytes,
+                       dx_addend, 0, 0, d_branch, scale, B, stream, phase);
 }
 
 int mtlora_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,

@@ -1503,13 +1503,14 @@ class BlockCall:
     """what one block of a ``SwinBlockRunFn`` call needs besides its tensors: the four linears' metas (seeds drawn, packed factors
     looked up), their frozen-weight copies, the attention geometry.  Built per call by ``SwinTransformerBlock._block_call``."""
     __slots__ = ("has_norm1", "metas", "weights", "mask", "mask_ids", "H", "W", "num_heads", "window_size", "shift", "hidden",
-                 "eps", "attn_scale", "mask_value", "factor_params", "desc", "params", "n_flat")
+                 "eps", "attn_scale", "mask_value", "factor_params", "norm_params", "desc", "params", "n_flat")
 
     def __init__(self, has_norm1, metas, weights, mask, mask_ids, H, W, num_heads, window_size, shift, hidden, eps, attn_scale,
-                 factor_params, mask_value=-100.0):
+                 factor_params, norm_params=(), mask_value=-100.0):
         self.has_norm1, self.metas, self.weights, self.mask, self.mask_ids = has_norm1, metas, weights, mask, mask_ids
         self.H, self.W, self.num_heads, self.window_size, self.shift, self.hidden = H, W, num_heads, window_size, shift, hidden
         self.eps, self.attn_scale, self.mask_value, self.factor_params = eps, attn_scale, mask_value, factor_params
+        self.norm_params = tuple(norm_params)
         self.desc = self.params = None
         self.n_flat = 17 if has_norm1 else 15
 
@@ -1645,7 +1646,9 @@ class SwinBlockRunFn(torch.autograd.Function):
             g.d_next_g, g.d_next_b, g.dbias = lnw[4].data_ptr(), lnw[5].data_ptr(), dbias.data_ptr()
             for i in range(4):
                 g.dA[i], g.dB[i] = fg[2 * i].data_ptr(), fg[2 * i + 1].data_ptr()
-            fparams = c.factor_params
+            # everything phase 2 writes on the side stream: the eight factor gradients and the LayerNorm dgamma / dbeta (their
+            # second-stage reduces ride along, csrc/internal.h) -- none of their Parameters may have a .grad to accumulate into
+            fparams = c.factor_params + c.norm_params
             use_side = (side is not None and side.device == dev and M >= _FACTOR_MIN_M
                         and all(q.grad is None for q in fparams))
             if _side_join_pending(fparams, dev):
@@ -1660,7 +1663,7 @@ class SwinBlockRunFn(torch.autograd.Function):
                 side.wait_event(ev)
                 L.check(lib.mtlora_block_bwd(*args, 2, ctypes.c_void_p(side.cuda_stream)), "mtlora_block_bwd (factor gradients)")
                 _side_mark_pending(fparams, side)
-                for t in (xs[bi], saves[bi], scratch, *fg) + (() if ns[bi] is None else (ns[bi],)):
+                for t in (xs[bi], xs[bi + 1], saves[bi], scratch, lnw, g_n, *fg) + (() if ns[bi] is None else (ns[bi],)):
                     t.record_stream(side)  # allocated on this stream, still in use on the side stream when freed here
             else:
                 L.check(lib.mtlora_block_bwd(*args, 0, L.stream_ptr()), "mtlora_block_bwd")

@@ -354,7 +354,9 @@ class SwinTransformerBlock(nn.Module):
         flat = [self.attn.dense_bias(), s1, s2]
         if has_norm1:
             flat += [self.norm1.weight, self.norm1.bias]
-        flat += [self.norm2.weight, self.norm2.bias, next_norm.weight, next_norm.bias, *fparams]
+        flat += [self.norm2.weight, self.norm2.bias, next_norm.weight, next_norm.bias]
+        call.norm_params = tuple(flat[3:])
+        flat += fparams
         return call, flat
 
     # -- attention half ------------------------------------------------------------------------------

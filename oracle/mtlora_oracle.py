@@ -347,7 +347,10 @@ def _lin(P, pre, x, x_tasks, tasks, stage, mt, train, rng):
     A_s, B_s = P.get(pre + ".lora_shared_A"), P.get(pre + ".lora_shared_B")
     p = mt.DROPOUT[stage] if train else 0.0
     keep = None
-    if p > 0.0 and not x.is_cuda:
+    if p > 0.0 and A_s is not None and hasattr(rng, "keep_mask"):
+        # replayed randomness (tests): the mask some other implementation drew for THIS call, in the row order of x
+        keep = rng.keep_mask(pre, x)
+    elif p > 0.0 and not x.is_cuda:
         keep = torch.rand(x.shape, generator=rng, device="cpu") >= p
     ss = P[pre + ".lora_shared_scale"] if (pre + ".lora_shared_scale") in P else mt.SHARED_SCALE[stage]
     return mtlora_linear(
@@ -360,7 +363,7 @@ def _lin(P, pre, x, x_tasks, tasks, stage, mt, train, rng):
         shared_mode=mt.SHARED_MODE if has_tasks else "matrix",
         keep_mask=keep, p=p,
         lora_norm=(P.get(pre + ".lora_norm.weight"), P.get(pre + ".lora_norm.bias")),
-        torch_dropout=x.is_cuda,
+        torch_dropout=x.is_cuda and keep is None,
     )
 
 
@@ -368,11 +371,15 @@ def _ln(P, pre, x):
     return F.layer_norm(x, (x.shape[-1],), P[pre + ".weight"], P[pre + ".bias"])
 
 
-def _drop_path(x, p, train, rng):
+def _drop_path(x, p, train, rng, tag=None):
     """timm DropPath (per-sample stochastic depth, scale_by_keep) -- timm==0.9.2, third-party;
-    call sites swin_transformer_mtlora.py:290-291, 390, 392, 399-407."""
+    call sites swin_transformer_mtlora.py:290-291, 390, 392, 399-407.  ``rng`` may be a replay object (tests) whose
+    ``droppath(tag, x)`` returns the per-sample factors mask / keep another implementation drew for the residual ``tag``."""
     if p == 0.0 or not train:
         return x
+    if hasattr(rng, "droppath"):
+        f = rng.droppath(tag, x)
+        return x * f.to(x.dtype).to(x.device).view((x.shape[0],) + (1,) * (x.ndim - 1))
     keep = 1.0 - p
     m = (torch.rand((x.shape[0],) + (1,) * (x.ndim - 1), generator=rng) < keep).to(x.dtype).to(x.device)
     return x * m / keep
@@ -402,8 +409,8 @@ def swin_block(P, pre, x, H, W, num_heads, ws, shift, tasks, stage, mt, drop_pat
         xt = {}
         for t in tasks:
             m = window_merge_and_roll(aw_t[t].reshape(-1, ws, ws, C), shift, ws, H, W).reshape(B, L, C)
-            xt[t] = shortcut + _drop_path(m, drop_path, train, rng)
-    x = shortcut + _drop_path(x, drop_path, train, rng)           # :392
+            xt[t] = shortcut + _drop_path(m, drop_path, train, rng, (pre, "attn", t))
+    x = shortcut + _drop_path(x, drop_path, train, rng, (pre, "attn", None))           # :392
     # --- Mlp (:68-81)
     h, h_t = _lin(P, pre + ".mlp.fc1", _ln(P, pre + ".norm2", x),
                   {t: _ln(P, pre + ".norm2", xt[t]) for t in tasks} if xt is not None else None,
@@ -413,12 +420,12 @@ def swin_block(P, pre, x, H, W, num_heads, ws, shift, tasks, stage, mt, drop_pat
         h_t = {t: F.gelu(v) for t, v in h_t.items()}
     y, y_t = _lin(P, pre + ".mlp.fc2", h, h_t, tasks, stage, mt, train, rng)
     if y_t is None:                                               # :398-408
-        return x + _drop_path(y, drop_path, train, rng), None
+        return x + _drop_path(y, drop_path, train, rng, (pre, "mlp", None)), None
     out_t = {}
     for t in tasks:
-        d = _drop_path(y_t[t], drop_path, train, rng)
+        d = _drop_path(y_t[t], drop_path, train, rng, (pre, "mlp", t))
         out_t[t] = d if xt is None else xt[t] + d
-    return x + _drop_path(y, drop_path, train, rng), out_t
+    return x + _drop_path(y, drop_path, train, rng, (pre, "mlp", None)), out_t
 
 
 def patch_merging(P, pre, x, H, W, stage, mt, train=False, rng=None):

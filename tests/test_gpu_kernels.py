@@ -26,8 +26,23 @@ def rel_err(a, b):
     return ((a - b).abs().max() / b.abs().max().clamp_min(1e-12)).item()
 
 
-def assert_close(a, b, dtype, what="", mult=1.0):
+def _log_parity(what, err, tol, mult):
+    """every measured error goes to gpurun_out/kernel_parity.jsonl (pulled back from the GPU box and committed as
+    profiles/rNN_kernel_parity.jsonl): the record the tolerance multipliers below are set from"""
+    import json
+    import os
+    try:
+        os.makedirs("gpurun_out", exist_ok=True)
+        with open("gpurun_out/kernel_parity.jsonl", "a") as f:
+            f.write(json.dumps({"test": os.environ.get("PYTEST_CURRENT_TEST", "").split(" ")[0], "what": what, "err": err,
+                                "tol": tol, "mult": mult}) + "\n")
+    except OSError:
+        pass
+
+
+def assert_close(a, b, dtype, what=""):
     e = rel_err(a, b)
+    _log_parity(what, e, TOL[dtype], mult)
     assert e <= TOL[dtype] * mult, f"{what}: rel err {e:.3e} > {TOL[dtype] * mult:.1e}"
 
 
@@ -142,16 +157,16 @@ def test_linear_golden(golden, case, dtype):
     else:
         assert yt is None
     loss.backward()
-    assert_close(x.grad, c["dx"], dtype, "dx", mult=2)
+    assert_close(x.grad, c["dx"], dtype, "dx")
     if xt is not None:
         for t in c["tasks"]:
-            assert_close(xt[t].grad, c["dx_tasks"][t], dtype, f"dx[{t}]", mult=2)
+            assert_close(xt[t].grad, c["dx_tasks"][t], dtype, f"dx[{t}]")
     named = dict(m.named_parameters())
     for n, g in c["grads"].items():
         if n.startswith("linear."):
             assert named[n].grad is None  # frozen
             continue
-        assert_close(named[n].grad, g, dtype, f"grad {n}", mult=2)
+        assert_close(named[n].grad, g, dtype, f"grad {n}")
 
 
 def _oracle_linear(m, x, xt, keep=None, p=0.0):
@@ -219,12 +234,12 @@ def test_linear_random_vs_oracle(shape, dtype):
         loss_o = loss_o + (yto[t] * gyt[t].double().cpu()).sum()
     loss.backward()
     loss_o.backward()
-    assert_close(x.grad, xs.grad, dtype, "dx", mult=2)
+    assert_close(x.grad, xs.grad, dtype, "dx")
     for t in (tasks or []) if use_xt else []:
-        assert_close(xt[t].grad, xts[t].grad, dtype, f"dx[{t}]", mult=2)
+        assert_close(xt[t].grad, xts[t].grad, dtype, f"dx[{t}]")
     for n, p in m.named_parameters():
         if p.requires_grad:
-            assert_close(p.grad, P[n].grad, dtype, f"grad {n}", mult=3)
+            assert_close(p.grad, P[n].grad, dtype, f"grad {n}")
 
 
 @pytest.mark.parametrize("geom", [(333, 96, 160, torch.float32), (333, 96, 192, torch.bfloat16), (1100, 384, 96, torch.bfloat16),
@@ -266,10 +281,10 @@ def test_linear_dropout_matches_specified_generator(use_xt, geom):
         loss, loss_o = loss + yt[t].float().sum() * (i + 1), loss_o + yto[t].sum() * (i + 1)
     loss.backward()
     loss_o.backward()
-    assert_close(x.grad, xs.grad, dtype, "dx", mult=2)
+    assert_close(x.grad, xs.grad, dtype, "dx")
     for n, p in m.named_parameters():
         if p.requires_grad:
-            assert_close(p.grad, P[n].grad, dtype, f"grad {n}", mult=3)
+            assert_close(p.grad, P[n].grad, dtype, f"grad {n}")
     m.eval()
     y2, _ = m(x, xt)
     P, xs, xts, yo2, _ = _oracle_linear(m, x, xt)
@@ -359,9 +374,9 @@ def test_linear_dropout_t0_matches_specified_generator(geom):
     assert_close(got["y"], ref["y"], dtype, "y")
     if kind == "gelu_out":
         assert_close(got["a"], ref["a"], dtype, "gelu(y)")
-    assert_close(got["dx"], ref["dx"], dtype, "dx", mult=2)
-    assert_close(got["dA"], ref["dA"], dtype, "dA", mult=3)
-    assert_close(got["dB"], ref["dB"], dtype, "dB", mult=3)
+    assert_close(got["dx"], ref["dx"], dtype, "dx")
+    assert_close(got["dA"], ref["dA"], dtype, "dA")
+    assert_close(got["dB"], ref["dB"], dtype, "dB")
 
 
 def test_linear_unused_output_gets_none_grad():
@@ -459,8 +474,8 @@ def test_attention_core_vs_oracle(cfg, dtype):
     g = torch.randn_like(out)
     out.backward(g)
     ref.backward(g.double().cpu())
-    assert_close(qkv_img.grad, q64.grad, dtype, "dqkv", mult=2)
-    assert_close(bias.grad, b64.grad, dtype, "dbias", mult=3)
+    assert_close(qkv_img.grad, q64.grad, dtype, "dqkv")
+    assert_close(bias.grad, b64.grad, dtype, "dbias")
     # window-major layout
     qkv_win = win.detach().to(dev()).to(dtype).contiguous().requires_grad_(True)
     nW = 1 if mask is None else mask.shape[0]
@@ -474,8 +489,8 @@ def test_attention_core_vs_oracle(cfg, dtype):
         out_d = Fn.WindowAttentionFn.apply(meta, q2, b2, mask_d, None)
         assert_close(out_d, ref, dtype, "attn out (dense mask)")
         out_d.backward(g)
-        assert_close(q2.grad, q64.grad, dtype, "dqkv (dense mask)", mult=2)
-        assert_close(b2.grad, b64.grad, dtype, "dbias (dense mask)", mult=3)
+        assert_close(q2.grad, q64.grad, dtype, "dqkv (dense mask)")
+        assert_close(b2.grad, b64.grad, dtype, "dbias (dense mask)")
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
@@ -499,10 +514,10 @@ def test_window_attention_module_golden(golden, case, dtype):
             assert_close(yt[t], c["y_tasks"][t], dtype, f"y[{t}]")
             loss = loss + (yt[t].float() * O.det_tensor(f"att.{case}.gy.{t}", y.shape, 1.0).to(dev())).sum()
     loss.backward()
-    assert_close(x.grad, c["dx"], dtype, "dx", mult=3)
+    assert_close(x.grad, c["dx"], dtype, "dx")
     named = dict(att.named_parameters())
     for n, g in c["grads"].items():
-        assert_close(named[n].grad, g, dtype, f"grad {n}", mult=3)
+        assert_close(named[n].grad, g, dtype, f"grad {n}")
 
 
 # ------------------------------------------------------------------------------------------------
@@ -534,7 +549,7 @@ def test_swin_block_golden(golden, case, dtype, layout):
     else:
         assert yt is None
     loss.backward()
-    assert_close(x.grad, c["dx"], dtype, "dx", mult=3)
+    assert_close(x.grad, c["dx"], dtype, "dx")
     named = dict(blk.named_parameters())
     for n, g in c["grads"].items():
         if isinstance(g, dict):
@@ -542,7 +557,7 @@ def test_swin_block_golden(golden, case, dtype, layout):
             ref = g["samples"]
             assert ((s[g["idx"]] - ref).abs().max() / ref.abs().max().clamp_min(1e-12)).item() <= TOL[dtype] * 3, n
         else:
-            assert_close(named[n].grad, g, dtype, f"grad {n}", mult=3)
+            assert_close(named[n].grad, g, dtype, f"grad {n}")
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
@@ -633,7 +648,7 @@ def test_backbone_options_golden(golden, case, dtype):
         # bf16: a scale gradient is ONE scalar = <dB, B> / s, an inner product of two near-zero-mean tensors, and the bf16
         # rounding of the activations behind dB leaves noise of ~5-10 % of the LARGEST scale gradient on each of them (fp32
         # holds 3e-3 per scalar, above): the 16 scalars are compared as one vector, relative to its largest entry
-        assert_close(torch.cat([a for a, _ in scale_grads]), torch.cat([b for _, b in scale_grads]), dtype, "scale grads", mult=10)
+        assert_close(torch.cat([a for a, _ in scale_grads]), torch.cat([b for _, b in scale_grads]), dtype, "scale grads", mult=3)
     assert sorted(n for n in c["trainable"] if named[n].grad is None or named[n].grad.abs().max() == 0) == c["grad_is_none"]
 
 
@@ -655,9 +670,9 @@ def test_layernorm_vs_torch(M, C, xdt, ydt):
     g = torch.randn(M, C, device=dev()).to(ydt)
     y.backward(g)
     ref.backward(g.double().cpu())
-    assert_close(x.grad, x64.grad, xdt, "dx", mult=2)
-    assert_close(w.grad, w64.grad, ydt, "dgamma", mult=2)
-    assert_close(b.grad, b64.grad, ydt, "dbeta", mult=2)
+    assert_close(x.grad, x64.grad, xdt, "dx")
+    assert_close(w.grad, w64.grad, ydt, "dgamma")
+    assert_close(b.grad, b64.grad, ydt, "dbeta")
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
@@ -677,14 +692,14 @@ def test_batchnorm_relu_vs_torch(R, C, relu, dtype):
     if relu:
         ref = torch.relu(ref)
     assert_close(y, ref, dtype, "y")
-    assert_close(rm, rm64, torch.float32, "running_mean", mult=5)
-    assert_close(rv, rv64, torch.float32, "running_var", mult=5)
+    assert_close(rm, rm64, torch.float32, "running_mean")
+    assert_close(rv, rv64, torch.float32, "running_var")
     g = torch.randn(R, C, device=dev()).to(dtype)
     y.backward(g)
     ref.backward(g.double().cpu())
-    assert_close(x.grad, x64.grad, dtype, "dx", mult=3)
-    assert_close(w.grad, w64.grad, dtype, "dgamma", mult=3)
-    assert_close(b.grad, b64.grad, dtype, "dbeta", mult=3)
+    assert_close(x.grad, x64.grad, dtype, "dx")
+    assert_close(w.grad, w64.grad, dtype, "dgamma")
+    assert_close(b.grad, b64.grad, dtype, "dbeta")
 
 
 @pytest.mark.parametrize("rdt,ydt", [(torch.float32, torch.bfloat16), (torch.bfloat16, torch.bfloat16), (torch.float32, torch.float32),
@@ -711,9 +726,9 @@ def test_residual_droppath(shared, rdt, ydt):
         if b.grad is None:
             assert a.grad is None
         else:
-            assert_close(a.grad, b.grad, rdt, "dres", mult=2)
+            assert_close(a.grad, b.grad, rdt, "dres")
     for k in (0, 2):
-        assert_close(ys[k].grad, y64[k].grad, ydt, f"dy{k}", mult=2)
+        assert_close(ys[k].grad, y64[k].grad, ydt, f"dy{k}")
     assert ys[1].grad is None
 
 
@@ -743,11 +758,11 @@ def test_residual_layer_norm_fused(rdt, ydt, B, Ltok, C, use_scale):
     yr = torch.nn.functional.layer_norm(xr_q, (C,), w64, bb64, 1e-5)
     torch.autograd.backward([xr_q, yr], [g_skip.double(), g_y.double()])
     assert_close(x_new, xr, rdt, "x_new")
-    assert_close(y, yr, ydt, "y", mult=2)
-    assert_close(sc_.grad, s64.grad, rdt, "d_shortcut", mult=3)
-    assert_close(br.grad, b64.grad, ydt, "d_branch", mult=3)
-    assert_close(w.grad, w64.grad, ydt, "dgamma", mult=4)
-    assert_close(b.grad, bb64.grad, ydt, "dbeta", mult=4)
+    assert_close(y, yr, ydt, "y")
+    assert_close(sc_.grad, s64.grad, rdt, "d_shortcut")
+    assert_close(br.grad, b64.grad, ydt, "d_branch")
+    assert_close(w.grad, w64.grad, ydt, "dgamma")
+    assert_close(b.grad, bb64.grad, ydt, "dbeta")
     # only the skip path used: plain residual backward
     sc2, br2 = sc_.detach().clone().requires_grad_(True), br.detach().clone().requires_grad_(True)
     x2, _ = Fn.ResidualLayerNormFn.apply(sc2, br2, scale, w, b, 1e-5, ydt)
@@ -786,8 +801,8 @@ def test_layer_norm_merge_multi(xdt, autocast, n, B, H, W, C):
     for k in range(n):
         assert torch.equal(xs[k].grad, gx_ref[k])
     dt = ref[0].dtype
-    assert_close(ln.weight.grad, gw_ref.double(), dt, "dgamma", mult=2)
-    assert_close(ln.bias.grad, gb_ref.double(), dt, "dbeta", mult=2)
+    assert_close(ln.weight.grad, gw_ref.double(), dt, "dgamma")
+    assert_close(ln.bias.grad, gb_ref.double(), dt, "dbeta")
 
 
 @pytest.mark.parametrize("use_scale", [True, False])
@@ -830,8 +845,8 @@ def test_residual_merge_norm_streams(rdt, ydt, n, B, H, W, C, use_scale):
             assert torch.equal(t.grad, r)
         else:  # bf16 stream: the unfused path scales the bf16-ROUNDED d_res, the fused kernel scales before rounding
             assert_close(t.grad, r.double(), ydt, f"d_branch{k}")
-    assert_close(ln.weight.grad, gw.double(), ydt, "dgamma", mult=2)
-    assert_close(ln.bias.grad, gb.double(), ydt, "dbeta", mult=2)
+    assert_close(ln.weight.grad, gw.double(), ydt, "dgamma")
+    assert_close(ln.bias.grad, gb.double(), ydt, "dbeta")
 
 
 @pytest.mark.parametrize("use_scale", [True, False])
@@ -869,11 +884,11 @@ def test_residual_layer_norm_multi(rdt, ydt, n, B, Ltok, C, use_scale):
                             [g_skip[k].double() for k in use_x] + [g_y[k].double() for k in use_y])
     for k in range(n):
         assert_close(xs[k], rx[k], rdt, f"x_new{k}")
-        assert_close(ys[k], ry[k], ydt, f"y{k}", mult=2)
-        assert_close(brs[k].grad, br64[k].grad, ydt, f"d_branch{k}", mult=3)
-    assert_close(sc_.grad, s64.grad, rdt, "d_shortcut", mult=4)
-    assert_close(w.grad, w64.grad, ydt, "dgamma", mult=6)
-    assert_close(b.grad, b64.grad, ydt, "dbeta", mult=6)
+        assert_close(ys[k], ry[k], ydt, f"y{k}")
+        assert_close(brs[k].grad, br64[k].grad, ydt, f"d_branch{k}")
+    assert_close(sc_.grad, s64.grad, rdt, "d_shortcut")
+    assert_close(w.grad, w64.grad, ydt, "dgamma")
+    assert_close(b.grad, b64.grad, ydt, "dbeta")
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
@@ -920,7 +935,7 @@ def test_linear_bwd_gelu_fused(dtype, with_tasks):
     for a_, b_ in zip(o0, o1):
         assert torch.equal(a_, b_)
     for i, (a_, b_) in enumerate(zip(g0, g1)):
-        assert_close(b_, a_.double(), dtype, f"dh{i}", mult=2)
+        assert_close(b_, a_.double(), dtype, f"dh{i}")
     assert p0.keys() == p1.keys()
     for k in p0:
         assert torch.equal(p0[k], p1[k]), k
@@ -978,12 +993,12 @@ def test_mlp_gelu_fused_both_ways(dtype, with_tasks):
     assert torch.equal(h0, h1)
     assert_close(a1, a0.double(), dtype, "gelu(h)")
     for i, (u, v) in enumerate(zip(o0, o1)):
-        assert_close(v, u.double(), dtype, f"y{i}", mult=2)
+        assert_close(v, u.double(), dtype, f"y{i}")
     for i, (u, v) in enumerate(zip(g0, g1)):
-        assert_close(v, u.double(), dtype, f"dx{i}", mult=3)
+        assert_close(v, u.double(), dtype, f"dx{i}")
     assert p0.keys() == p1.keys() and len(p0) >= 4
     for k in p0:
-        assert_close(p1[k], p0[k].double(), dtype, k, mult=3)
+        assert_close(p1[k], p0[k].double(), dtype, k)
 
 
 
@@ -1085,10 +1100,10 @@ def test_linear_seed_offset_is_added_on_device():
         assert_close(y, yo, torch.float32, "y")
         y.sum().backward()
         yo.sum().backward()
-        assert_close(x.grad, xs.grad, torch.float32, "dx", mult=2)
+        assert_close(x.grad, xs.grad, torch.float32, "dx")
         for n, p in m.named_parameters():
             if p.requires_grad:
-                assert_close(p.grad, P[n].grad, torch.float32, f"grad {n}", mult=3)
+                assert_close(p.grad, P[n].grad, torch.float32, f"grad {n}")
         # a different offset -> a different mask
         off.add_(12345)
         y2, _ = m(x, None)   # NB: draws the next host seed as well; only checks that the result moved
@@ -1183,7 +1198,7 @@ def test_concat_upsample_vs_torch(dtype):
     g3 = g.view(B, H, W, ld).double().cpu()
     sum((u.cpu() * g3[..., o:o + c]).sum() for o, c, u in zip(offs, chans, ups)).backward()
     for m, r in zip(maps, refs):
-        assert_close(m.grad, r.grad, dtype, "grad", mult=2)
+        assert_close(m.grad, r.grad, dtype, "grad")
 
 
 # ------------------------------------------------------------------------------------------------
@@ -1226,9 +1241,9 @@ def test_full_size_linear_rows_vs_oracle():
         assert_close(yt[t][idx], yto[t], dtype, f"y[{t}] rows")
         lo = lo + (yto[t] * gt[t][idx].double().cpu()).sum()
     lo.backward()
-    assert_close(x.grad[idx], xo.grad, dtype, "dx rows", mult=2)
+    assert_close(x.grad[idx], xo.grad, dtype, "dx rows")
     for t in tasks:
-        assert_close(xt[t].grad[idx], xto[t].grad, dtype, f"dx[{t}] rows", mult=2)
+        assert_close(xt[t].grad[idx], xto[t].grad, dtype, f"dx[{t}] rows")
     keep = torch.ones(M, dtype=torch.bool, device=dev())
     keep[idx] = False
     assert x.grad[keep].abs().max().item() == 0.0   # rows without an output gradient get an exactly zero dX
@@ -1311,9 +1326,9 @@ def test_pq_kernel_off_grid_shapes(geom):
     finally:
         Fn.set_tuning(**prev)
     assert_close(got["y"], ref["y"], dtype, "y")
-    assert_close(got["dx"], ref["dx"], dtype, "dx", mult=2)
-    assert_close(got["dA"], ref["dA"], dtype, "dA", mult=3)
-    assert_close(got["dB"], ref["dB"], dtype, "dB", mult=3)
+    assert_close(got["dx"], ref["dx"], dtype, "dx")
+    assert_close(got["dA"], ref["dA"], dtype, "dA")
+    assert_close(got["dB"], ref["dB"], dtype, "dB")
 
 
 _M0, _M1, _M2 = 32 * 112 * 112, 32 * 56 * 56, 32 * 28 * 28
@@ -1346,9 +1361,9 @@ def test_full_size_linear_t0_train_vs_oracle(name):
     assert_close(got["y"], ref["y"], dtype, f"{name} y")
     if kind == "gelu_out":
         assert_close(got["a"], ref["a"], dtype, f"{name} gelu(y)")
-    assert_close(got["dx"], ref["dx"], dtype, f"{name} dx", mult=2)
-    assert_close(got["dA"], ref["dA"], dtype, f"{name} dA", mult=3)
-    assert_close(got["dB"], ref["dB"], dtype, f"{name} dB", mult=3)
+    assert_close(got["dx"], ref["dx"], dtype, f"{name} dx")
+    assert_close(got["dA"], ref["dA"], dtype, f"{name} dA")
+    assert_close(got["dB"], ref["dB"], dtype, f"{name} dB")
     # per-row check as well: max |err| relative to the ROW's own scale must not blow up anywhere (a wrong slab / tile shows here
     # even when the global maximum hides it)
     e = (got["y"].double() - ref["y"]).abs().amax(1) / ref["y"].abs().amax(1).clamp_min(1e-6)
@@ -1357,25 +1372,37 @@ def test_full_size_linear_t0_train_vs_oracle(name):
     assert e.max().item() < 0.1, f"{name}: worst row of dx off by {e.max().item():.3e} (row {int(e.argmax())})"
 
 
-FULL_T4 = {  # the task-enabled layers of BASELINE configs[1] (last block of a stage), full M: name -> (M, K, N, x_tasks, gate)
+_MB1, _MB2 = 16 * 56 * 56, 16 * 28 * 28
+FULL_T4 = {  # the task-enabled layers (last block of a stage), full M: name -> (M, K, N, x_tasks, gate[, n_tasks, r_shared, r_task])
+    # BASELINE configs[1]: 4 tasks of rank 4 next to the shared rank 64
     "s0.projT": (_M0, 96, 96, False, False), "s0.fc1T": (_M0, 96, 384, True, False), "s0.fc2T": (_M0, 384, 96, True, True),
     "s1.fc1T": (_M1, 192, 768, True, False), "s1.fc2T": (_M1, 768, 192, True, True), "s2.fc2T": (_M2, 1536, 384, True, True),
+    # BASELINE configs[3] (Swin-B / 448, B = 16): 4 tasks, rank 128 shared AND per task -> R = 640, the multi-source k_pq passes (one
+    # grid slice per source), with and without the tasks' own inputs, with the GELU' gates
+    "b1.projT": (_MB1, 256, 256, False, False, 4, 128, 128), "b1.fc1T": (_MB1, 256, 1024, True, False, 4, 128, 128),
+    "b1.fc2T": (_MB1, 1024, 256, True, True, 4, 128, 128), "b2.fc2T": (_MB2, 2048, 512, True, True, 4, 128, 128),
+    # BASELINE configs[4]: 8 tasks at the two ends of the rank sweep
+    "c5r4.s0.fc1T": (_M0, 96, 384, True, False, 8, 4, 4), "c5r4.s0.fc2T": (_M0, 384, 96, True, True, 8, 4, 4),
+    "c5r256.s1.fc1T": (_M1, 192, 768, True, False, 8, 256, 256), "c5r256.s1.fc2T": (_M1, 768, 192, True, True, 8, 256, 256),
 }
+_TASKS8 = ["semseg", "normals", "sal", "human_parts", "t4", "t5", "t6", "t7"]
 
 
 @pytest.mark.parametrize("name", list(FULL_T4))
 def test_full_size_linear_t4_train_vs_oracle(name):
     """the layers WITH task outputs at full size, bf16, TRAIN mode (p = 0.05, specified mask): 4 tasks of rank 4 next to the shared rank
-    64, with and without their own task inputs, fc2 with the GELU' gates -- all 1 + T outputs, dX, every dX_t and all ten factor
-    gradients reduced over the full M against the fp64 oracle on the GPU (k_sp_proj / k_sp_projsum / k_rank_out / the multi-output tile
-    kernels / k_sp_tn in the regime the benchmark times; VERDICT r03 weak 1: the one full-size test of round 3 checked no factor gradient)."""
+    64 (c2), 4 tasks of rank 128 next to a shared rank 128 (c4), 8 tasks of rank 4 / 256 (c5), with and without their own task
+    inputs, fc2 with the GELU' gates -- all 1 + T outputs, dX, every dX_t and all 2 + 2 T factor gradients reduced over the full M
+    against the fp64 oracle on the GPU (k_sp_proj / k_sp_projsum / k_pq multi-source / k_rank_out / the multi-output tile kernels /
+    k_sp_tn in the regime the benchmark times)."""
     from mtlora_amd import functional as Fn
     from mtlora_amd.lora import MTLoRALinear
-    M, K, N, use_xt, gate = FULL_T4[name]
-    tasks = ["semseg", "normals", "sal", "human_parts"]
+    M, K, N, use_xt, gate, *more = FULL_T4[name]
+    nt, r_s, r_t = more if more else (4, 64, 4)
+    tasks = _TASKS8[:nt]
     dtype, p = torch.bfloat16, 0.05
     torch.manual_seed(len(name) + K)
-    m = MTLoRALinear(K, N, r={"shared": 64, **{t: 4 for t in tasks}}, lora_shared_scale=4.0, lora_task_scale={t: 4.0 for t in tasks},
+    m = MTLoRALinear(K, N, r={"shared": r_s, **{t: r_t for t in tasks}}, lora_shared_scale=4.0, lora_task_scale={t: 4.0 for t in tasks},
                      lora_dropout=p, tasks=tasks).to(dev())
     with torch.no_grad():
         for n_, q in m.named_parameters():
@@ -1418,10 +1445,66 @@ def test_full_size_linear_t4_train_vs_oracle(name):
             hd = leaf.detach().double().requires_grad_(True)
             torch.nn.functional.gelu(hd).backward(ref)
             ref = hd.grad
-        assert_close(leaf.grad, ref, dtype, f"{name} dx[{i}]", mult=2)
+        assert_close(leaf.grad, ref, dtype, f"{name} dx[{i}]")
     for n_, q in m.named_parameters():
         if q.requires_grad:
-            assert_close(q.grad, P[n_].grad, dtype, f"{name} grad {n_}", mult=3)
+            assert_close(q.grad, P[n_].grad, dtype, f"{name} grad {n_}")
+
+
+@pytest.mark.parametrize("geom", [
+    # (M, K, N, n_tasks, r_shared, r_task, x_tasks, dtype, p): MULTI-SOURCE k_pq (one grid slice per source) forced on off-grid shapes
+    (1000, 72, 104, 4, 24, 24, True, torch.bfloat16, 0.25),    # ragged M and K, rank stride 32 per source, masked shared source only
+    (4097, 136, 72, 4, 128, 128, True, torch.bfloat16, 0.1),   # c4's geometry in small: R = 640, five sources, one row past a tile
+    (4097, 136, 72, 4, 128, 128, False, torch.bfloat16, 0.1),  # the tasks read D(X): ONE masked source, five column segments
+    (700, 200, 264, 8, 40, 16, True, torch.float16, 0.0),      # 8 tasks, unmasked (column-split wave grid), fp16
+    (26000, 96, 96, 3, 64, 72, True, torch.bfloat16, 0.05),    # > 1.25 residency rounds: the 128-row tiles, per source
+])
+def test_pq_kernel_multi_source_shapes(geom):
+    """k_pq with SEVERAL activation sources / output gradients (the T > 0 layers whose projection rows do not fit in LDS: Swin-B at
+    rank 128, the r = 64 / 256 points of the 8-task sweep) forced on shapes off its tile grid: all outputs, dX, dX_t and every factor
+    gradient against the fp64 oracle with the specified mask (the multi-source launches beyond one residency
+    round were only ever run by bench.py)."""
+    from mtlora_amd import functional as Fn
+    from mtlora_amd.lora import MTLoRALinear
+    M, K, N, nt, r_s, r_t, use_xt, dtype, p = geom
+    tasks = _TASKS8[:nt]
+    torch.manual_seed(M + K + nt)
+    m = MTLoRALinear(K, N, r={"shared": r_s, **{t: r_t for t in tasks}}, lora_shared_scale=2.0, lora_task_scale={t: 1.5 for t in tasks},
+                     lora_dropout=p, tasks=tasks).to(dev())
+    with torch.no_grad():
+        for n_, q in m.named_parameters():
+            q.copy_((torch.randn_like(q) * (0.05 if "lora" in n_ else 0.02)).to(dtype).float())
+    m.linear.weight.requires_grad_(False)
+    m.linear.bias.requires_grad_(False)
+    m.train()
+    xs_in = [(0.5 * torch.randn(M, K, device=dev())).to(dtype).requires_grad_(True) for _ in range(1 + (nt if use_xt else 0))]
+    prev = Fn.set_tuning(projk=3)
+    try:
+        c0 = Fn._seed_counter
+        y, yt = m(xs_in[0], {t: xs_in[1 + i] for i, t in enumerate(tasks)} if use_xt else None)
+        Fn._seed_counter = c0
+        seed = Fn.next_seed() if p > 0 else 0
+        outs = [y] + [yt[t] for t in tasks]
+        gys = [torch.randn(M, N, device=dev()).to(dtype) for _ in outs]
+        torch.autograd.backward(outs, gys)
+    finally:
+        Fn.set_tuning(**prev)
+    gdev = torch.device("cpu") if M < 5000 else dev()
+    keep = O.dropout_keep_mask_t(seed, 0, M, K, p, device=gdev) if p > 0 else None
+    P = {k: v.detach().double().to(gdev).requires_grad_(v.requires_grad) for k, v in m.named_parameters()}
+    xo = [x.detach().double().to(gdev).requires_grad_(True) for x in xs_in]
+    yo, yto = O.mtlora_linear(xo[0], P["linear.weight"], P["linear.bias"], P["lora_shared_A"], P["lora_shared_B"], m.lora_shared_scale,
+                              tasks=tasks, A_t={t: P["lora_tasks_A." + t] for t in tasks}, B_t={t: P["lora_tasks_B." + t] for t in tasks},
+                              scale_t=m.lora_task_scale, x_tasks={t: xo[1 + i] for i, t in enumerate(tasks)} if use_xt else None,
+                              keep_mask=keep, p=p)
+    torch.autograd.backward([yo] + [yto[t] for t in tasks], [g.double().to(gdev) for g in gys])
+    for i, (a, b) in enumerate(zip(outs, [yo] + [yto[t] for t in tasks])):
+        assert_close(a, b.detach(), dtype, f"y[{i}]")
+    for i, x in enumerate(xs_in):
+        assert_close(x.grad, xo[i].grad, dtype, f"dx[{i}]")
+    for n_, q in m.named_parameters():
+        if q.requires_grad:
+            assert_close(q.grad, P[n_].grad, dtype, f"grad {n_}")
 
 
 def test_full_size_attention_windows_vs_oracle():
@@ -1448,7 +1531,7 @@ def test_full_size_attention_windows_vs_oracle():
     ref = O.window_merge_and_roll(core.reshape(-1, ws, ws, C), shift, ws, H, W)
     assert_close(out[sel], ref, dtype, "attn out (2 of 32 images)")
     ref.backward(g[sel].double().cpu())
-    assert_close(qkv.grad[sel], q64.grad, dtype, "dqkv", mult=2)
+    assert_close(qkv.grad[sel], q64.grad, dtype, "dqkv")
     assert qkv.grad[1:B - 1].abs().max().item() == 0.0
 
 
@@ -1580,9 +1663,9 @@ def test_split_reduction_linear_vs_f_linear(autocast, shape):
     yr = torch.nn.functional.linear(xr, wr, br)
     yr.backward(gy.double().cpu())
     assert_close(y, yr, dt, "y")
-    assert_close(x.grad, xr.grad, dt, "dx", mult=2)
-    assert_close(w.grad, wr.grad, dt, "dw", mult=3)
-    assert_close(b.grad, br.grad, dt, "db", mult=3)
+    assert_close(x.grad, xr.grad, dt, "dx")
+    assert_close(w.grad, wr.grad, dt, "dw")
+    assert_close(b.grad, br.grad, dt, "db")
     b.grad = None
     with torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
         Fn.linear_big_m(x, w, b, feeds_batchnorm=True).backward(gy.to(dt))

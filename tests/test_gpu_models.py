@@ -31,7 +31,7 @@ def _hip_loss(model, crit, img, tg, amp, concurrent=None):
                                   concurrent=concurrent))
 
 
-def _oracle_run(sd, trainable, img, tg, cfg, tasks, dtype, amp, train, device=None):
+def _oracle_run(sd, trainable, img, tg, cfg, tasks, dtype, amp, train, device=None, rng=None):
     """oracle.full_model + multi_task_loss in `dtype` (fp64 = the reference values; fp32 under bf16 autocast = the
     reference's own eager reduced-precision path); returns loss, per-task losses, {name: grad}.  Runs through ATen on the
     GPU; if this ROCm build lacks an fp64 kernel for one of the ops, the same code runs on the host cores instead."""
@@ -44,13 +44,13 @@ def _oracle_run(sd, trainable, img, tg, cfg, tasks, dtype, amp, train, device=No
         x = img.to(device=device, dtype=dtype)
         tgt = {t: v.to(device=device, dtype=dtype) for t, v in tg.items()}
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
-            out = O.full_model(P, x, cfg, train=train, rng=torch.Generator().manual_seed(0))
+            out = O.full_model(P, x, cfg, train=train, rng=rng if rng is not None else torch.Generator().manual_seed(0))
             loss, per = O.multi_task_loss({k: v.float() if amp else v for k, v in out.items()}, tgt, tasks)
         loss.backward()
     except RuntimeError:
         if device.type == "cpu" or amp:
             raise
-        return _oracle_run(sd, trainable, img, tg, cfg, tasks, dtype, amp, train, torch.device("cpu"))
+        return _oracle_run(sd, trainable, img, tg, cfg, tasks, dtype, amp, train, torch.device("cpu"), rng)
     return (loss.detach().cpu(), {t: v.detach().cpu() for t, v in per.items()},
             {k: (None if P[k].grad is None else P[k].grad.cpu()) for k in trainable})
 
@@ -112,8 +112,15 @@ def test_config_model_vs_oracle(case, amp):
 
     cfg = O.swin_t_cfg(img_size=224, tasks=tasks, r_shared=row["r_shared"], r_task=row["r_task"], embed_dim=row["embed_dim"],
                        depths=row["depths"], num_heads=row["num_heads"], drop_path_rate=0.0, dropout=0.0)
+    _compare_with_oracle(case, amp, model, sd, loss, per, img, tg, cfg, tasks)
+
+
+def _compare_with_oracle(case, amp, model, sd, loss, per, img, tg, cfg, tasks, rng=None):
+    """loss, per-task losses and every trainable gradient of ``model`` (already run: ``loss.backward()`` done) against the oracle in
+    fp64 on the state dict ``sd`` the run started from, calibrated by the oracle's own run at the model's precision (see
+    test_config_model_vs_oracle).  ``rng``: replayed randomness for train-mode dropout / DropPath (oracle ``_lin`` / ``_drop_path``)."""
     trainable = {n for n, p in model.named_parameters() if p.requires_grad}
-    rl, rper, rg = _oracle_run(sd, trainable, img, tg, cfg, tasks, torch.float64, False, True)
+    rl, rper, rg = _oracle_run(sd, trainable, img, tg, cfg, tasks, torch.float64, False, True, rng=rng)
     grads = {n: p.grad for n, p in model.named_parameters() if p.requires_grad}
     bn_bias = {n for n in trainable if n.endswith("last_layer.0.bias")}  # in front of a BatchNorm: gradient analytically 0
     errs, gmax = _grad_errors(grads, rg, skip=bn_bias)
@@ -127,7 +134,7 @@ def test_config_model_vs_oracle(case, amp):
     # calibration: the reference's OWN eager dataflow at the same precision (fp32, or fp32 parameters under bf16 autocast) on
     # the same parameters / batch, against the same fp64 values.  A gradient the eager path itself only resolves to x % is
     # held to max(floor, 2x) -- never looser than what the reference delivers, never tighter than its own rounding noise.
-    el, _, eg = _oracle_run(sd, trainable, img, tg, cfg, tasks, torch.float32, amp, True)
+    el, _, eg = _oracle_run(sd, trainable, img, tg, cfg, tasks, torch.float32, amp, True, rng=rng)
     eerrs, _ = _grad_errors(eg, rg, skip=bn_bias)
     assert abs(el.item() - rl.item()) <= (5e-2 if amp else 1e-3) * abs(rl.item())  # sanity of the calibration run itself
     floor = 1e-2 if amp else 5e-3
@@ -170,6 +177,95 @@ def test_config_model_vs_oracle(case, amp):
     # use atomics)
     worst = {n: v for n, v in bad.items() if v[0] > max(2e-2, 8.0 * v[1]) and grads[n].numel() >= 64}
     assert not worst, sorted(worst.items(), key=lambda kv: -kv[1][0])[:5]
+
+
+class _ReplayRandomness:
+    """the dropout masks and DropPath factors the HIP model drew in ONE forward, handed to the oracle (``rng`` of oracle._lin /
+    oracle._drop_path): masks from the specified generator (oracle.dropout_keep_mask_t of each layer's recorded seed, keyed by the
+    row index in IMAGE order -- the HIP path never leaves that order -- and permuted into the reference's window order for qkv /
+    proj), DropPath factors as recorded from functional.droppath_scale."""
+
+    def __init__(self, seeds, factors, blocks, tasks, p):
+        self.seeds, self.factors, self.blocks, self.tasks, self.p = seeds, factors, blocks, list(tasks), p
+
+    def keep_mask(self, pre, x):
+        blk = pre.rsplit(".", 2)[0]
+        B, H, W, ws, shift = self.blocks[blk]
+        K = x.shape[-1]
+        m = O.dropout_keep_mask_t(self.seeds[pre], 0, B * H * W, K, self.p, device=x.device)
+        if ".attn." in pre:  # the reference runs qkv / proj on window-ordered tokens (swin_transformer_mtlora.py:336-353)
+            m = O.roll_and_window_partition(m.view(B, H, W, K), shift, ws).reshape(-1, ws * ws, K)
+        return m.reshape(x.shape)
+
+    def droppath(self, tag, x):
+        blk, which, t = tag
+        f = self.factors[(blk, which)]
+        return f[0 if t is None else 1 + self.tasks.index(t)]
+
+
+@pytest.mark.parametrize("amp", [False, True], ids=["fp32", "bf16_streams"])
+def test_c2_train_mode_model_vs_oracle(amp):
+    """BASELINE configs[1] as the benchmark runs it -- 448 px, TRAIN mode with LoRA dropout 0.05 and DropPath 0.2, the one-call
+    blocks, the factor packer's signature bookkeeping, the DropPath pool, the per-task streams -- against the fp64 oracle fed with
+    the SAME randomness: every layer's dropout seed and every residual's DropPath factors are recorded while the HIP model runs,
+    the oracle rebuilds the masks with the specified generator (the composition of the per-layer seeds across
+    48 layers was only ever compared HIP-vs-HIP)."""
+    from mtlora_amd import functional as Fn
+    from mtlora_amd import mtl_harness as H
+    row = H.config("c2")
+    tasks = list(row["tasks"])
+    p_drop, dpr = 0.05, 0.2
+    torch.manual_seed(17)
+    model = H.build_config_model("c2", seed=3, img_size=448, drop_path_rate=dpr, DROPOUT=[p_drop] * 4).to(dev())
+    _condition_normals_heads(model, tasks)
+    model.train()
+    crit = H.MultiTaskLoss(tasks)
+    img, tg = H.synthetic_batch(2, 448, tasks, seed=5, device=dev())
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    seeds, dps = [], []
+    keep_ns, keep_dp = Fn.next_seed, Fn.droppath_scale
+
+    def rec_seed():
+        s_ = keep_ns()
+        seeds.append(s_)
+        return s_
+
+    def rec_dp(n, B, keep, device):
+        f = keep_dp(n, B, keep, device)
+        dps.append(f.detach().clone())
+        return f
+
+    Fn.next_seed, Fn.droppath_scale = rec_seed, rec_dp
+    try:
+        loss, per = _hip_loss(model, crit, img, tg, amp, concurrent=True if amp else False)
+    finally:
+        Fn.next_seed, Fn.droppath_scale = keep_ns, keep_dp
+    loss.backward()
+    torch.cuda.synchronize()
+    # which call drew what: four MTLoRALinear calls (qkv, proj, fc1, fc2) and -- where the block's drop_prob > 0 -- two residuals per
+    # block, in model order
+    bb = model.backbone
+    seed_of, fac_of, blocks = {}, {}, {}
+    si = di = 0
+    for i, layer in enumerate(bb.layers):
+        for j, blk in enumerate(layer.blocks):
+            pre = f"backbone.layers.{i}.blocks.{j}"
+            Hh, Ww = blk.input_resolution
+            blocks[pre] = (2, Hh, Ww, blk.window_size, blk.shift_size)
+            for nm in ("attn.qkv", "attn.proj", "mlp.fc1", "mlp.fc2"):
+                seed_of[f"{pre}.{nm}"] = seeds[si]
+                si += 1
+            if getattr(blk.drop_path, "drop_prob", 0.0) > 0.0:
+                for which in ("attn", "mlp"):
+                    f = dps[di]
+                    fac_of[(pre, which)] = f if f.dim() == 2 else f.view(1, -1)
+                    assert fac_of[(pre, which)].shape[0] == (1 + len(tasks) if blk.lora else 1), (pre, which, f.shape)
+                    di += 1
+    assert si == len(seeds) == 48 and di == len(dps) == 22, (si, len(seeds), di, len(dps))
+    cfg = O.swin_t_cfg(img_size=448, tasks=tasks, r_shared=row["r_shared"], r_task=row["r_task"], embed_dim=row["embed_dim"],
+                       depths=row["depths"], num_heads=row["num_heads"], drop_path_rate=dpr, dropout=p_drop)
+    replay = _ReplayRandomness(seed_of, fac_of, blocks, tasks, p_drop)
+    _compare_with_oracle("c2_train_448", amp, model, sd, loss, per, img, tg, cfg, tasks, rng=replay)
 
 
 def _condition_normals_heads(model, tasks):

@@ -120,7 +120,7 @@ def _static_traffic(cfg_name, n_hot, n_all):
     attribute the counters per launch kind (tools/pmc_traffic.py: hot-path launches only); older ones cover every launch of the GEMM
     kernels, i.e. the callers' rank-0 GEMMs too -- labelled as such."""
     suffix = "" if cfg_name == "c2" else "_" + cfg_name.replace(":", "_")
-    for rnd in ("r04", "r03", "r02", "r01"):
+    for rnd in ("r05", "r04", "r03", "r02", "r01"):
         fn = f"{rnd}_pmc_traffic{suffix}.json"
         try:
             pm = json.load(open(os.path.join(ROOT, "profiles", fn)))
@@ -302,7 +302,9 @@ def run_config(args, name, rank, world, dev, steps, warmup, want_roofline, batch
     opt = H.build_optimizer(model, lr=5e-4 * B * world / 512.0,  # main.py:578-583 linear LR scaling
                             capturable=args.graph or args.capturable)
     # replicas start from rank 0's parameters / buffers (GradReducer broadcasts them), not from "every rank seeds 0"
-    reducer = (GradReducer(model.parameters(), bucket_mb=16.0, force=args.force_reducer, buffers=model.buffers())
+    # ONE bucket for the whole trainable set (33.4 MB at c2; SURVEY 8e: over 7 x 153 GB/s xGMI links the exchange is latency-, not
+    # bandwidth-bound, so one large all-reduce lets RCCL pick a direct algorithm instead of several ring passes)
+    reducer = (GradReducer(model.parameters(), bucket_mb=34.0, force=args.force_reducer, buffers=model.buffers())
                if (world > 1 or args.force_reducer) else None)
     img, tg = H.synthetic_batch(B, row["img_size"], tasks, seed=1234 + rank, device=dev)
     torch.manual_seed(1234 + rank)

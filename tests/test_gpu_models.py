@@ -426,10 +426,24 @@ def test_bias_all_trains_frozen_linears_biases():
         assert err <= 2e-3, (n, err)
 
 
-def test_reducer_on_the_real_model_matches_plain_backward():
+@pytest.mark.parametrize("setup", ["buckets_1mb", "one_bucket_34mb_2cores"])
+def test_reducer_on_the_real_model_matches_plain_backward(setup):
     """GradReducer(force=True) on the MTLoRA model itself (RCCL at world size 1, per-task head streams on, bf16 autocast):
     3 train steps must leave loss and every parameter BIT-identical to the run without a reducer -- pack / all-reduce /
-    unpack and the stream joins may not change a single gradient bit; and the construction-time broadcast must be a no-op."""
+    unpack and the stream joins may not change a single gradient bit; and the construction-time broadcast must be a no-op.
+    ``one_bucket_34mb_2cores`` is the configuration bench.py runs at N > 1 (ONE bucket of >= 34 MB, launched from the hook
+    of the last gradient) with the rank pinned to two host cores -- the per-rank host budget of 8 ranks on a 16-core node."""
+    import os
+    affinity = os.sched_getaffinity(0)
+    if setup == "one_bucket_34mb_2cores":
+        os.sched_setaffinity(0, set(sorted(affinity)[:2]))
+    try:
+        _reducer_case(34.0 if setup == "one_bucket_34mb_2cores" else 1.0)
+    finally:
+        os.sched_setaffinity(0, affinity)
+
+
+def _reducer_case(bucket_mb):
     import os
     import torch.distributed as dist
     from mtlora_amd import mtl_harness as H
@@ -450,9 +464,9 @@ def test_reducer_on_the_real_model_matches_plain_backward():
             Fn.droppath_reset()   # ... and the same DropPath draw history
             model = H.build_model(img_size=224, tasks=tasks, depths=(2, 2, 2, 2), r_shared=16, r_task=4, seed=3).to(dev()).train()
             crit, opt = H.MultiTaskLoss(tasks), H.build_optimizer(model, lr=1e-3)
-            red = GradReducer(model.parameters(), bucket_mb=1.0, force=True, buffers=model.buffers()) if use else None
+            red = GradReducer(model.parameters(), bucket_mb=bucket_mb, force=True, buffers=model.buffers()) if use else None
             if use:
-                assert red.active and len(red.buckets) > 3
+                assert red.active and (len(red.buckets) > 3 if bucket_mb < 2 else len(red.buckets) == 1)
             losses = []
             for _ in range(3):
                 l, _ = H.train_step(model, crit, opt, img, tg, reducer=red)

@@ -23,10 +23,10 @@ else
   # list with the per-dispatch counters: hot-path launches vs the callers' rank-0 GEMMs on the same kernels)
   KINDS=1 bash tools/pmc.sh FETCH_SIZE fetch && cp gpurun_out/pmc_fetch*.csv $OUT/
   KINDS=1 bash tools/pmc.sh WRITE_SIZE write && cp gpurun_out/pmc_write*.csv $OUT/
-  python tools/pmc_traffic.py gpurun_out/pmc_fetch.csv gpurun_out/pmc_write.csv 4 r04_pmc_fetch.csv r04_pmc_write.csv > $OUT/pmc_traffic.json
+  python tools/pmc_traffic.py gpurun_out/pmc_fetch.csv gpurun_out/pmc_write.csv 4 r05_pmc_fetch.csv r05_pmc_write.csv > $OUT/pmc_traffic.json
   KINDS=1 BENCH_ARGS="--config c4" bash tools/pmc.sh FETCH_SIZE fetch_c4 && cp gpurun_out/pmc_fetch_c4*.csv $OUT/
   KINDS=1 BENCH_ARGS="--config c4" bash tools/pmc.sh WRITE_SIZE write_c4 && cp gpurun_out/pmc_write_c4*.csv $OUT/
-  python tools/pmc_traffic.py gpurun_out/pmc_fetch_c4.csv gpurun_out/pmc_write_c4.csv 4 r04_pmc_fetch_c4.csv r04_pmc_write_c4.csv > $OUT/pmc_traffic_c4.json
+  python tools/pmc_traffic.py gpurun_out/pmc_fetch_c4.csv gpurun_out/pmc_write_c4.csv 4 r05_pmc_fetch_c4.csv r05_pmc_write_c4.csv > $OUT/pmc_traffic_c4.json
   bash tools/pmc.sh "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES" sq && cp gpurun_out/pmc_sq.csv $OUT/
   cd $REPO
   python tools/bench_linear.py --kinds > $OUT/bench_linear.txt 2>&1

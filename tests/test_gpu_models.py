@@ -433,17 +433,10 @@ def test_reducer_on_the_real_model_matches_plain_backward(setup):
     unpack and the stream joins may not change a single gradient bit; and the construction-time broadcast must be a no-op.
     ``one_bucket_34mb_2cores`` is the configuration bench.py runs at N > 1 (ONE bucket of >= 34 MB, launched from the hook
     of the last gradient) with the rank pinned to two host cores -- the per-rank host budget of 8 ranks on a 16-core node."""
-    import os
-    affinity = os.sched_getaffinity(0)
-    if setup == "one_bucket_34mb_2cores":
-        os.sched_setaffinity(0, set(sorted(affinity)[:2]))
-    try:
-        _reducer_case(34.0 if setup == "one_bucket_34mb_2cores" else 1.0)
-    finally:
-        os.sched_setaffinity(0, affinity)
+    _reducer_case(34.0 if setup == "one_bucket_34mb_2cores" else 1.0, pin=setup == "one_bucket_34mb_2cores")
 
 
-def _reducer_case(bucket_mb):
+def _reducer_case(bucket_mb, pin=False):
     import os
     import torch.distributed as dist
     from mtlora_amd import mtl_harness as H
@@ -468,10 +461,21 @@ def _reducer_case(bucket_mb):
             if use:
                 assert red.active and (len(red.buckets) > 3 if bucket_mb < 2 else len(red.buckets) == 1)
             losses = []
-            for _ in range(3):
-                l, _ = H.train_step(model, crit, opt, img, tg, reducer=red)
-                losses.append(l.clone())
-            torch.cuda.synchronize()
+            # (pinned only around the steps: building a model with the intra-op pool of a 256-core box squeezed onto two cores took
+            # 2.5 minutes)
+            affinity, nthr = os.sched_getaffinity(0), torch.get_num_threads()
+            if pin:
+                os.sched_setaffinity(0, set(sorted(affinity)[:2]))
+                torch.set_num_threads(2)
+            try:
+                for _ in range(3):
+                    l, _ = H.train_step(model, crit, opt, img, tg, reducer=red)
+                    losses.append(l.clone())
+                torch.cuda.synchronize()
+            finally:
+                if pin:
+                    os.sched_setaffinity(0, affinity)
+                    torch.set_num_threads(nthr)
             runs.append((losses, {n: p.detach().clone() for n, p in model.named_parameters()}))
             if red is not None:
                 red.remove()

@@ -304,9 +304,9 @@ class SwinTransformerBlock(nn.Module):
     # -- the whole block as ONE library call per direction (functional.SwinBlockRunFn, mtlora_block_fwd / _bwd) ------------------
     def _fusable_static(self, next_norm) -> bool:
         """structure-only part of the eligibility test (cached per (block, next_norm) by ``BasicLayer``): the stock tasks-free block
-        of every shipped config -- four frozen-weight MTLoRALinear layers with a shared 'matrix' update and constant scales, exact
-        GELU, no dropout modules in play, plain nn.LayerNorm's, image-order attention, and NO hooks on any module inside (a hook
-        expects to see its module called: such a block takes the per-layer path)."""
+        of every shipped config -- four MTLoRALinear layers with a shared 'matrix' update and constant scales, exact GELU, no dropout
+        modules in play, plain nn.LayerNorm's, image-order attention.  What may change between calls (hooks, un-frozen pretrained
+        weights, merged weights) is checked per call in ``_block_call``."""
         def plain_ln(m):
             return (type(m) is nn.LayerNorm and m.elementwise_affine and m.bias is not None and len(m.normalized_shape) == 1
                     and m.weight.dtype == torch.float32)
@@ -314,29 +314,31 @@ class SwinTransformerBlock(nn.Module):
         def stock_linear(m):
             return (isinstance(m, MTLoRALinear) and m.r > 0 and m.tasks is None and hasattr(m, "lora_shared_A")
                     and m.shared_mode == "matrix" and not isinstance(m.lora_shared_scale, torch.Tensor)
-                    and not m.linear.weight.requires_grad and (m.linear.bias is None or not m.linear.bias.requires_grad)
                     and m.lora_shared_A.dtype == torch.float32 and m.lora_shared_A.is_contiguous() and m.lora_shared_B.is_contiguous())
 
-        def hookless(m):
-            return not (m._forward_hooks or m._forward_pre_hooks or m._backward_hooks or m._backward_pre_hooks)
-
         lin = (self.attn.qkv, self.attn.proj, self.mlp.fc1, self.mlp.fc2)
-        mods = (self, self.attn, self.mlp, self.norm1, self.norm2, next_norm, self.mlp.act, self.drop_path) + lin
         C = self.dim
         return (not self.lora and self.attention_layout == "image" and next_norm is not None
                 and all(stock_linear(m) for m in lin) and all(plain_ln(m) for m in (self.norm1, self.norm2, next_norm))
                 and type(self.mlp.act) is nn.GELU and getattr(self.mlp.act, "approximate", "none") == "none"
                 and self.mlp.drop.p == 0.0 and self.attn.proj_drop.p == 0.0 and self.attn.attn_drop.p == 0.0
-                and all(hookless(m) for m in mods) and C % 8 == 0 and self.mlp.fc1.linear.out_features % 8 == 0
+                and C % 8 == 0 and self.mlp.fc1.linear.out_features % 8 == 0
                 and C // self.num_heads == 32 and self.window_size * self.window_size <= 64)
 
     def _block_call(self, has_norm1: bool, next_norm, cdtype, x):
         """(BlockCall, flat tensor list) of this block for a ``SwinBlockRunFn`` call, or None when a layer cannot run fused now
         (merged weights, factors on another device ...).  Draws the dropout seeds and DropPath factors in the order of ``forward``."""
         lin = (self.attn.qkv, self.attn.proj, self.mlp.fc1, self.mlp.fc2)
+        # what can change between calls is looked at on every call (a dozen attribute reads): a hook registered on any module inside
+        # must see its module called, an un-frozen pretrained weight needs the dense gradients of the per-layer Function, a merged
+        # weight has no shared update to apply
+        for m in (self, self.attn, self.mlp, self.norm1, self.norm2, next_norm, self.mlp.act, self.drop_path) + lin:
+            if m._forward_hooks or m._forward_pre_hooks or m._backward_hooks or m._backward_pre_hooks:
+                return None
         metas, weights, fparams = [], [], []
         for m in lin:
-            if m.merged or not m.lora_shared_A.is_cuda:
+            if (m.merged or not m.lora_shared_A.is_cuda or m.linear.weight.requires_grad
+                    or (m.linear.bias is not None and m.linear.bias.requires_grad)):
                 return None
             metas.append(m.meta_t0(cdtype, x.device))
             weights.append(m._weights(cdtype))
@@ -525,7 +527,8 @@ class BasicLayer(nn.Module):
         return len(calls), x, normed
 
     def invalidate_fused_cache(self) -> None:
-        """forget which blocks qualify for the one-call path (after registering hooks on / swapping modules inside a block)"""
+        """forget which blocks qualify STRUCTURALLY for the one-call path (after swapping modules inside a block; hooks, frozen / merged
+        state are looked at on every call and need nothing)"""
         self.__dict__.pop("_fusable_cache", None)
 
     def forward(self, x):

@@ -606,17 +606,21 @@ def test_block_call_falls_back_for_hooked_or_merged_blocks():
         # a hook on the second block's fc1: the run ends in front of that block, the hook fires, results unchanged
         seen = []
         h = bb.layers[0].blocks[1].mlp.fc1.register_forward_hook(lambda m, i, o: seen.append(1))
-        for lyr in bb.layers:
-            lyr.invalidate_fused_cache()
         n_calls[0] = 0
         got = run()
         assert n_calls[0] == 2 and seen
         for n in ref[1]:
             assert torch.equal(ref[1][n], got[1][n]), n
         h.remove()
+        # an un-frozen pretrained weight (MTLORA.FREEZE_PRETRAINED False) needs the per-layer Function's dense gradients -- seen per call
+        w = bb.layers[1].blocks[0].attn.proj.linear.weight
+        w.requires_grad_(True)
+        n_calls[0] = 0
+        run()
+        assert n_calls[0] == 2 and w.grad is not None  # stage 0's run stays fused, stage 1's block does not
+        w.requires_grad_(False)
+        w.grad = None
         # merged weights (inference): no fused call for that block; with torch.no_grad() none at all
-        for lyr in bb.layers:
-            lyr.invalidate_fused_cache()
         bb.layers[0].blocks[0].attn.qkv.merge()
         n_calls[0] = 0
         with torch.autocast("cuda", dtype=torch.bfloat16):

@@ -1263,6 +1263,33 @@ class UpsampleLossFn(torch.autograd.Function):
 # ----------------------------------------------------------------------------------------------
 # plain (library) GEMM linears with a huge row count: weight gradient as a batched GEMM over row chunks
 # ----------------------------------------------------------------------------------------------
+def _layout_weight(weight, bias, cdtype, col_index, n_cols, pad_rows):
+    """the weight as the kernel takes it: ``col_index`` scatters its columns into ``n_cols`` (zero elsewhere: the padded channel
+    layout of ConcatUpsampleFn), ``pad_rows`` appends zero rows (classes padded to a multiple of 8).  Done inside the Function: no
+    autograd nodes of their own for the scatter / cat, the matching gather / slice of the gradient is part of its backward.
+    (Round 5 also tried the weight / bias gradients of these linears on the factor-gradient side stream -- nothing in the backward
+    chain reads them: c2 -0.7 %, c4 -1.0 %, c5:4 -1.0 %: they leave four concurrent task streams for one.  Removed.)"""
+    w = weight.detach().to(cdtype)
+    if col_index is not None:
+        w = w.new_zeros(w.shape[0], n_cols).index_copy(1, col_index, w)
+    b = None if bias is None else bias.detach()
+    if pad_rows:
+        w = torch.cat([w, w.new_zeros(pad_rows, w.shape[1])], 0)
+        b = None if b is None else torch.cat([b, b.new_zeros(pad_rows)], 0)
+    return w.contiguous(), b
+
+
+def _unlayout_grads(dw, db, col_index, pad_rows):
+    if pad_rows:
+        dw = None if dw is None else dw[:dw.shape[0] - pad_rows]
+        db = None if db is None else db[:db.shape[0] - pad_rows].contiguous()
+    if col_index is not None and dw is not None:
+        dw = dw.index_select(1, col_index)
+    elif dw is not None and pad_rows:
+        dw = dw.contiguous()
+    return dw, db
+
+
 class SplitKLinearFn(torch.autograd.Function):
     """y = x W^T + b on hipBLASLt, like F.linear, but with dW = dY^T X evaluated as a batched GEMM over S row chunks
     + a sum: with M = 100k..400k rows and an output of a few hundred x a few hundred elements the single GEMM runs on
@@ -1271,15 +1298,16 @@ class SplitKLinearFn(torch.autograd.Function):
     their gradients are returned in the masters' dtype straight from the fp32 chunk sum (no bf16 round trip)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, splits: int, zero_bias_grad: bool, cdtype):
-        w = weight.detach().to(cdtype)
+    def forward(ctx, x, weight, bias, splits: int, zero_bias_grad: bool, cdtype, col_index=None, n_cols=0, pad_rows=0):
+        w, bl = _layout_weight(weight, bias, cdtype, col_index, n_cols, pad_rows)
         ctx.save_for_backward(x, w)
+        ctx.wlayout = (col_index, pad_rows)
         ctx.has_bias = bias is not None
         ctx.splits = splits
         ctx.zero_bias_grad = zero_bias_grad
         ctx.wdtype = weight.dtype
         ctx.bdtype = None if bias is None else bias.dtype
-        return torch.nn.functional.linear(x, w, None if bias is None else bias.detach().to(cdtype))
+        return torch.nn.functional.linear(x, w, None if bl is None else bl.to(cdtype))
 
     @staticmethod
     def backward(ctx, gy):
@@ -1289,20 +1317,25 @@ class SplitKLinearFn(torch.autograd.Function):
         N = w.shape[0]
         S = ctx.splits
         dx = gy @ w if ctx.needs_input_grad[0] else None
-        dw = None
-        if ctx.needs_input_grad[1]:
-            part = torch.bmm(gy.view(S, M // S, N).transpose(1, 2), x.view(S, M // S, K))  # (S, N, K)
-            dw = part.sum(0, dtype=torch.float32).to(ctx.wdtype)
-        db = None
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            # zero_bias_grad: the output feeds a training-mode BatchNorm, whose backward returns columns that sum to zero
-            # EXACTLY (dx = scale (dy' - mean(dy') - xhat mean(dy' xhat)), sum(xhat) = 0): the bias gradient is 0, and
-            # summing 400k x 1080 elements only to obtain rounding noise costs a full pass over the gradient
-            if ctx.zero_bias_grad:
-                db = torch.zeros(N, dtype=ctx.bdtype, device=gy.device)
-            else:  # two-stage column sum: a (400k x 21) sum(0) runs on 64 workgroups for 256 us in one stage
-                db = column_sum(gy).to(ctx.bdtype)
-        return dx, dw, db, None, None, None
+
+        def wgrads():
+            dw = None
+            if ctx.needs_input_grad[1]:
+                part = torch.bmm(gy.view(S, M // S, N).transpose(1, 2), x.view(S, M // S, K))  # (S, N, K)
+                dw = part.sum(0, dtype=torch.float32).to(ctx.wdtype)
+            db = None
+            if ctx.has_bias and ctx.needs_input_grad[2]:
+                # zero_bias_grad: the output feeds a training-mode BatchNorm, whose backward returns columns that sum to zero
+                # EXACTLY (dx = scale (dy' - mean(dy') - xhat mean(dy' xhat)), sum(xhat) = 0): the bias gradient is 0, and
+                # summing 400k x 1080 elements only to obtain rounding noise costs a full pass over the gradient
+                if ctx.zero_bias_grad:
+                    db = torch.zeros(N, dtype=ctx.bdtype, device=gy.device)
+                else:  # two-stage column sum: a (400k x 21) sum(0) runs on 64 workgroups for 256 us in one stage
+                    db = column_sum(gy).to(ctx.bdtype)
+            return _unlayout_grads(dw, db, *ctx.wlayout)
+
+        dw, db = wgrads()
+        return dx, dw, db, None, None, None, None, None, None
 
 
 class PlainLinearFn(torch.autograd.Function):
@@ -1312,11 +1345,11 @@ class PlainLinearFn(torch.autograd.Function):
     stay on hipBLASLt as the split-reduction batched GEMM of SplitKLinearFn."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, splits: int, zero_bias_grad: bool, cdtype):
+    def forward(ctx, x, weight, bias, splits: int, zero_bias_grad: bool, cdtype, col_index=None, n_cols=0, pad_rows=0):
         L.require_gpu(x, weight)
         M, K = x.shape
-        N = weight.shape[0]
-        w = weight.detach().to(cdtype).contiguous()
+        w, bias_l = _layout_weight(weight, bias, cdtype, col_index, n_cols, pad_rows)
+        N = w.shape[0]
         meta = LinearMeta(K=K, N=N, r_s=0, r_t=(), scale_s=0.0, scale_t=(), mode=0, has_x_tasks=False, dropout_p=0.0, seed=0,
                           dtype=cdtype)
         d = meta.desc(M)
@@ -1326,12 +1359,13 @@ class PlainLinearFn(torch.autograd.Function):
             raise RuntimeError(f"mtlora_amd: invalid plain-linear shape M={M} K={K} N={N}")
         ctxbuf = torch.empty(max(ctx_bytes, 16), dtype=torch.uint8, device=x.device)
         y = torch.empty((M, N), dtype=cdtype, device=x.device)
-        bf = None if bias is None else bias.detach().float().contiguous()
+        bf = None if bias_l is None else bias_l.float().contiguous()
         st = lib.mtlora_linear_fwd(ctypes.byref(d), L.ptr(x), L.ptr_array(None), L.ptr(w), L.ptr(bf), L.ptr(None), L.ptr(None),
                                    L.ptr_array(None), L.ptr_array(None), L.ptr(y), L.ptr_array(None), L.ptr(ctxbuf), ctx_bytes,
                                    L.stream_ptr())
         L.check(st, "mtlora_linear_fwd (rank 0)")
         ctx.save_for_backward(x, w, ctxbuf)
+        ctx.wlayout = (col_index, pad_rows)
         ctx.meta, ctx.splits, ctx.zero_bias_grad = meta, splits, zero_bias_grad
         ctx.has_bias, ctx.wdtype = bias is not None, weight.dtype
         ctx.bdtype = None if bias is None else bias.dtype
@@ -1356,20 +1390,24 @@ class PlainLinearFn(torch.autograd.Function):
                                        L.ptr(ctxbuf), ctxbuf.numel(), L.ptr(dx), L.ptr_array(None), L.ptr(None), L.ptr(None),
                                        L.ptr_array(None), L.ptr_array(None), L.ptr(scratch), sb, L.stream_ptr())
             L.check(st, "mtlora_linear_bwd (rank 0)")
-        dw = None
-        if ctx.needs_input_grad[1]:
-            if N <= 64:  # narrow output: the library's split-M TN reduction reads x once (hipBLASLt: 0.8 TB/s here)
-                dw = gemm_tn(gy, x).to(ctx.wdtype)
-            else:
-                part = torch.bmm(gy.view(S, M // S, N).transpose(1, 2), x.view(S, M // S, K))
-                dw = part.sum(0, dtype=torch.float32).to(ctx.wdtype)
-        db = None
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            if ctx.zero_bias_grad:
-                db = torch.zeros(N, dtype=ctx.bdtype, device=gy.device)
-            else:
-                db = column_sum(gy).to(ctx.bdtype)
-        return dx, dw, db, None, None, None
+        def wgrads():
+            dw = None
+            if ctx.needs_input_grad[1]:
+                if N <= 64:  # narrow output: the library's split-M TN reduction reads x once (hipBLASLt: 0.8 TB/s here)
+                    dw = gemm_tn(gy, x).to(ctx.wdtype)
+                else:
+                    part = torch.bmm(gy.view(S, M // S, N).transpose(1, 2), x.view(S, M // S, K))
+                    dw = part.sum(0, dtype=torch.float32).to(ctx.wdtype)
+            db = None
+            if ctx.has_bias and ctx.needs_input_grad[2]:
+                if ctx.zero_bias_grad:
+                    db = torch.zeros(N, dtype=ctx.bdtype, device=gy.device)
+                else:
+                    db = column_sum(gy).to(ctx.bdtype)
+            return _unlayout_grads(dw, db, *ctx.wlayout)
+
+        dw, db = wgrads()
+        return dx, dw, db, None, None, None, None, None, None
 
 
 def gemm_tn(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
@@ -1395,18 +1433,20 @@ def gemm_tn(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
 _PLAIN_VIA_KNT = os.environ.get("MTLORA_HEAD_GEMM", "knt") != "blas"
 
 
-def _big_linear(x, weight, bias, S, feeds_batchnorm, cdtype):
-    K, N = weight.shape[1], weight.shape[0]
+def _big_linear(x, weight, bias, S, feeds_batchnorm, cdtype, col_index=None, pad_rows=0):
+    K, N = x.shape[1], weight.shape[0] + pad_rows
     if (_PLAIN_VIA_KNT and cdtype in _HOT_DTYPES and K % 8 == 0 and N % 8 == 0
             and x.dtype == cdtype):
-        return PlainLinearFn.apply(x, weight, bias, S, feeds_batchnorm, cdtype)
-    return SplitKLinearFn.apply(x, weight, bias, S, feeds_batchnorm, cdtype)
+        return PlainLinearFn.apply(x, weight, bias, S, feeds_batchnorm, cdtype, col_index, K, pad_rows)
+    return SplitKLinearFn.apply(x, weight, bias, S, feeds_batchnorm, cdtype, col_index, K, pad_rows)
 
 
 def linear_big_m(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor],
-                 feeds_batchnorm: bool = False) -> torch.Tensor:
+                 feeds_batchnorm: bool = False, col_index: Optional[torch.Tensor] = None, pad_rows: int = 0) -> torch.Tensor:
     """F.linear for (M, K) inputs; switches to SplitKLinearFn when M is large and the weight is trained.
-    feeds_batchnorm=True: the output goes straight into a training-mode BatchNorm -> the bias gradient is exactly 0."""
+    feeds_batchnorm=True: the output goes straight into a training-mode BatchNorm -> the bias gradient is exactly 0.
+    col_index: x has MORE columns than the weight -- column c of the weight multiplies column col_index[c] of x (the padded channel
+    layout of ConcatUpsampleFn; the other columns of x meet zeros).  pad_rows: the output gets that many extra all-zero columns."""
     M = x.shape[0]
     if x.dim() == 2 and x.is_cuda and weight.requires_grad and torch.is_grad_enabled() and M >= 1 and x.is_contiguous():
         S = 1  # small M: one chunk -- still this Function, so that the bias gradient is ``column_sum`` (ATen's sum(0) of a mid-size
@@ -1423,8 +1463,13 @@ def linear_big_m(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Ten
         if torch.is_autocast_enabled("cuda"):
             dt = torch.get_autocast_dtype("cuda")
             with torch.autocast("cuda", enabled=False):
-                return _big_linear(x.to(dt), weight, bias, S, feeds_batchnorm, dt)
-        return _big_linear(x, weight, bias, S, feeds_batchnorm, x.dtype)
+                return _big_linear(x.to(dt), weight, bias, S, feeds_batchnorm, dt, col_index, pad_rows)
+        return _big_linear(x, weight, bias, S, feeds_batchnorm, x.dtype, col_index, pad_rows)
+    if col_index is not None:
+        weight = weight.new_zeros(weight.shape[0], x.shape[1]).index_copy(1, col_index, weight)
+    if pad_rows:
+        weight = torch.cat([weight, weight.new_zeros(pad_rows, weight.shape[1])], 0)
+        bias = None if bias is None else torch.cat([bias, bias.new_zeros(pad_rows)], 0)
     return torch.nn.functional.linear(x, weight, bias)
 
 

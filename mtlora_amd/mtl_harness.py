@@ -168,16 +168,18 @@ class HighResolutionHead(nn.Module):
             # matching zero columns
             t = Fn.ConcatUpsampleFn.apply(*xc)
             offs, ld = Fn.ConcatUpsampleFn.layout(chans)
-            if ld != w2d.shape[1]:  # one scatter of the weight columns (backward: one gather), not a cat of slices
-                key = (tuple(offs), tuple(chans), w2d.device)
+            col_idx = None
+            if ld != w2d.shape[1]:  # the weight's columns are scattered to the padded channel positions INSIDE the linear Function
+                key = (tuple(offs), tuple(chans), w2d.device)  # (forward one index_copy, backward one gather next to the weight gradient)
                 if getattr(self, "_col_key", None) != key:
                     self._col_idx = torch.cat([torch.arange(o, o + c) for o, c in zip(offs, chans)]).to(w2d.device)
                     self._col_key = key
-                w2d = w2d.new_zeros(w2d.shape[0], ld).index_copy(1, self._col_idx, w2d)
+                col_idx = self._col_idx
         else:
             cat = torch.cat([x[0]] + [F.interpolate(m, (Hh, Ww), mode="bilinear") for m in x[1:]], 1)
             t = cat.permute(0, 2, 3, 1).reshape(B * Hh * Ww, cat.shape[1])
-        h = Fn.linear_big_m(t, w2d, c0.bias, feeds_batchnorm=bn.training)
+            col_idx = None
+        h = Fn.linear_big_m(t, w2d, c0.bias, feeds_batchnorm=bn.training, col_index=col_idx)
         if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
             bn.num_batches_tracked.add_(1)
         if bn.training and h.is_cuda and h.dtype in (torch.float32, torch.bfloat16, torch.float16) and h.shape[1] % 8 == 0:
@@ -190,11 +192,8 @@ class HighResolutionHead(nn.Module):
             if getattr(self, "relu", True):  # (False only in the kink-free parity probe of tests/test_gpu_models.py)
                 h = F.relu(h)
         w3, b3, nc = c3.weight.view(c3.out_channels, c3.in_channels), c3.bias, c3.out_channels
-        if h.is_cuda and nc % 8:  # zero rows up to a multiple of 8 classes: the library's GEMM kernels take 16-byte rows
-            pad = 8 - nc % 8
-            w3 = torch.cat([w3, w3.new_zeros(pad, w3.shape[1])], 0)
-            b3 = None if b3 is None else torch.cat([b3, b3.new_zeros(pad)], 0)
-        o = Fn.linear_big_m(h, w3, b3)
+        # zero rows up to a multiple of 8 classes (the library's GEMM kernels take 16-byte rows): appended inside the linear Function
+        o = Fn.linear_big_m(h, w3, b3, pad_rows=(8 - nc % 8) if (h.is_cuda and nc % 8) else 0)
         o = (o if o.shape[1] == nc else o[:, :nc].contiguous()).view(B, Hh, Ww, nc)
         return o if channels_last_out else o.permute(0, 3, 1, 2)
 

@@ -25,8 +25,8 @@ Extra objects in the line (this tier's contract):
                 `linear_path` covers every kernel of the MTLoRALinear path (k_nt + k_tn + pack / reduce / sum).
   eager_gpu     the north star's ">= 4x" comparator, timed in the same process: the oracle's ATen-op dataflow (== the
                 reference's eager PyTorch-ROCm path: 6+4T launches per MTLoRALinear, roll / partition / materialised
-                scores per block) on the same GPU, same config, same batch, bf16 autocast, same train step; a bounded
-                sample (1 warm-up + 3 steps).
+                scores per block) on the same GPU, same config, same batch, bf16 autocast, same train step, in a process
+                of its own without this file's MIOPEN_FIND_MODE default; 3 warm-up + 10 timed steps, median (min / max reported).
   cpu_baseline  the oracle (a plain-PyTorch port of the reference) on this box's host cores on a bounded sample
                 (B=2, fp32) -- kind "port".  Reported baselines, not targets.
 """
@@ -40,7 +40,8 @@ import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")  # no exhaustive conv search for the (few) MIOpen ops left
+if "--eager-leg" not in sys.argv:  # (the eager comparator's own process keeps MIOpen's defaults: see eager_leg)
+    os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")  # no exhaustive conv search for the (few) MIOpen ops left
 
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s achievable)
 HBM_ACHIEVABLE_GBS = 6290.0  # same guide: measured float4 copy
@@ -67,6 +68,7 @@ def parse():
     ap.add_argument("--cores", type=int, default=0,
                     help="pin this process to N host cores (sched_setaffinity + torch.set_num_threads): the host budget of one rank "
                          "when 8 ranks share a node (16 cores / 8 ranks = 2)")
+    ap.add_argument("--eager-leg", default="", help=argparse.SUPPRESS)  # child process of the eager_gpu leg: --eager-leg <config> --batch B
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the short c4 / c5:4 legs the default (c2, 1 GPU) run appends under `other_configs`")
     return ap.parse_args()
@@ -120,7 +122,7 @@ def _static_traffic(cfg_name, n_hot, n_all):
     attribute the counters per launch kind (tools/pmc_traffic.py: hot-path launches only); older ones cover every launch of the GEMM
     kernels, i.e. the callers' rank-0 GEMMs too -- labelled as such."""
     suffix = "" if cfg_name == "c2" else "_" + cfg_name.replace(":", "_")
-    for rnd in ("r05", "r04", "r03", "r02", "r01"):
+    for rnd in ("r06", "r05", "r04", "r03", "r02", "r01"):
         fn = f"{rnd}_pmc_traffic{suffix}.json"
         try:
             pm = json.load(open(os.path.join(ROOT, "profiles", fn)))
@@ -140,7 +142,7 @@ def _static_traffic(cfg_name, n_hot, n_all):
     return {"traffic": None, "traffic_ratio": None, "traffic_source": None, "linear_traffic_GB": None, "linear_traffic_ratio": None}
 
 
-def roofline(step_fn, steps, cfg_name="c2"):
+def roofline(step_fn, steps, cfg_name="c2", step_ms=0.0):
     """HIP-event timing of every library launch over `steps` extra steps (same stream as the launches)."""
     import ctypes
     from mtlora_amd import _lib as L
@@ -184,7 +186,17 @@ def roofline(step_fn, steps, cfg_name="c2"):
     tfl = (fl / 1e12) / (ms / 1e3) if ms > 0 else 0.0
     hbm_frac, mfma_frac = ach8 / HBM_PEAK_GBS, tfl / MFMA_PEAK_TFLOPS
     tr = _static_traffic(cfg_name, n / steps, agg(nt + ["k_nt:plain_fwd", "k_nt:plain_dX"])[0] / steps)
-    return {"bound": "hbm" if hbm_frac >= mfma_frac else "mfma",
+    # the same fraction over wider scopes: hot path + factor gradients + pack / reduce + the attention kernels
+    # (kernel time), and ALL 8(d) bytes of a step against the step's wall time (everything outside the path counts as time only)
+    an, ams, _, ab8, _ = agg(nt + ["k_tn:dA_dB", "k_pack", "k_tn_reduce", "k_sum", "k_attn_fwd", "k_attn_bwd"])
+    wider = {"hot_path_with_attention": {"what": "hot-path launches + factor gradients + pack / reduce / sum + window attention fwd / bwd: 8(d) bytes / kernel time",
+                                         "launches_per_step": an / steps, "ms_per_step": round(ams / steps, 3), "s8d_GB_per_step": round(ab8 / steps / 1e9, 3),
+                                         "GBps": round(gbs(ab8, ams), 1), "frac": round(gbs(ab8, ams) / HBM_PEAK_GBS, 4)}}
+    if step_ms:
+        wider["whole_step_vs_8d"] = {"what": "all SURVEY 8(d) bytes of one step (MTLoRALinear + attention) / the timed step (glue, heads, losses, optimizer "
+                                             "count as time only)", "s8d_GB_per_step": round(ab8 / steps / 1e9, 3), "ms_per_step": round(step_ms, 3),
+                                     "GBps": round(gbs(ab8 / steps, step_ms), 1), "frac": round(gbs(ab8 / steps, step_ms) / HBM_PEAK_GBS, 4)}
+    return {"bound": "hbm" if hbm_frac >= mfma_frac else "mfma", **wider,
             "kernel": "MTLoRALinear hot-path launches: fused forward / dX (k_sp_xres / k_sp_ares wave-streaming, k_nt / k_ntl / k_ntd tiled) "
                       "and the low-rank P / Q passes that remain (k_sp_proj / k_sp_projsum / k_sp_projk / k_nt)",
             "achieved": round(ach8, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hbm_frac, 4),
@@ -246,24 +258,53 @@ def _oracle_step_factory(cfgrow, B, device, amp):
     return step
 
 
-def eager_gpu(cfgrow, B, dev, ours_ips):
-    """north star comparator: the reference's eager PyTorch-ROCm dataflow on the same GPU / config / batch."""
+def eager_leg(cfg_name, B, warm=3, k=10):
+    """child process of ``eager_gpu``: time the oracle's ATen dataflow (== the reference's eager PyTorch-ROCm path) and print one JSON
+    line.  Runs WITHOUT this file's MIOPEN_FIND_MODE=FAST default (the comparator must not sit on MIOpen's
+    fallback solvers): the environment is whatever a user of the reference would have."""
+    from mtlora_amd import mtl_harness as H
+    row = H.config(cfg_name)
+    dev = torch.device("cuda", 0)
     try:
-        step = _oracle_step_factory(cfgrow, B, dev, amp=True)
-        step()
-        torch.cuda.synchronize()
-        k = 3
-        t0 = time.perf_counter()
-        for _ in range(k):
+        step = _oracle_step_factory(row, B, dev, amp=True)
+        for _ in range(warm):
             step()
         torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / k
-        res = {"value": round(B / dt, 2), "unit": "images/sec", "ms_per_step": round(1e3 * dt, 2), "kind": "port",
-               "sample": f"oracle ATen dataflow on cuda, bf16 autocast, B={B}, 1 warm-up + {k} timed steps",
-               "speedup": round(ours_ips / (B / dt), 2)}
+        ts = []
+        for _ in range(k):
+            t0 = time.perf_counter()
+            step()
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+        ts.sort()
+        med = ts[len(ts) // 2] if len(ts) % 2 else 0.5 * (ts[len(ts) // 2 - 1] + ts[len(ts) // 2])
+        res = {"value": round(B / med, 2), "unit": "images/sec", "ms_per_step": round(1e3 * med, 2), "ms_per_step_min": round(1e3 * ts[0], 2),
+               "ms_per_step_max": round(1e3 * ts[-1], 2), "value_best": round(B / ts[0], 2), "kind": "port",
+               "miopen_find_mode": os.environ.get("MIOPEN_FIND_MODE", "default"),
+               "sample": f"oracle ATen dataflow on cuda, bf16 autocast, B={B}, own process, {warm} warm-up + {k} timed steps (median; min / max next to it)"}
     except torch.OutOfMemoryError as e:  # the eager path materialises every score / per-task tensor
         res = {"value": None, "error": f"OOM: {str(e)[:80]}"}
+    print("EAGER_LEG " + json.dumps(res), flush=True)
+
+
+def eager_gpu(cfg_name, B, ours_ips):
+    """north star comparator: the reference's eager PyTorch-ROCm dataflow on the same GPU / config / batch, in a process of its own
+    (clean MIOpen environment, nothing of the product path resident), 3 warm-up + 10 timed steps, median."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k != "MIOPEN_FIND_MODE"}
     torch.cuda.empty_cache()
+    try:
+        out = subprocess.run([sys.executable, os.path.abspath(__file__), "--eager-leg", cfg_name, "--batch", str(B)], env=env,
+                             capture_output=True, text=True, timeout=900)
+        line = [ln for ln in out.stdout.splitlines() if ln.startswith("EAGER_LEG ")]
+        if not line:
+            return {"value": None, "error": f"eager leg failed (rc {out.returncode}): {out.stderr[-200:]}"}
+        res = json.loads(line[-1][len("EAGER_LEG "):])
+    except Exception as e:  # noqa: BLE001  (a failing baseline leg must not lose the headline line)
+        return {"value": None, "error": f"{type(e).__name__}: {str(e)[:120]}"}
+    if res.get("value"):
+        res["speedup"] = round(ours_ips / res["value"], 2)
+        res["speedup_vs_best_eager_step"] = round(ours_ips / res["value_best"], 2)
     return res
 
 
@@ -337,7 +378,7 @@ def run_config(args, name, rank, world, dev, steps, warmup, want_roofline, batch
     }
     if rank == 0 and want_roofline:
         # profiled EAGERLY: the library's HIP-event brackets are recorded at launch time (same kernels as the graph)
-        fields["roofline"] = roofline(eager_step, args.roofline_steps or max(2, min(steps, 5)), name)
+        fields["roofline"] = roofline(eager_step, args.roofline_steps or max(2, min(steps, 5)), name, 1e3 * dt / steps)
     elif want_roofline and world > 1:
         for _ in range(1 + (args.roofline_steps or max(2, min(steps, 5)))):  # keep ranks in lock-step with rank 0's profiled steps
             eager_step()
@@ -348,6 +389,9 @@ def run_config(args, name, rank, world, dev, steps, warmup, want_roofline, batch
 
 def main():
     args = parse()
+    if args.eager_leg:
+        from mtlora_amd import mtl_harness as H
+        return eager_leg(args.eager_leg, args.batch or H.config(args.eager_leg)["batch"])
     if args.cores > 0:  # the host budget of one rank on a shared node (before any thread pool starts)
         allowed = sorted(os.sched_getaffinity(0))
         os.sched_setaffinity(0, set(allowed[:max(1, min(args.cores, len(allowed)))]))
@@ -389,7 +433,7 @@ def main():
                 others[name] = {"error": f"{type(e).__name__}: {str(e)[:120]}"}
         result["other_configs"] = others
     if rank == 0 and world == 1 and not args.no_eager_gpu:
-        result["eager_gpu"] = eager_gpu(row, B, dev, ips)
+        result["eager_gpu"] = eager_gpu(args.config, B, ips)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(row)
     if world > 1:

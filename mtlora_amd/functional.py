@@ -96,7 +96,21 @@ def _side_join_pending(params, dev) -> bool:
     cur = torch.cuda.current_stream(dev) if streams else None
     for st in streams.values():
         cur.wait_stream(st)
+    if same_pass:
+        # a THIRD (fourth ...) use of the layer in this pass must see the same-pass rule too -- the entries popped above are
+        # put back under the current graph task, so every later use keeps its factor gradients on the stream autograd sums them on
+        side = next(iter(streams.values()))
+        for p in params:
+            if p is not None:
+                _side_pending[p] = (side, task)
     return same_pass
+
+
+def _side_safe_params(params) -> bool:
+    """may the gradients of ``params`` be WRITTEN on the side stream?  Only when autograd will take the gradient tensor as it is:
+    no existing .grad to accumulate into (an add on the backward's stream) and no tensor hook on the Parameter (a hook receives --
+    and may replace, i.e. force a copy of -- the gradient on the backward's stream while the side stream is still writing it)."""
+    return all(p is None or (p.grad is None and not p._backward_hooks) for p in params)
 
 
 def _side_mark_pending(params, side) -> None:
@@ -488,8 +502,7 @@ class MTLoRALinearFn(torch.autograd.Function):
         # the factor gradients go to the side stream only when nothing on this stream reads them inside backward: no
         # trainable-scale gradient (formed from dB below) and no gradient accumulation into an existing .grad
         use_side = (side is not None and fgrads and not ctx.has_scale_s and meta.n_scale_t == 0
-                    and side.device == dev and M >= _FACTOR_MIN_M
-                    and all(p is None or p.grad is None for p in ctx.factor_params))
+                    and side.device == dev and M >= _FACTOR_MIN_M and _side_safe_params(ctx.factor_params))
         if _side_join_pending(ctx.factor_params, dev):
             use_side = False  # same layer earlier in THIS backward pass: autograd sums the two gradients on this stream
         if use_side:
@@ -1578,8 +1591,8 @@ _blk_bytes_cache: dict = {}
 
 def _block_bytes(call: "BlockCall", d, B: int, C: int) -> Tuple[int, int, int]:
     """(save, fwd tmp, bwd scratch) bytes of a block call -- three host calls into the library per new geometry"""
-    key = (B, call.H, call.W, C, call.hidden, call.has_norm1, d.dtype, d.x_dtype,
-           tuple((m.r_s, m.packed is not None) for m in call.metas))
+    key = (B, call.H, call.W, C, call.hidden, call.has_norm1, d.dtype, d.x_dtype, call.window_size, call.num_heads, call.shift,
+           call.mask_ids is not None, tuple((m.r_s, m.packed is not None) for m in call.metas))
     v = _blk_bytes_cache.get(key)
     if v is None:
         lib = L.lib()
@@ -1618,6 +1631,19 @@ class SwinBlockRunFn(torch.autograd.Function):
         for c in calls:
             t = flat[at:at + c.n_flat]
             at += c.n_flat
+            # every tensor whose raw address goes into BlockParams: on x's device, contiguous, in the dtype the kernels read it as
+            # (the per-layer Functions report a mismatch as an error; here it would be an illegal access)
+            for q in t:
+                if q is not None and (q.device != dev or q.dtype != torch.float32 or not q.is_contiguous()):
+                    raise RuntimeError("mtlora_amd: SwinBlockRunFn needs contiguous fp32 bias / DropPath / LayerNorm / factor tensors on the input's device")
+            for wc, wt, bf in c.weights:
+                if (wc.device != dev or wt.device != dev or wc.dtype != cdtype or wt.dtype != cdtype or not wc.is_contiguous()
+                        or not wt.is_contiguous() or (bf is not None and (bf.device != dev or bf.dtype != torch.float32 or not bf.is_contiguous()))):
+                    raise RuntimeError("mtlora_amd: SwinBlockRunFn needs the frozen-weight copies in the compute dtype on the input's device")
+            if c.mask_ids is not None and (c.mask_ids.device != dev or c.mask_ids.dtype != torch.int32 or not c.mask_ids.is_contiguous()):
+                raise RuntimeError("mtlora_amd: SwinBlockRunFn needs a contiguous int32 region-id map on the input's device")
+            if c.mask is not None and c.mask_ids is None and (c.mask.device != dev or c.mask.dtype != torch.float32 or not c.mask.is_contiguous()):
+                raise RuntimeError("mtlora_amd: SwinBlockRunFn needs a contiguous fp32 attention mask on the input's device")
             d = c.build_desc(B, C, cdtype, x.dtype)
             sb, tb, _ = _block_bytes(c, d, B, C)
             p = L.BlockParams()
@@ -1694,8 +1720,7 @@ class SwinBlockRunFn(torch.autograd.Function):
             # everything phase 2 writes on the side stream: the eight factor gradients and the LayerNorm dgamma / dbeta (their
             # second-stage reduces ride along, csrc/internal.h) -- none of their Parameters may have a .grad to accumulate into
             fparams = c.factor_params + c.norm_params
-            use_side = (side is not None and side.device == dev and M >= _FACTOR_MIN_M
-                        and all(q.grad is None for q in fparams))
+            use_side = side is not None and side.device == dev and M >= _FACTOR_MIN_M and _side_safe_params(fparams)
             if _side_join_pending(fparams, dev):
                 use_side = False
             args = (ctypes.byref(d), ctypes.byref(p), xs[bi].data_ptr(), 0 if ns[bi] is None else ns[bi].data_ptr(),

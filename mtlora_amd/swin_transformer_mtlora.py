@@ -303,44 +303,60 @@ class SwinTransformerBlock(nn.Module):
 
     # -- the whole block as ONE library call per direction (functional.SwinBlockRunFn, mtlora_block_fwd / _bwd) ------------------
     def _fusable_static(self, next_norm) -> bool:
-        """structure-only part of the eligibility test (cached per (block, next_norm) by ``BasicLayer``): the stock tasks-free block
-        of every shipped config -- four MTLoRALinear layers with a shared 'matrix' update and constant scales, exact GELU, no dropout
-        modules in play, plain nn.LayerNorm's, image-order attention.  What may change between calls (hooks, un-frozen pretrained
-        weights, merged weights) is checked per call in ``_block_call``."""
+        """STRUCTURE-only part of the eligibility test (cached per (block, next_norm) by ``BasicLayer``, dropped by its ``_apply`` and
+        by ``invalidate_fused_cache``): the stock tasks-free block of every shipped config -- four MTLoRALinear layers with a shared
+        'matrix' update, exact GELU, plain nn.LayerNorm's, 32-wide heads.  Nothing here can change without a module being swapped:
+        what a ``.to()`` / ``.half()``, an attribute assignment or a hook CAN change (parameter dtypes / devices / contiguity,
+        ``attention_layout``, the dropout probabilities, frozen / merged state) is looked at on every call in ``_block_call``."""
         def plain_ln(m):
-            return (type(m) is nn.LayerNorm and m.elementwise_affine and m.bias is not None and len(m.normalized_shape) == 1
-                    and m.weight.dtype == torch.float32)
+            return type(m) is nn.LayerNorm and m.elementwise_affine and m.bias is not None and len(m.normalized_shape) == 1
 
         def stock_linear(m):
-            return (isinstance(m, MTLoRALinear) and m.r > 0 and m.tasks is None and hasattr(m, "lora_shared_A")
-                    and m.shared_mode == "matrix" and not isinstance(m.lora_shared_scale, torch.Tensor)
-                    and m.lora_shared_A.dtype == torch.float32 and m.lora_shared_A.is_contiguous() and m.lora_shared_B.is_contiguous())
+            return isinstance(m, MTLoRALinear) and m.r > 0 and m.tasks is None and hasattr(m, "lora_shared_A") and m.shared_mode == "matrix"
 
         lin = (self.attn.qkv, self.attn.proj, self.mlp.fc1, self.mlp.fc2)
         C = self.dim
-        return (not self.lora and self.attention_layout == "image" and next_norm is not None
+        return (not self.lora and next_norm is not None
                 and all(stock_linear(m) for m in lin) and all(plain_ln(m) for m in (self.norm1, self.norm2, next_norm))
                 and type(self.mlp.act) is nn.GELU and getattr(self.mlp.act, "approximate", "none") == "none"
-                and self.mlp.drop.p == 0.0 and self.attn.proj_drop.p == 0.0 and self.attn.attn_drop.p == 0.0
+                and all(isinstance(d, nn.Dropout) for d in (self.mlp.drop, self.attn.proj_drop, self.attn.attn_drop))
                 and C % 8 == 0 and self.mlp.fc1.linear.out_features % 8 == 0
                 and C // self.num_heads == 32 and self.window_size * self.window_size <= 64)
 
     def _block_call(self, has_norm1: bool, next_norm, cdtype, x):
-        """(BlockCall, flat tensor list) of this block for a ``SwinBlockRunFn`` call, or None when a layer cannot run fused now
-        (merged weights, factors on another device ...).  Draws the dropout seeds and DropPath factors in the order of ``forward``."""
+        """(BlockCall, flat tensor list) of this block for a ``SwinBlockRunFn`` call, or None when the block cannot run fused NOW.
+        Every eligibility check comes first; only then are the dropout seeds and DropPath factors drawn, in the order of ``forward``
+        (a call that falls back must not have consumed seeds the per-layer path then draws again)."""
         lin = (self.attn.qkv, self.attn.proj, self.mlp.fc1, self.mlp.fc2)
-        # what can change between calls is looked at on every call (a dozen attribute reads): a hook registered on any module inside
-        # must see its module called, an un-frozen pretrained weight needs the dense gradients of the per-layer Function, a merged
-        # weight has no shared update to apply
+        dev = x.device
+        # what can change between calls is looked at on every call (a few dozen attribute reads): a hook registered on any module
+        # inside must see its module called, an un-frozen pretrained weight needs the dense gradients of the per-layer Function, a
+        # merged weight has no shared update to apply, a model.to(bf16) / .half() leaves fp32-typed raw pointers stale
+        if self.attention_layout != "image" or self.mlp.drop.p != 0.0 or self.attn.proj_drop.p != 0.0 or self.attn.attn_drop.p != 0.0:
+            return None
         for m in (self, self.attn, self.mlp, self.norm1, self.norm2, next_norm, self.mlp.act, self.drop_path) + lin:
             if m._forward_hooks or m._forward_pre_hooks or m._backward_hooks or m._backward_pre_hooks:
                 return None
-        metas, weights, fparams = [], [], []
+        for n in (self.norm1, self.norm2, next_norm):
+            for t in (n.weight, n.bias):
+                if t.dtype != torch.float32 or t.device != dev or not t.is_contiguous():
+                    return None
         for m in lin:
-            if (m.merged or not m.lora_shared_A.is_cuda or m.linear.weight.requires_grad
+            if (m.merged or isinstance(m.lora_shared_scale, torch.Tensor) or m.linear.weight.requires_grad
                     or (m.linear.bias is not None and m.linear.bias.requires_grad)):
                 return None
-            metas.append(m.meta_t0(cdtype, x.device))
+            for t in (m.lora_shared_A, m.lora_shared_B):
+                if t.dtype != torch.float32 or t.device != dev or not t.is_contiguous():
+                    return None
+            if m.linear.weight.device != dev:
+                return None
+        tab = self.attn.relative_position_bias_table
+        if tab.device != dev or (self._attn_mask_ids is not None and (self._attn_mask_ids.device != dev or self._attn_mask_ids.dtype != torch.int32
+                                                                      or not self._attn_mask_ids.is_contiguous())):
+            return None
+        metas, weights, fparams = [], [], []
+        for m in lin:
+            metas.append(m.meta_t0(cdtype, dev))
             weights.append(m._weights(cdtype))
             fparams += [m.lora_shared_A, m.lora_shared_B]
         p_dp = self.drop_path.drop_prob if isinstance(self.drop_path, DropPath) else 0.0
@@ -525,6 +541,10 @@ class BasicLayer(nn.Module):
             return 0, x, None
         x, normed = Fn.SwinBlockRunFn.apply(calls, x, None, *flat)
         return len(calls), x, normed
+
+    def _apply(self, fn, *a, **k):  # .to() / .cuda() / .half(): nothing cached about the blocks survives a conversion
+        self.__dict__.pop("_fusable_cache", None)
+        return super()._apply(fn, *a, **k)
 
     def invalidate_fused_cache(self) -> None:
         """forget which blocks qualify STRUCTURALLY for the one-call path (after swapping modules inside a block; hooks, frozen / merged

@@ -427,7 +427,7 @@ def test_factor_side_stream_pending_paths():
         Fn._FACTOR_MIN_M = 0
         ref1, n0 = run(1, False)
         got1, n1 = run(1, True)
-        assert n0 == 0 and n1 == 2  # pending at the end of the pass: m2's two factors (m's second call joined the stream and popped its own)
+        assert n0 == 0 and n1 == 4  # pending at the end of the pass: m2's two factors and m's (re-marked under the current pass: round 6)
         ref2, _ = run(2, False)
         got2, _ = run(2, True)
         got3, n3 = run(2, True, zero_between=True)
@@ -436,7 +436,55 @@ def test_factor_side_stream_pending_paths():
         Fn._FACTOR_MIN_M = keep_m
     for a, b in zip(ref1 + ref2 + ref3, got1 + got2 + got3):
         assert torch.equal(a, b)
-    assert n3 == 2
+    assert n3 == 4
+
+
+def test_factor_side_stream_three_uses_and_tensor_hooks():
+    """(a) the same layer THREE times in one graph -- the second use pops the entry of the first; unless it is put back the
+    third use goes to the side stream again and autograd sums it with the first two on the main stream without waiting; (b) a tensor
+    hook on a factor Parameter receives the gradient on the backward's stream, so that layer must keep its factor gradients there.
+    Both must reproduce the single-stream gradients bit for bit, and (b) must not have marked the hooked layer's factors."""
+    from mtlora_amd import functional as Fn
+    torch.manual_seed(4)
+    dtype = torch.bfloat16
+    m = _t0_layer(96, 96, 16, dtype, 0.0, scale=2.0)
+    x = (0.5 * torch.randn(9000, 96, device=dev())).to(dtype)
+    keep_m = Fn._FACTOR_MIN_M
+    side = torch.cuda.Stream()
+    seen = []
+
+    def run(use_side, hook=False):
+        m.zero_grad(set_to_none=True)
+        Fn.factor_stream_joined()
+        Fn.set_factor_stream(side if use_side else None)
+        h = m.lora_shared_A.register_hook(lambda g: seen.append(float(g.float().abs().sum())) or g * 1.0) if hook else None
+        try:
+            xi = x.clone().requires_grad_(True)
+            y, _ = m(xi)
+            y, _ = m(y)
+            y, _ = m(y)   # third use in the same graph
+            (y.float() ** 2).mean().backward()
+            marked = len(Fn._side_pending)
+        finally:
+            Fn.set_factor_stream(None)
+            if h is not None:
+                h.remove()
+        torch.cuda.current_stream().wait_stream(side)
+        Fn.factor_stream_joined()
+        torch.cuda.synchronize()
+        return [m.lora_shared_A.grad.detach().clone(), m.lora_shared_B.grad.detach().clone()], marked
+
+    try:
+        Fn._FACTOR_MIN_M = 0
+        ref, _ = run(False)
+        got, n = run(True)
+        ref_h, _ = run(False, hook=True)
+        got_h, n_h = run(True, hook=True)
+    finally:
+        Fn._FACTOR_MIN_M = keep_m
+    assert n == 2 and n_h == 0
+    for a, b in zip(ref + ref_h, got + got_h):
+        assert torch.equal(a, b)
 
 
 def test_linear_unused_output_gets_none_grad():

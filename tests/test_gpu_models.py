@@ -636,6 +636,79 @@ def test_block_call_falls_back_for_hooked_or_merged_blocks():
         S.set_fused_blocks(prev)
 
 
+def test_block_call_sees_conversions_and_attribute_changes():
+    """what the one-call path caches per stage is STRUCTURE only.  After the first grad-enabled forward (a) switching a block
+    to the reference's window layout, (b) setting a dropout probability inside a block, (c) ``model.to(torch.bfloat16)`` (LayerNorm and
+    factor parameters no longer fp32: their raw pointers must not reach kernels that read fp32) each keep the affected blocks off the
+    one-call path -- and the results still agree with the per-layer path; a second stage with another window size but the same
+    (B, H, W, C, hidden) gets its own scratch size (the byte-size cache is keyed by the attention geometry too)."""
+    from mtlora_amd import functional as Fn
+    from mtlora_amd import mtl_harness as H
+    from mtlora_amd import swin_transformer_mtlora as S
+    tasks = ["semseg", "normals"]
+    model = H.build_model(img_size=224, tasks=tasks, depths=(3, 2), num_heads=(3, 6), r_shared=8, r_task=4, seed=3).to(dev()).eval()
+    bb = model.backbone
+    x = torch.randn(2, 3, 224, 224, device=dev())
+    n_calls = [0]
+    orig = Fn.SwinBlockRunFn.forward
+
+    def counting(ctx, cl, *a):
+        n_calls[0] += len(cl)
+        return orig(ctx, cl, *a)
+
+    def run(amp=True):
+        bb.zero_grad(set_to_none=True)
+        n_calls[0] = 0
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
+            st = bb(x if amp else x.to(torch.bfloat16), return_stages=True)
+        sum((s.float() ** 2).sum() + sum((v.float() ** 2).sum() for v in tl.values()) for s, tl in st).backward()
+        return [s.detach().float().clone() for s, _ in st]
+
+    Fn.SwinBlockRunFn.forward = staticmethod(counting)
+    prev = S.set_fused_blocks(True)
+    try:
+        ref = run()
+        assert n_calls[0] == 3
+        blk = bb.layers[0].blocks[0]
+        blk.attention_layout = "windows"          # (a) no invalidate_fused_cache() call: seen per call
+        got = run()
+        assert n_calls[0] == 1                    # stage 0's run ends in front of its first block; stage 1's block stays fused
+        for a, b in zip(ref, got):
+            assert (b - a).abs().max().item() <= 1e-2 * a.abs().max().item(), "windows layout after the first fused forward"
+        blk.attention_layout = "image"
+        bb.layers[0].blocks[1].mlp.drop.p = 0.5   # (b) eval mode: still the identity, but the block is no longer the stock one
+        got = run()
+        assert n_calls[0] == 2
+        for a, b in zip(ref, got):
+            assert torch.equal(a, b)
+        bb.layers[0].blocks[1].mlp.drop.p = 0.0
+        run()
+        assert n_calls[0] == 3
+        model.to(torch.bfloat16)                  # (c) every parameter bf16 now, the cached weight copies are gone too
+        got = run(amp=False)
+        assert n_calls[0] == 0
+        for a, b in zip(ref, got):
+            assert (b - a).abs().max().item() <= 3e-2 * a.abs().max().item(), "bf16 parameters after the first fused forward"
+    finally:
+        Fn.SwinBlockRunFn.forward = staticmethod(orig)
+        S.set_fused_blocks(prev)
+    # same (B, H, W, C, hidden), window 7 vs 8: two entries in the byte-size cache, both calls run
+    keys = len(Fn._blk_bytes_cache)
+    for ws in (7, 8):
+        torch.manual_seed(0)
+        lay = S.BasicLayer(dim=96, input_resolution=(56, 56), depth=2, num_heads=3, window_size=ws, tasks=None,
+                           mtlora=H.mtlora_namespace([], 8, 4, n_stages=1), layer_idx=0).to(dev())
+        for n, q in lay.named_parameters():
+            if "lora_" not in n and "norm" not in n:
+                q.requires_grad_(False)
+        xx = torch.randn(2, 56 * 56, 96, device=dev(), requires_grad=True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y, _ = lay(xx)
+        y.float().pow(2).sum().backward()
+        assert torch.isfinite(xx.grad).all()
+    assert len(Fn._blk_bytes_cache) >= keys + 2
+
+
 def test_factor_packer_one_launch_per_step_is_bit_identical():
     """lora.FactorPacker: the low-rank factors of every MTLoRALinear packed by ONE launch per step (mtlora_linear_pack_table, from the
     second step on: the first records each layer's call signature) instead of one k_pack per layer and forward -- four train steps must

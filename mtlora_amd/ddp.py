@@ -63,7 +63,10 @@ class GradReducer:
         self._global_seen: Optional[List[List[bool]]] = None
         all_params = list(params)
         if broadcast and self.active:
-            self._broadcast_from_rank0([p.data for p in all_params] + ([] if buffers is None else list(buffers)))
+            # p.detach(), not p.data: the copy must bump the Parameter's version counter -- a layer that has already run a forward
+            # holds compute-dtype copies of its frozen weights keyed by that version (lora.MTLoRALinear._weights) and would keep
+            # multiplying with the pre-broadcast values (found by the two-rank test of round 6, where rank 1 is seeded differently)
+            self._broadcast_from_rank0([p.detach() for p in all_params] + ([] if buffers is None else list(buffers)))
         plist = [p for p in all_params if p.requires_grad]
         plist.reverse()  # approximate backward completion order
         cap = int(bucket_mb * 1024 * 1024 / 4)

@@ -46,6 +46,39 @@ def assert_close(a, b, dtype, what="", mult=1.0):
     assert e <= TOL[dtype] * mult, f"{what}: rel err {e:.3e} > {TOL[dtype] * mult:.1e}"
 
 
+def eager_backbone_errors(cfg, x, dtype, c, tag, loss_tensors):
+    """what the REFERENCE's own eager dataflow (the oracle's ATen ops under the same autocast dtype, on this GPU) loses against the
+    fp64 fixture on the same 2-stage backbone: {parameter name: rel. gradient error}.  Stage outputs are held to the north-star
+    tolerance (x1); a gradient behind four 16-bit blocks in a row to tolerance + the eager path's own error on that tensor,
+    measured here -- never to a free multiplier."""
+    P = {k: v.to(dev()).requires_grad_(True) for k, v in O.make_params(O.backbone_param_shapes(cfg)).items()}
+    with torch.autocast("cuda", dtype=dtype):
+        stages = O.backbone_stages(P, x, cfg)
+    loss = 0
+    for i, (st, tl) in enumerate(stages):
+        loss = loss + (st.float() * O.det_tensor(f"{tag}.g.{i}", st.shape, 1.0).to(dev())).sum()
+        for t in cfg["tasks"]:
+            loss = loss + (tl[t].float() * O.det_tensor(f"{tag}.g.{i}.{t}", st.shape, 1.0).to(dev())).sum()
+    loss.backward()
+    errs = {}
+    for n, g in c["grads"].items():
+        if g is None or P[n].grad is None:
+            continue
+        got = P[n].grad.double().flatten().cpu()
+        if isinstance(g, dict):
+            scale = max(g["samples"].abs().max().item(), g.get("abssum", 0.0) / got.numel())
+            errs[n] = ((got[g["idx"]] - g["samples"]).abs().max() / max(scale, 1e-12)).item()
+        else:
+            errs[n] = rel_err(P[n].grad, g)
+    return errs
+
+
+def grad_tol(dtype, eager, n):
+    """north-star tolerance + the distance of the reference's own eager 16-bit result from the fp64 fixture on this tensor: what
+    |hip - eager| <= tol (the north star's "match the reference PyTorch path within 1e-2 bf16") implies for the error against fp64"""
+    return TOL[dtype] + eager.get(n, 0.0)
+
+
 # ------------------------------------------------------------------------------------------------
 def test_library_loaded_and_layouts():
     """MFMA C/D layout and ds_read_b64_tr_b16 gather the kernels assume."""
@@ -728,22 +761,26 @@ def test_backbone_small_golden(golden, dtype):
         stages = bb(x, return_stages=True)
     loss = 0
     for i, (s, tl) in enumerate(stages):
-        assert_close(s, c["stages"][i][0], dtype, f"stage {i}", mult=2)
+        assert_close(s, c["stages"][i][0], dtype, f"stage {i}")
         loss = loss + (s.float() * O.det_tensor(f"bbs.g.{i}", s.shape, 1.0).to(dev())).sum()
         for t in tasks:
-            assert_close(tl[t], c["stages"][i][1][t], dtype, f"stage {i} {t}", mult=2)
+            assert_close(tl[t], c["stages"][i][1][t], dtype, f"stage {i} {t}")
             loss = loss + (tl[t].float() * O.det_tensor(f"bbs.g.{i}.{t}", s.shape, 1.0).to(dev())).sum()
     loss.backward()
     named = dict(bb.named_parameters())
+    # gradients: the north-star tolerance + what the reference's own eager 16-bit dataflow loses on that tensor (grad_tol)
+    eager = eager_backbone_errors(cfg, x, dtype, c, "bbs", None) if dtype != torch.float32 else {}
     for n, g in c["grads"].items():
         if g is None:
             assert named[n].grad is None, n
         elif isinstance(g, dict):
             s = named[n].grad.double().flatten().cpu()
             ref = g["samples"]
-            assert ((s[g["idx"]] - ref).abs().max() / ref.abs().max().clamp_min(1e-12)).item() <= TOL[dtype] * 3, n
+            e = ((s[g["idx"]] - ref).abs().max() / ref.abs().max().clamp_min(1e-12)).item()
+            _log_parity(f"grad {n} (samples; eager {eager.get(n, 0.0):.2e})", e, TOL[dtype], grad_tol(dtype, eager, n) / TOL[dtype])
+            assert e <= grad_tol(dtype, eager, n), (n, e, eager.get(n))
         else:
-            assert_close(named[n].grad, g, dtype, f"grad {n}", mult=3)
+            assert_close(named[n].grad, g, dtype, f"grad {n} (eager {eager.get(n, 0.0):.2e})", mult=grad_tol(dtype, eager, n) / TOL[dtype])
     assert sorted(n for n, p in bb.named_parameters() if p.grad is None) == c["grad_is_none"]
 
 
@@ -775,30 +812,39 @@ def test_backbone_options_golden(golden, case, dtype):
         stages = bb(x, return_stages=True)
     loss = 0
     for i, (s, tl) in enumerate(stages):
-        assert_close(s, c["stages"][i][0], dtype, f"stage {i}", mult=2)
+        assert_close(s, c["stages"][i][0], dtype, f"stage {i}")
         loss = loss + (s.float() * O.det_tensor(f"bbo.g.{i}", s.shape, 1.0).to(dev())).sum()
         for t in tasks:
-            assert_close(tl[t], c["stages"][i][1][t], dtype, f"stage {i} {t}", mult=2)
+            assert_close(tl[t], c["stages"][i][1][t], dtype, f"stage {i} {t}")
             loss = loss + (tl[t].float() * O.det_tensor(f"bbo.g.{i}.{t}", s.shape, 1.0).to(dev())).sum()
     loss.backward()
     named = dict(bb.named_parameters())
-    scale_grads = []
+    # gradients: the north-star tolerance + what the reference's own eager bf16 dataflow loses on that tensor (grad_tol; measured
+    # here, on the same fixture); fp32: the scale gradients -- ONE scalar each, an inner product of two near-zero-mean tensors -- keep 3e-3
+    eager = eager_backbone_errors(cfg, x, dtype, c, "bbo", None) if dtype != torch.float32 else {}
+    scale_grads, scale_eager = [], []
     for n, g in c["grads"].items():
         got = named[n].grad
         assert got is not None, n
         if isinstance(g, dict):
             f = got.double().flatten().cpu()
             scale = max(g["samples"].abs().max().item(), g["abssum"] / f.numel())
-            assert (f[g["idx"]] - g["samples"]).abs().max().item() <= TOL[dtype] * 3 * scale, n
+            e = (f[g["idx"]] - g["samples"]).abs().max().item() / scale
+            _log_parity(f"{n} (samples; eager {eager.get(n, 0.0):.2e})", e, TOL[dtype], grad_tol(dtype, eager, n) / TOL[dtype])
+            assert e <= grad_tol(dtype, eager, n), (n, e, eager.get(n))
         elif n.endswith("lora_shared_scale") and dtype == torch.bfloat16:
             scale_grads.append((got.detach().float().cpu().reshape(1), g.float().reshape(1)))
-        else:
+            scale_eager.append(eager.get(n, 0.0) * g.abs().item())
+        elif n.endswith("lora_shared_scale"):
             assert_close(got, g, dtype, n, mult=3)
+        else:
+            assert_close(got, g, dtype, f"{n} (eager {eager.get(n, 0.0):.2e})", mult=grad_tol(dtype, eager, n) / TOL[dtype])
     if scale_grads:
-        # bf16: a scale gradient is ONE scalar = <dB, B> / s, an inner product of two near-zero-mean tensors, and the bf16
-        # rounding of the activations behind dB leaves noise of ~5-10 % of the LARGEST scale gradient on each of them (fp32
-        # holds 3e-3 per scalar, above): the 16 scalars are compared as one vector, relative to its largest entry
-        assert_close(torch.cat([a for a, _ in scale_grads]), torch.cat([b for _, b in scale_grads]), dtype, "scale grads", mult=3)
+        # bf16: the 16 scale scalars are compared as one vector, relative to its largest entry -- tolerance + the eager bf16 path's
+        # error on the same vector
+        ref_v = torch.cat([b for _, b in scale_grads])
+        ev = max(scale_eager) / ref_v.abs().max().item()
+        assert_close(torch.cat([a for a, _ in scale_grads]), ref_v, dtype, f"scale grads (eager {ev:.2e})", mult=1.0 + ev / TOL[dtype])
     assert sorted(n for n in c["trainable"] if named[n].grad is None or named[n].grad.abs().max() == 0) == c["grad_is_none"]
 
 

@@ -488,6 +488,113 @@ def _reducer_case(bucket_mb, pin=False):
             dist.destroy_process_group()
 
 
+_TWO_RANK_WORKER = r'''
+import os, sys
+import torch
+import torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from mtlora_amd import functional as Fn
+from mtlora_amd import mtl_harness as H
+from mtlora_amd.ddp import GradReducer
+
+rank = int(os.environ["RANK"])
+torch.cuda.set_device(0)                      # BOTH ranks on cuda:0: RCCL cannot do that, gloo stages device tensors through the host
+dist.init_process_group("gloo", init_method="env://")
+dev = torch.device("cuda", 0)
+tasks = ["semseg", "normals", "sal", "human_parts"]
+Fn._FACTOR_MIN_M = 0                          # the factor-gradient side stream also for these small layers
+model = H.build_model(img_size=224, tasks=tasks, depths=(2, 2, 2, 2), r_shared=16, r_task=4, seed=3 + 10 * rank).to(dev)
+model.eval()                                  # SURVEY 8e: heads' BatchNorm on running statistics, no dropout / DropPath -> per-sample linear
+
+
+class Probe:                                  # a loss that is a plain mean over samples: rank-mean of gradients == gradient of the joint batch
+    def task_low(self, t, lo, w):
+        return (lo.float() * w).sum() / lo.shape[0]
+
+    def combine(self, per):
+        return sum(per.values()), per
+
+
+class Keep:                                   # optimizer stand-in: keeps the (reduced) gradients train_step would hand to AdamW
+    def __init__(self, params):
+        self.param_groups = [{"params": [p for p in params if p.requires_grad]}]
+        self.grads = None
+
+    def step(self):
+        self.grads = [None if p.grad is None else p.grad.detach().clone() for p in self.param_groups[0]["params"]]
+
+    def zero_grad(self, set_to_none=True):
+        for p in self.param_groups[0]["params"]:
+            p.grad = None
+
+
+g = torch.Generator().manual_seed(99)
+img_all = torch.randn(4, 3, 224, 224, generator=g)
+with torch.no_grad():
+    lows = model(img_all[:1].to(dev), upsample=False, concurrent=False)
+w_all = {t: torch.randn(4, *lows[t].shape[1:], generator=g) for t in tasks}
+red = GradReducer(model.parameters(), bucket_mb=34.0, buffers=model.buffers())   # broadcasts rank 0's parameters: ranks were seeded differently
+assert red.active and red.world == 2 and len(red.buckets) == 1
+opt = Keep(list(model.parameters()))
+sl = slice(2 * rank, 2 * rank + 2)
+for _ in range(2):                            # second step: static_graph path (the used-set agreed on at step one)
+    H.train_step(model, Probe(), opt, img_all[sl].to(dev), {t: w_all[t][sl].to(dev) for t in tasks}, clip_grad=0.0, reducer=red,
+                 amp_dtype=None)
+torch.cuda.synchronize()
+mine = opt.grads
+names = [n for n, p in model.named_parameters() if p.requires_grad]
+# (i) both ranks hold identical gradients
+flat = torch.cat([q.reshape(-1).cpu() for q in mine if q is not None])
+both = [torch.empty_like(flat) for _ in range(2)]
+dist.all_gather(both, flat)
+assert torch.equal(both[0], both[1]), "ranks disagree after the all-reduce"
+# (iii) the structurally unused factors stay without a gradient on both ranks
+none = sorted(n for n, q in zip(names, mine) if q is None)
+assert none == ["backbone.layers.3.blocks.1.mlp.fc2.lora_shared_A", "backbone.layers.3.blocks.1.mlp.fc2.lora_shared_B"], none
+# (ii) == one process on the concatenated batch (same parameters: the broadcast made them rank 0's)
+red.remove()
+ref = Keep(list(model.parameters()))
+H.train_step(model, Probe(), ref, img_all.to(dev), {t: w_all[t].to(dev) for t in tasks}, clip_grad=0.0, reducer=None, amp_dtype=None)
+torch.cuda.synchronize()
+gmax = max(float(r.abs().max()) for r in ref.grads if r is not None)
+worst, bad = 0.0, []
+for n, a, r in zip(names, mine, ref.grads):
+    assert (a is None) == (r is None), n
+    if r is not None:
+        e = float((a.double() - r.double()).abs().max()) / max(float(r.abs().max()), 1e-6 * gmax)
+        worst = max(worst, e)
+        if e > 1e-3:
+            bad.append((n, e))
+assert not bad, (len(bad), len(names), bad[:8])
+dist.barrier()
+dist.destroy_process_group()
+print("OK", rank, "worst rel err vs joint batch %.2e" % worst)
+'''
+
+
+def test_two_ranks_on_one_gpu_real_model_gloo(tmp_path):
+    """VERDICT r05 item 7 / SURVEY 8e: the REAL 4-task model through ``train_step`` + ``GradReducer`` at world size 2 -- two processes
+    on cuda:0 over gloo (RCCL cannot place two ranks on one device), task streams, factor-gradient stream and the one-call blocks ON,
+    one 34 MB bucket as bench.py uses: (i) both ranks end with identical gradients, (ii) they equal the single-process gradients on the
+    concatenated batch at 1e-3 (fp32; heads' BatchNorm on running statistics and a per-sample-mean probe loss, so that the joint
+    gradient IS the rank mean), (iii) ``layers.3.blocks.1.mlp.fc2.lora_shared_*`` keep ``grad is None`` on both; ranks are seeded
+    differently and made identical by the reducer's broadcast."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "two_rank_worker.py"
+    script.write_text(_TWO_RANK_WORKER)
+    port = 29600 + (os.getpid() % 300)
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script), root], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0 and "OK" in o, o[-3000:]
+
+
 def test_factor_gradient_stream_is_bit_identical():
     """train_step runs the MTLoRALinear factor gradients (k_tn) on a second stream next to the backward chain
     (functional.set_factor_stream; joined before clip / AdamW): three steps must leave loss and every parameter bit-identical

@@ -108,9 +108,10 @@ def _side_join_pending(params, dev) -> bool:
 
 def _side_safe_params(params) -> bool:
     """may the gradients of ``params`` be WRITTEN on the side stream?  Only when autograd will take the gradient tensor as it is:
-    no existing .grad to accumulate into (an add on the backward's stream) and no tensor hook on the Parameter (a hook receives --
-    and may replace, i.e. force a copy of -- the gradient on the backward's stream while the side stream is still writing it)."""
-    return all(p is None or (p.grad is None and not p._backward_hooks) for p in params)
+    no existing .grad to accumulate into (an add on the backward's stream), no tensor hook on the Parameter (a hook receives --
+    and may replace, i.e. force a copy of -- the gradient on the backward's stream while the side stream is still writing it) and
+    no NON-LEAF factor (lora.py's rank-aware Delta W: its producer's backward reads the gradient on the backward's stream)."""
+    return all(p is None or (p.grad is None and not p._backward_hooks and (p.is_leaf or not p.requires_grad)) for p in params)
 
 
 def _side_mark_pending(params, side) -> None:
@@ -473,11 +474,14 @@ class MTLoRALinearFn(torch.autograd.Function):
         dx = torch.empty(ishape, dtype=meta.dtype, device=dev)
         dxt = [torch.empty(ishape, dtype=meta.dtype, device=dev) for _ in range(nx)]
         has_s = meta.r_s > 0 and (dy_s is not None or (meta.mode == 1 and any(g is not None for g in dy_t)))
-        dA_s = torch.empty((meta.r_s, meta.K), dtype=torch.float32, device=dev) if has_s else None
-        dB_s = torch.empty((meta.N, meta.r_s), dtype=torch.float32, device=dev) if has_s else None
-        dA_t = [torch.empty((meta.r_t[t], meta.K), dtype=torch.float32, device=dev) if dy_t[t] is not None else None
+        # (a factor that takes no gradient -- the identity side of a rank-aware update, a frozen factor -- is not reduced at all: the
+        # library skips the problems whose output pointer is null)
+        nA, nB = 10 + nx, 10 + nx + T
+        dA_s = torch.empty((meta.r_s, meta.K), dtype=torch.float32, device=dev) if (has_s and need[7]) else None
+        dB_s = torch.empty((meta.N, meta.r_s), dtype=torch.float32, device=dev) if (has_s and need[8]) else None
+        dA_t = [torch.empty((meta.r_t[t], meta.K), dtype=torch.float32, device=dev) if (dy_t[t] is not None and need[nA + t]) else None
                 for t in range(T)]
-        dB_t = [torch.empty((meta.N, meta.r_t[t]), dtype=torch.float32, device=dev) if dy_t[t] is not None else None
+        dB_t = [torch.empty((meta.N, meta.r_t[t]), dtype=torch.float32, device=dev) if (dy_t[t] is not None and need[nB + t]) else None
                 for t in range(T)]
         if nx:  # a task input whose output got no gradient still needs a defined (zero) gradient
             for t in range(T):

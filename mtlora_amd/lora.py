@@ -9,6 +9,7 @@ Only the classes the reference actually instantiates are provided (``LoRALinear`
 from __future__ import annotations
 
 import math
+import os
 from typing import Any, Dict, Mapping, Optional, Tuple, Union
 
 import torch
@@ -35,6 +36,38 @@ class LoRALayer(nn.Module):
     def dropout_p(self) -> float:
         d = self.lora_dropout
         return float(d.p) if isinstance(d, nn.Dropout) else 0.0
+
+
+# Rank-aware association.  y = x W^T + s (x_in A^T) B^T costs 2 M r (K + N) flops and moves M x r intermediates
+# (P forward, Q backward, both again for the factor gradients); for r > min(K, N) -- BASELINE configs[4] at r = 256: K = 96 / 192 in
+# stages 0 / 1, up to nine outputs per layer, i.e. 2304 intermediate columns per token -- the update is cheaper as the K x N matrix it
+# is.  The library's fused kernels take any pair (A', B') with y += (x_in A'^T) B'^T, so the update is handed over as
+#     K <= N:  A' = I_K,        B' = s B A  (N x K)      [P' = D(x_in), Q' = dY Delta W]
+#     K >  N:  A' = s B A,      B' = I_N                 [P' = the update itself, Q' = dY]
+# i.e. "rank" min(K, N) instead of r, with exactly the reference's semantics (lora.py:253-284: dropout in front of A only, x_tasks
+# layers see their own input).  Delta W is formed per call in fp32 by autograd-tracked matmuls, so dA = s B^T Z and dB = s Z A^T
+# (Z = dB' or dA', the N x K gradient the library returns) come out of autograd; the identity side gets no gradient (and the
+# library skips that reduction).  MTLORA_RANK_AWARE=0 keeps the low-rank form everywhere (A/B runs).
+RANK_AWARE = os.environ.get("MTLORA_RANK_AWARE", "1") != "0"
+_eyes: Dict[Any, torch.Tensor] = {}
+
+
+def _delta_factors(As, Bs, scales, K: int, N: int):
+    """effective (A', B') of updates s_i B_i A_i, each N x K: one batched matmul when the ranks agree"""
+    dev = As[0].device
+    key = (min(K, N), dev)
+    eye = _eyes.get(key)
+    if eye is None:
+        eye = _eyes[key] = torch.eye(min(K, N), dtype=torch.float32, device=dev)
+    with torch.autocast(dev.type, enabled=False):
+        if len(As) > 1 and len({a.shape[0] for a in As}) == 1:
+            sc = torch.tensor(scales, dtype=torch.float32, device=dev).view(-1, 1, 1) if len(set(scales)) > 1 else scales[0]
+            dW = list((torch.bmm(torch.stack([b.float() for b in Bs]), torch.stack([a.float() for a in As])) * sc).unbind(0))
+        else:
+            dW = [(b.float() @ a.float()) * s for a, b, s in zip(As, Bs, scales)]
+    if K <= N:
+        return [eye] * len(As), dW
+    return dW, [eye] * len(As)
 
 
 class MTLoRALinear(LoRALayer):
@@ -233,6 +266,15 @@ class MTLoRALinear(LoRALayer):
             self.unmerge()
         return super().train(mode)  # (the cached copies stay: W did not change, and a captured graph may hold their addresses)
 
+    def _rank_aware(self, r: int, scale) -> bool:
+        """apply an update of rank ``r`` as Delta W = s B A?  Only when that SHRINKS the intermediates (r > min(K, N)) and the scale
+        is a constant (a trainable scale gets its gradient from <dB, B> / s of the low-rank form)."""
+        return (RANK_AWARE and r > min(self.linear.in_features, self.linear.out_features) and not isinstance(scale, torch.Tensor)
+                and not self.merged)
+
+    def rank_aware_shared(self) -> bool:
+        return self.r > 0 and hasattr(self, "lora_shared_A") and self._rank_aware(self.r, self.lora_shared_scale)
+
     def meta_t0(self, dtype: torch.dtype, device) -> "Fn.LinearMeta":
         """the LinearMeta of a call of a layer WITHOUT tasks and with a constant shared scale (``tasks is None``, shared_mode 'matrix',
         not merged) -- what ``forward`` builds for such a layer, for callers that issue the library call themselves (the one-call
@@ -264,16 +306,35 @@ class MTLoRALinear(LoRALayer):
         par = lambda s: s if isinstance(s, nn.Parameter) else None
         ss = self.lora_shared_scale if shared else 0.0
         st = [self.lora_task_scale[t] for t in tasks]
+        # rank-aware association (round 6): an update of rank r > min(K, N) is applied as the (K x N)-sized Delta W = s B A it is
+        # (``_delta_factors``): the M x r intermediates of the low-rank form become M x min(K, N)
+        ra_s = shared and self.rank_aware_shared()
+        ra_t = [bool(tasks) and self._rank_aware(self._ranks[t], st[0]) for t in tasks]
+        A_s, B_s = (self.lora_shared_A, self.lora_shared_B) if shared else (None, None)
+        A_t, B_t = [self.lora_tasks_A[t] for t in tasks], [self.lora_tasks_B[t] for t in tasks]
+        r_s, r_t = (self.r if shared else 0), [self._ranks[t] for t in tasks]
+        vs, vt = val(ss), [val(s) for s in st]
+        if ra_s or any(ra_t):
+            K_, N_ = self.linear.in_features, self.linear.out_features
+            if ra_s:
+                (A_s,), (B_s,) = _delta_factors([A_s], [B_s], [vs], K_, N_)
+                r_s, vs = min(K_, N_), 1.0
+            idx = [i for i, f in enumerate(ra_t) if f]
+            if idx:
+                Ae, Be = _delta_factors([A_t[i] for i in idx], [B_t[i] for i in idx], [vt[i] for i in idx], K_, N_)
+                for j, i in enumerate(idx):
+                    A_t[i], B_t[i], r_t[i], vt[i] = Ae[j], Be[j], min(K_, N_), 1.0
         meta = Fn.LinearMeta(
             K=self.linear.in_features, N=self.linear.out_features,
-            r_s=self.r if shared else 0, r_t=tuple(self._ranks[t] for t in tasks),
-            scale_s=val(ss), scale_t=tuple(val(s) for s in st),
+            r_s=r_s, r_t=tuple(r_t), scale_s=vs, scale_t=tuple(vt),
             mode=1 if (self.shared_mode == "matrixv2" and tasks and not self.merged) else 0,
             has_x_tasks=bool(tasks) and x_tasks is not None, dropout_p=p, seed=Fn.next_seed() if p > 0 else 0,
             dtype=dtype, weight_requires_grad=self.linear.weight.requires_grad or (
                 self.linear.bias is not None and self.linear.bias.requires_grad),
             n_scale_t=len(tasks) if (tasks and isinstance(st[0], nn.Parameter)) else 0)
-        if has_lora:
+        if has_lora and (ra_s or any(ra_t)):
+            self._call_sig = None  # (the effective factors are formed per call: nothing for a FactorPacker to pack ahead of time)
+        elif has_lora:
             # (what the packed factors depend on besides the masters: the alpha-scaled copies carry the scales and the dropout scale)
             sig = (dtype, meta.r_s, meta.r_t, meta.scale_s, meta.scale_t, meta.mode, meta.has_x_tasks, p, str(x.device))
             self._call_sig = sig
@@ -287,11 +348,10 @@ class MTLoRALinear(LoRALayer):
         if gelu_gate is not None:
             gates = [gelu_gate[0]] + ([gelu_gate[1][t] for t in tasks] if meta.has_x_tasks else [])
             meta.n_gate = len(gates)
-        args = [meta, x, wc, wt, bf, self.linear.weight, self.linear.bias,
-                self.lora_shared_A if shared else None, self.lora_shared_B if shared else None, par(ss)]
+        args = [meta, x, wc, wt, bf, self.linear.weight, self.linear.bias, A_s, B_s, None if ra_s else par(ss)]
         if meta.has_x_tasks:
             args += [x_tasks[t] for t in tasks]
-        args += [self.lora_tasks_A[t] for t in tasks] + [self.lora_tasks_B[t] for t in tasks]
+        args += A_t + B_t
         if meta.n_scale_t:
             args += st
         args += gates

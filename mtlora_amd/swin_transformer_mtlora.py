@@ -342,7 +342,7 @@ class SwinTransformerBlock(nn.Module):
                 if t.dtype != torch.float32 or t.device != dev or not t.is_contiguous():
                     return None
         for m in lin:
-            if (m.merged or isinstance(m.lora_shared_scale, torch.Tensor) or m.linear.weight.requires_grad
+            if (m.merged or isinstance(m.lora_shared_scale, torch.Tensor) or m.rank_aware_shared() or m.linear.weight.requires_grad
                     or (m.linear.bias is not None and m.linear.bias.requires_grad)):
                 return None
             for t in (m.lora_shared_A, m.lora_shared_B):

@@ -84,7 +84,7 @@ def pytest_collection_modifyitems(config, items):
             continue
         if variant and "2cores" in it.name:  # (a host-side configuration: one family is enough)
             continue
-        if variant and "config_model" in it.name and "c5_8task" in it.name:
+        if variant and "config_model" in it.name and ("c5_8task" in it.name or "448px" in it.name):
             continue  # (whole-model c5 cases: [auto] only -- the 8-task layers run in [tiled] at full size in FULL_T4; 10 s each)
         if variant:
             is_gpu = it.get_closest_marker("gpu") is not None

@@ -79,6 +79,16 @@ def grad_tol(dtype, eager, n):
     return TOL[dtype] + eager.get(n, 0.0)
 
 
+@pytest.fixture
+def lowrank_form():
+    """tests that aim at the kernels of the LOW-RANK form at ranks beyond min(K, N) (k_pq with 128-column tiles, rank strides of 256
+    and more) switch lora.py's rank-aware association off: with it those shapes would run at rank min(K, N)"""
+    from mtlora_amd import lora
+    keep, lora.RANK_AWARE = lora.RANK_AWARE, False
+    yield
+    lora.RANK_AWARE = keep
+
+
 # ------------------------------------------------------------------------------------------------
 def test_library_loaded_and_layouts():
     """MFMA C/D layout and ds_read_b64_tr_b16 gather the kernels assume."""
@@ -379,6 +389,76 @@ def _t0_train_case(m, M, dtype, p, kind, gdev, in_scale=1.0):
         torch.nn.functional.gelu(hd).backward(xo.grad)
         ref["dx"] = hd.grad
     return got, ref, keep
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("geom", [
+    # (M, K, N, r_shared, r_task, T, x_tasks, p)
+    (1500, 96, 288, 256, 0, 0, False, 0.1),     # T = 0, K < N: A' = I_96, B' = s B A -- the fused k_sp_xres / k_sp_ares at rank 96 instead of k_pq at 256
+    (900, 384, 96, 256, 0, 0, False, 0.1),      # T = 0, K > N: A' = s B A, B' = I_96
+    (700, 96, 384, 256, 256, 8, True, 0.05),    # c5:256 fc1T: 9 outputs, the tasks on their own inputs: 864 intermediate columns instead of 2304
+    (700, 384, 96, 256, 256, 8, True, 0.05),    # c5:256 fc2T
+    (500, 192, 192, 256, 256, 8, False, 0.05),  # c5:256 projT at stage 1: the tasks read D(x)
+    (600, 96, 288, 64, 128, 2, True, 0.1),      # mixed: the shared update stays low-rank (64 < 96), the tasks' (128 > 96) do not
+])
+def test_linear_rank_aware_association_vs_oracle(geom, dtype):
+    """lora.py's rank-aware association: an update of rank r > min(K, N) is applied as Delta W = s B A through
+    the same library kernels (identity on one side), in TRAIN mode with the specified dropout mask -- outputs, dX, every dX_t and
+    every factor gradient (formed by autograd from the N x K gradient the library returns) against the fp64 oracle, which evaluates
+    the reference's low-rank formula (lora.py:253-284); the call must have gone out at rank min(K, N)."""
+    from mtlora_amd import functional as Fn
+    from mtlora_amd import lora
+    M, K, N, r_s, r_t, nt, use_xt, p = geom
+    tasks = _TASKS8[:nt] or None
+    torch.manual_seed(M + K + nt)
+    m = lora.MTLoRALinear(K, N, r={"shared": r_s, **{t: r_t for t in (tasks or [])}}, lora_shared_scale=2.0,
+                          lora_task_scale={t: 1.5 for t in tasks} if tasks else 1.0, lora_dropout=p, tasks=tasks).to(dev())
+    with torch.no_grad():
+        for n_, q in m.named_parameters():
+            q.copy_((torch.randn_like(q) * (0.05 if "lora" in n_ else 0.02)).to(dtype).float())
+    m.linear.weight.requires_grad_(False)
+    m.linear.bias.requires_grad_(False)
+    m.train()
+    xs_in = [(0.5 * torch.randn(M, K, device=dev())).to(dtype).requires_grad_(True) for _ in range(1 + (nt if use_xt else 0))]
+    seen = []
+    orig = Fn.MTLoRALinearFn.forward
+
+    def spy(ctx, meta, *a):
+        seen.append((meta.r_s, meta.r_t))
+        return orig(ctx, meta, *a)
+
+    Fn.MTLoRALinearFn.forward = staticmethod(spy)
+    try:
+        c0 = Fn._seed_counter
+        y, yt = m(xs_in[0], {t: xs_in[1 + i] for i, t in enumerate(tasks)} if use_xt else None)
+        Fn._seed_counter = c0
+        seed = Fn.next_seed()
+    finally:
+        Fn.MTLoRALinearFn.forward = staticmethod(orig)
+    rm = min(K, N)
+    assert seen == [(min(r_s, rm), tuple(min(r_t, rm) for _ in (tasks or [])))], seen
+    outs = [y] + [yt[t] for t in (tasks or [])]
+    gys = [torch.randn(M, N, device=dev()).to(dtype) for _ in outs]
+    torch.autograd.backward(outs, gys)
+    gdev = torch.device("cpu")
+    keep = O.dropout_keep_mask_t(seed, 0, M, K, p, device=gdev)
+    P = {k: v.detach().double().to(gdev).requires_grad_(v.requires_grad) for k, v in m.named_parameters()}
+    xo = [x.detach().double().to(gdev).requires_grad_(True) for x in xs_in]
+    kw = {}
+    if tasks:
+        kw = dict(tasks=tasks, A_t={t: P["lora_tasks_A." + t] for t in tasks}, B_t={t: P["lora_tasks_B." + t] for t in tasks},
+                  scale_t=m.lora_task_scale, x_tasks={t: xo[1 + i] for i, t in enumerate(tasks)} if use_xt else None)
+    yo, yto = O.mtlora_linear(xo[0], P["linear.weight"], P["linear.bias"], P["lora_shared_A"], P["lora_shared_B"], m.lora_shared_scale,
+                              keep_mask=keep, p=p, **kw)
+    refs = [yo] + [yto[t] for t in (tasks or [])]
+    torch.autograd.backward(refs, [g.double().to(gdev) for g in gys])
+    for i, (a, b) in enumerate(zip(outs, refs)):
+        assert_close(a, b.detach(), dtype, f"y[{i}]")
+    for i, (a, b) in enumerate(zip(xs_in, xo)):
+        assert_close(a.grad, b.grad, dtype, f"dx[{i}]")
+    for n_, q in m.named_parameters():
+        if q.requires_grad:
+            assert_close(q.grad, P[n_].grad, dtype, f"grad {n_}")
 
 
 @pytest.mark.parametrize("geom", [
@@ -1508,7 +1588,7 @@ def test_linear_accepts_strided_and_wider_inputs():
     (700, 384, 200, 256, torch.bfloat16, 0.1),    # rank stride 256: two 128-column tiles (blockIdx.y)
     (300, 136, 72, 328, torch.float16, 0.0),      # rank stride 336: three column tiles, the last one 62 % full
 ])
-def test_pq_kernel_off_grid_shapes(geom):
+def test_pq_kernel_off_grid_shapes(geom, lowrank_form):
     """k_pq (csrc/pq.h) on shapes that do not line up with its tiles: ragged M, K not a multiple of the 32-wide k-tile (zero-page
     chunks), rank strides of 16 - 128 (half-empty column tiles, clamped projection rows), more k-tiles than ring stages, both wave grids
     and both tile heights -- forward, dX and both factor gradients against the fp64 oracle with the specified dropout mask."""
@@ -1655,7 +1735,7 @@ def test_full_size_linear_t4_train_vs_oracle(name):
     (700, 200, 264, 8, 40, 16, True, torch.float16, 0.0),      # 8 tasks, unmasked (column-split wave grid), fp16
     (26000, 96, 96, 3, 64, 72, True, torch.bfloat16, 0.05),    # > 1.25 residency rounds: the 128-row tiles, per source
 ])
-def test_pq_kernel_multi_source_shapes(geom):
+def test_pq_kernel_multi_source_shapes(geom, lowrank_form):
     """k_pq with SEVERAL activation sources / output gradients (the T > 0 layers whose projection rows do not fit in LDS: Swin-B at
     rank 128, the r = 64 / 256 points of the 8-task sweep) forced on shapes off its tile grid: all outputs, dX, dX_t and every factor
     gradient against the fp64 oracle with the specified mask (the multi-source launches beyond one residency

@@ -88,6 +88,9 @@ MODEL_CASES = {
     "c5_8task_r16": ("c5:16", {}),
     "c5_8task_r64": ("c5:64", {}),
     "c5_8task_r256": ("c5:256", {}),
+    # the MFMA-balance config at the BASELINE resolution (448 px: stage-0 M = 25 088 rows at B = 2, the shapes bench.py's c4 leg
+    # launches per image) -- VERDICT r05 item 8; [auto] only (the 224 px case above runs in every family)
+    "c4_swin_b_r128_448px": ("c4", {"_img": 448}),
 }
 
 
@@ -98,19 +101,21 @@ def test_config_model_vs_oracle(case, amp):
     residual + PatchMerging kernels, fused GELU, fused losses) vs the oracle in fp64."""
     from mtlora_amd import mtl_harness as H
     name, over = MODEL_CASES[case]
+    over = dict(over)
+    px = over.pop("_img", 224)
     row = H.config(name)
     tasks = list(row["tasks"])
-    model = H.build_config_model(name, seed=3, img_size=224, drop_path_rate=0.0, DROPOUT=[0.0] * 4, **over).to(dev())
+    model = H.build_config_model(name, seed=3, img_size=px, drop_path_rate=0.0, DROPOUT=[0.0] * 4, **over).to(dev())
     _condition_normals_heads(model, tasks)
     model.train()
     crit = H.MultiTaskLoss(tasks)
-    img, tg = H.synthetic_batch(2, 224, tasks, seed=5, device=dev())
+    img, tg = H.synthetic_batch(2, px, tasks, seed=5, device=dev())
     sd = {k: v.detach().clone() for k, v in model.state_dict().items()}  # before the forward updates the BN running stats
     loss, per = _hip_loss(model, crit, img, tg, amp, concurrent=True if amp else False)
     loss.backward()
     torch.cuda.synchronize()
 
-    cfg = O.swin_t_cfg(img_size=224, tasks=tasks, r_shared=row["r_shared"], r_task=row["r_task"], embed_dim=row["embed_dim"],
+    cfg = O.swin_t_cfg(img_size=px, tasks=tasks, r_shared=row["r_shared"], r_task=row["r_task"], embed_dim=row["embed_dim"],
                        depths=row["depths"], num_heads=row["num_heads"], drop_path_rate=0.0, dropout=0.0)
     _compare_with_oracle(case, amp, model, sd, loss, per, img, tg, cfg, tasks)
 

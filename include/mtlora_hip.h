@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MTLORA_ABI_VERSION 7
+#define MTLORA_ABI_VERSION 8
 #define MTLORA_MAX_TASKS 8
 
 typedef enum mtlora_dtype {
@@ -126,7 +126,21 @@ typedef struct mtlora_linear_desc {
                             fwd then skips its own packing launch and ctx only holds P; bwd must get the same pointer.  The masters
                             change once per optimizer step, so a trainer packs every layer in ONE launch per step instead of one
                             launch per layer and call. */
+    int32_t hid;         /* ABI v8, 0 = none: role of this call inside an Mlp whose TASK hidden tensors stay implicit (MTLORA_HID_*, see
+                            mtlora_mlp_hid_* below) */
+    int32_t hid_pad_;
+    const void* hid_ptr; /* ABI v8: MTLORA_HID_FWD_BASE: OUT (M x N), the pretrained product x W^T + b without any low-rank update;
+                            MTLORA_HID_Q_GIVEN: IN (M x N), the summed output gradient G the dense part of dX is formed from (nullable) */
 } mtlora_linear_desc;
+
+/* d->hid flags (ABI v8) */
+#define MTLORA_HID_FWD_BASE 1 /* fwd (the Mlp's fc1): writes y_s (+ a_s) and the base product to d->hid_ptr; NO task outputs (y_t / a_t are
+                                 not touched) -- P (all segments) is written to ctx as usual */
+#define MTLORA_HID_P_GIVEN 2  /* fwd (the Mlp's fc2): the TASK columns of P in ctx were written by mtlora_mlp_hid_proj before this call; the
+                                 P pass runs for the shared source only, x_t is not read */
+#define MTLORA_HID_Q_GIVEN 4  /* bwd (the Mlp's fc1): the TASK columns of Q (head of `scratch`) were written by mtlora_mlp_hid_bwd; dy_t is
+                                 all-null, the dense part of dx comes from d->hid_ptr (G), dx_t / dA_t are formed from the given Q, dB_t
+                                 must be null (mtlora_mlp_hid_bwd returns them) */
 
 /* bytes of the context buffer written by fwd and read by bwd (packed low-rank factors + P; P alone when d->packed is set). */
 int64_t mtlora_linear_ctx_bytes(const mtlora_linear_desc* d);
@@ -181,6 +195,34 @@ int mtlora_linear_bwd_gelu(const mtlora_linear_desc* d, const void* x, const voi
                            const void* dy_s, const void* const* dy_t, const void* ctx, int64_t ctx_bytes, void* dx,
                            void* const* dx_t, float* dA_s, float* dB_s, float* const* dA_t, float* const* dB_t,
                            void* scratch, int64_t scratch_bytes, const void* h_s, const void* const* h_t, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Task-enabled Mlp with IMPLICIT task hidden tensors (ABI v8) -- replaces, for the T task streams of
+ * `Mlp.forward` called with x_tasks (models/swin_transformer_mtlora.py:57-78: fc1 -> GELU -> fc2, both
+ * MTLoRALinear with tasks, lora.py:262-266), the 3 T tensors of M x 4C elements the per-layer path writes
+ * and re-reads (h_t = fc1 task outputs, gelu(h_t), and the gradients dH_t):
+ *     h_t = h_base + P1_t B1_t^T   (h_base = x W1^T + b1, P1_t = s_t x_t A1_t^T: M x r_t)
+ * enters fc2 ONLY through P2_t = s_t gelu(h_t) A2_t^T (M x r_t), and dH_t = (Q2_t A2_t) .* gelu'(h_t) is
+ * consumed by G = dH_s + sum_t dH_t, Q1_t = s_t dH_t B1_t and the factor gradients dB1_t = dH_t^T P1_t,
+ * dA2_t = Q2_t^T gelu(h_t).  Call sequence (d1 / d2 = descriptors of fc1 / fc2, same M, d1->N == d2->K):
+ *   forward : mtlora_linear_fwd_gelu(d1 | HID_FWD_BASE) ; mtlora_mlp_hid_proj ; mtlora_linear_fwd(d2 | HID_P_GIVEN)
+ *   backward: mtlora_linear_bwd_gelu(d2, dx_t = dA_t = null) ; mtlora_mlp_hid_bwd ; mtlora_linear_bwd(d1 | HID_Q_GIVEN)
+ * Supported: 16-bit dtype, mode 'matrix', has_x_tasks, 1 <= T, every r_t <= 8, d1->N a multiple of 128 and
+ * <= 2048 (mtlora_mlp_hid_supported returns 1).  Deterministic (fixed-order partial sums).
+ * ------------------------------------------------------------------------------------------ */
+int mtlora_mlp_hid_supported(const mtlora_linear_desc* d1, const mtlora_linear_desc* d2);
+/* bytes of the partial-sum scratch of mtlora_mlp_hid_bwd (-1: unsupported shape) */
+int64_t mtlora_mlp_hid_bwd_scratch_bytes(const mtlora_linear_desc* d1, const mtlora_linear_desc* d2);
+/* ctx1: fc1's context (P1; and the packed factors when d1->packed is null); ctx2: fc2's context, whose task columns of P are written
+ * (and whose packed factors must already be there when d2->packed is null: mtlora_linear_pack into its head first). */
+int mtlora_mlp_hid_proj(const mtlora_linear_desc* d1, const mtlora_linear_desc* d2, const void* h_base, const void* ctx1,
+                        void* ctx2, void* stream);
+/* dh_s: gradient w.r.t. the shared pre-activation (dx of fc2's bwd_gelu); scratch2: fc2's backward scratch after its phase 1 (holds
+ * Q2); scratch1: fc1's backward scratch (its Q task columns are written); g: OUT (M x H) = dh_s + sum_t dH_t; dB1_t[t] (H x r_t) /
+ * dA2_t[t] (r_t x H): fp32 OUT, nullable. */
+int mtlora_mlp_hid_bwd(const mtlora_linear_desc* d1, const mtlora_linear_desc* d2, const void* h_base, const void* dh_s,
+                       const void* ctx1, const void* ctx2, const void* scratch2, void* scratch1, void* g, float* const* dB1_t,
+                       float* const* dA2_t, void* part, int64_t part_bytes, void* stream);
 
 /* Weight gradient of a plain linear layer with a NARROW output (the decoder heads' final 1x1 convolutions,
  * models/seg_hrnet.py:518-526: nn.Conv2d(1080, num_classes, 1) on B*H*W pixels; autograd's dW = dY^T X):

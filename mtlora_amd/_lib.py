@@ -12,7 +12,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int6
 import torch
 
 MAX_TASKS = 8
-ABI_VERSION = 7
+ABI_VERSION = 8
 F32, BF16, F16 = 0, 1, 2
 _DT = {torch.float32: F32, torch.bfloat16: BF16, torch.float16: F16}
 
@@ -27,7 +27,12 @@ class LinearDesc(Structure):
                 ("seed", c_uint64), ("seed_offset", c_void_p), ("bwd_phase", c_int32),
                 # kernel selection (ABI v6): 0 = the library's own choice; see include/mtlora_hip.h
                 ("sel_stream", c_int32), ("sel_dense", c_int32), ("sel_tn", c_int32), ("sel_projk", c_int32),
-                ("max_cu", c_int32), ("packed", c_void_p)]
+                ("max_cu", c_int32), ("packed", c_void_p),
+                # ABI v8: role inside an Mlp with implicit task hidden tensors (HID_* flags) and its extra pointer
+                ("hid", c_int32), ("hid_pad_", c_int32), ("hid_ptr", c_void_p)]
+
+
+HID_FWD_BASE, HID_P_GIVEN, HID_Q_GIVEN = 1, 2, 4
 
 
 class AttnDesc(Structure):
@@ -100,6 +105,11 @@ _SIGS = {
     "mtlora_linear_bwd_gelu": (c_int, [POINTER(LinearDesc), c_void_p, POINTER(c_void_p), c_void_p, c_void_p, POINTER(c_void_p),
                                        c_void_p, c_int64, c_void_p, POINTER(c_void_p), c_void_p, c_void_p, POINTER(c_void_p),
                                        POINTER(c_void_p), c_void_p, c_int64, c_void_p, POINTER(c_void_p), c_void_p]),
+    "mtlora_mlp_hid_supported": (c_int, [POINTER(LinearDesc), POINTER(LinearDesc)]),
+    "mtlora_mlp_hid_bwd_scratch_bytes": (c_int64, [POINTER(LinearDesc), POINTER(LinearDesc)]),
+    "mtlora_mlp_hid_proj": (c_int, [POINTER(LinearDesc), POINTER(LinearDesc), c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mtlora_mlp_hid_bwd": (c_int, [POINTER(LinearDesc), POINTER(LinearDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                   c_void_p, POINTER(c_void_p), POINTER(c_void_p), c_void_p, c_int64, c_void_p]),
     "mtlora_window_attn_bwd_scratch_bytes": (c_int64, [POINTER(AttnDesc)]),
     "mtlora_window_attn_fwd": (c_int, [POINTER(AttnDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mtlora_window_attn_bwd": (c_int, [POINTER(AttnDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

@@ -1093,6 +1093,7 @@ __global__ __launch_bounds__(512, 4) void k_ntl(const NlParams P) {
 #include "stream.h"
 #include "dense.h"
 #include "pq.h"
+#include "hid.h"
 
 // ------------------------------------------------------------------------------------------------
 // k_tn : Out[a][b] = sum_m SrcA[m][a0 + a] * SrcB[m][b0 + b], split over m.
@@ -2423,6 +2424,7 @@ static int fwd_impl(const mtlora_linear_desc* d, const void* x, const void* cons
                 q.nz = 0;
                 for (int o = 0; o < sg.n; ++o) {
                     if (sg.rp[o] == 0) continue;
+                    if (o > 0 && (d->hid & MTLORA_HID_P_GIVEN)) continue;  // (task columns of P: mtlora_mlp_hid_proj wrote them)
                     q.zact[q.nz] = (o == 0) ? x : x_t[o - 1];
                     q.zrow0[q.nz] = sg.off[o];
                     q.zrows[q.nz] = sg.rp[o];
@@ -2453,6 +2455,7 @@ static int fwd_impl(const mtlora_linear_desc* d, const void* x, const void* cons
                     const bool own = d->T > 0 && d->has_x_tasks;
                     if (!own && o > 0) break;
                     if (own && sg.rp[o] == 0) continue;
+                    if (own && o > 0 && (d->hid & MTLORA_HID_P_GIVEN)) continue;
                     SpSrc& ss = sp.src[sp.n_src++];
                     ss.act = (o == 0) ? x : x_t[o - 1];
                     ss.col_lo = own ? sg.off[o] : 0;
@@ -2468,7 +2471,9 @@ static int fwd_impl(const mtlora_linear_desc* d, const void* x, const void* cons
                 // k_pq first: forced (3: the "[pq]" test family), instead of a one-slot k_sp_proj ring (which cannot overlap its loads), and
                 // instead of k_sp_proj for launches of about one residency round (tools/pq_times.py: stage 2 of Swin-T 13 vs 16 us, Swin-B 14
                 // vs 21 us); where k_sp_proj does not fit at all, k_sp_projk's single-round rule comes first (stage 3: 15 vs 21 us)
-                if (mb > 0 && (tu.projk == 3 || ns == 1 || (ns > 1 && pq_one_round(tu, pq, mb))))
+                if (sp.n_src == 0)
+                    ;  // (no source left: r_s = 0 and the task columns are given)
+                else if (mb > 0 && (tu.projk == 3 || ns == 1 || (ns > 1 && pq_one_round(tu, pq, mb))))
                     launch_pq<T>(pq, mb, s, PK_NT_FWD_P, xb, xb, 2.0 * d->M * d->K * rsum);
                 else if (ns > 0)
                     launch_sp_proj<T>(tu, sp, ch, ns, s, PK_NT_FWD_P, xb, xb, 2.0 * d->M * d->K * rsum);
@@ -2510,10 +2515,20 @@ static int fwd_impl(const mtlora_linear_desc* d, const void* x, const void* cons
         O.fold = (o == 0 && d->mode == 1 && d->T > 0) ? 1 : 0;
         O.act = (o == 0) ? a_s : (a_t ? a_t[o - 1] : nullptr);
     }
+    if (d->hid & MTLORA_HID_FWD_BASE) {  // the Mlp's fc1 with implicit task hiddens: the shared output and the bare pretrained product
+        m.n_out = 2;
+        NtOut& O = m.out[1];
+        O.ptr = const_cast<void*>(d->hid_ptr);
+        O.seg_lo = O.seg_hi = 0;
+        O.use_base = 1;
+        O.mask_lr = 0;
+        O.fold = 0;
+        O.act = nullptr;
+    }
     int n_actout = 0;  // GELU second outputs: one more M x N write each
     for (int o = 0; o < m.n_out; ++o) n_actout += m.out[o].act ? 1 : 0;
     {
-        const double b8d = (double)sizeof(T) * d->M * (d->K + (double)(1 + d->T) * d->N);
+        const double b8d = (double)sizeof(T) * d->M * (d->K + (double)(1 + d->T) * d->N);  // (SURVEY 8(d) counts every module output)
         double rsum = 0.0;
         for (int o = 0; o < sg.n; ++o) rsum += sg.r[o];
         const double fl = 2.0 * d->M * d->K * d->N + 2.0 * d->M * d->N * rsum;
@@ -2590,6 +2605,7 @@ static int bwd_impl(const mtlora_linear_desc* d, const void* x, const void* cons
     float* part = reinterpret_cast<float*>(sc + S.part);
     const DropoutCfg dc = mtl_make_dropout(d->dropout_p, d->seed, d->seed_offset);
     const bool v2 = d->mode == 1 && d->T > 0;
+    const bool hid_q = (d->hid & MTLORA_HID_Q_GIVEN) != 0;  // fc1 of an Mlp with implicit task hiddens (hid.h): Q task columns given
 
     // gradient sources per output
     const void* dy[MAXO];
@@ -2708,7 +2724,7 @@ static int bwd_impl(const mtlora_linear_desc* d, const void* x, const void* cons
         bool any_missing = false;
         for (int o = 0; o < sg.n; ++o)
             if (sg.rp[o] > 0 && !dyo[o]) any_missing = true;
-        if (any_missing) mtl_zero_async(Qm, (size_t)(d->M * sg.R * sizeof(T)), s);
+        if (any_missing && !hid_q) mtl_zero_async(Qm, (size_t)(d->M * sg.R * sizeof(T)), s);  // (hid_q: the task columns are given)
         NtParams q = {};
         q.n_act = 1;
         q.ld_act = d->N;
@@ -2783,12 +2799,16 @@ static int bwd_impl(const mtlora_linear_desc* d, const void* x, const void* cons
             m.n_act = n_dy;
             for (int i = 0; i < n_dy; ++i) m.act[i] = dy_all[i];
         }
+        if (hid_q && d->hid_ptr) {  // G = dH_s + sum_t dH_t was formed by k_hid_bwd
+            m.n_act = 1;
+            m.act[0] = d->hid_ptr;
+        }
         m.ld_act = d->N;
         m.wgt = Wt;
         m.ld_wgt = d->N;
         m.M = d->M;
         m.n_rows = (int)d->K;
-        m.K = n_dy > 0 ? (int)d->N : 0;
+        m.K = (n_dy > 0 || (hid_q && d->hid_ptr)) ? (int)d->N : 0;
         m.L = Qm;
         m.ldL = sg.R;
         m.Rm = at_cat;
@@ -2896,9 +2916,11 @@ static int bwd_impl(const mtlora_linear_desc* d, const void* x, const void* cons
         float* pp = part;
         int max_tiles = 0;
         for (int o = 0; o < sg.n; ++o) {
-            if (sg.rp[o] == 0 || !dyo[o]) continue;
+            const bool q_given = hid_q && o > 0;  // Q[:, seg_o] came from k_hid_bwd (which also returns dB_o): dA_o only
+            if (sg.rp[o] == 0 || (!dyo[o] && !q_given)) continue;
             float* dAo = (o == 0) ? dA_s : (dA_t ? dA_t[o - 1] : nullptr);
             float* dBo = (o == 0) ? dB_s : (dB_t ? dB_t[o - 1] : nullptr);
+            if (!dyo[o]) dBo = nullptr;
             if (dBo) {  // (N x r_o) = dY_o^T P[:, seg_o], evaluated as its transpose P[:, seg_o]^T dY_o
                 TnProblem& p = tp.p[tp.n_prob++];
                 p.A = Pm;
@@ -3016,9 +3038,223 @@ static int bwd_impl(const mtlora_linear_desc* d, const void* x, const void* cons
     return MTLORA_OK;
 }
 
+// ---- Mlp with implicit task hidden tensors (hid.h): shape rules, launch geometry, the two launches
+struct HidPlan {
+    int tg, rr, nthr, nw, groups, n_wg;
+};
+static int hid_check(const mtlora_linear_desc* d1, const mtlora_linear_desc* d2) {
+    int st = check_desc(d1);
+    if (st != MTLORA_OK) return st;
+    st = check_desc(d2);
+    if (st != MTLORA_OK) return st;
+    if (d1->dtype == MTLORA_F32 || d1->dtype != d2->dtype) return MTLORA_ERR_UNSUPPORTED;
+    if (d1->M != d2->M || d1->N != d2->K || d1->T != d2->T || d1->T < 1) return MTLORA_ERR_UNSUPPORTED;
+    if (d1->mode != 0 || d2->mode != 0 || !d1->has_x_tasks || !d2->has_x_tasks) return MTLORA_ERR_UNSUPPORTED;
+    if (d1->N % 128 != 0 || d1->N > 2048 || d1->M <= 0) return MTLORA_ERR_UNSUPPORTED;
+    for (int t = 0; t < d1->T; ++t)
+        if (d1->r_t[t] < 1 || d1->r_t[t] > 8 || d2->r_t[t] < 1 || d2->r_t[t] > 8) return MTLORA_ERR_UNSUPPORTED;
+    return MTLORA_OK;
+}
+static HidPlan hid_plan(const mtlora_linear_desc* d1, const mtlora_linear_desc* d2) {
+    HidPlan pl;
+    int rmax = 0;
+    for (int t = 0; t < d1->T; ++t) rmax = std::max(rmax, std::max(d1->r_t[t], d2->r_t[t]));
+    pl.rr = rmax <= 4 ? 4 : 8;
+    pl.nthr = (int)(d1->N / 2);
+    pl.nw = pl.nthr / 64;
+    // register budget: the backward kernel holds 8 * TG * RR factor + accumulator registers per lane: TG * RR = 16 needs the 256-register
+    // budget of <= 512-thread workgroups (2 waves per SIMD), 8 fits the 168 registers of 768 threads, 1024 threads are capped at 128
+    const int cap = pl.nthr <= 512 ? 16 : 8;
+    pl.tg = std::max(1, cap / pl.rr);
+    if (pl.nthr > 768 && pl.rr == 8) pl.tg = 1;
+    pl.groups = (d1->T + pl.tg - 1) / pl.tg;
+    const Tune tu = make_tune(d1);
+    const int wg_per_cu = std::max(1, (8 + pl.nw - 1) / pl.nw);
+    const int64_t nblk = (d1->M + HID_RB - 1) / HID_RB;
+    pl.n_wg = (int)std::min<int64_t>(nblk, (int64_t)num_cu(tu) * wg_per_cu);
+    return pl;
+}
+static int64_t hid_part_bytes(const mtlora_linear_desc* d1, const HidPlan& pl) {
+    return (int64_t)pl.n_wg * pl.tg * 2 * pl.rr * d1->N * 4 + 256;
+}
+
+template <typename T, bool BWD>
+static void hid_launch(const HidPlan& pl, const HidParams& q, hipStream_t s) {
+    const dim3 g((unsigned)pl.n_wg), b((unsigned)pl.nthr);
+#define HID_GO(TG_, RR_, NT_)                                                              \
+    do {                                                                                   \
+        if constexpr (BWD)                                                                 \
+            hipLaunchKernelGGL((k_hid_bwd<T, TG_, RR_, NT_>), g, b, 0, s, q);               \
+        else                                                                               \
+            hipLaunchKernelGGL((k_hid_proj<T, TG_, RR_, NT_>), g, b, 0, s, q);              \
+    } while (0)
+    if (pl.rr == 4 && pl.tg == 4)
+        HID_GO(4, 4, 512);
+    else if (pl.rr == 4 && pl.nthr <= 768)
+        HID_GO(2, 4, 768);
+    else if (pl.rr == 4)
+        HID_GO(2, 4, 1024);
+    else if (pl.tg == 2)
+        HID_GO(2, 8, 512);
+    else if (pl.nthr <= 768)
+        HID_GO(1, 8, 768);
+    else
+        HID_GO(1, 8, 1024);
+#undef HID_GO
+}
+
+template <typename T>
+static int hid_proj_impl(const mtlora_linear_desc* d1, const mtlora_linear_desc* d2, const void* h_base, const void* ctx1, void* ctx2,
+                         hipStream_t s) {
+    const Segs s1 = make_segs(d1), s2 = make_segs(d2);
+    const CtxLayout L1 = ctx_layout(d1, s1), L2 = ctx_layout(d2, s2);
+    const unsigned char* c1 = reinterpret_cast<const unsigned char*>(ctx1);
+    unsigned char* c2 = reinterpret_cast<unsigned char*>(ctx2);
+    const unsigned char* pk1 = d1->packed ? reinterpret_cast<const unsigned char*>(d1->packed) : c1;
+    const unsigned char* pk2 = reinterpret_cast<const unsigned char*>(d2->packed);
+    const HidPlan pl = hid_plan(d1, d2);
+    const int H = (int)d1->N;
+    mtl_prof_tag("hid_proj M%lld H%d T%d tg%d rr%d", (long long)d1->M, H, d1->T, pl.tg, pl.rr);
+    const double hb = (double)sizeof(T) * d1->M * H;
+    MtlProfScope prof(PK_NT_FWD_P, hb * pl.groups, s, (double)sizeof(T) * d1->M * (double)d1->T * H, 0.0);
+    for (int gI = 0; gI < pl.groups; ++gI) {
+        HidParams q = {};
+        q.hbase = h_base;
+        q.p1 = c1 + L1.p;
+        q.p2 = c2 + L2.p;
+        q.b1t = pk1 + L1.bt_cat;
+        q.a2 = pk2 + L2.a_cat;
+        q.alpha1 = reinterpret_cast<const float*>(pk1 + L1.alpha);
+        q.alpha2 = reinterpret_cast<const float*>(pk2 + L2.alpha);
+        q.M = d1->M;
+        q.H = H;
+        q.ldp1 = s1.R;
+        q.ldp2 = s2.R;
+        q.nt = std::min(pl.tg, d1->T - gI * pl.tg);
+        for (int i = 0; i < q.nt; ++i) {
+            q.off1[i] = s1.off[1 + gI * pl.tg + i];
+            q.off2[i] = s2.off[1 + gI * pl.tg + i];
+        }
+        hid_launch<T, false>(pl, q, s);
+    }
+    return MTLORA_OK;
+}
+
+template <typename T>
+static int hid_bwd_impl(const mtlora_linear_desc* d1, const mtlora_linear_desc* d2, const void* h_base, const void* dh_s, const void* ctx1,
+                        const void* ctx2, const void* scratch2, void* scratch1, void* g, float* const* dB1_t, float* const* dA2_t, void* part,
+                        hipStream_t s) {
+    const Segs s1 = make_segs(d1), s2 = make_segs(d2);
+    const CtxLayout L1 = ctx_layout(d1, s1), L2 = ctx_layout(d2, s2);
+    const BwdScratch S1 = bwd_scratch(d1, s1), S2 = bwd_scratch(d2, s2);
+    const unsigned char* c1 = reinterpret_cast<const unsigned char*>(ctx1);
+    const unsigned char* c2 = reinterpret_cast<const unsigned char*>(ctx2);
+    const unsigned char* pk1 = d1->packed ? reinterpret_cast<const unsigned char*>(d1->packed) : c1;
+    const unsigned char* pk2 = d2->packed ? reinterpret_cast<const unsigned char*>(d2->packed) : c2;
+    const HidPlan pl = hid_plan(d1, d2);
+    const int H = (int)d1->N;
+    for (int gI = 0; gI < pl.groups; ++gI) {
+        HidParams q = {};
+        q.hbase = h_base;
+        q.p1 = c1 + L1.p;
+        q.q2 = reinterpret_cast<const unsigned char*>(scratch2) + S2.q;
+        q.q1 = reinterpret_cast<unsigned char*>(scratch1) + S1.q;
+        q.gsrc = gI == 0 ? dh_s : g;
+        q.g = g;
+        q.b1t = pk1 + L1.bt_cat;
+        q.a2 = pk2 + L2.a_cat;
+        q.alpha1 = reinterpret_cast<const float*>(pk1 + L1.alpha);
+        q.alpha2 = reinterpret_cast<const float*>(pk2 + L2.alpha);
+        q.part = reinterpret_cast<float*>(part);
+        q.M = d1->M;
+        q.H = H;
+        q.ldp1 = s1.R;
+        q.ldq1 = s1.R;
+        q.ldq2 = s2.R;
+        q.nt = std::min(pl.tg, d1->T - gI * pl.tg);
+        HidRedParams r = {};
+        for (int i = 0; i < q.nt; ++i) {
+            const int t = gI * pl.tg + i;
+            q.off1[i] = s1.off[1 + t];
+            q.off2[i] = s2.off[1 + t];
+            r.r[i] = 0;
+            r.dB1[i] = dB1_t ? dB1_t[t] : nullptr;
+            r.dA2[i] = dA2_t ? dA2_t[t] : nullptr;
+        }
+        {
+            mtl_prof_tag("hid_bwd M%lld H%d T%d tg%d rr%d", (long long)d1->M, H, d1->T, pl.tg, pl.rr);
+            const double hb = (double)sizeof(T) * d1->M * H;
+            MtlProfScope prof(PK_NT_BWD_DX, 3.0 * hb, s, (double)sizeof(T) * d1->M * (double)q.nt * H, 0.0);
+            hid_launch<T, true>(pl, q, s);
+        }
+        // dB1_t (fc1's N x r_t, un-padded rank d1->r_t) and dA2_t (fc2's r_t x K) share one reduce: per kind the un-padded rank differs
+        // only if the two layers were built with different task ranks -- reduce them separately then
+        r.part = q.part;
+        r.n_wg = pl.n_wg;
+        r.nt = q.nt;
+        r.RR = pl.rr;
+        r.H = H;
+        const int64_t per = (int64_t)q.nt * 2 * pl.rr * H;
+        bool same = true;
+        for (int i = 0; i < q.nt; ++i) same = same && d1->r_t[gI * pl.tg + i] == d2->r_t[gI * pl.tg + i];
+        MtlProfScope prof(PK_REDUCE, 0.0, s);
+        if (same) {
+            for (int i = 0; i < q.nt; ++i) r.r[i] = d1->r_t[gI * pl.tg + i];
+            hipLaunchKernelGGL(k_hid_reduce, dim3((unsigned)((per + 255) / 256)), dim3(256), 0, s, r);
+        } else {
+            HidRedParams rb = r, ra = r;
+            for (int i = 0; i < q.nt; ++i) {
+                rb.r[i] = d1->r_t[gI * pl.tg + i];
+                rb.dA2[i] = nullptr;
+                ra.r[i] = d2->r_t[gI * pl.tg + i];
+                ra.dB1[i] = nullptr;
+            }
+            hipLaunchKernelGGL(k_hid_reduce, dim3((unsigned)((per + 255) / 256)), dim3(256), 0, s, rb);
+            hipLaunchKernelGGL(k_hid_reduce, dim3((unsigned)((per + 255) / 256)), dim3(256), 0, s, ra);
+        }
+    }
+    return MTLORA_OK;
+}
+
 }  // namespace
 
 extern "C" {
+
+int mtlora_mlp_hid_supported(const mtlora_linear_desc* d1, const mtlora_linear_desc* d2) {
+    return (d1 && d2 && hid_check(d1, d2) == MTLORA_OK) ? 1 : 0;
+}
+
+int64_t mtlora_mlp_hid_bwd_scratch_bytes(const mtlora_linear_desc* d1, const mtlora_linear_desc* d2) {
+    if (!d1 || !d2 || hid_check(d1, d2) != MTLORA_OK) return -1;
+    return hid_part_bytes(d1, hid_plan(d1, d2));
+}
+
+int mtlora_mlp_hid_proj(const mtlora_linear_desc* d1, const mtlora_linear_desc* d2, const void* h_base, const void* ctx1, void* ctx2,
+                        void* stream) {
+    if (!d1 || !d2) return MTLORA_ERR_NULL;
+    const int st = hid_check(d1, d2);
+    if (st != MTLORA_OK) return st;
+    if (!h_base || !ctx1 || !ctx2 || !d2->packed) return MTLORA_ERR_NULL;
+    if (misaligned(h_base) || misaligned(ctx1) || misaligned(ctx2) || misaligned(d2->packed) || misaligned(d1->packed)) return MTLORA_ERR_ALIGN;
+    hipStream_t s = (hipStream_t)stream;
+    return d1->dtype == MTLORA_F16 ? hid_proj_impl<f16>(d1, d2, h_base, ctx1, ctx2, s) : hid_proj_impl<bf16>(d1, d2, h_base, ctx1, ctx2, s);
+}
+
+int mtlora_mlp_hid_bwd(const mtlora_linear_desc* d1, const mtlora_linear_desc* d2, const void* h_base, const void* dh_s, const void* ctx1,
+                       const void* ctx2, const void* scratch2, void* scratch1, void* g, float* const* dB1_t, float* const* dA2_t, void* part,
+                       int64_t part_bytes, void* stream) {
+    if (!d1 || !d2) return MTLORA_ERR_NULL;
+    const int st = hid_check(d1, d2);
+    if (st != MTLORA_OK) return st;
+    if (!h_base || !ctx1 || !ctx2 || !scratch1 || !scratch2 || !g || !part) return MTLORA_ERR_NULL;
+    if (misaligned(h_base) || misaligned(dh_s) || misaligned(ctx1) || misaligned(ctx2) || misaligned(scratch1) || misaligned(scratch2) ||
+        misaligned(g) || misaligned(part))
+        return MTLORA_ERR_ALIGN;
+    if (part_bytes < hid_part_bytes(d1, hid_plan(d1, d2))) return MTLORA_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    return d1->dtype == MTLORA_F16 ? hid_bwd_impl<f16>(d1, d2, h_base, dh_s, ctx1, ctx2, scratch2, scratch1, g, dB1_t, dA2_t, part, s)
+                                   : hid_bwd_impl<bf16>(d1, d2, h_base, dh_s, ctx1, ctx2, scratch2, scratch1, g, dB1_t, dA2_t, part, s);
+}
 
 int64_t mtlora_linear_ctx_bytes(const mtlora_linear_desc* d) {
     if (check_desc(d) != MTLORA_OK) return -1;
@@ -3120,12 +3356,16 @@ static int linear_fwd_entry(const mtlora_linear_desc* d, const void* x, const vo
     if (!x || !W || !y_s) return MTLORA_ERR_NULL;
     if (d->r_s > 0 && !d->packed && (!A_s || !B_s)) return MTLORA_ERR_NULL;
     if (misaligned(x) || misaligned(W) || misaligned(y_s) || misaligned(bias) || misaligned(d->packed)) return MTLORA_ERR_ALIGN;
+    const bool hid_base = (d->hid & MTLORA_HID_FWD_BASE) != 0, hid_p = (d->hid & MTLORA_HID_P_GIVEN) != 0;
+    if (hid_base && (!d->hid_ptr || d->T < 1 || !d->has_x_tasks || d->mode != 0)) return MTLORA_ERR_NULL;
+    if (hid_base && misaligned(d->hid_ptr)) return MTLORA_ERR_ALIGN;
+    if (hid_p && (d->T < 1 || !d->has_x_tasks || d->mode != 0)) return MTLORA_ERR_UNSUPPORTED;
     for (int t = 0; t < d->T; ++t) {
-        if (!y_t || !y_t[t]) return MTLORA_ERR_NULL;
+        if (!hid_base && (!y_t || !y_t[t])) return MTLORA_ERR_NULL;  // (HID_FWD_BASE: no task outputs)
         if (!d->packed && (!A_t || !B_t || !A_t[t] || !B_t[t])) return MTLORA_ERR_NULL;
-        if (misaligned(y_t[t])) return MTLORA_ERR_ALIGN;
-        if (d->has_x_tasks && (!x_t || !x_t[t])) return MTLORA_ERR_NULL;
-        if (d->has_x_tasks && misaligned(x_t[t])) return MTLORA_ERR_ALIGN;
+        if (!hid_base && misaligned(y_t[t])) return MTLORA_ERR_ALIGN;
+        if (d->has_x_tasks && !hid_p && (!x_t || !x_t[t])) return MTLORA_ERR_NULL;  // (HID_P_GIVEN: x_t is not read)
+        if (d->has_x_tasks && !hid_p && misaligned(x_t[t])) return MTLORA_ERR_ALIGN;
     }
     const Segs sg = make_segs(d);
     if (sg.R > 0) {
@@ -3157,9 +3397,9 @@ int mtlora_linear_fwd_gelu(const mtlora_linear_desc* d, const void* x, const voi
                            const float* bias, const float* A_s, const float* B_s, const float* const* A_t,
                            const float* const* B_t, void* y_s, void* const* y_t, void* a_s, void* const* a_t, void* ctx,
                            int64_t ctx_bytes, void* stream) {
-    if (!a_s) return MTLORA_ERR_NULL;
+    if (!a_s || !d) return MTLORA_ERR_NULL;
     if (misaligned(a_s)) return MTLORA_ERR_ALIGN;
-    for (int t = 0; t < d->T; ++t) {
+    for (int t = 0; t < d->T && !(d->hid & MTLORA_HID_FWD_BASE); ++t) {  // (HID_FWD_BASE: no task outputs)
         if (!a_t || !a_t[t]) return MTLORA_ERR_NULL;
         if (misaligned(a_t[t])) return MTLORA_ERR_ALIGN;
     }
@@ -3182,8 +3422,11 @@ static int linear_bwd_entry(const mtlora_linear_desc* d, const void* x, const vo
         if (ctx_bytes < ctx_layout(d, sg).total) return MTLORA_ERR_WORKSPACE;
         if (scratch_bytes < bwd_scratch(d, sg).total) return MTLORA_ERR_WORKSPACE;
     }
+    if ((d->hid & MTLORA_HID_Q_GIVEN) && (d->T < 1 || !d->has_x_tasks || d->mode != 0 || misaligned(d->hid_ptr))) return MTLORA_ERR_UNSUPPORTED;
     for (int t = 0; t < d->T; ++t) {
-        if (d->has_x_tasks && (!x_t || !x_t[t])) return MTLORA_ERR_NULL;
+        // a task's own input is only read for its factor gradient dA_t (an Mlp with implicit task hiddens asks fc2 for none: hid.h)
+        if (d->has_x_tasks && dA_t && dA_t[t] && (!x_t || !x_t[t])) return MTLORA_ERR_NULL;
+        if (d->has_x_tasks && x_t && misaligned(x_t[t])) return MTLORA_ERR_ALIGN;
         if (dy_t && misaligned(dy_t[t])) return MTLORA_ERR_ALIGN;
         if (dx_t && misaligned(dx_t[t])) return MTLORA_ERR_ALIGN;
     }

@@ -549,6 +549,207 @@ class MTLoRALinearFn(torch.autograd.Function):
         return (None, dxo, None, None, None, dW, dbias, dA_s, dB_s, d_ss, *dxto, *dA_t, *dB_t, *d_st, *([None] * meta.n_gate))
 
 
+# ----------------------------------------------------------------------------------------------
+# Task-enabled Mlp with IMPLICIT task hidden tensors (csrc/hid.h, ABI v8)
+# ----------------------------------------------------------------------------------------------
+_MLP_HID = os.environ.get("MTLORA_MLP_HID", "1") != "0"
+_hid_ok_cache: dict = {}
+
+
+def mlp_hid_enabled() -> bool:
+    return _MLP_HID
+
+
+def set_mlp_hid(on: bool) -> bool:
+    """switch the implicit-task-hiddens path of the task-enabled Mlp on / off (tests compare the two paths); returns the old value"""
+    global _MLP_HID
+    old, _MLP_HID = _MLP_HID, bool(on)
+    return old
+
+
+def mlp_hid_supported(meta1: "LinearMeta", meta2: "LinearMeta", M: int) -> bool:
+    key = (M, meta1.K, meta1.N, meta2.N, meta1.r_t, meta2.r_t, meta1.dtype, meta1.mode, meta2.mode, meta1.has_x_tasks, meta2.has_x_tasks)
+    v = _hid_ok_cache.get(key)
+    if v is None:
+        d1, d2 = meta1.desc(M), meta2.desc(M)
+        v = bool(L.lib().mtlora_mlp_hid_supported(ctypes.byref(d1), ctypes.byref(d2)))
+        _hid_ok_cache[key] = v
+    return v
+
+
+def _ensure_packed(meta: "LinearMeta", A_s, B_s, A_t, B_t, device) -> None:
+    """the k_hid kernels read the layers' packed factors: a layer without a current FactorPacker buffer packs into a per-call one"""
+    if meta.packed is not None:
+        return
+    buf = torch.empty(packed_bytes(meta), dtype=torch.uint8, device=device)
+    d = meta.desc(1)
+    d.packed = 0
+    st = L.lib().mtlora_linear_pack(ctypes.byref(d), L.ptr(A_s), L.ptr(B_s), L.ptr_array(A_t), L.ptr_array(B_t), L.ptr(buf), buf.numel(),
+                                    L.stream_ptr())
+    L.check(st, "mtlora_linear_pack")
+    meta.packed = buf
+
+
+class MlpHidFn(torch.autograd.Function):
+    """(y_s, y_t[0..T-1]) = fc2(gelu(fc1(x, x_t)), gelu(fc1 task outputs)) of a task-enabled Mlp (swin_transformer_mtlora.py:57-78 of the
+    reference with both layers MTLoRALinear called with x_tasks, lora.py:262-266) WITHOUT the 3 T hidden-width task tensors of the
+    per-layer path: h_t = h_base + P1_t B1_t^T only enters fc2 through P2_t = s_t gelu(h_t) A2_t^T, and its gradient only feeds
+    G, Q1_t and two rank-r_t factor gradients (csrc/hid.h).  Same parameters, same results up to rounding (the implicit tensors stay
+    in fp32 registers instead of being rounded to the compute dtype).
+
+    args: meta1, meta2, x, W1c, W1t, b1, W2c, W2t, b2, A1_s, B1_s, A2_s, B2_s, *x_t(T), *A1_t(T), *B1_t(T), *A2_t(T), *B2_t(T)"""
+
+    NFIX = 13
+
+    @staticmethod
+    def forward(ctx, meta1: LinearMeta, meta2: LinearMeta, x, W1c, W1t, b1, W2c, W2t, b2, A1_s, B1_s, A2_s, B2_s, *rest):
+        ctx.set_materialize_grads(False)
+        T = meta1.T
+        x_t = list(rest[:T])
+        A1_t, B1_t, A2_t, B2_t = (list(rest[T * k:T * (k + 1)]) for k in range(1, 5))
+        L.require_gpu(x, W1c, W2c, *x_t)
+        lead = x.shape[:-1]
+        x2 = _flat(x, meta1.dtype)
+        xt2 = [_flat(t, meta1.dtype) for t in x_t]
+        M = x2.numel() // meta1.K
+        if x2.shape[-1] != meta1.K or any(t.shape != x2.shape for t in xt2):
+            raise RuntimeError(f"mtlora_amd: Mlp input of shape {tuple(x.shape)} for in_features = {meta1.K}")
+        dev, dt, H = x.device, meta1.dtype, meta1.N
+        f1 = (_f32c(A1_s), _f32c(B1_s), [_f32c(a) for a in A1_t], [_f32c(b) for b in B1_t])
+        f2 = (_f32c(A2_s), _f32c(B2_s), [_f32c(a) for a in A2_t], [_f32c(b) for b in B2_t])
+        _ensure_packed(meta1, *f1, dev)
+        _ensure_packed(meta2, *f2, dev)
+        lib = L.lib()
+        d1, d2 = meta1.desc(M), meta2.desc(M)
+        cb1 = _desc_bytes("ctx", lib.mtlora_linear_ctx_bytes, meta1, M, d1)
+        cb2 = _desc_bytes("ctx", lib.mtlora_linear_ctx_bytes, meta2, M, d2)
+        if cb1 < 0 or cb2 < 0:
+            raise RuntimeError(f"mtlora_amd: invalid Mlp shape M={M} K={meta1.K} hidden={H} N={meta2.N}")
+        ctx1 = torch.empty(cb1, dtype=torch.uint8, device=dev)
+        ctx2 = torch.empty(cb2, dtype=torch.uint8, device=dev)
+        hshape = (*lead, H)
+        h_s = torch.empty(hshape, dtype=dt, device=dev)
+        a_s = torch.empty(hshape, dtype=dt, device=dev)
+        h_base = torch.empty(hshape, dtype=dt, device=dev)
+        # fc1: shared output (+ its GELU) and the bare pretrained product; P1 for every segment
+        d1.hid, d1.hid_ptr = L.HID_FWD_BASE, h_base.data_ptr()
+        st = lib.mtlora_linear_fwd_gelu(ctypes.byref(d1), L.ptr(x2), L.ptr_array(xt2), L.ptr(W1c), L.ptr(b1), L.ptr(f1[0]), L.ptr(f1[1]),
+                                        L.ptr_array(f1[2]), L.ptr_array(f1[3]), L.ptr(h_s), L.ptr_array(None), L.ptr(a_s),
+                                        L.ptr_array(None), L.ptr(ctx1), cb1, L.stream_ptr())
+        L.check(st, "mtlora_linear_fwd_gelu (fc1, implicit task hiddens)")
+        d1.hid, d1.hid_ptr = 0, 0
+        # the task columns of fc2's P straight from h_base and P1
+        st = lib.mtlora_mlp_hid_proj(ctypes.byref(d1), ctypes.byref(d2), L.ptr(h_base), L.ptr(ctx1), L.ptr(ctx2), L.stream_ptr())
+        L.check(st, "mtlora_mlp_hid_proj")
+        oshape = (*lead, meta2.N)
+        ys = torch.empty(oshape, dtype=dt, device=dev)
+        yt = [torch.empty(oshape, dtype=dt, device=dev) for _ in range(T)]
+        d2.hid = L.HID_P_GIVEN
+        st = lib.mtlora_linear_fwd(ctypes.byref(d2), L.ptr(a_s), L.ptr_array(None), L.ptr(W2c), L.ptr(b2), L.ptr(f2[0]), L.ptr(f2[1]),
+                                   L.ptr_array(f2[2]), L.ptr_array(f2[3]), L.ptr(ys), L.ptr_array(yt), L.ptr(ctx2), cb2, L.stream_ptr())
+        L.check(st, "mtlora_linear_fwd (fc2, implicit task hiddens)")
+        ctx.meta1, ctx.meta2, ctx.lead, ctx.M = meta1, meta2, lead, M
+        ctx.in_dtypes = [x.dtype] + [t.dtype for t in x_t]
+        ctx.save_for_backward(x2, W1t, W2t, ctx1, ctx2, h_s, a_s, h_base, *xt2)
+        ctx.factor_params = (A1_s, B1_s, *A1_t, *B1_t, A2_s, B2_s, *A2_t, *B2_t)
+        return (ys, *yt)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        meta1, meta2 = ctx.meta1, ctx.meta2
+        T, NF = meta1.T, MlpHidFn.NFIX
+        n_in = NF + 5 * T
+        if all(g is None for g in grads):
+            return (None,) * n_in
+        x2, W1t, W2t, ctx1, ctx2, h_s, a_s, h_base, *xt2 = ctx.saved_tensors
+        M, dev, dt, H = ctx.M, x2.device, meta1.dtype, meta1.N
+        g2 = [None if g is None else _flat(g, dt) for g in grads]
+        dy_s, dy_t = g2[0], g2[1:1 + T]
+        need = ctx.needs_input_grad
+        lib = L.lib()
+        d1, d2 = meta1.desc(M), meta2.desc(M)
+        sb1 = _desc_bytes("bwd", lib.mtlora_linear_bwd_scratch_bytes, meta1, M, d1)
+        sb2 = _desc_bytes("bwd", lib.mtlora_linear_bwd_scratch_bytes, meta2, M, d2)
+        key = ("hidpart", M, meta1.K, H, meta2.N, meta1.r_t, meta2.r_t, dt)
+        pb = _bytes_cache.get(key)
+        if pb is None:
+            pb = lib.mtlora_mlp_hid_bwd_scratch_bytes(ctypes.byref(d1), ctypes.byref(d2))
+            _bytes_cache[key] = pb
+        scratch1 = torch.empty(sb1, dtype=torch.uint8, device=dev)
+        scratch2 = torch.empty(sb2, dtype=torch.uint8, device=dev)
+        part = torch.empty(pb, dtype=torch.uint8, device=dev)
+        f32 = torch.float32
+        hshape, ishape = (*ctx.lead, H), (*ctx.lead, meta1.K)
+        dh_s = torch.empty(hshape, dtype=dt, device=dev)
+        G = torch.empty(hshape, dtype=dt, device=dev)
+        dx = torch.empty(ishape, dtype=dt, device=dev)
+        dxt = [torch.empty(ishape, dtype=dt, device=dev) for _ in range(T)]
+        # argument positions: A1_s 9, B1_s 10, A2_s 11, B2_s 12, x_t NF.., A1_t NF+T.., B1_t NF+2T.., A2_t NF+3T.., B2_t NF+4T..
+        has_s2 = meta2.r_s > 0 and dy_s is not None
+        has_s1 = meta1.r_s > 0
+        any_t = [dy_t[t] is not None for t in range(T)]
+        dA1_s = torch.empty((meta1.r_s, meta1.K), dtype=f32, device=dev) if (has_s1 and need[9]) else None
+        dB1_s = torch.empty((H, meta1.r_s), dtype=f32, device=dev) if (has_s1 and need[10]) else None
+        dA2_s = torch.empty((meta2.r_s, H), dtype=f32, device=dev) if (has_s2 and need[11]) else None
+        dB2_s = torch.empty((meta2.N, meta2.r_s), dtype=f32, device=dev) if (has_s2 and need[12]) else None
+        mk = lambda shape, pos, t: torch.empty(shape, dtype=f32, device=dev) if (any_t[t] and need[pos + t]) else None
+        dA1_t = [mk((meta1.r_t[t], meta1.K), NF + T, t) for t in range(T)]
+        dB1_t = [mk((H, meta1.r_t[t]), NF + 2 * T, t) for t in range(T)]
+        dA2_t = [mk((meta2.r_t[t], H), NF + 3 * T, t) for t in range(T)]
+        dB2_t = [mk((meta2.N, meta2.r_t[t]), NF + 4 * T, t) for t in range(T)]
+
+        def fc2(phase, stream_ptr):  # dh_s (through gelu'(h_s)), Q2 [phase 1]; dA2_s, dB2_s, dB2_t [phase 2]
+            d2.bwd_phase = phase
+            st = lib.mtlora_linear_bwd_gelu(ctypes.byref(d2), L.ptr(a_s), L.ptr_array(None), L.ptr(W2t), L.ptr(dy_s), L.ptr_array(dy_t),
+                                            L.ptr(ctx2), ctx2.numel(), L.ptr(dh_s), L.ptr_array(None), L.ptr(dA2_s), L.ptr(dB2_s),
+                                            L.ptr_array(None), L.ptr_array(dB2_t), L.ptr(scratch2), sb2, L.ptr(h_s), L.ptr_array(None),
+                                            stream_ptr)
+            L.check(st, "mtlora_linear_bwd_gelu (fc2, implicit task hiddens)")
+
+        def hid(stream_ptr):  # G = dh_s + sum_t dH_t, Q1 task columns, dB1_t, dA2_t
+            st = lib.mtlora_mlp_hid_bwd(ctypes.byref(d1), ctypes.byref(d2), L.ptr(h_base), L.ptr(dh_s), L.ptr(ctx1), L.ptr(ctx2),
+                                        L.ptr(scratch2), L.ptr(scratch1), L.ptr(G), L.ptr_array(dB1_t), L.ptr_array(dA2_t), L.ptr(part), pb,
+                                        stream_ptr)
+            L.check(st, "mtlora_mlp_hid_bwd")
+
+        def fc1(phase, stream_ptr):  # dx, dx_t [phase 1]; dA1_s, dB1_s, dA1_t [phase 2]
+            d1.bwd_phase = phase
+            d1.hid, d1.hid_ptr = L.HID_Q_GIVEN, G.data_ptr()
+            st = lib.mtlora_linear_bwd(ctypes.byref(d1), L.ptr(x2), L.ptr_array(xt2), L.ptr(W1t), L.ptr(dh_s), L.ptr_array(None),
+                                       L.ptr(ctx1), ctx1.numel(), L.ptr(dx), L.ptr_array(dxt), L.ptr(dA1_s), L.ptr(dB1_s),
+                                       L.ptr_array(dA1_t), L.ptr_array(None), L.ptr(scratch1), sb1, stream_ptr)
+            L.check(st, "mtlora_linear_bwd (fc1, implicit task hiddens)")
+
+        side = _factor_stream
+        fgrads = [t for t in [dA1_s, dB1_s, dA2_s, dB2_s, *dA1_t, *dB1_t, *dA2_t, *dB2_t] if t is not None]
+        use_side = (side is not None and fgrads and side.device == dev and M >= _FACTOR_MIN_M and _side_safe_params(ctx.factor_params))
+        if _side_join_pending(ctx.factor_params, dev):
+            use_side = False
+        main = L.stream_ptr()
+        if use_side:
+            fc2(1, main)
+            hid(main)
+            fc1(1, main)
+            ev = torch.cuda.Event()
+            ev.record()
+            side.wait_event(ev)
+            sp = ctypes.c_void_p(side.cuda_stream)
+            fc2(2, sp)
+            fc1(2, sp)
+            _side_mark_pending(ctx.factor_params, side)
+            for t in [x2, ctx1, ctx2, a_s, dh_s, scratch1, scratch2, *xt2, *fgrads] + [g for g in g2 if g is not None]:
+                t.record_stream(side)
+        else:
+            fc2(1, main)
+            hid(main)
+            fc1(1, main)
+            fc2(2, main)
+            fc1(2, main)
+        dxo = dx if ctx.in_dtypes[0] == dt else dx.to(ctx.in_dtypes[0])
+        dxto = [dxt[t] if ctx.in_dtypes[1 + t] == dt else dxt[t].to(ctx.in_dtypes[1 + t]) for t in range(T)]
+        return (None, None, dxo, None, None, None, None, None, None, dA1_s, dB1_s, dA2_s, dB2_s, *dxto, *dA1_t, *dB1_t, *dA2_t, *dB2_t)
+
+
 class GeluDeferredGradFn(torch.autograd.Function):
     """a = gelu(h) (exact erf form) whose backward is the IDENTITY: the consumer is an MTLoRALinear called with
     ``gelu_gate=h``, whose dX kernel multiplies by gelu'(h) itself (``mtlora_linear_bwd_gelu``) -- the standalone GELU

@@ -289,6 +289,32 @@ class MTLoRALinear(LoRALayer):
             meta.packed = self._packed
         return meta
 
+    def hid_call(self, dtype: torch.dtype, device):
+        """(meta, weights, factors) of a call WITH x_tasks of a task-enabled layer in shared_mode 'matrix' -- what ``forward`` builds for
+        such a layer, for the Mlp that issues fc1 / fc2 itself with the task hidden tensors left implicit (``Fn.MlpHidFn``); None when
+        the layer does not qualify (no tasks, merged, trainable scales, rank-aware association, trained pretrained weight).  Draws the
+        call's dropout seed."""
+        if not (self.r > 0 and self.tasks and self.shared_mode == "matrix" and not self.merged and hasattr(self, "lora_tasks_A")
+                and hasattr(self, "lora_shared_A")):
+            return None
+        tasks = list(self.tasks)
+        if isinstance(self.lora_shared_scale, torch.Tensor) or any(isinstance(self.lora_task_scale[t], torch.Tensor) for t in tasks):
+            return None
+        if self.linear.weight.requires_grad or (self.linear.bias is not None and self.linear.bias.requires_grad):
+            return None
+        if self.rank_aware_shared() or any(self._rank_aware(self._ranks[t], self.lora_task_scale[t]) for t in tasks):
+            return None
+        p = self.dropout_p if self.training else 0.0
+        ss, st = float(self.lora_shared_scale), tuple(float(self.lora_task_scale[t]) for t in tasks)
+        meta = Fn.LinearMeta(K=self.linear.in_features, N=self.linear.out_features, r_s=self.r, r_t=tuple(self._ranks[t] for t in tasks),
+                             scale_s=ss, scale_t=st, mode=0, has_x_tasks=True, dropout_p=p, seed=Fn.next_seed() if p > 0 else 0, dtype=dtype)
+        sig = (dtype, meta.r_s, meta.r_t, meta.scale_s, meta.scale_t, meta.mode, True, p, str(device))  # (as forward: FactorPacker key)
+        self._call_sig = sig
+        if self._packed is not None and self._packed_sig == (sig, tuple(q._version for q in self._factor_params())):
+            meta.packed = self._packed
+        factors = (self.lora_shared_A, self.lora_shared_B, [self.lora_tasks_A[t] for t in tasks], [self.lora_tasks_B[t] for t in tasks])
+        return meta, self._weights(dtype), factors
+
     def forward(self, x: torch.Tensor, x_tasks: Optional[Dict[str, torch.Tensor]] = None, gelu_gate=None, gelu_out: bool = False
                 ) -> Tuple[torch.Tensor, Optional[Dict[str, torch.Tensor]]]:
         """gelu_gate = (h, {task: h_t} or None): x = gelu(h) and x_tasks[t] = gelu(h_t) came from a deferred-gradient GELU

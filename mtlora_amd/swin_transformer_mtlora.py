@@ -126,7 +126,40 @@ class Mlp(nn.Module):
                 and (self.drop.p == 0.0 or not self.training) and torch.is_grad_enabled() and x.is_cuda and x.requires_grad
                 and self.fc1.tasks == self.fc2.tasks)
 
+    def _hid_forward(self, x, x_tasks):
+        """task-enabled Mlp called with x_tasks: the T task hidden tensors (fc1's task outputs, their GELU, and the gradients w.r.t. them)
+        stay implicit -- ``Fn.MlpHidFn`` (csrc/hid.h); None when the call does not qualify (the per-layer path then runs)."""
+        tasks = self.tasks
+        if not (Fn.mlp_hid_enabled() and x_tasks is not None and tasks and self.fc1.tasks is not None
+                and list(self.fc1.tasks) == list(tasks) and list(self.fc2.tasks) == list(tasks)
+                and self.fc1.linear.out_features == self.fc2.linear.in_features and all(t in x_tasks for t in tasks)):
+            return None
+        dtype = Fn.compute_dtype(x)
+        if dtype not in (torch.bfloat16, torch.float16) or x.shape[-1] != self.fc1.linear.in_features:
+            return None
+        xt = [x_tasks[t] for t in tasks]
+        if any((not v.is_cuda) or v.shape != x.shape for v in xt):
+            return None
+        # (shape rules first: ``hid_call`` draws the layers' dropout seeds)
+        H, r1, r2 = self.fc1.linear.out_features, self.fc1._ranks, self.fc2._ranks
+        if H % 128 or H > 2048 or any(not (1 <= r1.get(t, 0) <= 8 and 1 <= r2.get(t, 0) <= 8) for t in tasks):
+            return None
+        c1 = self.fc1.hid_call(dtype, x.device)
+        c2 = self.fc2.hid_call(dtype, x.device) if c1 is not None else None
+        if c1 is None or c2 is None:
+            return None
+        (m1, (W1c, W1t, b1), f1), (m2, (W2c, W2t, b2), f2) = c1, c2
+        M = x.numel() // m1.K
+        if not Fn.mlp_hid_supported(m1, m2, M):
+            return None
+        outs = Fn.MlpHidFn.apply(m1, m2, x, W1c, W1t, b1, W2c, W2t, b2, f1[0], f1[1], f2[0], f2[1], *xt, *f1[2], *f1[3], *f2[2], *f2[3])
+        return outs[0], {t: outs[1 + i] for i, t in enumerate(tasks)}
+
     def forward(self, x, x_tasks=None):
+        if x_tasks is not None and self._fused_gelu(x):
+            out = self._hid_forward(x, x_tasks)
+            if out is not None:
+                return out
         if self._fused_gelu(x):
             h, h_t, a, a_t = self.fc1(x, x_tasks, gelu_out=True)
             return self.fc2(a, a_t, gelu_gate=(h.detach(), None if h_t is None else {t: v.detach() for t, v in h_t.items()}))

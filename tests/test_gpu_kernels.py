@@ -1278,6 +1278,101 @@ def test_mlp_gelu_fused_both_ways(dtype, with_tasks):
 
 
 
+def _mlp_with_tasks(tasks, C, Hd, r_s, r_t, p_drop, seed):
+    from mtlora_amd.swin_transformer_mtlora import Mlp
+    from mtlora_amd import mtl_harness as H
+    torch.manual_seed(seed)
+    ns = H.mtlora_namespace(tasks, r_shared=r_s, r_task=r_t, scale=2.0, dropout=p_drop)
+    mlp = Mlp(C, Hd, lora=True, tasks=tasks, mtlora=ns, layer_idx=0).to(dev())
+    with torch.no_grad():
+        for n_, p_ in mlp.named_parameters():
+            if "lora_" in n_:
+                p_.normal_(0, 0.1)
+            else:
+                p_.requires_grad_(False)
+    return mlp.train()
+
+
+def _mlp_reference_fp64(mlp, xs, tasks, gys):
+    """fc1 -> GELU -> fc2 of a task-enabled Mlp (reference lora.py:262-266 with x_tasks, swin_transformer_mtlora.py:68-81) in fp64,
+    dropout off: outputs, input gradients and factor gradients"""
+    P = {n: p.detach().double().requires_grad_(p.requires_grad) for n, p in mlp.named_parameters()}
+    X = [x.detach().double().requires_grad_(True) for x in xs]
+
+    def lin(pre, x, xt):
+        W, b = P[f"{pre}.linear.weight"], P[f"{pre}.linear.bias"]
+        base = x @ W.t() + b
+        s = float(getattr(mlp, pre).lora_shared_scale)
+        ys = base + s * (x @ P[f"{pre}.lora_shared_A"].t()) @ P[f"{pre}.lora_shared_B"].t()
+        yt = []
+        for i, t in enumerate(tasks):
+            st = float(getattr(mlp, pre).lora_task_scale[t])
+            yt.append(base + st * (xt[i] @ P[f"{pre}.lora_tasks_A.{t}"].t()) @ P[f"{pre}.lora_tasks_B.{t}"].t())
+        return ys, yt
+    h, ht = lin("fc1", X[0], X[1:])
+    g = torch.nn.functional.gelu
+    y, yt = lin("fc2", g(h), [g(v) for v in ht])
+    outs = [y] + yt
+    torch.autograd.backward(outs, [q.double() for q in gys])
+    return outs, [x.grad for x in X], {n: p.grad for n, p in P.items() if p.grad is not None}
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("geom", ["c2s0", "t8", "r8", "wide", "t3mixed"])
+def test_mlp_implicit_task_hiddens(dtype, geom):
+    """``Fn.MlpHidFn`` (csrc/hid.h: the task hidden tensors of a task-enabled Mlp never reach HBM) against (i) the per-layer path with the
+    SAME dropout seeds -- train mode, p = 0.1 -- and (ii) the fp64 formulas of the reference (lora.py:262-266, Mlp :68-81), dropout off:
+    outputs, every input gradient and every factor gradient at the north-star tolerance.  Geometries: Swin-T stage 0 of c2 (4 tasks of
+    rank 4), 8 tasks (two task groups per launch), rank 8 (the rank-8 register geometry), hidden 2048 (1024-thread workgroups) and three
+    tasks of mixed ranks with a row count that is no multiple of the row batch."""
+    from mtlora_amd import functional as Fn
+    C, Hd, T, r_t, M = {"c2s0": (96, 384, 4, 4, 3 * 977), "t8": (96, 384, 8, 4, 2 * 515), "r8": (192, 768, 2, 8, 1030),
+                        "wide": (128, 2048, 4, 4, 2 * 301), "t3mixed": (96, 384, 3, 3, 1027)}[geom]
+    tasks = [f"t{i}" for i in range(T)]
+    tol = {torch.bfloat16: 1e-2, torch.float16: 2e-3}[dtype]
+    for p_drop in (0.1, 0.0):
+        mlp = _mlp_with_tasks(tasks, C, Hd, 16, r_t, p_drop, seed=23)
+        xs = [torch.randn(M, C, device=dev()).requires_grad_(True) for _ in range(1 + T)]
+        gys = None
+        res = []
+        for hid in (False, True):
+            old = Fn.set_mlp_hid(hid)
+            try:
+                Fn._seed_counter = 900
+                for x in xs:
+                    x.grad = None
+                mlp.zero_grad()
+                with torch.autocast("cuda", dtype=dtype):
+                    y, y_t = mlp(xs[0], {t: xs[1 + i] for i, t in enumerate(tasks)})
+                outs = [y] + [y_t[t] for t in tasks]
+                if gys is None:
+                    gys = [torch.randn_like(o) for o in outs]
+                torch.autograd.backward(outs, gys)
+                res.append(([o.detach().clone() for o in outs], [x.grad.clone() for x in xs],
+                            {n_: p_.grad.clone() for n_, p_ in mlp.named_parameters() if p_.grad is not None}))
+            finally:
+                Fn.set_mlp_hid(old)
+        (o0, g0, p0), (o1, g1, p1) = res
+        assert p0.keys() == p1.keys() and len(p0) == 4 * (1 + T)
+        refs = [("per-layer path", o0, g0, p0, 1.0)]
+        if p_drop == 0.0:
+            ro, rg, rp = _mlp_reference_fp64(mlp, xs, tasks, gys)
+            refs.append(("fp64 reference", ro, rg, rp, 1.0))
+        for what, ro, rg, rp, mult in refs:
+            for i, (u, v) in enumerate(zip(ro, o1)):
+                e = rel_err(v, u)
+                _log_parity(f"hid y{i} vs {what}", e, tol, mult)
+                assert e <= tol * mult, (what, "y", i, e)
+            for i, (u, v) in enumerate(zip(rg, g1)):
+                e = rel_err(v, u)
+                _log_parity(f"hid dx{i} vs {what}", e, tol, mult)
+                assert e <= tol * mult, (what, "dx", i, e)
+            for k in p1:
+                e = rel_err(p1[k], rp[k])
+                _log_parity(f"hid d{k} vs {what}", e, tol, mult)
+                assert e <= tol * mult, (what, k, e)
+
+
 # ------------------------------------------------------------------------------------------------
 # fused bilinear upsample + loss (+ backward)
 # ------------------------------------------------------------------------------------------------

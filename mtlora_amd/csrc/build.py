@@ -11,7 +11,7 @@ import sys
 from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SOURCES = ["window_process.hip", "linear.hip", "attention.hip", "glue.hip", "loss.hip", "upsample.hip", "reduce.hip", "selftest.hip", "block.hip"]
+SOURCES = ["window_process.hip", "linear.hip", "attention.hip", "glue.hip", "loss.hip", "upsample.hip", "reduce.hip", "selftest.hip", "block.hip", "hid.hip"]
 LIB = os.path.join(HERE, "libmtlora_hip.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-Wno-unused-result"]
 if os.environ.get("MTLORA_ABLATE") == "1":  # developer build: MTLORA_NT_DBG ablation toggles in the NT kernels (use --force)

@@ -19,3 +19,10 @@ MTL_INTERNAL int mtli_residual_layernorm_bwd(const void* dy, const void* x_new, 
                                              void* d_shortcut, void* d_branch, float* dgamma, float* dbeta, const float* scale,
                                              int64_t B, int64_t M, int64_t C, int x_dtype, int dy_dtype, void* scratch,
                                              int64_t scratch_bytes, const void* dx_addend, int phase, void* stream);
+
+// k_hid_* (hid.hip): the task streams of a task-enabled Mlp without their hidden-width tensors; linear.hip fills the parameter blocks
+struct HidLaunch;
+struct HidParams;
+struct HidRedParams;
+MTL_INTERNAL void mtli_hid_launch(const HidLaunch* L, const HidParams* q, void* stream);
+MTL_INTERNAL void mtli_hid_reduce(const HidRedParams* r, int64_t per, void* stream);

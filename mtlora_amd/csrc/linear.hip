@@ -43,6 +43,8 @@
 #include <type_traits>
 
 #include "common.h"
+#include "internal.h"
+#include "hid_params.h"
 
 namespace {
 
@@ -1093,7 +1095,6 @@ __global__ __launch_bounds__(512, 4) void k_ntl(const NlParams P) {
 #include "stream.h"
 #include "dense.h"
 #include "pq.h"
-#include "hid.h"
 
 // ------------------------------------------------------------------------------------------------
 // k_tn : Out[a][b] = sum_m SrcA[m][a0 + a] * SrcB[m][b0 + b], split over m.
@@ -2439,7 +2440,8 @@ static int fwd_impl(const mtlora_linear_desc* d, const void* x, const void* cons
                 q.nz = 0;
             }
             {
-                const double xb = (double)sizeof(T) * (d->has_x_tasks ? d->T : 0) * d->M * d->K;
+                // (HID_P_GIVEN: the tasks' own inputs are read -- implicitly -- by k_hid_proj, which carries their 8(d) bytes)
+                const double xb = (double)sizeof(T) * ((d->has_x_tasks && !(d->hid & MTLORA_HID_P_GIVEN)) ? d->T : 0) * d->M * d->K;
                 double rsum = 0.0;  // un-padded ranks
                 for (int o = 0; o < sg.n; ++o) rsum += sg.r[o];
                 // wave-streaming form (stream.h) when the alpha-scaled factor rows fit in LDS next to the slab ring
@@ -3075,32 +3077,31 @@ static HidPlan hid_plan(const mtlora_linear_desc* d1, const mtlora_linear_desc* 
     return pl;
 }
 static int64_t hid_part_bytes(const mtlora_linear_desc* d1, const HidPlan& pl) {
-    return (int64_t)pl.n_wg * pl.tg * 2 * pl.rr * d1->N * 4 + 256;
+    // (either form of the backward kernel: VALU n_wg x tg tasks, MFMA <= one workgroup per CU x HID_TG tasks)
+    const Tune tu = make_tune(d1);
+    const int64_t slots = std::max<int64_t>((int64_t)pl.n_wg * pl.tg, (int64_t)num_cu(tu) * HID_TG);
+    return slots * 2 * pl.rr * d1->N * 4 + 256;
 }
 
-template <typename T, bool BWD>
-static void hid_launch(const HidPlan& pl, const HidParams& q, hipStream_t s) {
-    const dim3 g((unsigned)pl.n_wg), b((unsigned)pl.nthr);
-#define HID_GO(TG_, RR_, NT_)                                                              \
-    do {                                                                                   \
-        if constexpr (BWD)                                                                 \
-            hipLaunchKernelGGL((k_hid_bwd<T, TG_, RR_, NT_>), g, b, 0, s, q);               \
-        else                                                                               \
-            hipLaunchKernelGGL((k_hid_proj<T, TG_, RR_, NT_>), g, b, 0, s, q);              \
-    } while (0)
-    if (pl.rr == 4 && pl.tg == 4)
-        HID_GO(4, 4, 512);
-    else if (pl.rr == 4 && pl.nthr <= 768)
-        HID_GO(2, 4, 768);
-    else if (pl.rr == 4)
-        HID_GO(2, 4, 1024);
-    else if (pl.tg == 2)
-        HID_GO(2, 8, 512);
-    else if (pl.nthr <= 768)
-        HID_GO(1, 8, 768);
-    else
-        HID_GO(1, 8, 1024);
-#undef HID_GO
+static void hid_launch_valu(int dtype, bool bwd, const HidPlan& pl, const HidParams& q, hipStream_t s) {
+    HidLaunch L = {};
+    L.kind = bwd ? 1 : 0;
+    L.dtype = dtype;
+    L.tg = pl.tg;
+    L.rr = pl.rr;
+    L.nthr = pl.nthr;
+    L.n_wg = pl.n_wg;
+    mtli_hid_launch(&L, &q, s);
+}
+static void hid_launch_mfma(int dtype, bool bwd, int rr, int nthr, int n_wg, size_t lds, const HidParams& q, hipStream_t s) {
+    HidLaunch L = {};
+    L.kind = bwd ? 3 : 2;
+    L.dtype = dtype;
+    L.rr = rr;
+    L.nthr = nthr;
+    L.n_wg = n_wg;
+    L.lds = lds;
+    mtli_hid_launch(&L, &q, s);
 }
 
 template <typename T>
@@ -3114,10 +3115,14 @@ static int hid_proj_impl(const mtlora_linear_desc* d1, const mtlora_linear_desc*
     const unsigned char* pk2 = reinterpret_cast<const unsigned char*>(d2->packed);
     const HidPlan pl = hid_plan(d1, d2);
     const int H = (int)d1->N;
-    mtl_prof_tag("hid_proj M%lld H%d T%d tg%d rr%d", (long long)d1->M, H, d1->T, pl.tg, pl.rr);
-    const double hb = (double)sizeof(T) * d1->M * H;
-    MtlProfScope prof(PK_NT_FWD_P, hb * pl.groups, s, (double)sizeof(T) * d1->M * (double)d1->T * H, 0.0);
-    for (int gI = 0; gI < pl.groups; ++gI) {
+    const Tune tu = make_tune(d1);
+    // MFMA form (hid.h, k_hid_proj_m): 4 tasks per launch whatever the rank, one workgroup of H / 128 waves per 32-row block; the VALU
+    // form (k_hid_proj) where its tables do not fit in LDS (hidden > 1536) and as the "tiled only" family of the tests (sel_stream = 1)
+    const size_t mlds = pl.rr == 4 ? HidMGeom<T, 4>::lds_bytes(H) : HidMGeom<T, 8>::lds_bytes(H);
+    const bool mfma = tu.sp != 0 && mlds <= (size_t)150 * 1024;
+    const int tg = mfma ? HID_TG : pl.tg;
+    const int groups = (d1->T + tg - 1) / tg;
+    for (int gI = 0; gI < groups; ++gI) {
         HidParams q = {};
         q.hbase = h_base;
         q.p1 = c1 + L1.p;
@@ -3130,12 +3135,25 @@ static int hid_proj_impl(const mtlora_linear_desc* d1, const mtlora_linear_desc*
         q.H = H;
         q.ldp1 = s1.R;
         q.ldp2 = s2.R;
-        q.nt = std::min(pl.tg, d1->T - gI * pl.tg);
-        for (int i = 0; i < q.nt; ++i) {
-            q.off1[i] = s1.off[1 + gI * pl.tg + i];
-            q.off2[i] = s2.off[1 + gI * pl.tg + i];
+        q.nt = std::min(tg, d1->T - gI * tg);
+        for (int i = 0; i < HID_TG; ++i) {  // (slots past nt: valid offsets, never stored -- hid.h)
+            const int t = gI * tg + (i < q.nt ? i : 0);
+            q.off1[i] = s1.off[1 + t];
+            q.off2[i] = s2.off[1 + t];
         }
-        hid_launch<T, false>(pl, q, s);
+        const double hb = (double)sizeof(T) * d1->M * H;
+        mtl_prof_tag("hid_proj%s M%lld H%d T%d nt%d rr%d", mfma ? "_m" : "", (long long)d1->M, H, d1->T, q.nt, pl.rr);
+        MtlProfScope prof(PK_NT_FWD_P, hb, s, (double)sizeof(T) * d1->M * (double)q.nt * H, 0.0);
+        if (mfma) {
+            const int nw = H / HIDM_CW;
+            int wgpc = (int)std::min<size_t>((size_t)(150 * 1024) / mlds, (size_t)std::max(1, 12 / nw));
+            if (wgpc < 1) wgpc = 1;
+            const int64_t nblk = (d1->M + 31) / 32;
+            const unsigned grid = (unsigned)std::min<int64_t>(nblk, (int64_t)num_cu(tu) * wgpc);
+            hid_launch_mfma(d1->dtype, false, pl.rr, nw * 64, (int)grid, mlds, q, s);
+        } else {
+            hid_launch_valu(d1->dtype, false, pl, q, s);
+        }
     }
     return MTLORA_OK;
 }
@@ -3151,8 +3169,18 @@ static int hid_bwd_impl(const mtlora_linear_desc* d1, const mtlora_linear_desc* 
     const unsigned char* c2 = reinterpret_cast<const unsigned char*>(ctx2);
     const unsigned char* pk1 = d1->packed ? reinterpret_cast<const unsigned char*>(d1->packed) : c1;
     const unsigned char* pk2 = d2->packed ? reinterpret_cast<const unsigned char*>(d2->packed) : c2;
-    const HidPlan pl = hid_plan(d1, d2);
+    const HidPlan pl0 = hid_plan(d1, d2);
     const int H = (int)d1->N;
+    const Tune tu = make_tune(d1);
+    // MFMA form (k_hid_bwd_m): one workgroup of H / 32 waves per 32-row block, 4 tasks per launch; needs <= 12 waves and its tables in LDS
+    const size_t mlds = pl0.rr == 4 ? HidBGeom<T, 4>::lds_bytes(H) : HidBGeom<T, 8>::lds_bytes(H);
+    const bool mfma = tu.sp != 0 && H % HIDB_CW == 0 && H / HIDB_CW <= 12 && mlds <= (size_t)150 * 1024;
+    HidPlan pl = pl0;
+    if (mfma) {
+        pl.tg = HID_TG;
+        pl.groups = (d1->T + HID_TG - 1) / HID_TG;
+        pl.n_wg = (int)std::min<int64_t>((d1->M + 31) / 32, (int64_t)num_cu(tu));
+    }
     for (int gI = 0; gI < pl.groups; ++gI) {
         HidParams q = {};
         q.hbase = h_base;
@@ -3173,19 +3201,26 @@ static int hid_bwd_impl(const mtlora_linear_desc* d1, const mtlora_linear_desc* 
         q.ldq2 = s2.R;
         q.nt = std::min(pl.tg, d1->T - gI * pl.tg);
         HidRedParams r = {};
-        for (int i = 0; i < q.nt; ++i) {
-            const int t = gI * pl.tg + i;
+        for (int i = 0; i < HID_TG; ++i) {  // (slots past nt: valid offsets, never stored -- hid.h)
+            const int t = gI * pl.tg + (i < q.nt ? i : 0);
             q.off1[i] = s1.off[1 + t];
             q.off2[i] = s2.off[1 + t];
+        }
+        for (int i = 0; i < q.nt; ++i) {
+            const int t = gI * pl.tg + i;
             r.r[i] = 0;
             r.dB1[i] = dB1_t ? dB1_t[t] : nullptr;
             r.dA2[i] = dA2_t ? dA2_t[t] : nullptr;
         }
         {
-            mtl_prof_tag("hid_bwd M%lld H%d T%d tg%d rr%d", (long long)d1->M, H, d1->T, pl.tg, pl.rr);
+            mtl_prof_tag("hid_bwd%s M%lld H%d T%d tg%d rr%d", mfma ? "_m" : "", (long long)d1->M, H, d1->T, pl.tg, pl.rr);
             const double hb = (double)sizeof(T) * d1->M * H;
             MtlProfScope prof(PK_NT_BWD_DX, 3.0 * hb, s, (double)sizeof(T) * d1->M * (double)q.nt * H, 0.0);
-            hid_launch<T, true>(pl, q, s);
+            if (mfma) {
+                hid_launch_mfma(d1->dtype, true, pl.rr, H / HIDB_CW * 64, pl.n_wg, mlds, q, s);
+            } else {
+                hid_launch_valu(d1->dtype, true, pl, q, s);
+            }
         }
         // dB1_t (fc1's N x r_t, un-padded rank d1->r_t) and dA2_t (fc2's r_t x K) share one reduce: per kind the un-padded rank differs
         // only if the two layers were built with different task ranks -- reduce them separately then
@@ -3200,7 +3235,7 @@ static int hid_bwd_impl(const mtlora_linear_desc* d1, const mtlora_linear_desc* 
         MtlProfScope prof(PK_REDUCE, 0.0, s);
         if (same) {
             for (int i = 0; i < q.nt; ++i) r.r[i] = d1->r_t[gI * pl.tg + i];
-            hipLaunchKernelGGL(k_hid_reduce, dim3((unsigned)((per + 255) / 256)), dim3(256), 0, s, r);
+            mtli_hid_reduce(&r, per, s);
         } else {
             HidRedParams rb = r, ra = r;
             for (int i = 0; i < q.nt; ++i) {
@@ -3209,8 +3244,8 @@ static int hid_bwd_impl(const mtlora_linear_desc* d1, const mtlora_linear_desc* 
                 ra.r[i] = d2->r_t[gI * pl.tg + i];
                 ra.dB1[i] = nullptr;
             }
-            hipLaunchKernelGGL(k_hid_reduce, dim3((unsigned)((per + 255) / 256)), dim3(256), 0, s, rb);
-            hipLaunchKernelGGL(k_hid_reduce, dim3((unsigned)((per + 255) / 256)), dim3(256), 0, s, ra);
+            mtli_hid_reduce(&rb, per, s);
+            mtli_hid_reduce(&ra, per, s);
         }
     }
     return MTLORA_OK;

@@ -211,12 +211,13 @@ int mtlora_linear_bwd_gelu(const mtlora_linear_desc* d, const void* x, const voi
  * <= 2048 (mtlora_mlp_hid_supported returns 1).  Deterministic (fixed-order partial sums).
  * ------------------------------------------------------------------------------------------ */
 int mtlora_mlp_hid_supported(const mtlora_linear_desc* d1, const mtlora_linear_desc* d2);
-/* bytes of the partial-sum scratch of mtlora_mlp_hid_bwd (-1: unsupported shape) */
+/* bytes of the scratch buffers of mtlora_mlp_hid_proj / mtlora_mlp_hid_bwd (-1: unsupported shape) */
+int64_t mtlora_mlp_hid_fwd_scratch_bytes(const mtlora_linear_desc* d1, const mtlora_linear_desc* d2);
 int64_t mtlora_mlp_hid_bwd_scratch_bytes(const mtlora_linear_desc* d1, const mtlora_linear_desc* d2);
-/* ctx1: fc1's context (P1; and the packed factors when d1->packed is null); ctx2: fc2's context, whose task columns of P are written
- * (and whose packed factors must already be there when d2->packed is null: mtlora_linear_pack into its head first). */
+/* ctx1: fc1's context (P1; and the packed factors when d1->packed is null); ctx2: fc2's context, whose task columns of P are written;
+ * d2->packed must be set (mtlora_linear_pack / _pack_table before the call). */
 int mtlora_mlp_hid_proj(const mtlora_linear_desc* d1, const mtlora_linear_desc* d2, const void* h_base, const void* ctx1,
-                        void* ctx2, void* stream);
+                        void* ctx2, void* scratch, int64_t scratch_bytes, void* stream);
 /* dh_s: gradient w.r.t. the shared pre-activation (dx of fc2's bwd_gelu); scratch2: fc2's backward scratch after its phase 1 (holds
  * Q2); scratch1: fc1's backward scratch (its Q task columns are written); g: OUT (M x H) = dh_s + sum_t dH_t; dB1_t[t] (H x r_t) /
  * dA2_t[t] (r_t x H): fp32 OUT, nullable. */

@@ -107,7 +107,8 @@ _SIGS = {
                                        POINTER(c_void_p), c_void_p, c_int64, c_void_p, POINTER(c_void_p), c_void_p]),
     "mtlora_mlp_hid_supported": (c_int, [POINTER(LinearDesc), POINTER(LinearDesc)]),
     "mtlora_mlp_hid_bwd_scratch_bytes": (c_int64, [POINTER(LinearDesc), POINTER(LinearDesc)]),
-    "mtlora_mlp_hid_proj": (c_int, [POINTER(LinearDesc), POINTER(LinearDesc), c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mtlora_mlp_hid_fwd_scratch_bytes": (c_int64, [POINTER(LinearDesc), POINTER(LinearDesc)]),
+    "mtlora_mlp_hid_proj": (c_int, [POINTER(LinearDesc), POINTER(LinearDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "mtlora_mlp_hid_bwd": (c_int, [POINTER(LinearDesc), POINTER(LinearDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                    c_void_p, POINTER(c_void_p), POINTER(c_void_p), c_void_p, c_int64, c_void_p]),
     "mtlora_window_attn_bwd_scratch_bytes": (c_int64, [POINTER(AttnDesc)]),

@@ -21,6 +21,7 @@
 #include "internal.h"
 #include "hid_params.h"
 #include <atomic>
+#include <type_traits>
 
 namespace {
 
@@ -197,156 +198,68 @@ __global__ __launch_bounds__(NTHR) void k_hid_proj(const HidParams P) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// MFMA form of the forward kernel (round 6, second version).  The VALU form above is bound by its own instruction stream (~200 VALU per row
-// and lane, 30 % of it the cross-lane butterfly) and by latency at <= 2-3 waves per SIMD: 1.0 ms at stage 0 of c2.  Here the row sums ARE a
-// matrix product:  P2[m][(t, rho)] = sum_j a_t[m][j] A2_t[rho][j]  -- one v_mfma_f32_32x32x16 per task and 16-column step, the tasks of a launch
-// sharing ONE accumulator (the B operand of task t is zero outside its own rank columns n = t RR + rho), no cross-lane reduction at all.
-//   * lane (m = l & 31, jg = l >> 5) owns row m of the workgroup's 32-row block and, in step s of its wave, the 8 columns
-//     w * 128 + 16 s + 8 jg ..: h_base arrives as one 16-byte load per step, the row's P1 values as one 16-byte load per task;
-//   * h_t = h_base + sum_rho P1_t[m][rho] B1_t[:, rho]: the factor rows come from an fp32 LDS table (broadcast reads: a half-wave reads one
-//     address), 4 v_pk_fma_f32 per rank column; gelu in registers; the 8 activations, packed to one 16-byte fragment, ARE the A operand;
-//   * the B operand is a 16-byte LDS read of the A2 row (t, rho) = n (rows padded by 16 B: conflict-free), the zero row for the lanes of
-//     other tasks; after the 8 steps the lanes n < nt RR hold the wave's share of P2 for 16 rows each: summed across the waves through LDS
-//     (double-buffered: one barrier per row block), scaled by alpha2 and stored as whole 16-byte rank segments.
+// MFMA forms (k_hid_fwd_d / k_hid_bwd_d; rank <= 4, 4 tasks per launch: n = 4 t + rho).  The VALU forms above are bound by their own instruction
+// stream (~200 / ~310 VALU per row and lane, a third of it cross-lane butterflies) at 2-3 waves per SIMD: 1.0 / 2.6 ms at stage 0 of c2.
+// Here every contraction is a v_mfma_f32_32x32x16 and the element-wise work happens in the ACCUMULATOR layout:
+//   * a workgroup owns 32-row blocks x one chunk of HC hidden columns (blockIdx.y), wave w the 32 columns cw = 32 w of it;
+//     "D layout" = lane (c = l & 31, hh = l >> 5) holds rows a(r) = (r & 3) + 8 (r >> 2) + 4 hh, r = 0..15, of column cw + c;
+//   * h_t = h_base + P1_t B1_t^T is ONE mfma: A = the row block's P1 values (lane (m, kg): columns n = 8 kg .. 8 kg + 7 of a [32][32] LDS image),
+//     B = task t's four B1 values of column c placed in its own k slots (zero elsewhere; 8 bytes per (t, c) in LDS), C = h_base in D layout;
+//     u_t = Q2_t A2_t likewise (backward).  No per-element FMAs, no factor table traffic.
+//   * gelu / gelu' on the 16 accumulator values; dH_t = u_t gelu'(h_t); G += dH_t in registers;
+//   * the ROW reductions dB1_t^T[c][n] = sum_m dH_t[m][c] P1[m][n], dA2_t[c][n] = sum_m a_t[m][c] Q2[m][n] take their A operand straight from the
+//     registers (a lane's 16 values ARE 16 rows of one column = the k axis) and their B operand from the P1 / Q2 images by transposed reads
+//     (ds_read_b64_tr_b16) in the same row order, masked to task t's columns: all tasks share one accumulator each;
+//   * the COLUMN reduction (forward P2 = a_t A2_t^T, backward Q1 = dH_t B1_t^T) needs rows along lanes: the packed values go through a per-wave
+//     [32][32] LDS image (4 x 8-byte writes, read back transposed) once per task;
+//   * h_base / dH_s enter and G leaves through the same image (row-major global accesses of 16 bytes per lane);
+//   * the waves' shares of the row sums meet in LDS and go, unscaled fp32, to a (chunk, row) partial that k_hid_rows_finish adds over the chunks,
+//     scales by alpha and stores as 16-byte rank segments; the factor-gradient accumulators go to the workgroup's partial (k_hid_reduce).
 // ------------------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ uint32_t hid_pk(float a, float b) { return mtl_pk2<T>(a, b); }
 
-
-__device__ __forceinline__ void hid_unpack8(const u32x4& v, f32x2 (&f)[4], bf16*) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) f[i] = f32x2{__builtin_bit_cast(float, v[i] << 16), __builtin_bit_cast(float, v[i] & 0xFFFF0000u)};
-}
-__device__ __forceinline__ void hid_unpack8(const u32x4& v, f32x2 (&f)[4], f16*) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) f[i] = f32x2{mtl_lo2<f16>(v[i]), mtl_hi2<f16>(v[i])};
-}
-
-template <typename T, int RR, int HC>
-__global__ __launch_bounds__(HC / 2) void k_hid_proj_m(const HidParams P) {
-    typedef HidMGeom<T, RR> G;
-    constexpr int NV = G::NV;
-    extern __shared__ __attribute__((aligned(16))) unsigned char hid_smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    constexpr int H = HC, NW = HC / HIDM_CW;  // (compile-time: every LDS table offset is an instruction immediate)
-    const int nt = P.nt, m = lane & 31, jg = lane >> 5;
-    constexpr int a2s = H * 2 + 16;
-    float* b1f = reinterpret_cast<float*>(hid_smem);                               // [NV][H]
-    unsigned char* a2b = hid_smem + (size_t)NV * H * 4;                            // [NV + 1][a2s]  (row NV: zeros)
-    float* red = reinterpret_cast<float*>(a2b + (size_t)(NV + 1) * a2s);           // [2][NW][NV][32]
-    // ---- factor tables (once per workgroup)
-    for (int i = tid; i < NV * (H / 2); i += (int)blockDim.x) {
-        const int row = i / (H / 2), c = 2 * (i - row * (H / 2)), t = row / RR, rho = row - t * RR;
-        uint32_t wb = 0u, wa = 0u;
-        if (t < nt) {
-            wb = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const T*>(P.b1t) + (int64_t)(P.off1[t] + rho) * H + c);
-            wa = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const T*>(P.a2) + (int64_t)(P.off2[t] + rho) * H + c);
-        }
-        *reinterpret_cast<f32x2*>(b1f + (size_t)row * H + c) = f32x2{mtl_lo2<T>(wb), mtl_hi2<T>(wb)};
-        *reinterpret_cast<uint32_t*>(a2b + (size_t)row * a2s + c * 2) = wa;
-    }
-    for (int i = tid; i < a2s / 4; i += (int)blockDim.x) *reinterpret_cast<uint32_t*>(a2b + (size_t)NV * a2s + i * 4) = 0u;
-    __syncthreads();
-    const T* hbase = reinterpret_cast<const T*>(P.hbase);
-    const T* p1 = reinterpret_cast<const T*>(P.p1);
-    const int col_w = wave * HIDM_CW + 8 * jg;   // this lane's first column of step 0
-    const int n = lane & 31;
-    // B-operand row of this lane per task: its own rank row, or the zero row
-    int brow[HID_TG];
-#pragma unroll
-    for (int t = 0; t < HID_TG; ++t) brow[t] = ((n / RR) == t && n < NV ? n : NV) * a2s;
-    const int64_t nblk = (P.M + 31) / 32;
-    int buf = 0;
-    for (int64_t rb = blockIdx.x; rb < nblk; rb += gridDim.x, buf ^= 1) {
-        const int64_t m0 = rb * 32;
-        const int64_t row = (m0 + m < P.M) ? m0 + m : P.M - 1;  // (rows past M: a valid row, never stored)
-        u32x4 hv[8], pw[HID_TG];
-#pragma unroll
-        for (int s = 0; s < 8; ++s) hv[s] = *reinterpret_cast<const u32x4*>(hbase + row * H + col_w + 16 * s);
-#pragma unroll
-        for (int t = 0; t < HID_TG; ++t) pw[t] = *reinterpret_cast<const u32x4*>(p1 + row * P.ldp1 + P.off1[t]);
-        float pv[HID_TG][RR];
-#pragma unroll
-        for (int t = 0; t < HID_TG; ++t) {
-            f32x2 q[4];
-            hid_unpack8(pw[t], q, (T*)nullptr);
-#pragma unroll
-            for (int rho = 0; rho < RR; ++rho) pv[t][rho] = (rho & 1) ? q[rho >> 1].y : q[rho >> 1].x;
-        }
-        f32x16 acc;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-#pragma unroll
-        for (int s = 0; s < 8; ++s) {
-            const int col = col_w + 16 * s;
-            f32x2 hb[4];
-            hid_unpack8(hv[s], hb, (T*)nullptr);
-#pragma unroll
-            for (int t = 0; t < HID_TG; ++t) {
-                f32x2 h[4] = {hb[0], hb[1], hb[2], hb[3]};
-#pragma unroll
-                for (int rho = 0; rho < RR; ++rho) {
-                    const float* br = b1f + (size_t)(t * RR + rho) * H + col;
-                    const f32x4 b0 = *reinterpret_cast<const f32x4*>(br), b1v = *reinterpret_cast<const f32x4*>(br + 4);
-                    const float pz = pv[t][rho];
-                    h[0] += pz * f32x2{b0[0], b0[1]};
-                    h[1] += pz * f32x2{b0[2], b0[3]};
-                    h[2] += pz * f32x2{b1v[0], b1v[1]};
-                    h[3] += pz * f32x2{b1v[2], b1v[3]};
-                }
-                u32x4 fa;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const f32x2 a = hid_gelu2_fwd(h[i]);
-                    fa[i] = mtl_pk2<T>(a.x, a.y);
-                }
-                const u32x4 fb = *reinterpret_cast<const u32x4*>(a2b + brow[t] + col * 2);
-                sp_mma1<T>(fa, fb, acc);
-            }
-        }
-        // the wave's share of P2: lane n holds rows (r & 3) + 8 (r >> 2) + 4 jg of column n
-        float* rd = red + (size_t)buf * NW * NV * 32;
-        if (n < NV) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) rd[((size_t)wave * NV + n) * 32 + (r & 3) + 8 * (r >> 2) + 4 * jg] = acc[r];
-        }
-        __syncthreads();
-        if (tid < 32 * HID_TG) {
-            const int rr = tid & 31, t = tid >> 5;
-            if (t < nt && m0 + rr < P.M) {
-                float sv[8];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) sv[e] = 0.f;
-#pragma unroll
-                for (int rho = 0; rho < RR; ++rho) {
-                    float a = 0.f;
-                    for (int w = 0; w < NW; ++w) a += rd[((size_t)w * NV + t * RR + rho) * 32 + rr];
-                    sv[rho] = a * P.alpha2[P.off2[t] + rho];
-                }
-                const u32x4 o = {mtl_pack2<T>(sv[0], sv[1]), mtl_pack2<T>(sv[2], sv[3]), mtl_pack2<T>(sv[4], sv[5]), mtl_pack2<T>(sv[6], sv[7])};
-                *reinterpret_cast<u32x4*>(reinterpret_cast<T*>(P.p2) + (m0 + rr) * P.ldp2 + P.off2[t]) = o;
-            }
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// MFMA form of the backward kernel.  Same lane map as k_hid_proj_m (lane = row m of a 32-row block x 8 columns per 16-column step), a wave owns
-// HIDB_CW = 32 columns (two steps), the workgroup's H / 32 waves cover the row block's H columns together (H = 384: 12 waves, 3 per SIMD).
-//   per (step, task):  h_t and u_t = Q2_t A2_t from two fp32 LDS tables (broadcast reads), gelu / gelu' in registers, dH_t = u_t gelu'(h_t),
-//                      G += dH_t;  Q1 += dH_t B1_t^T as ONE mfma (dH_t packed = A operand; B = the B1 row of lane n, zero outside task t);
-//                      the packed dH_t and a_t fragments also go to the wave's two [32 rows][32 columns] LDS images;
-//   per task:          the two row reductions as mfma with BOTH operands read back transposed (ds_read_b64_tr_b16: a lane then holds 8
-//                      consecutive rows of one column = the k axis):  dB1^T[j][n] += sum_m dH_t[m][j] P1[m][n],  dA2[j][n] += sum_m a_t[m][j] Q2[m][n],
-//                      P1 / Q2 from workgroup-wide [32][32] images of the row block (columns n = t RR + rho), masked to task t's columns;
-//   per row block:     the waves' Q1 shares meet in LDS (overlaying the images), alpha-scaled, stored as 16-byte rank segments;
-//   at the end:        the two accumulators of the wave go to the workgroup's partial (k_hid_reduce sums the workgroups in fixed order).
-// ------------------------------------------------------------------------------------------------
-
-
-// transposed fragment of a [32 rows][>= col0 + 32 columns] 16-bit LDS image with 64-byte rows: lane (i = l & 31, hh = l >> 5) gets the 16
-// elements Src[m][col0 + i], m in the slot order of tn_frag16 (linear.hip) -- the same order for both operands of an mfma pair
-__device__ __forceinline__ void hid_tr_frag(const unsigned char* img, int col0, int lane, u32x4& f0, u32x4& f1) {
+// [32 rows][32 cols] 16-bit image with 64-byte rows -> lane (c, hh): the 16 rows a(r) of column c, raw (two fragments of 8) or as floats
+__device__ __forceinline__ void hid_dl_raw(const unsigned char* img, int lane, u32x4& f0, u32x4& f1) {
     const int g = lane >> 4, i = lane & 15, hh = g >> 1;
-    const int col = col0 + 16 * (g & 1) + 4 * (i & 3);
+    const int col = 16 * (g & 1) + 4 * (i & 3);
+    uint32_t w[8];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int row = 8 * q + 4 * hh + (i >> 2);
+        s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(img + row * 64 + col * 2));
+        const u32x2 u = __builtin_bit_cast(u32x2, v);
+        w[2 * q] = u[0];
+        w[2 * q + 1] = u[1];
+    }
+    f0 = u32x4{w[0], w[1], w[2], w[3]};
+    f1 = u32x4{w[4], w[5], w[6], w[7]};
+}
+template <typename T>
+__device__ __forceinline__ void hid_dl_f32(const unsigned char* img, int lane, f32x16& v) {
+    u32x4 f0, f1;
+    hid_dl_raw(img, lane, f0, f1);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        v[2 * i] = mtl_lo2<T>(f0[i]);
+        v[2 * i + 1] = mtl_hi2<T>(f0[i]);
+        v[8 + 2 * i] = mtl_lo2<T>(f1[i]);
+        v[8 + 2 * i + 1] = mtl_hi2<T>(f1[i]);
+    }
+}
+// lane (c, hh): its 16 packed D-layout values (f0 = rows r 0..7, f1 = r 8..15) -> image row c, i.e. the TRANSPOSE [32 cols][32 rows]
+__device__ __forceinline__ void hid_dl_store_t(unsigned char* img, int lane, const u32x4& f0, const u32x4& f1) {
+    const int c = lane & 31, hh = lane >> 5;
+    unsigned char* p = img + c * 64 + 8 * hh;
+    *reinterpret_cast<u32x2*>(p) = u32x2{f0[0], f0[1]};        // rows 4 hh + 0..3
+    *reinterpret_cast<u32x2*>(p + 16) = u32x2{f0[2], f0[3]};   // rows 8 + 4 hh ..
+    *reinterpret_cast<u32x2*>(p + 32) = u32x2{f1[0], f1[1]};   // rows 16 + 4 hh ..
+    *reinterpret_cast<u32x2*>(p + 48) = u32x2{f1[2], f1[3]};   // rows 24 + 4 hh ..
+}
+// transposed fragment pair of a [32][32] image with 64-byte rows: lane (i = l & 31, hh) gets Img[8 hh + e][i] (f0) and Img[16 + 8 hh + e][i] (f1)
+__device__ __forceinline__ void hid_tr_frag(const unsigned char* img, int lane, u32x4& f0, u32x4& f1) {
+    const int g = lane >> 4, i = lane & 15, hh = g >> 1;
+    const int col = 16 * (g & 1) + 4 * (i & 3);
     uint32_t w[8];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -359,53 +272,172 @@ __device__ __forceinline__ void hid_tr_frag(const unsigned char* img, int col0, 
     f0 = u32x4{w[0], w[1], w[2], w[3]};
     f1 = u32x4{w[4], w[5], w[6], w[7]};
 }
+#define HID_LGKM0() __builtin_amdgcn_s_waitcnt(0xc07f)
 
-template <typename T, int RR, int HC>
-__global__ __launch_bounds__(HC * 2) void k_hid_bwd_m(const HidParams P) {
-    typedef HidBGeom<T, RR> G_;
-    constexpr int NV = G_::NV;
-    extern __shared__ __attribute__((aligned(16))) unsigned char hid_smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    constexpr int H = HC, NW = HC / HIDB_CW;  // (compile-time: every LDS table offset is an instruction immediate)
-    const int nt = P.nt, m = lane & 31, jg = lane >> 5, n = lane & 31;
-    constexpr int bs = H * 2 + 16;
-    float* b1f = reinterpret_cast<float*>(hid_smem);                                     // [NV][H]  B1 rows (h update)
-    float* a2f = b1f + (size_t)NV * H;                                                   // [NV][H]  A2 rows (u)
-    unsigned char* b1b = reinterpret_cast<unsigned char*>(a2f + (size_t)NV * H);         // [NV + 1][bs] 16-bit B1 rows (Q1's B operand), zero row
-    unsigned char* pimg = b1b + (size_t)(NV + 1) * bs;                                   // [32][32] P1 columns n
-    unsigned char* qimg = pimg + 32 * 64;                                                // [32][32] Q2 columns n
-    unsigned char* tiles = qimg + 32 * 64;                                               // per wave: dH image, a image ([32][32] each)
-    float* red = reinterpret_cast<float*>(tiles);                                        // overlays the tiles: [NW][NV][32]
-    for (int i = tid; i < NV * (H / 2); i += (int)blockDim.x) {
-        const int row = i / (H / 2), c = 2 * (i - row * (H / 2)), t = row / RR, rho = row - t * RR;
-        uint32_t wb = 0u, wa = 0u;
+// task t's four factor values of a column (8 bytes) as the B operand of the rank update: k slot e of lane (c, kg) is n = 8 kg + e
+template <int t>
+__device__ __forceinline__ u32x4 hid_place(const u32x2 tb, int kg) {
+    const uint32_t sel = kg == (t >> 1) ? 0xFFFFFFFFu : 0u;
+    if constexpr (t & 1)
+        return u32x4{0u, 0u, tb[0] & sel, tb[1] & sel};
+    else
+        return u32x4{tb[0] & sel, tb[1] & sel, 0u, 0u};
+}
+
+// shared prologue: compact factor tables + projection rows of this chunk
+template <typename T, int HC, bool BWD>
+__device__ __forceinline__ void hid_d_tables(const HidParams& P, int tid, int nthr, int c_base, unsigned char* tabH, unsigned char* tabU, unsigned char* bq) {
+    const int nt = P.nt, H = P.H;
+    constexpr int bs = HC * 2 + 16;
+    const uint16_t* b1 = reinterpret_cast<const uint16_t*>(P.b1t);
+    const uint16_t* a2 = reinterpret_cast<const uint16_t*>(P.a2);
+    for (int i = tid; i < HID_TG * HC; i += nthr) {
+        const int t = i / HC, cc = i - t * HC;
+        uint32_t h0 = 0u, h1 = 0u, u0 = 0u, u1 = 0u;
         if (t < nt) {
-            wb = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const T*>(P.b1t) + (int64_t)(P.off1[t] + rho) * H + c);
-            wa = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const T*>(P.a2) + (int64_t)(P.off2[t] + rho) * H + c);
+            const int64_t cb = c_base + cc;
+            h0 = (uint32_t)b1[(int64_t)(P.off1[t] + 0) * H + cb] | ((uint32_t)b1[(int64_t)(P.off1[t] + 1) * H + cb] << 16);
+            h1 = (uint32_t)b1[(int64_t)(P.off1[t] + 2) * H + cb] | ((uint32_t)b1[(int64_t)(P.off1[t] + 3) * H + cb] << 16);
+            if (BWD) {
+                u0 = (uint32_t)a2[(int64_t)(P.off2[t] + 0) * H + cb] | ((uint32_t)a2[(int64_t)(P.off2[t] + 1) * H + cb] << 16);
+                u1 = (uint32_t)a2[(int64_t)(P.off2[t] + 2) * H + cb] | ((uint32_t)a2[(int64_t)(P.off2[t] + 3) * H + cb] << 16);
+            }
         }
-        *reinterpret_cast<f32x2*>(b1f + (size_t)row * H + c) = f32x2{mtl_lo2<T>(wb), mtl_hi2<T>(wb)};
-        *reinterpret_cast<f32x2*>(a2f + (size_t)row * H + c) = f32x2{mtl_lo2<T>(wa), mtl_hi2<T>(wa)};
-        *reinterpret_cast<uint32_t*>(b1b + (size_t)row * bs + c * 2) = wb;
+        *reinterpret_cast<u32x2*>(tabH + (size_t)i * 8) = u32x2{h0, h1};
+        if (BWD) *reinterpret_cast<u32x2*>(tabU + (size_t)i * 8) = u32x2{u0, u1};
     }
-    for (int i = tid; i < bs / 4; i += (int)blockDim.x) *reinterpret_cast<uint32_t*>(b1b + (size_t)NV * bs + i * 4) = 0u;
-    for (int i = tid; i < 2 * 32 * 64 / 4; i += (int)blockDim.x) *reinterpret_cast<uint32_t*>(pimg + i * 4) = 0u;  // (columns >= NV stay zero)
+    // projection rows n = 4 t + rho: forward A2 rows (P2 = a A2^T), backward B1 rows (Q1 = dH B1^T); row 16 = zeros
+    const uint16_t* src = BWD ? b1 : a2;
+    for (int i = tid; i < 16 * (HC / 2); i += nthr) {
+        const int row = i / (HC / 2), c2 = 2 * (i - row * (HC / 2)), t = row >> 2, rho = row & 3;
+        uint32_t w = 0u;
+        if (t < nt) w = *reinterpret_cast<const uint32_t*>(src + (int64_t)((BWD ? P.off1[t] : P.off2[t]) + rho) * H + c_base + c2);
+        *reinterpret_cast<uint32_t*>(bq + (size_t)row * bs + c2 * 2) = w;
+    }
+    for (int i = tid; i < bs / 4; i += nthr) *reinterpret_cast<uint32_t*>(bq + (size_t)16 * bs + i * 4) = 0u;
+}
+
+template <typename T, int HC>
+__global__ __launch_bounds__(HC * 2) void k_hid_fwd_d(const HidParams P) {
+    constexpr int NW = HC / 32, bs = HC * 2 + 16;
+    extern __shared__ __attribute__((aligned(16))) unsigned char hid_smem[];
+    unsigned char* tabH = hid_smem;                              // [4][HC] x 8 B
+    unsigned char* bq = tabH + (size_t)HID_TG * HC * 8;           // [17][bs]
+    unsigned char* pimg = bq + (size_t)17 * bs;                   // [32][32]
+    unsigned char* wimgs = pimg + 2048;                           // [NW][32][32]; `red` overlays it
+    float* red = reinterpret_cast<float*>(wimgs);                 // [NW][16][32]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nt = P.nt, H = P.H, m = lane & 31, kg = lane >> 5, c = lane & 31, hh = lane >> 5, n = lane & 31;
+    const int chunk = blockIdx.y, c_base = chunk * HC, cw = wave * 32;
+    hid_d_tables<T, HC, false>(P, tid, NW * 64, c_base, tabH, nullptr, bq);
+    for (int i = tid; i < 2048 / 4; i += NW * 64) *reinterpret_cast<uint32_t*>(pimg + i * 4) = 0u;
     __syncthreads();
+    unsigned char* wimg = wimgs + (size_t)wave * 2048;
+    const T* hbase = reinterpret_cast<const T*>(P.hbase);
+    const T* p1 = reinterpret_cast<const T*>(P.p1);
+    int brow[HID_TG];
+#pragma unroll
+    for (int t = 0; t < HID_TG; ++t) brow[t] = ((n >> 2) == t && n < 16 ? n : 16) * bs;
+    const int64_t nblk = (P.M + 31) / 32;
+    for (int64_t rb = blockIdx.x; rb < nblk; rb += gridDim.x) {
+        const int64_t m0 = rb * 32;
+        const bool live = m0 + m < P.M;
+        const int64_t row = live ? m0 + m : P.M - 1;
+        const u32x4 hv0 = *reinterpret_cast<const u32x4*>(hbase + row * H + c_base + cw + 16 * kg);
+        const u32x4 hv1 = *reinterpret_cast<const u32x4*>(hbase + row * H + c_base + cw + 16 * kg + 8);
+        if (wave == 0) {  // the row block's P1 columns n = 4 t + rho: lanes kg = 0 write tasks 0, 1, lanes kg = 1 tasks 2, 3
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) {
+                const int t = 2 * kg + tt;
+                u32x2 v = {0u, 0u};
+                if (t < nt && live) v = *reinterpret_cast<const u32x2*>(p1 + row * P.ldp1 + P.off1[t]);
+                *reinterpret_cast<u32x2*>(pimg + m * 64 + t * 8) = v;
+            }
+        }
+        __syncthreads();  // pimg complete; the previous block's `red` reads are done
+        *reinterpret_cast<u32x4*>(wimg + m * 64 + kg * 32) = hv0;
+        *reinterpret_cast<u32x4*>(wimg + m * 64 + kg * 32 + 16) = hv1;
+        HID_LGKM0();
+        __builtin_amdgcn_wave_barrier();
+        f32x16 hbD;
+        hid_dl_f32<T>(wimg, lane, hbD);
+        const u32x4 fp = *reinterpret_cast<const u32x4*>(pimg + m * 64 + kg * 16);
+        HID_LGKM0();
+        __builtin_amdgcn_wave_barrier();
+        f32x16 accP;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) accP[e] = 0.f;
+        auto task = [&](auto tc) __attribute__((always_inline)) {
+            constexpr int t = decltype(tc)::value;
+            const u32x2 tb = *reinterpret_cast<const u32x2*>(tabH + ((size_t)t * HC + cw + c) * 8);
+            f32x16 h = hbD;
+            sp_mma1<T>(fp, hid_place<t>(tb, kg), h);
+            u32x4 a0, a1;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const f32x2 av = hid_gelu2_fwd(f32x2{h[2 * i], h[2 * i + 1]});
+                const uint32_t w = hid_pk<T>(av.x, av.y);
+                if (i < 4)
+                    a0[i] = w;
+                else
+                    a1[i - 4] = w;
+            }
+            hid_dl_store_t(wimg, lane, a0, a1);
+            HID_LGKM0();
+            __builtin_amdgcn_wave_barrier();
+            u32x4 f0, f1;
+            hid_tr_frag(wimg, lane, f0, f1);
+            const u32x4 fb0 = *reinterpret_cast<const u32x4*>(bq + brow[t] + (cw + 8 * hh) * 2);
+            const u32x4 fb1 = *reinterpret_cast<const u32x4*>(bq + brow[t] + (cw + 16 + 8 * hh) * 2);
+            sp_mma1<T>(f0, fb0, accP);
+            sp_mma1<T>(f1, fb1, accP);
+            __builtin_amdgcn_wave_barrier();
+        };
+        task(std::integral_constant<int, 0>{});
+        task(std::integral_constant<int, 1>{});
+        task(std::integral_constant<int, 2>{});
+        task(std::integral_constant<int, 3>{});
+        __syncthreads();  // every wave is done with its image: `red` may overlay them
+        if (n < 16) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) red[((size_t)wave * 16 + n) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh] = accP[r];
+        }
+        __syncthreads();
+        if (tid < 512) {
+            const int rr = tid & 31, nn = tid >> 5;
+            if (m0 + rr < P.M) {
+                float a = 0.f;
+#pragma unroll
+                for (int w = 0; w < NW; ++w) a += red[((size_t)w * 16 + nn) * 32 + rr];
+                P.rowpart[((int64_t)chunk * P.M + m0 + rr) * 16 + nn] = a;
+            }
+        }
+    }
+}
+
+template <typename T, int HC>
+__global__ __launch_bounds__(HC * 2) void k_hid_bwd_d(const HidParams P) {
+    constexpr int NW = HC / 32, bs = HC * 2 + 16;
+    extern __shared__ __attribute__((aligned(16))) unsigned char hid_smem[];
+    unsigned char* tabH = hid_smem;                              // [4][HC] x 8 B   B1
+    unsigned char* tabU = tabH + (size_t)HID_TG * HC * 8;         // [4][HC] x 8 B   A2
+    unsigned char* bq = tabU + (size_t)HID_TG * HC * 8;           // [17][bs]        B1 rows
+    unsigned char* pimg = bq + (size_t)17 * bs;                   // [32][32] P1 columns n
+    unsigned char* qimg = pimg + 2048;                            // [32][32] Q2 columns n
+    unsigned char* wimgs = qimg + 2048;                           // [NW][32][32]; `red` overlays it
+    float* red = reinterpret_cast<float*>(wimgs);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nt = P.nt, H = P.H, m = lane & 31, kg = lane >> 5, c = lane & 31, hh = lane >> 5, n = lane & 31;
+    const int chunk = blockIdx.y, c_base = chunk * HC, cw = wave * 32;
+    hid_d_tables<T, HC, true>(P, tid, NW * 64, c_base, tabH, tabU, bq);
+    for (int i = tid; i < 4096 / 4; i += NW * 64) *reinterpret_cast<uint32_t*>(pimg + i * 4) = 0u;
+    __syncthreads();
+    unsigned char* wimg = wimgs + (size_t)wave * 2048;
     const T* hbase = reinterpret_cast<const T*>(P.hbase);
     const T* gsrc = reinterpret_cast<const T*>(P.gsrc);
     T* gout = reinterpret_cast<T*>(P.g);
     const T* p1 = reinterpret_cast<const T*>(P.p1);
     const T* q2 = reinterpret_cast<const T*>(P.q2);
-    const int col_w = wave * HIDB_CW;          // the wave's first column
-    unsigned char* dimg = tiles + (size_t)wave * (2 * 32 * 64);
-    unsigned char* aimg = dimg + 32 * 64;
-    int brow[HID_TG];
-    uint32_t tmask[HID_TG];  // all-ones for the lanes whose column n belongs to task t
-#pragma unroll
-    for (int t = 0; t < HID_TG; ++t) {
-        const bool own = (n / RR) == t && n < NV;
-        brow[t] = (own ? n : NV) * bs;
-        tmask[t] = own ? 0xFFFFFFFFu : 0u;
-    }
     f32x16 accB, accA;
 #pragma unroll
     for (int e = 0; e < 16; ++e) accB[e] = accA[e] = 0.f;
@@ -414,150 +446,193 @@ __global__ __launch_bounds__(HC * 2) void k_hid_bwd_m(const HidParams P) {
         const int64_t m0 = rb * 32;
         const bool live = m0 + m < P.M;
         const int64_t row = live ? m0 + m : P.M - 1;
-        u32x4 hv[2], gv[2], pw[HID_TG], qw[HID_TG];
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-            hv[s2] = *reinterpret_cast<const u32x4*>(hbase + row * H + col_w + 16 * s2 + 8 * jg);
-            gv[s2] = gsrc ? *reinterpret_cast<const u32x4*>(gsrc + row * H + col_w + 16 * s2 + 8 * jg) : u32x4{0u, 0u, 0u, 0u};
+        const int64_t go = row * H + c_base + cw + 16 * kg;
+        const u32x4 hv0 = *reinterpret_cast<const u32x4*>(hbase + go), hv1 = *reinterpret_cast<const u32x4*>(hbase + go + 8);
+        u32x4 gv0 = {0u, 0u, 0u, 0u}, gv1 = {0u, 0u, 0u, 0u};
+        if (gsrc) {
+            gv0 = *reinterpret_cast<const u32x4*>(gsrc + go);
+            gv1 = *reinterpret_cast<const u32x4*>(gsrc + go + 8);
         }
+        if (wave < 2) {  // wave 0: P1 image, wave 1: Q2 image (rows past M: zeros -> nothing reaches the factor gradients)
+            const T* src = wave ? q2 : p1;
+            const int64_t ld = wave ? P.ldq2 : P.ldp1;
+            unsigned char* img = wave ? qimg : pimg;
 #pragma unroll
-        for (int t = 0; t < HID_TG; ++t) {
-            pw[t] = *reinterpret_cast<const u32x4*>(p1 + row * P.ldp1 + P.off1[t]);
-            qw[t] = *reinterpret_cast<const u32x4*>(q2 + row * P.ldq2 + P.off2[t]);
-            if (!live) pw[t] = qw[t] = u32x4{0u, 0u, 0u, 0u};  // rows past M add nothing to the factor gradients (dH = 0, Q2 = 0)
-        }
-        // the row block's P1 / Q2 columns n = t RR + rho as [32][32] images (wave 0: lanes jg = 0 write P1, jg = 1 write Q2)
-        if (wave == 0) {
-#pragma unroll
-            for (int t = 0; t < HID_TG; ++t) {
-                if (t < nt) {
-                    unsigned char* dst = (jg ? qimg : pimg) + m * 64 + t * RR * 2;
-                    const u32x4 v = jg ? qw[t] : pw[t];
-                    if constexpr (RR == 4)
-                        *reinterpret_cast<u32x2*>(dst) = u32x2{v[0], v[1]};
-                    else
-                        *reinterpret_cast<u32x4*>(dst) = v;
-                }
+            for (int tt = 0; tt < 2; ++tt) {
+                const int t = 2 * kg + tt;
+                u32x2 v = {0u, 0u};
+                if (t < nt && live) v = *reinterpret_cast<const u32x2*>(src + row * ld + (wave ? P.off2[t] : P.off1[t]));
+                *reinterpret_cast<u32x2*>(img + m * 64 + t * 8) = v;
             }
         }
-        __syncthreads();  // images of this row block complete (and the previous block's `red` reads are done)
+        __syncthreads();
+        u32x4 hb0, hb1;  // h_base in D layout, packed (unpacked into the accumulator of each task's rank update)
+        *reinterpret_cast<u32x4*>(wimg + m * 64 + kg * 32) = hv0;
+        *reinterpret_cast<u32x4*>(wimg + m * 64 + kg * 32 + 16) = hv1;
+        HID_LGKM0();
+        __builtin_amdgcn_wave_barrier();
+        hid_dl_raw(wimg, lane, hb0, hb1);
+        HID_LGKM0();
+        __builtin_amdgcn_wave_barrier();
+        *reinterpret_cast<u32x4*>(wimg + m * 64 + kg * 32) = gv0;
+        *reinterpret_cast<u32x4*>(wimg + m * 64 + kg * 32 + 16) = gv1;
+        HID_LGKM0();
+        __builtin_amdgcn_wave_barrier();
+        f32x2 G2[8];  // (pairs, not one 16-wide vector: element-wise updates of an f32x16 cost the compiler ~100 registers of copies)
+        {
+            u32x4 r0, r1;
+            hid_dl_raw(wimg, lane, r0, r1);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                G2[i] = f32x2{mtl_lo2<T>(r0[i]), mtl_hi2<T>(r0[i])};
+                G2[4 + i] = f32x2{mtl_lo2<T>(r1[i]), mtl_hi2<T>(r1[i])};
+            }
+        }
+        HID_LGKM0();
+        __builtin_amdgcn_wave_barrier();
         f32x16 accQ;
 #pragma unroll
         for (int e = 0; e < 16; ++e) accQ[e] = 0.f;
-        f32x2 Gs[2][4];
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) hid_unpack8(gv[s2], Gs[s2], (T*)nullptr);
-#pragma unroll
-        for (int t = 0; t < HID_TG; ++t) {
-            float pv[RR], qv[RR];  // (unpacked per task: the raw words are what stays live across the task loop)
-            {
-                f32x2 a[4], b[4];
-                hid_unpack8(pw[t], a, (T*)nullptr);
-                hid_unpack8(qw[t], b, (T*)nullptr);
-#pragma unroll
-                for (int rho = 0; rho < RR; ++rho) {
-                    pv[rho] = (rho & 1) ? a[rho >> 1].y : a[rho >> 1].x;
-                    qv[rho] = (rho & 1) ? b[rho >> 1].y : b[rho >> 1].x;
-                }
-            }
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                const int col = col_w + 16 * s2 + 8 * jg;
-                u32x4 fd, fa;
-                // four columns at a time (two passes per 8-column fragment): half the live h / u / table registers of the 8-wide form
-#pragma unroll
-                for (int hf = 0; hf < 2; ++hf) {
-                    f32x2 h[2], u[2];
-                    h[0] = f32x2{mtl_lo2<T>(hv[s2][2 * hf]), mtl_hi2<T>(hv[s2][2 * hf])};
-                    h[1] = f32x2{mtl_lo2<T>(hv[s2][2 * hf + 1]), mtl_hi2<T>(hv[s2][2 * hf + 1])};
-                    u[0] = u[1] = f32x2{0.f, 0.f};
-#pragma unroll
-                    for (int rho = 0; rho < RR; ++rho) {
-                        const f32x4 b0 = *reinterpret_cast<const f32x4*>(b1f + (size_t)(t * RR + rho) * H + col + 4 * hf);
-                        const f32x4 a0 = *reinterpret_cast<const f32x4*>(a2f + (size_t)(t * RR + rho) * H + col + 4 * hf);
-                        const float pz = pv[rho], qz = qv[rho];
-                        h[0] += pz * f32x2{b0[0], b0[1]};
-                        h[1] += pz * f32x2{b0[2], b0[3]};
-                        u[0] += qz * f32x2{a0[0], a0[1]};
-                        u[1] += qz * f32x2{a0[2], a0[3]};
-                    }
-#pragma unroll
-                    for (int i = 0; i < 2; ++i) {
-                        f32x2 av, gd;
-                        hid_gelu2(h[i], av, gd);
-                        const f32x2 dh = u[i] * gd;
-                        Gs[s2][2 * hf + i] += dh;
-                        fd[2 * hf + i] = mtl_pk2<T>(dh.x, dh.y);
-                        fa[2 * hf + i] = mtl_pk2<T>(av.x, av.y);
-                    }
-                }
-                const u32x4 fb = *reinterpret_cast<const u32x4*>(b1b + brow[t] + col * 2);
-                sp_mma1<T>(fd, fb, accQ);
-                *reinterpret_cast<u32x4*>(dimg + m * 64 + (16 * s2 + 8 * jg) * 2) = fd;
-                *reinterpret_cast<u32x4*>(aimg + m * 64 + (16 * s2 + 8 * jg) * 2) = fa;
-            }
-            // row reductions of task t over this block's 32 rows (the images are private to the wave: in-order LDS, no barrier)
-            __builtin_amdgcn_s_waitcnt(0xc07f);
-            __builtin_amdgcn_wave_barrier();
-            u32x4 d0, d1, x0, x1, p0, p1f, q0, q1f;
-            hid_tr_frag(dimg, 0, lane, d0, d1);
-            hid_tr_frag(aimg, 0, lane, x0, x1);
-            hid_tr_frag(pimg, 0, lane, p0, p1f);
-            hid_tr_frag(qimg, 0, lane, q0, q1f);
+        auto task = [&](auto tc) __attribute__((always_inline)) {
+            constexpr int t = decltype(tc)::value;
+            const u32x2 tbh = *reinterpret_cast<const u32x2*>(tabH + ((size_t)t * HC + cw + c) * 8);
+            const u32x2 tbu = *reinterpret_cast<const u32x2*>(tabU + ((size_t)t * HC + cw + c) * 8);
+            __builtin_amdgcn_sched_barrier(0);  // (tasks interleaved by the scheduler would need all their temporaries at once)
+            f32x16 h, u;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                p0[i] &= tmask[t];
-                p1f[i] &= tmask[t];
-                q0[i] &= tmask[t];
-                q1f[i] &= tmask[t];
+                h[2 * i] = mtl_lo2<T>(hb0[i]);
+                h[2 * i + 1] = mtl_hi2<T>(hb0[i]);
+                h[8 + 2 * i] = mtl_lo2<T>(hb1[i]);
+                h[8 + 2 * i + 1] = mtl_hi2<T>(hb1[i]);
             }
-            sp_mma1<T>(d0, p0, accB);
-            sp_mma1<T>(d1, p1f, accB);
-            sp_mma1<T>(x0, q0, accA);
-            sp_mma1<T>(x1, q1f, accA);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) u[e] = 0.f;
+            {   // (the row block's P1 / Q2 values as A operands: re-read per task, 16 bytes each, instead of 8 registers held across the block)
+                const u32x4 fp = *reinterpret_cast<const u32x4*>(pimg + m * 64 + kg * 16);
+                const u32x4 fq = *reinterpret_cast<const u32x4*>(qimg + m * 64 + kg * 16);
+                sp_mma1<T>(fp, hid_place<t>(tbh, kg), h);
+                sp_mma1<T>(fq, hid_place<t>(tbu, kg), u);
+            }
+            u32x4 d0, d1, x0, x1;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                if ((i & 1) == 0) __builtin_amdgcn_sched_barrier(0);  // two pairs in flight: all eight at once cost ~100 registers of temporaries
+                f32x2 av, gd;
+                hid_gelu2(f32x2{h[2 * i], h[2 * i + 1]}, av, gd);
+                const f32x2 dh = f32x2{u[2 * i], u[2 * i + 1]} * gd;
+                G2[i] += dh;
+                const uint32_t wd = hid_pk<T>(dh.x, dh.y), wa = hid_pk<T>(av.x, av.y);
+                if (i < 4) {
+                    d0[i] = wd;
+                    x0[i] = wa;
+                } else {
+                    d1[i - 4] = wd;
+                    x1[i - 4] = wa;
+                }
+            }
+            // row reductions: A operands from the registers, B operands = the P1 / Q2 images in the same row order, task t's columns only
+            const uint32_t tm = (n >> 2) == t ? 0xFFFFFFFFu : 0u;  // (columns n >= 16 of the images are zero)
+            u32x4 pT0, pT1, qT0, qT1;
+            hid_dl_raw(pimg, lane, pT0, pT1);
+            hid_dl_raw(qimg, lane, qT0, qT1);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                pT0[i] &= tm;
+                pT1[i] &= tm;
+                qT0[i] &= tm;
+                qT1[i] &= tm;
+            }
+            sp_mma1<T>(d0, pT0, accB);
+            sp_mma1<T>(d1, pT1, accB);
+            sp_mma1<T>(x0, qT0, accA);
+            sp_mma1<T>(x1, qT1, accA);
+            // column reduction Q1 += dH_t B1_t^T: rows along lanes through the wave's image
+            hid_dl_store_t(wimg, lane, d0, d1);
+            HID_LGKM0();
             __builtin_amdgcn_wave_barrier();
-        }
+            u32x4 f0, f1;
+            hid_tr_frag(wimg, lane, f0, f1);
+            const int br = ((n >> 2) == t ? n : 16) * bs;
+            const u32x4 fb0 = *reinterpret_cast<const u32x4*>(bq + br + (cw + 8 * hh) * 2);
+            const u32x4 fb1 = *reinterpret_cast<const u32x4*>(bq + br + (cw + 16 + 8 * hh) * 2);
+            sp_mma1<T>(f0, fb0, accQ);
+            sp_mma1<T>(f1, fb1, accQ);
+            __builtin_amdgcn_wave_barrier();
+        };
+        task(std::integral_constant<int, 0>{});
+        task(std::integral_constant<int, 1>{});
+        task(std::integral_constant<int, 2>{});
+        task(std::integral_constant<int, 3>{});
+        {   // G leaves as it came: transposed through the image, 16-byte row-major stores
+            u32x4 g0, g1;
 #pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-            const u32x4 o = {mtl_pk2<T>(Gs[s2][0].x, Gs[s2][0].y), mtl_pk2<T>(Gs[s2][1].x, Gs[s2][1].y), mtl_pk2<T>(Gs[s2][2].x, Gs[s2][2].y),
-                             mtl_pk2<T>(Gs[s2][3].x, Gs[s2][3].y)};
-            if (live) *reinterpret_cast<u32x4*>(gout + row * H + col_w + 16 * s2 + 8 * jg) = o;
-        }
-        __syncthreads();  // every wave is done with its images: `red` may overlay them
-        if (n < NV) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) red[((size_t)wave * NV + n) * 32 + (r & 3) + 8 * (r >> 2) + 4 * jg] = accQ[r];
+            for (int i = 0; i < 4; ++i) {
+                g0[i] = hid_pk<T>(G2[i].x, G2[i].y);
+                g1[i] = hid_pk<T>(G2[4 + i].x, G2[4 + i].y);
+            }
+            hid_dl_store_t(wimg, lane, g0, g1);
+            HID_LGKM0();
+            __builtin_amdgcn_wave_barrier();
+            u32x4 f0, f1;
+            hid_tr_frag(wimg, lane, f0, f1);  // lane (m, hh): columns 8 hh .. + 7 and 16 + 8 hh .. + 7 of row m
+            if (live) {
+                *reinterpret_cast<u32x4*>(gout + row * H + c_base + cw + 8 * hh) = f0;
+                *reinterpret_cast<u32x4*>(gout + row * H + c_base + cw + 16 + 8 * hh) = f1;
+            }
         }
         __syncthreads();
-        if (tid < 32 * HID_TG) {
-            const int rr = tid & 31, t = tid >> 5;
-            if (t < nt && m0 + rr < P.M) {
-                float sv[8];
+        if (n < 16) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) sv[e] = 0.f;
+            for (int r = 0; r < 16; ++r) red[((size_t)wave * 16 + n) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh] = accQ[r];
+        }
+        __syncthreads();
+        if (tid < 512) {
+            const int rr = tid & 31, nn = tid >> 5;
+            if (m0 + rr < P.M) {
+                float a = 0.f;
 #pragma unroll
-                for (int rho = 0; rho < RR; ++rho) {
-                    float a = 0.f;
-                    for (int w = 0; w < NW; ++w) a += red[((size_t)w * NV + t * RR + rho) * 32 + rr];
-                    sv[rho] = a * P.alpha1[P.off1[t] + rho];
-                }
-                const u32x4 o = {mtl_pack2<T>(sv[0], sv[1]), mtl_pack2<T>(sv[2], sv[3]), mtl_pack2<T>(sv[4], sv[5]), mtl_pack2<T>(sv[6], sv[7])};
-                *reinterpret_cast<u32x4*>(reinterpret_cast<T*>(P.q1) + (m0 + rr) * P.ldq1 + P.off1[t]) = o;
+                for (int w = 0; w < NW; ++w) a += red[((size_t)w * 16 + nn) * 32 + rr];
+                P.rowpart[((int64_t)chunk * P.M + m0 + rr) * 16 + nn] = a;
             }
         }
         // (the next block's first barrier orders these reads before the images are written again)
     }
-    // the wave's share of the factor gradients: lane n holds rows a(r) (the wave's columns j = col_w + a) of column n
-    if (n < nt * RR) {
-        const int t = n / RR, rho = n - t * RR;
-        float* part = P.part + (int64_t)blockIdx.x * nt * 2 * RR * H;
+    // the wave's share of the factor gradients: lane (n, hh) holds columns cw + a(r) of rank column n
+    if (n < nt * 4) {
+        const int t = n >> 2, rho = n & 3;
+        float* part = P.part + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * nt * 2 * 4 * HC;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int j = col_w + (r & 3) + 8 * (r >> 2) + 4 * jg;
-            part[((int64_t)(t * 2 + 0) * RR + rho) * H + j] = accB[r];
-            part[((int64_t)(t * 2 + 1) * RR + rho) * H + j] = accA[r];
+            const int j = cw + (r & 3) + 8 * (r >> 2) + 4 * hh;
+            part[((int64_t)(t * 2 + 0) * 4 + rho) * HC + j] = accB[r];
+            part[((int64_t)(t * 2 + 1) * 4 + rho) * HC + j] = accA[r];
         }
     }
+}
+
+// (chunk, row) partial row sums -> alpha-scaled 16-byte rank segments of P2 / Q1 (columns past the rank written as zeros)
+template <typename T>
+__global__ __launch_bounds__(256) void k_hid_rows_finish(const float* __restrict__ rowpart, int n_chunk, int64_t M, int nt, const float* alpha,
+                                                         HidOff off, T* out, int ldo) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= M * nt) return;
+    const int64_t row = i / nt;
+    const int t = (int)(i - row * nt);
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int ch = 0; ch < n_chunk; ++ch) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(rowpart + ((int64_t)ch * M + row) * 16 + 4 * t);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s[e] += v[e];
+    }
+    int o = 0;
+#pragma unroll
+    for (int q = 0; q < HID_TG; ++q)
+        if (q == t) o = off.v[q];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) s[e] *= alpha[o + e];
+    const u32x4 w = {mtl_pack2<T>(s[0], s[1]), mtl_pack2<T>(s[2], s[3]), 0u, 0u};
+    *reinterpret_cast<u32x4*>(out + row * ldo + o) = w;
 }
 
 template <typename T, int TG, int RR, int NTHR>
@@ -647,6 +722,7 @@ __global__ __launch_bounds__(NTHR) void k_hid_bwd(const HidParams P) {
 }
 
 __global__ __launch_bounds__(256) void k_hid_reduce(const HidRedParams P) {
+    // element i = (t, kind, rho, j) of the H-wide result; its partials live in the workgroups of chunk j / chunk_cols
     const int64_t per = (int64_t)P.nt * 2 * P.RR * P.H;
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= per) return;
@@ -661,18 +737,21 @@ __global__ __launch_bounds__(256) void k_hid_reduce(const HidRedParams P) {
             dst = kind ? P.dA2[q] : P.dB1[q];
         }
     if (rho >= r_t || !dst) return;
+    const int ch = j / P.chunk_cols, jl = j - ch * P.chunk_cols;
+    const int64_t per_wg = (int64_t)P.nt * 2 * P.RR * P.chunk_cols;
+    const float* src = P.part + (int64_t)ch * P.n_wg * per_wg + ((int64_t)(t * 2 + kind) * P.RR + rho) * P.chunk_cols + jl;
     float s0 = 0.f, s1 = 0.f;
     int w = 0;
     for (; w + 1 < P.n_wg; w += 2) {
-        s0 += P.part[(int64_t)w * per + i];
-        s1 += P.part[(int64_t)(w + 1) * per + i];
+        s0 += src[(int64_t)w * per_wg];
+        s1 += src[(int64_t)(w + 1) * per_wg];
     }
-    if (w < P.n_wg) s0 += P.part[(int64_t)w * per + i];
-    const float s = s0 + s1;
+    if (w < P.n_wg) s0 += src[(int64_t)w * per_wg];
+    const float sv = s0 + s1;
     if (kind)
-        dst[(int64_t)rho * P.H + j] = s;
+        dst[(int64_t)rho * P.H + j] = sv;
     else
-        dst[(int64_t)j * r_t + rho] = s;
+        dst[(int64_t)j * r_t + rho] = sv;
 }
 
 // ---- launcher (the host side that knows the layers' layouts lives in linear.hip)
@@ -716,23 +795,23 @@ void hid_go(const HidLaunch& L, const HidParams& q, hipStream_t s) {
 #undef HID_GO
             break;
         case 2:
-#define HID_M(K, RR_, HC_)                                                 \
+        case 3: {
+            const dim3 gd((unsigned)L.n_wg, (unsigned)L.n_chunk);
+#define HID_D(K, HC_)                                                      \
     do {                                                                   \
-        HID_RAISE_LDS((K<T, RR_, HC_>));                                   \
-        hipLaunchKernelGGL((K<T, RR_, HC_>), g, b, L.lds, s, q);           \
+        HID_RAISE_LDS((K<T, HC_>));                                        \
+        hipLaunchKernelGGL((K<T, HC_>), gd, dim3(HC_ * 2), L.lds, s, q);   \
     } while (0)
-            if (L.rr == 4 && q.H == 384) HID_M(k_hid_proj_m, 4, 384);
-            else if (L.rr == 4 && q.H == 768) HID_M(k_hid_proj_m, 4, 768);
-            else if (L.rr == 4 && q.H == 512) HID_M(k_hid_proj_m, 4, 512);
-            else if (L.rr == 4 && q.H == 1024) HID_M(k_hid_proj_m, 4, 1024);
-            else if (q.H == 384) HID_M(k_hid_proj_m, 8, 384);
-            else if (q.H == 768) HID_M(k_hid_proj_m, 8, 768);
+            if (L.kind == 2) {
+                if (L.hc == 384) HID_D(k_hid_fwd_d, 384);
+                else HID_D(k_hid_fwd_d, 256);
+            } else {
+                if (L.hc == 384) HID_D(k_hid_bwd_d, 384);
+                else HID_D(k_hid_bwd_d, 256);
+            }
+#undef HID_D
             break;
-        case 3:
-            if (L.rr == 4 && q.H == 384) HID_M(k_hid_bwd_m, 4, 384);
-            else if (q.H == 384) HID_M(k_hid_bwd_m, 8, 384);
-#undef HID_M
-            break;
+        }
         default: break;
     }
 }
@@ -744,6 +823,18 @@ MTL_INTERNAL void mtli_hid_launch(const HidLaunch* L, const HidParams* q, void* 
         hid_go<f16>(*L, *q, s);
     else
         hid_go<bf16>(*L, *q, s);
+}
+MTL_INTERNAL void mtli_hid_rows_finish(int dtype, const float* rowpart, int n_chunk, int64_t M, int nt, const float* alpha, const int* off,
+                                       void* out, int ldo, void* stream) {
+    HidOff o;
+    for (int i = 0; i < HID_TG; ++i) o.v[i] = off[i];
+    const unsigned blocks = (unsigned)((M * nt + 255) / 256);
+    if (dtype == MTLORA_F16)
+        hipLaunchKernelGGL(k_hid_rows_finish<f16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, rowpart, n_chunk, M, nt, alpha, o,
+                           reinterpret_cast<f16*>(out), ldo);
+    else
+        hipLaunchKernelGGL(k_hid_rows_finish<bf16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, rowpart, n_chunk, M, nt, alpha, o,
+                           reinterpret_cast<bf16*>(out), ldo);
 }
 MTL_INTERNAL void mtli_hid_reduce(const HidRedParams* r, int64_t per, void* stream) {
     hipLaunchKernelGGL(k_hid_reduce, dim3((unsigned)((per + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *r);

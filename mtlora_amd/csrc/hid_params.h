@@ -19,7 +19,8 @@ struct HidParams {
     const void* a2;       // (R2 x H) a_cat of fc2: row rr = A2[rr, :], unscaled
     const float* alpha1;  // (R1)
     const float* alpha2;  // (R2)
-    float* part;          // backward: [gridDim.x][nt][2][RR][H]  (kind 0: dB1^T[rho][j], kind 1: dA2[rho][j])
+    float* part;          // backward: [workgroup][nt][2][RR][chunk columns]  (kind 0: dB1^T[rho][j], kind 1: dA2[rho][j])
+    float* rowpart;       // MFMA forms: [chunk][M][16] unscaled fp32 row sums (P2 forward, Q1 backward), finished by k_hid_rows_finish
     int64_t M;
     int H, nt;
     int ldp1, ldp2, ldq1, ldq2;
@@ -27,41 +28,28 @@ struct HidParams {
 };
 
 
+struct HidOff {
+    int v[HID_TG];
+};
 struct HidRedParams {
-    const float* part;  // [n_wg][nt][2][RR][H]
+    const float* part;  // [chunk][n_wg][nt][2][RR][chunk_cols]
     int n_wg, nt, RR, H;
+    int chunk_cols;     // columns per chunk (H: one chunk)
     int r[HID_TG];         // un-padded ranks
     float* dB1[HID_TG];    // (H x r) row-major, nullable
     float* dA2[HID_TG];    // (r x H) row-major, nullable
 };
 
-constexpr int HIDM_CW = 128;  // columns per wave
-constexpr int HIDB_CW = 32;
-
-template <typename T, int RR>
-struct HidMGeom {
-    static constexpr int NV = HID_TG * RR;                  // accumulator columns in use (<= 32)
-    static __host__ __device__ int a2_stride(int H) { return H * 2 + 16; }
-    static __host__ __device__ size_t lds_bytes(int H) {
-        const int NW = H / HIDM_CW;
-        return (size_t)NV * H * 4 + (size_t)(NV + 1) * a2_stride(H) + (size_t)2 * NW * NV * 32 * 4;
-    }
-};
-
-template <typename T, int RR>
-struct HidBGeom {
-    static constexpr int NV = HID_TG * RR;
-    static __host__ __device__ int b_stride(int H) { return H * 2 + 16; }
-    static __host__ __device__ size_t lds_bytes(int H) {
-        const int NW = H / HIDB_CW;
-        const size_t tiles = (size_t)NW * 2 * 32 * 64, red = (size_t)NW * NV * 32 * 4;
-        return (size_t)2 * NV * H * 4 + (size_t)(NV + 1) * b_stride(H) + 2 * 32 * 64 + (tiles > red ? tiles : red);
-    }
-};
+// MFMA forms: LDS bytes of a workgroup serving a chunk of hc columns (hc / 32 waves)
+static inline size_t hid_d_lds_bytes(int hc, bool bwd) {
+    return (size_t)(bwd ? 2 : 1) * HID_TG * hc * 8 + (size_t)17 * (hc * 2 + 16) + (bwd ? 4096 : 2048) + (size_t)(hc / 32) * 2048;
+}
+static inline int hid_d_chunk(int H) { return H % 384 == 0 ? 384 : (H % 256 == 0 ? 256 : 0); }
 
 // launch descriptor filled by linear.hip (which owns the layer layouts), executed by hid.hip
 struct HidLaunch {
-    int kind;        // 0 k_hid_proj (VALU), 1 k_hid_bwd (VALU), 2 k_hid_proj_m, 3 k_hid_bwd_m, 4 k_hid_reduce
+    int kind;        // 0 k_hid_proj (VALU), 1 k_hid_bwd (VALU), 2 k_hid_fwd_d, 3 k_hid_bwd_d (MFMA, accumulator layout)
+    int hc, n_chunk; // MFMA forms: chunk width (384 or 256 columns) and chunks (grid y)
     int dtype;       // MTLORA_BF16 / MTLORA_F16
     int tg, rr;      // VALU forms: tasks per launch / rank block (4 or 8); MFMA forms: rr
     int nthr, n_wg;  // threads per workgroup, workgroups

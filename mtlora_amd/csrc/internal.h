@@ -25,4 +25,6 @@ struct HidLaunch;
 struct HidParams;
 struct HidRedParams;
 MTL_INTERNAL void mtli_hid_launch(const HidLaunch* L, const HidParams* q, void* stream);
+MTL_INTERNAL void mtli_hid_rows_finish(int dtype, const float* rowpart, int n_chunk, int64_t M, int nt, const float* alpha, const int* off,
+                                       void* out, int ldo, void* stream);
 MTL_INTERNAL void mtli_hid_reduce(const HidRedParams* r, int64_t per, void* stream);

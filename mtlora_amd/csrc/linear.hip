@@ -3093,20 +3093,57 @@ static void hid_launch_valu(int dtype, bool bwd, const HidPlan& pl, const HidPar
     L.n_wg = pl.n_wg;
     mtli_hid_launch(&L, &q, s);
 }
-static void hid_launch_mfma(int dtype, bool bwd, int rr, int nthr, int n_wg, size_t lds, const HidParams& q, hipStream_t s) {
+// MFMA forms (hid.hip, k_hid_fwd_d / k_hid_bwd_d): rank <= 4, hidden width a multiple of 384 or 256 columns (one chunk per grid y)
+struct HidDPlan {
+    bool on;
+    int hc, n_chunk, n_wg, groups;
+    size_t lds_f, lds_b;
+    int64_t rowpart_bytes;
+};
+static HidDPlan hid_d_plan(const mtlora_linear_desc* d1, const HidPlan& pl) {
+    HidDPlan dp = {};
+    const Tune tu = make_tune(d1);
+    const int H = (int)d1->N;
+    dp.hc = hid_d_chunk(H);
+    dp.on = tu.sp != 0 && pl.rr == 4 && dp.hc != 0;
+    if (!dp.on) return dp;
+    dp.n_chunk = H / dp.hc;
+    dp.groups = (d1->T + HID_TG - 1) / HID_TG;
+    dp.lds_f = hid_d_lds_bytes(dp.hc, false);
+    dp.lds_b = hid_d_lds_bytes(dp.hc, true);
+    const int64_t nblk = (d1->M + 31) / 32;
+    dp.n_wg = (int)std::min<int64_t>(nblk, std::max<int64_t>(1, (int64_t)num_cu(tu) / dp.n_chunk));
+    dp.rowpart_bytes = (int64_t)dp.n_chunk * d1->M * 16 * 4 + 256;
+    return dp;
+}
+static void hid_launch_d(int dtype, bool bwd, const HidDPlan& dp, const HidParams& q, hipStream_t s) {
     HidLaunch L = {};
     L.kind = bwd ? 3 : 2;
     L.dtype = dtype;
-    L.rr = rr;
-    L.nthr = nthr;
-    L.n_wg = n_wg;
-    L.lds = lds;
+    L.rr = 4;
+    L.hc = dp.hc;
+    L.n_chunk = dp.n_chunk;
+    L.n_wg = dp.n_wg;
+    L.nthr = dp.hc * 2;
+    L.lds = bwd ? dp.lds_b : dp.lds_f;
     mtli_hid_launch(&L, &q, s);
+}
+static int64_t hid_fwd_scratch_bytes(const mtlora_linear_desc* d1, const mtlora_linear_desc* d2) {
+    const HidPlan pl = hid_plan(d1, d2);
+    const HidDPlan dp = hid_d_plan(d1, pl);
+    return dp.on ? dp.rowpart_bytes : 256;
+}
+static int64_t hid_bwd_part_bytes(const mtlora_linear_desc* d1, const mtlora_linear_desc* d2) {
+    const HidPlan pl = hid_plan(d1, d2);
+    const HidDPlan dp = hid_d_plan(d1, pl);
+    if (!dp.on) return hid_part_bytes(d1, pl);
+    // [chunk][n_wg][nt <= 4][2][4][hc] factor-gradient partials, then the row-sum partials
+    return (int64_t)dp.n_chunk * dp.n_wg * HID_TG * 2 * 4 * dp.hc * 4 + 256 + dp.rowpart_bytes;
 }
 
 template <typename T>
 static int hid_proj_impl(const mtlora_linear_desc* d1, const mtlora_linear_desc* d2, const void* h_base, const void* ctx1, void* ctx2,
-                         hipStream_t s) {
+                         void* scratch, hipStream_t s) {
     const Segs s1 = make_segs(d1), s2 = make_segs(d2);
     const CtxLayout L1 = ctx_layout(d1, s1), L2 = ctx_layout(d2, s2);
     const unsigned char* c1 = reinterpret_cast<const unsigned char*>(ctx1);
@@ -3114,13 +3151,9 @@ static int hid_proj_impl(const mtlora_linear_desc* d1, const mtlora_linear_desc*
     const unsigned char* pk1 = d1->packed ? reinterpret_cast<const unsigned char*>(d1->packed) : c1;
     const unsigned char* pk2 = reinterpret_cast<const unsigned char*>(d2->packed);
     const HidPlan pl = hid_plan(d1, d2);
+    const HidDPlan dp = hid_d_plan(d1, pl);
     const int H = (int)d1->N;
-    const Tune tu = make_tune(d1);
-    // MFMA form (hid.h, k_hid_proj_m): 4 tasks per launch whatever the rank, one workgroup of H / 128 waves per 32-row block; the VALU
-    // form (k_hid_proj) where its tables do not fit in LDS (hidden > 1536) and as the "tiled only" family of the tests (sel_stream = 1)
-    const size_t mlds = pl.rr == 4 ? HidMGeom<T, 4>::lds_bytes(H) : HidMGeom<T, 8>::lds_bytes(H);
-    const bool mfma = tu.sp != 0 && mlds <= (size_t)150 * 1024;
-    const int tg = mfma ? HID_TG : pl.tg;
+    const int tg = dp.on ? HID_TG : pl.tg;
     const int groups = (d1->T + tg - 1) / tg;
     for (int gI = 0; gI < groups; ++gI) {
         HidParams q = {};
@@ -3131,26 +3164,23 @@ static int hid_proj_impl(const mtlora_linear_desc* d1, const mtlora_linear_desc*
         q.a2 = pk2 + L2.a_cat;
         q.alpha1 = reinterpret_cast<const float*>(pk1 + L1.alpha);
         q.alpha2 = reinterpret_cast<const float*>(pk2 + L2.alpha);
+        q.rowpart = reinterpret_cast<float*>(scratch);
         q.M = d1->M;
         q.H = H;
         q.ldp1 = s1.R;
         q.ldp2 = s2.R;
         q.nt = std::min(tg, d1->T - gI * tg);
-        for (int i = 0; i < HID_TG; ++i) {  // (slots past nt: valid offsets, never stored -- hid.h)
+        for (int i = 0; i < HID_TG; ++i) {  // (slots past nt: valid offsets, never stored -- hid.hip)
             const int t = gI * tg + (i < q.nt ? i : 0);
             q.off1[i] = s1.off[1 + t];
             q.off2[i] = s2.off[1 + t];
         }
         const double hb = (double)sizeof(T) * d1->M * H;
-        mtl_prof_tag("hid_proj%s M%lld H%d T%d nt%d rr%d", mfma ? "_m" : "", (long long)d1->M, H, d1->T, q.nt, pl.rr);
+        mtl_prof_tag("hid_fwd%s M%lld H%d T%d nt%d rr%d", dp.on ? "_d" : "", (long long)d1->M, H, d1->T, q.nt, pl.rr);
         MtlProfScope prof(PK_NT_FWD_P, hb, s, (double)sizeof(T) * d1->M * (double)q.nt * H, 0.0);
-        if (mfma) {
-            const int nw = H / HIDM_CW;
-            int wgpc = (int)std::min<size_t>((size_t)(150 * 1024) / mlds, (size_t)std::max(1, 12 / nw));
-            if (wgpc < 1) wgpc = 1;
-            const int64_t nblk = (d1->M + 31) / 32;
-            const unsigned grid = (unsigned)std::min<int64_t>(nblk, (int64_t)num_cu(tu) * wgpc);
-            hid_launch_mfma(d1->dtype, false, pl.rr, nw * 64, (int)grid, mlds, q, s);
+        if (dp.on) {
+            hid_launch_d(d1->dtype, false, dp, q, s);
+            mtli_hid_rows_finish(d1->dtype, q.rowpart, dp.n_chunk, d1->M, q.nt, q.alpha2, q.off2, q.p2, q.ldp2, s);
         } else {
             hid_launch_valu(d1->dtype, false, pl, q, s);
         }
@@ -3169,19 +3199,14 @@ static int hid_bwd_impl(const mtlora_linear_desc* d1, const mtlora_linear_desc* 
     const unsigned char* c2 = reinterpret_cast<const unsigned char*>(ctx2);
     const unsigned char* pk1 = d1->packed ? reinterpret_cast<const unsigned char*>(d1->packed) : c1;
     const unsigned char* pk2 = d2->packed ? reinterpret_cast<const unsigned char*>(d2->packed) : c2;
-    const HidPlan pl0 = hid_plan(d1, d2);
+    const HidPlan pl = hid_plan(d1, d2);
+    const HidDPlan dp = hid_d_plan(d1, pl);
     const int H = (int)d1->N;
-    const Tune tu = make_tune(d1);
-    // MFMA form (k_hid_bwd_m): one workgroup of H / 32 waves per 32-row block, 4 tasks per launch; needs <= 12 waves and its tables in LDS
-    const size_t mlds = pl0.rr == 4 ? HidBGeom<T, 4>::lds_bytes(H) : HidBGeom<T, 8>::lds_bytes(H);
-    const bool mfma = tu.sp != 0 && H % HIDB_CW == 0 && H / HIDB_CW <= 12 && mlds <= (size_t)150 * 1024;
-    HidPlan pl = pl0;
-    if (mfma) {
-        pl.tg = HID_TG;
-        pl.groups = (d1->T + HID_TG - 1) / HID_TG;
-        pl.n_wg = (int)std::min<int64_t>((d1->M + 31) / 32, (int64_t)num_cu(tu));
-    }
-    for (int gI = 0; gI < pl.groups; ++gI) {
+    const int tg = dp.on ? HID_TG : pl.tg;
+    const int groups = (d1->T + tg - 1) / tg;
+    const int rr = pl.rr;
+    const int64_t fact_bytes = dp.on ? (int64_t)dp.n_chunk * dp.n_wg * HID_TG * 2 * 4 * dp.hc * 4 + 256 : 0;
+    for (int gI = 0; gI < groups; ++gI) {
         HidParams q = {};
         q.hbase = h_base;
         q.p1 = c1 + L1.p;
@@ -3194,30 +3219,32 @@ static int hid_bwd_impl(const mtlora_linear_desc* d1, const mtlora_linear_desc* 
         q.alpha1 = reinterpret_cast<const float*>(pk1 + L1.alpha);
         q.alpha2 = reinterpret_cast<const float*>(pk2 + L2.alpha);
         q.part = reinterpret_cast<float*>(part);
+        q.rowpart = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(part) + fact_bytes);
         q.M = d1->M;
         q.H = H;
         q.ldp1 = s1.R;
         q.ldq1 = s1.R;
         q.ldq2 = s2.R;
-        q.nt = std::min(pl.tg, d1->T - gI * pl.tg);
-        HidRedParams r = {};
-        for (int i = 0; i < HID_TG; ++i) {  // (slots past nt: valid offsets, never stored -- hid.h)
-            const int t = gI * pl.tg + (i < q.nt ? i : 0);
+        q.nt = std::min(tg, d1->T - gI * tg);
+        for (int i = 0; i < HID_TG; ++i) {  // (slots past nt: valid offsets, never stored -- hid.hip)
+            const int t = gI * tg + (i < q.nt ? i : 0);
             q.off1[i] = s1.off[1 + t];
             q.off2[i] = s2.off[1 + t];
         }
+        HidRedParams r = {};
         for (int i = 0; i < q.nt; ++i) {
-            const int t = gI * pl.tg + i;
+            const int t = gI * tg + i;
             r.r[i] = 0;
             r.dB1[i] = dB1_t ? dB1_t[t] : nullptr;
             r.dA2[i] = dA2_t ? dA2_t[t] : nullptr;
         }
         {
-            mtl_prof_tag("hid_bwd%s M%lld H%d T%d tg%d rr%d", mfma ? "_m" : "", (long long)d1->M, H, d1->T, pl.tg, pl.rr);
+            mtl_prof_tag("hid_bwd%s M%lld H%d T%d nt%d rr%d", dp.on ? "_d" : "", (long long)d1->M, H, d1->T, q.nt, rr);
             const double hb = (double)sizeof(T) * d1->M * H;
             MtlProfScope prof(PK_NT_BWD_DX, 3.0 * hb, s, (double)sizeof(T) * d1->M * (double)q.nt * H, 0.0);
-            if (mfma) {
-                hid_launch_mfma(d1->dtype, true, pl.rr, H / HIDB_CW * 64, pl.n_wg, mlds, q, s);
+            if (dp.on) {
+                hid_launch_d(d1->dtype, true, dp, q, s);
+                mtli_hid_rows_finish(d1->dtype, q.rowpart, dp.n_chunk, d1->M, q.nt, q.alpha1, q.off1, q.q1, q.ldq1, s);
             } else {
                 hid_launch_valu(d1->dtype, true, pl, q, s);
             }
@@ -3225,23 +3252,24 @@ static int hid_bwd_impl(const mtlora_linear_desc* d1, const mtlora_linear_desc* 
         // dB1_t (fc1's N x r_t, un-padded rank d1->r_t) and dA2_t (fc2's r_t x K) share one reduce: per kind the un-padded rank differs
         // only if the two layers were built with different task ranks -- reduce them separately then
         r.part = q.part;
-        r.n_wg = pl.n_wg;
+        r.n_wg = dp.on ? dp.n_wg : pl.n_wg;
         r.nt = q.nt;
-        r.RR = pl.rr;
+        r.RR = rr;
         r.H = H;
-        const int64_t per = (int64_t)q.nt * 2 * pl.rr * H;
+        r.chunk_cols = dp.on ? dp.hc : H;
+        const int64_t per = (int64_t)q.nt * 2 * rr * H;
         bool same = true;
-        for (int i = 0; i < q.nt; ++i) same = same && d1->r_t[gI * pl.tg + i] == d2->r_t[gI * pl.tg + i];
+        for (int i = 0; i < q.nt; ++i) same = same && d1->r_t[gI * tg + i] == d2->r_t[gI * tg + i];
         MtlProfScope prof(PK_REDUCE, 0.0, s);
         if (same) {
-            for (int i = 0; i < q.nt; ++i) r.r[i] = d1->r_t[gI * pl.tg + i];
+            for (int i = 0; i < q.nt; ++i) r.r[i] = d1->r_t[gI * tg + i];
             mtli_hid_reduce(&r, per, s);
         } else {
             HidRedParams rb = r, ra = r;
             for (int i = 0; i < q.nt; ++i) {
-                rb.r[i] = d1->r_t[gI * pl.tg + i];
+                rb.r[i] = d1->r_t[gI * tg + i];
                 rb.dA2[i] = nullptr;
-                ra.r[i] = d2->r_t[gI * pl.tg + i];
+                ra.r[i] = d2->r_t[gI * tg + i];
                 ra.dB1[i] = nullptr;
             }
             mtli_hid_reduce(&rb, per, s);
@@ -3259,20 +3287,31 @@ int mtlora_mlp_hid_supported(const mtlora_linear_desc* d1, const mtlora_linear_d
     return (d1 && d2 && hid_check(d1, d2) == MTLORA_OK) ? 1 : 0;
 }
 
+int64_t mtlora_mlp_hid_fwd_scratch_bytes(const mtlora_linear_desc* d1, const mtlora_linear_desc* d2) {
+    if (!d1 || !d2 || hid_check(d1, d2) != MTLORA_OK) return -1;
+    return hid_fwd_scratch_bytes(d1, d2);
+}
+
 int64_t mtlora_mlp_hid_bwd_scratch_bytes(const mtlora_linear_desc* d1, const mtlora_linear_desc* d2) {
     if (!d1 || !d2 || hid_check(d1, d2) != MTLORA_OK) return -1;
-    return hid_part_bytes(d1, hid_plan(d1, d2));
+    return hid_bwd_part_bytes(d1, d2);
 }
 
 int mtlora_mlp_hid_proj(const mtlora_linear_desc* d1, const mtlora_linear_desc* d2, const void* h_base, const void* ctx1, void* ctx2,
-                        void* stream) {
+                        void* scratch, int64_t scratch_bytes, void* stream) {
     if (!d1 || !d2) return MTLORA_ERR_NULL;
     const int st = hid_check(d1, d2);
     if (st != MTLORA_OK) return st;
-    if (!h_base || !ctx1 || !ctx2 || !d2->packed) return MTLORA_ERR_NULL;
-    if (misaligned(h_base) || misaligned(ctx1) || misaligned(ctx2) || misaligned(d2->packed) || misaligned(d1->packed)) return MTLORA_ERR_ALIGN;
+    if (!h_base || !ctx1 || !ctx2 || !d2->packed || !scratch) return MTLORA_ERR_NULL;
+    if (misaligned(h_base) || misaligned(ctx1) || misaligned(ctx2) || misaligned(d2->packed) || misaligned(d1->packed) || misaligned(scratch))
+        return MTLORA_ERR_ALIGN;
+    if (scratch_bytes < hid_fwd_scratch_bytes(d1, d2)) return MTLORA_ERR_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
-    return d1->dtype == MTLORA_F16 ? hid_proj_impl<f16>(d1, d2, h_base, ctx1, ctx2, s) : hid_proj_impl<bf16>(d1, d2, h_base, ctx1, ctx2, s);
+    const int r = d1->dtype == MTLORA_F16 ? hid_proj_impl<f16>(d1, d2, h_base, ctx1, ctx2, scratch, s)
+                                          : hid_proj_impl<bf16>(d1, d2, h_base, ctx1, ctx2, scratch, s);
+    if (r != MTLORA_OK) return r;
+    MTL_CHECK_LAUNCH();
+    return MTLORA_OK;
 }
 
 int mtlora_mlp_hid_bwd(const mtlora_linear_desc* d1, const mtlora_linear_desc* d2, const void* h_base, const void* dh_s, const void* ctx1,
@@ -3285,10 +3324,13 @@ int mtlora_mlp_hid_bwd(const mtlora_linear_desc* d1, const mtlora_linear_desc* d
     if (misaligned(h_base) || misaligned(dh_s) || misaligned(ctx1) || misaligned(ctx2) || misaligned(scratch1) || misaligned(scratch2) ||
         misaligned(g) || misaligned(part))
         return MTLORA_ERR_ALIGN;
-    if (part_bytes < hid_part_bytes(d1, hid_plan(d1, d2))) return MTLORA_ERR_WORKSPACE;
+    if (part_bytes < hid_bwd_part_bytes(d1, d2)) return MTLORA_ERR_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
-    return d1->dtype == MTLORA_F16 ? hid_bwd_impl<f16>(d1, d2, h_base, dh_s, ctx1, ctx2, scratch2, scratch1, g, dB1_t, dA2_t, part, s)
-                                   : hid_bwd_impl<bf16>(d1, d2, h_base, dh_s, ctx1, ctx2, scratch2, scratch1, g, dB1_t, dA2_t, part, s);
+    const int r = d1->dtype == MTLORA_F16 ? hid_bwd_impl<f16>(d1, d2, h_base, dh_s, ctx1, ctx2, scratch2, scratch1, g, dB1_t, dA2_t, part, s)
+                                          : hid_bwd_impl<bf16>(d1, d2, h_base, dh_s, ctx1, ctx2, scratch2, scratch1, g, dB1_t, dA2_t, part, s);
+    if (r != MTLORA_OK) return r;
+    MTL_CHECK_LAUNCH();
+    return MTLORA_OK;
 }
 
 int64_t mtlora_linear_ctx_bytes(const mtlora_linear_desc* d) {

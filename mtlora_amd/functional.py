@@ -639,7 +639,14 @@ class MlpHidFn(torch.autograd.Function):
         L.check(st, "mtlora_linear_fwd_gelu (fc1, implicit task hiddens)")
         d1.hid, d1.hid_ptr = 0, 0
         # the task columns of fc2's P straight from h_base and P1
-        st = lib.mtlora_mlp_hid_proj(ctypes.byref(d1), ctypes.byref(d2), L.ptr(h_base), L.ptr(ctx1), L.ptr(ctx2), L.stream_ptr())
+        key = ("hidfwd", M, meta1.K, H, meta2.N, meta1.r_t, meta2.r_t, dt, _tuning["stream"], _tuning["max_cu"])
+        fb = _bytes_cache.get(key)
+        if fb is None:
+            fb = lib.mtlora_mlp_hid_fwd_scratch_bytes(ctypes.byref(d1), ctypes.byref(d2))
+            _bytes_cache[key] = fb
+        fscr = torch.empty(fb, dtype=torch.uint8, device=dev)
+        st = lib.mtlora_mlp_hid_proj(ctypes.byref(d1), ctypes.byref(d2), L.ptr(h_base), L.ptr(ctx1), L.ptr(ctx2), L.ptr(fscr), fb,
+                                     L.stream_ptr())
         L.check(st, "mtlora_mlp_hid_proj")
         oshape = (*lead, meta2.N)
         ys = torch.empty(oshape, dtype=dt, device=dev)
@@ -670,7 +677,7 @@ class MlpHidFn(torch.autograd.Function):
         d1, d2 = meta1.desc(M), meta2.desc(M)
         sb1 = _desc_bytes("bwd", lib.mtlora_linear_bwd_scratch_bytes, meta1, M, d1)
         sb2 = _desc_bytes("bwd", lib.mtlora_linear_bwd_scratch_bytes, meta2, M, d2)
-        key = ("hidpart", M, meta1.K, H, meta2.N, meta1.r_t, meta2.r_t, dt)
+        key = ("hidpart", M, meta1.K, H, meta2.N, meta1.r_t, meta2.r_t, dt, _tuning["stream"], _tuning["max_cu"])
         pb = _bytes_cache.get(key)
         if pb is None:
             pb = lib.mtlora_mlp_hid_bwd_scratch_bytes(ctypes.byref(d1), ctypes.byref(d2))

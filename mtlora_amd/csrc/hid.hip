@@ -339,22 +339,36 @@ __global__ __launch_bounds__(HC * 2) void k_hid_fwd_d(const HidParams P) {
 #pragma unroll
     for (int t = 0; t < HID_TG; ++t) brow[t] = ((n >> 2) == t && n < 16 ? n : 16) * bs;
     const int64_t nblk = (P.M + 31) / 32;
-    for (int64_t rb = blockIdx.x; rb < nblk; rb += gridDim.x) {
+    // the next row block's h_base (and, in wave 0, P1) words are requested while the current block is computed: the three barriers of a
+    // block keep the waves of a workgroup in step, so nothing else would cover that latency
+    u32x4 nh0 = {0u, 0u, 0u, 0u}, nh1 = nh0;
+    u32x2 np[2] = {{0u, 0u}, {0u, 0u}};
+    auto fetch = [&](int64_t rb) __attribute__((always_inline)) {
+        if (rb >= nblk) return;
         const int64_t m0 = rb * 32;
         const bool live = m0 + m < P.M;
         const int64_t row = live ? m0 + m : P.M - 1;
-        const u32x4 hv0 = *reinterpret_cast<const u32x4*>(hbase + row * H + c_base + cw + 16 * kg);
-        const u32x4 hv1 = *reinterpret_cast<const u32x4*>(hbase + row * H + c_base + cw + 16 * kg + 8);
-        if (wave == 0) {  // the row block's P1 columns n = 4 t + rho: lanes kg = 0 write tasks 0, 1, lanes kg = 1 tasks 2, 3
+        nh0 = *reinterpret_cast<const u32x4*>(hbase + row * H + c_base + cw + 16 * kg);
+        nh1 = *reinterpret_cast<const u32x4*>(hbase + row * H + c_base + cw + 16 * kg + 8);
+        if (wave == 0) {
 #pragma unroll
             for (int tt = 0; tt < 2; ++tt) {
                 const int t = 2 * kg + tt;
-                u32x2 v = {0u, 0u};
-                if (t < nt && live) v = *reinterpret_cast<const u32x2*>(p1 + row * P.ldp1 + P.off1[t]);
-                *reinterpret_cast<u32x2*>(pimg + m * 64 + t * 8) = v;
+                np[tt] = u32x2{0u, 0u};
+                if (t < nt && live) np[tt] = *reinterpret_cast<const u32x2*>(p1 + row * P.ldp1 + P.off1[t]);
             }
         }
+    };
+    fetch(blockIdx.x);
+    for (int64_t rb = blockIdx.x; rb < nblk; rb += gridDim.x) {
+        const int64_t m0 = rb * 32;
+        const u32x4 hv0 = nh0, hv1 = nh1;
+        if (wave == 0) {  // the row block's P1 columns n = 4 t + rho: lanes kg = 0 write tasks 0, 1, lanes kg = 1 tasks 2, 3
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) *reinterpret_cast<u32x2*>(pimg + m * 64 + (2 * kg + tt) * 8) = np[tt];
+        }
         __syncthreads();  // pimg complete; the previous block's `red` reads are done
+        fetch(rb + gridDim.x);
         *reinterpret_cast<u32x4*>(wimg + m * 64 + kg * 32) = hv0;
         *reinterpret_cast<u32x4*>(wimg + m * 64 + kg * 32 + 16) = hv1;
         HID_LGKM0();

@@ -805,7 +805,6 @@ def test_block_call_sees_conversions_and_attribute_changes():
         Fn.SwinBlockRunFn.forward = staticmethod(orig)
         S.set_fused_blocks(prev)
     # same (B, H, W, C, hidden), window 7 vs 8: two entries in the byte-size cache, both calls run
-    keys = len(Fn._blk_bytes_cache)
     for ws in (7, 8):
         torch.manual_seed(0)
         lay = S.BasicLayer(dim=96, input_resolution=(56, 56), depth=2, num_heads=3, window_size=ws, tasks=None,
@@ -818,7 +817,10 @@ def test_block_call_sees_conversions_and_attribute_changes():
             y, _ = lay(xx)
         y.float().pow(2).sum().backward()
         assert torch.isfinite(xx.grad).all()
-    assert len(Fn._blk_bytes_cache) >= keys + 2
+    # (key layout of functional._block_bytes: (B, H, W, C, hidden, has_norm1, dtype, x_dtype, window_size, ...); counted by content, not by
+    # how many entries earlier tests of the process left behind)
+    seen = {k[8] for k in Fn._blk_bytes_cache if k[:5] == (2, 56, 56, 96, 384)}
+    assert {7, 8} <= seen, seen
 
 
 def test_factor_packer_one_launch_per_step_is_bit_identical():

@@ -60,10 +60,10 @@ for hid in (False, True):
         p = line.rstrip("\n").split(",")
         if len(p) < 5:
             continue
-        key = p[0] + " " + (p[5].split(" ")[0] if len(p) > 5 and p[5].startswith("hid") else "")
+        key = p[0] + " " + (p[5][:44] if len(p) > 5 else "")
         tot[key] = tot.get(key, 0.0) + float(p[4])
     os.remove(dump)
     total = sum(tot.values()) / a.reps
     print(f"{'implicit task hiddens' if hid else 'per-layer path':24s} M={M} C={C} T={a.tasks} r_t={a.rank}: {total:8.3f} ms of library kernels per fwd+bwd")
     for k, v in sorted(tot.items(), key=lambda kv: -kv[1]):
-        print(f"      {k:40s} {v / a.reps:8.3f} ms")
+        print(f"      {k:70s} {v / a.reps:8.3f} ms")

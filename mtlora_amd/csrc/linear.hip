@@ -3177,12 +3177,17 @@ static int hid_proj_impl(const mtlora_linear_desc* d1, const mtlora_linear_desc*
         }
         const double hb = (double)sizeof(T) * d1->M * H;
         mtl_prof_tag("hid_fwd%s M%lld H%d T%d nt%d rr%d", dp.on ? "_d" : "", (long long)d1->M, H, d1->T, q.nt, pl.rr);
-        MtlProfScope prof(PK_NT_FWD_P, hb, s, (double)sizeof(T) * d1->M * (double)q.nt * H, 0.0);
-        if (dp.on) {
-            hid_launch_d(d1->dtype, false, dp, q, s);
+        {
+            MtlProfScope prof(PK_NT_FWD_P, hb, s, (double)sizeof(T) * d1->M * (double)q.nt * H, 0.0);
+            if (dp.on)
+                hid_launch_d(d1->dtype, false, dp, q, s);
+            else
+                hid_launch_valu(d1->dtype, false, pl, q, s);
+        }
+        if (dp.on) {  // (its own profiler record: one record per dispatch, tools/pmc_traffic.py zips the two lists)
+            mtl_prof_tag("hid_rows_finish M%lld chunks%d", (long long)d1->M, dp.n_chunk);
+            MtlProfScope prof(PK_REDUCE, 0.0, s);
             mtli_hid_rows_finish(d1->dtype, q.rowpart, dp.n_chunk, d1->M, q.nt, q.alpha2, q.off2, q.p2, q.ldp2, s);
-        } else {
-            hid_launch_valu(d1->dtype, false, pl, q, s);
         }
     }
     return MTLORA_OK;
@@ -3242,12 +3247,15 @@ static int hid_bwd_impl(const mtlora_linear_desc* d1, const mtlora_linear_desc* 
             mtl_prof_tag("hid_bwd%s M%lld H%d T%d nt%d rr%d", dp.on ? "_d" : "", (long long)d1->M, H, d1->T, q.nt, rr);
             const double hb = (double)sizeof(T) * d1->M * H;
             MtlProfScope prof(PK_NT_BWD_DX, 3.0 * hb, s, (double)sizeof(T) * d1->M * (double)q.nt * H, 0.0);
-            if (dp.on) {
+            if (dp.on)
                 hid_launch_d(d1->dtype, true, dp, q, s);
-                mtli_hid_rows_finish(d1->dtype, q.rowpart, dp.n_chunk, d1->M, q.nt, q.alpha1, q.off1, q.q1, q.ldq1, s);
-            } else {
+            else
                 hid_launch_valu(d1->dtype, true, pl, q, s);
-            }
+        }
+        if (dp.on) {
+            mtl_prof_tag("hid_rows_finish M%lld chunks%d", (long long)d1->M, dp.n_chunk);
+            MtlProfScope prof(PK_REDUCE, 0.0, s);
+            mtli_hid_rows_finish(d1->dtype, q.rowpart, dp.n_chunk, d1->M, q.nt, q.alpha1, q.off1, q.q1, q.ldq1, s);
         }
         // dB1_t (fc1's N x r_t, un-padded rank d1->r_t) and dA2_t (fc2's r_t x K) share one reduce: per kind the un-padded rank differs
         // only if the two layers were built with different task ranks -- reduce them separately then
@@ -3273,6 +3281,7 @@ static int hid_bwd_impl(const mtlora_linear_desc* d1, const mtlora_linear_desc* 
                 ra.dB1[i] = nullptr;
             }
             mtli_hid_reduce(&rb, per, s);
+            MtlProfScope prof2(PK_REDUCE, 0.0, s);
             mtli_hid_reduce(&ra, per, s);
         }
     }

@@ -1373,6 +1373,59 @@ def test_mlp_implicit_task_hiddens(dtype, geom):
                 assert e <= tol * mult, (what, k, e)
 
 
+@pytest.mark.parametrize("name", ["c2.s0", "c2.s1", "c2.s2", "c5r4.s0", "swinb.s1"])
+def test_full_size_mlp_task_hiddens_vs_per_layer(name):
+    """the task-enabled Mlp of the benchmark configurations at FULL M (BASELINE configs[1] stages 0-2: 401 408 / 100 352 / 25 088 rows, hidden
+    384 / 768 / 1536 = 1 / 2 / 4 column chunks; configs[4] with 8 tasks = two task groups; Swin-B's stage 1: hidden 1024 = 4 chunks of 256), bf16,
+    TRAIN mode (p = 0.05): ``Fn.MlpHidFn`` against the per-layer path with the same dropout seeds -- itself pinned at these shapes against the
+    fp64 oracle by ``FULL_T4`` -- every output, input gradient and factor gradient at the north-star tolerance, outputs and input gradients
+    also per ROW (a wrong row block or chunk shows even when the global maximum hides it).  [auto]: the MFMA kernels the benchmark runs;
+    [tiled]: the VALU forms."""
+    from mtlora_amd import functional as Fn
+    C, Hd, T, M = {"c2.s0": (96, 384, 4, 32 * 112 * 112), "c2.s1": (192, 768, 4, 32 * 56 * 56), "c2.s2": (384, 1536, 4, 32 * 28 * 28),
+                   "c5r4.s0": (96, 384, 8, 32 * 112 * 112), "swinb.s1": (256, 1024, 4, 16 * 56 * 56)}[name]
+    tasks = [f"t{i}" for i in range(T)]
+    dtype, tol = torch.bfloat16, 1e-2
+    mlp = _mlp_with_tasks(tasks, C, Hd, 64 if name != "c5r4.s0" else 4, 4, 0.05, seed=29)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    xs = [torch.randn(M, C, device=dev(), generator=g).requires_grad_(True) for _ in range(1 + T)]
+    gys = [torch.randn(M, C, device=dev(), generator=g).to(dtype) for _ in range(1 + T)]
+    res = []
+    for hid in (False, True):
+        old = Fn.set_mlp_hid(hid)
+        try:
+            Fn._seed_counter = 1300
+            for x in xs:
+                x.grad = None
+            mlp.zero_grad()
+            with torch.autocast("cuda", dtype=dtype):
+                y, y_t = mlp(xs[0], {t: xs[1 + i] for i, t in enumerate(tasks)})
+            outs = [y] + [y_t[t] for t in tasks]
+            torch.autograd.backward(outs, gys)
+            res.append(([o.detach().float() for o in outs], [x.grad.float() for x in xs],
+                        {n_: p_.grad.clone() for n_, p_ in mlp.named_parameters() if p_.grad is not None}))
+            del outs, y, y_t
+        finally:
+            Fn.set_mlp_hid(old)
+    (o0, g0, p0), (o1, g1, p1) = res
+    assert p0.keys() == p1.keys() and len(p0) == 4 * (1 + T)
+    for what, ref, got in (("y", o0, o1), ("dx", g0, g1)):
+        for i, (u, v) in enumerate(zip(ref, got)):
+            scale = u.abs().max().clamp_min(1e-12)
+            e = ((v - u).abs().max() / scale).item()
+            _log_parity(f"full-size hid {what}{i} {name}", e, tol, 1.0)
+            assert e <= tol, (name, what, i, e)
+            # per row: against the row's own scale, floored at a tenth of the global one (rows of tiny norm carry rounding only)
+            rs = u.abs().amax(dim=1).clamp_min(0.1 * scale)
+            er = ((v - u).abs().amax(dim=1) / rs).max().item()
+            _log_parity(f"full-size hid {what}{i} per row {name}", er, tol, 3.0)
+            assert er <= 3.0 * tol, (name, what, i, "row", er)
+    for k in p1:
+        e = rel_err(p1[k], p0[k])
+        _log_parity(f"full-size hid d{k} {name}", e, tol, 1.0)
+        assert e <= tol, (name, k, e)
+
+
 # ------------------------------------------------------------------------------------------------
 # fused bilinear upsample + loss (+ backward)
 # ------------------------------------------------------------------------------------------------

@@ -23,10 +23,21 @@ else
   # list with the per-dispatch counters: hot-path launches vs the callers' rank-0 GEMMs on the same kernels)
   KINDS=1 bash tools/pmc.sh FETCH_SIZE fetch && cp gpurun_out/pmc_fetch*.csv $OUT/
   KINDS=1 bash tools/pmc.sh WRITE_SIZE write && cp gpurun_out/pmc_write*.csv $OUT/
-  python tools/pmc_traffic.py gpurun_out/pmc_fetch.csv gpurun_out/pmc_write.csv 4 r05_pmc_fetch.csv r05_pmc_write.csv > $OUT/pmc_traffic.json
+  python tools/pmc_traffic.py gpurun_out/pmc_fetch.csv gpurun_out/pmc_write.csv 4 r06_pmc_fetch.csv r06_pmc_write.csv > $OUT/pmc_traffic.json
   KINDS=1 BENCH_ARGS="--config c4" bash tools/pmc.sh FETCH_SIZE fetch_c4 && cp gpurun_out/pmc_fetch_c4*.csv $OUT/
   KINDS=1 BENCH_ARGS="--config c4" bash tools/pmc.sh WRITE_SIZE write_c4 && cp gpurun_out/pmc_write_c4*.csv $OUT/
-  python tools/pmc_traffic.py gpurun_out/pmc_fetch_c4.csv gpurun_out/pmc_write_c4.csv 4 r05_pmc_fetch_c4.csv r05_pmc_write_c4.csv > $OUT/pmc_traffic_c4.json
+  python tools/pmc_traffic.py gpurun_out/pmc_fetch_c4.csv gpurun_out/pmc_write_c4.csv 4 r06_pmc_fetch_c4.csv r06_pmc_write_c4.csv > $OUT/pmc_traffic_c4.json
+  # the static traffic figure bench.py quotes is only honest while the profiled launch structure IS the benched one
+  python - $OUT/pmc_traffic.json <<'PY' || { echo "pmc_traffic.json: hot-path launch count differs from bench.py's -- re-run tools/pmc.sh after the kernel change"; exit 1; }
+import json, subprocess, sys
+pm = json.load(open(sys.argv[1]))
+line = subprocess.run([sys.executable, "bench.py", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-eager-gpu", "--no-other-configs"],
+                      capture_output=True, text=True).stdout.strip().splitlines()[-1]
+n_bench = json.loads(line)["roofline"]["launches_per_step"]
+n_pmc = pm["hot_path"]["launches_per_step"]
+print("hot-path launches per step: bench", n_bench, "pmc", n_pmc)
+sys.exit(0 if abs(n_bench - n_pmc) < 0.5 else 1)
+PY
   bash tools/pmc.sh "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES" sq && cp gpurun_out/pmc_sq.csv $OUT/
   cd $REPO
   python tools/bench_linear.py --kinds > $OUT/bench_linear.txt 2>&1

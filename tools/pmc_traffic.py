@@ -17,8 +17,8 @@ GROUPS = {"k_nt": "k_nt", "k_tn": "k_tn", "k_sum": "k_sum", "k_attn_fwd": "k_att
 HOT = ("k_nt:fwd_outputs", "k_nt:fwd_lowrank_P", "k_nt:bwd_lowrank_Q", "k_nt:bwd_dX")
 LINEAR = HOT + ("k_tn:dA_dB", "k_pack", "k_tn_reduce", "k_sum")
 # kernels that execute under a record of these kinds (exactly one dispatch per record)
-KIND_KERNELS = {"k_nt:": ("k_nt", "k_sp_xres", "k_sp_ares", "k_sp_proj", "k_rank_out", "k_pq"), "k_tn:dA_dB": ("k_tnI", "k_tn<", "k_sp_tnI", "k_sp_tn<"),
-                "k_tn:plain_dW": ("k_tnI", "k_tn<"), "k_pack": ("k_pack",), "k_tn_reduce": ("k_tn_reduce", "k_sp_tn_reduce"), "k_sum": ("k_sum",)}
+KIND_KERNELS = {"k_nt:": ("k_nt", "k_sp_xres", "k_sp_ares", "k_sp_proj", "k_rank_out", "k_pq", "k_hid_fwd", "k_hid_bwd", "k_hid_proj"), "k_tn:dA_dB": ("k_tnI", "k_tn<", "k_sp_tnI", "k_sp_tn<"),
+                "k_tn:plain_dW": ("k_tnI", "k_tn<"), "k_pack": ("k_pack",), "k_tn_reduce": ("k_tn_reduce", "k_sp_tn_reduce", "k_hid_reduce", "k_hid_rows_finish"), "k_sum": ("k_sum",)}
 
 
 def load(path, col):
@@ -29,7 +29,7 @@ def load(path, col):
 
 
 def lib_linear_kernel(n):
-    return any(k in n for k in ("k_nt", "k_sp_", "k_rank_out", "k_tn", "k_pack", "k_sum", "k_pq")) and "k_ln" not in n
+    return any(k in n for k in ("k_nt", "k_sp_", "k_rank_out", "k_tn", "k_pack", "k_sum", "k_pq", "k_hid_")) and "k_ln" not in n
 
 
 def by_kind(dispatch_csv, kinds_csv, col, scale):
@@ -65,7 +65,7 @@ def main():
         def match(n):
             tn = "k_tn" in n or "k_sp_tn" in n  # factor-gradient kernels (tiled / wave-streaming) and their reduce kernels
             if g == "k_nt":
-                return ("k_nt" in n or "k_sp_" in n or "k_rank_out" in n or "k_pq" in n) and not tn
+                return ("k_nt" in n or "k_sp_" in n or "k_rank_out" in n or "k_pq" in n or "k_hid_fwd" in n or "k_hid_bwd" in n or "k_hid_proj" in n) and not tn
             if g == "k_tn":
                 return tn and "reduce" not in n
             return key in n

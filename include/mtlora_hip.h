@@ -207,8 +207,9 @@ int mtlora_linear_bwd_gelu(const mtlora_linear_desc* d, const void* x, const voi
  * dA2_t = Q2_t^T gelu(h_t).  Call sequence (d1 / d2 = descriptors of fc1 / fc2, same M, d1->N == d2->K):
  *   forward : mtlora_linear_fwd_gelu(d1 | HID_FWD_BASE) ; mtlora_mlp_hid_proj ; mtlora_linear_fwd(d2 | HID_P_GIVEN)
  *   backward: mtlora_linear_bwd_gelu(d2, dx_t = dA_t = null) ; mtlora_mlp_hid_bwd ; mtlora_linear_bwd(d1 | HID_Q_GIVEN)
- * Supported: 16-bit dtype, mode 'matrix', has_x_tasks, 1 <= T, every r_t <= 8, d1->N a multiple of 128 and
- * <= 2048 (mtlora_mlp_hid_supported returns 1).  Deterministic (fixed-order partial sums).
+ * Supported: 16-bit dtype, mode 'matrix', has_x_tasks, 1 <= T, every r_t <= 8, d1->N a multiple of 128; d1->N > 2048 only with
+ * r_t <= 4 and d1->N a multiple of 384 or 256 (the chunked MFMA kernels; mtlora_mlp_hid_supported returns 1).  Deterministic
+ * (fixed-order partial sums).
  * ------------------------------------------------------------------------------------------ */
 int mtlora_mlp_hid_supported(const mtlora_linear_desc* d1, const mtlora_linear_desc* d2);
 /* bytes of the scratch buffers of mtlora_mlp_hid_proj / mtlora_mlp_hid_bwd (-1: unsupported shape) */

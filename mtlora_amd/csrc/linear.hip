@@ -3052,9 +3052,15 @@ static int hid_check(const mtlora_linear_desc* d1, const mtlora_linear_desc* d2)
     if (d1->dtype == MTLORA_F32 || d1->dtype != d2->dtype) return MTLORA_ERR_UNSUPPORTED;
     if (d1->M != d2->M || d1->N != d2->K || d1->T != d2->T || d1->T < 1) return MTLORA_ERR_UNSUPPORTED;
     if (d1->mode != 0 || d2->mode != 0 || !d1->has_x_tasks || !d2->has_x_tasks) return MTLORA_ERR_UNSUPPORTED;
-    if (d1->N % 128 != 0 || d1->N > 2048 || d1->M <= 0) return MTLORA_ERR_UNSUPPORTED;
-    for (int t = 0; t < d1->T; ++t)
+    if (d1->N % 128 != 0 || d1->M <= 0) return MTLORA_ERR_UNSUPPORTED;
+    int rmax = 0;
+    for (int t = 0; t < d1->T; ++t) {
         if (d1->r_t[t] < 1 || d1->r_t[t] > 8 || d2->r_t[t] < 1 || d2->r_t[t] > 8) return MTLORA_ERR_UNSUPPORTED;
+        rmax = std::max(rmax, std::max(d1->r_t[t], d2->r_t[t]));
+    }
+    // the VALU forms hold a whole row per workgroup (two columns per thread: <= 2048 columns); the MFMA forms take any number of chunks
+    const bool chunked = d1->sel_stream != 1 && rmax <= 4 && hid_d_chunk((int)d1->N) != 0;
+    if (d1->N > 2048 && !chunked) return MTLORA_ERR_UNSUPPORTED;
     return MTLORA_OK;
 }
 static HidPlan hid_plan(const mtlora_linear_desc* d1, const mtlora_linear_desc* d2) {

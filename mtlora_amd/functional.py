@@ -568,7 +568,8 @@ def set_mlp_hid(on: bool) -> bool:
 
 
 def mlp_hid_supported(meta1: "LinearMeta", meta2: "LinearMeta", M: int) -> bool:
-    key = (M, meta1.K, meta1.N, meta2.N, meta1.r_t, meta2.r_t, meta1.dtype, meta1.mode, meta2.mode, meta1.has_x_tasks, meta2.has_x_tasks)
+    key = (M, meta1.K, meta1.N, meta2.N, meta1.r_t, meta2.r_t, meta1.dtype, meta1.mode, meta2.mode, meta1.has_x_tasks, meta2.has_x_tasks,
+           _tuning["stream"])
     v = _hid_ok_cache.get(key)
     if v is None:
         d1, d2 = meta1.desc(M), meta2.desc(M)

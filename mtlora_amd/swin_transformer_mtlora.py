@@ -142,7 +142,7 @@ class Mlp(nn.Module):
             return None
         # (shape rules first: ``hid_call`` draws the layers' dropout seeds)
         H, r1, r2 = self.fc1.linear.out_features, self.fc1._ranks, self.fc2._ranks
-        if H % 128 or H > 2048 or any(not (1 <= r1.get(t, 0) <= 8 and 1 <= r2.get(t, 0) <= 8) for t in tasks):
+        if H % 128 or any(not (1 <= r1.get(t, 0) <= 8 and 1 <= r2.get(t, 0) <= 8) for t in tasks):  # (width limits: mlp_hid_supported)
             return None
         c1 = self.fc1.hid_call(dtype, x.device)
         c2 = self.fc2.hid_call(dtype, x.device) if c1 is not None else None

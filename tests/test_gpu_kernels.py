@@ -1293,7 +1293,7 @@ def _mlp_with_tasks(tasks, C, Hd, r_s, r_t, p_drop, seed):
     return mlp.train()
 
 
-def _mlp_reference_fp64(mlp, xs, tasks, gys):
+def _mlp_reference_fp64(mlp, xs, tasks, gys, q_floor=None, floors=None):
     """fc1 -> GELU -> fc2 of a task-enabled Mlp (reference lora.py:262-266 with x_tasks, swin_transformer_mtlora.py:68-81) in fp64,
     dropout off: outputs, input gradients and factor gradients"""
     P = {n: p.detach().double().requires_grad_(p.requires_grad) for n, p in mlp.named_parameters()}
@@ -1310,10 +1310,19 @@ def _mlp_reference_fp64(mlp, xs, tasks, gys):
             yt.append(base + st * (xt[i] @ P[f"{pre}.lora_tasks_A.{t}"].t()) @ P[f"{pre}.lora_tasks_B.{t}"].t())
         return ys, yt
     h, ht = lin("fc1", X[0], X[1:])
+    for v in ht:
+        v.retain_grad()
     g = torch.nn.functional.gelu
     y, yt = lin("fc2", g(h), [g(v) for v in ht])
     outs = [y] + yt
     torch.autograd.backward(outs, [q.double() for q in gys])
+    if q_floor is not None:
+        # what ANY path that keeps Q1_t = s_t dH_t B1_t (M x r_t) in `q_floor` precision loses on dX_t = Q1_t A1_t: the exact Q rounded once
+        for i, t in enumerate(tasks):
+            st = float(mlp.fc1.lora_task_scale[t])
+            Q = st * (ht[i].grad @ P[f"fc1.lora_tasks_B.{t}"].detach())
+            dxq = Q.to(q_floor).double() @ P[f"fc1.lora_tasks_A.{t}"].detach()
+            floors.append(((dxq - X[1 + i].grad).abs().max() / X[1 + i].grad.abs().max().clamp_min(1e-300)).item())
     return outs, [x.grad for x in X], {n: p.grad for n, p in P.items() if p.grad is not None}
 
 
@@ -1374,27 +1383,32 @@ def test_mlp_implicit_task_hiddens(dtype, geom):
 
 
 @pytest.mark.parametrize("name", ["c2.s0", "c2.s1", "c2.s2", "c5r4.s0", "swinb.s1"])
-def test_full_size_mlp_task_hiddens_vs_per_layer(name):
+def test_full_size_mlp_task_hiddens_vs_oracle(name):
     """the task-enabled Mlp of the benchmark configurations at FULL M (BASELINE configs[1] stages 0-2: 401 408 / 100 352 / 25 088 rows, hidden
-    384 / 768 / 1536 = 1 / 2 / 4 column chunks; configs[4] with 8 tasks = two task groups; Swin-B's stage 1: hidden 1024 = 4 chunks of 256), bf16,
-    TRAIN mode (p = 0.05): ``Fn.MlpHidFn`` against the per-layer path with the same dropout seeds -- itself pinned at these shapes against the
-    fp64 oracle by ``FULL_T4`` -- every output, input gradient and factor gradient at the north-star tolerance, outputs and input gradients
-    also per ROW (a wrong row block or chunk shows even when the global maximum hides it).  [auto]: the MFMA kernels the benchmark runs;
+    384 / 768 / 1536 = 1 / 2 / 4 column chunks; configs[4] with 8 tasks = two task groups; Swin-B's stage 1: hidden 1024 = 4 chunks of 256), bf16:
+    ``Fn.MlpHidFn`` AND the per-layer path against the fp64 formulas of the reference (lora.py:262-266, Mlp :68-81; ATen fp64 on the GPU,
+    dropout off -- train-mode masks are pinned by ``test_mlp_implicit_task_hiddens`` and ``FULL_T4``): every output, input gradient and factor
+    gradient of the new path at the north-star tolerance; per ROW (a wrong row block or column chunk shows even when the global maximum hides
+    it) the new path must stay within 3x the tolerance of the row's own scale, or within 1.5x of what the per-layer path loses on that tensor
+    (the worst of 400 k rows is a cancellation row of a rank-4 product whose M x 4 factor Q is rounded to 16 bits on BOTH paths: 3.7 % vs
+    4.1 % on the task input gradients of stage 0 -- two draws of the same rounding noise).  [auto]: the MFMA kernels the benchmark runs;
     [tiled]: the VALU forms."""
     from mtlora_amd import functional as Fn
     C, Hd, T, M = {"c2.s0": (96, 384, 4, 32 * 112 * 112), "c2.s1": (192, 768, 4, 32 * 56 * 56), "c2.s2": (384, 1536, 4, 32 * 28 * 28),
                    "c5r4.s0": (96, 384, 8, 32 * 112 * 112), "swinb.s1": (256, 1024, 4, 16 * 56 * 56)}[name]
     tasks = [f"t{i}" for i in range(T)]
     dtype, tol = torch.bfloat16, 1e-2
-    mlp = _mlp_with_tasks(tasks, C, Hd, 64 if name != "c5r4.s0" else 4, 4, 0.05, seed=29)
+    mlp = _mlp_with_tasks(tasks, C, Hd, 64 if name != "c5r4.s0" else 4, 4, 0.0, seed=29)
     g = torch.Generator(device="cuda").manual_seed(5)
-    xs = [torch.randn(M, C, device=dev(), generator=g).requires_grad_(True) for _ in range(1 + T)]
+    xs = [torch.randn(M, C, device=dev(), generator=g).to(dtype).float().requires_grad_(True) for _ in range(1 + T)]
     gys = [torch.randn(M, C, device=dev(), generator=g).to(dtype) for _ in range(1 + T)]
+    floors = []
+    ro, rg, rp = _mlp_reference_fp64(mlp, xs, tasks, gys, q_floor=dtype, floors=floors)
+    ro, rg = [t.detach() for t in ro], [t.detach() for t in rg]
     res = []
     for hid in (False, True):
         old = Fn.set_mlp_hid(hid)
         try:
-            Fn._seed_counter = 1300
             for x in xs:
                 x.grad = None
             mlp.zero_grad()
@@ -1402,26 +1416,32 @@ def test_full_size_mlp_task_hiddens_vs_per_layer(name):
                 y, y_t = mlp(xs[0], {t: xs[1 + i] for i, t in enumerate(tasks)})
             outs = [y] + [y_t[t] for t in tasks]
             torch.autograd.backward(outs, gys)
-            res.append(([o.detach().float() for o in outs], [x.grad.float() for x in xs],
+            res.append(([o.detach().double() for o in outs], [x.grad.double() for x in xs],
                         {n_: p_.grad.clone() for n_, p_ in mlp.named_parameters() if p_.grad is not None}))
             del outs, y, y_t
         finally:
             Fn.set_mlp_hid(old)
     (o0, g0, p0), (o1, g1, p1) = res
     assert p0.keys() == p1.keys() and len(p0) == 4 * (1 + T)
-    for what, ref, got in (("y", o0, o1), ("dx", g0, g1)):
-        for i, (u, v) in enumerate(zip(ref, got)):
-            scale = u.abs().max().clamp_min(1e-12)
-            e = ((v - u).abs().max() / scale).item()
-            _log_parity(f"full-size hid {what}{i} {name}", e, tol, 1.0)
-            assert e <= tol, (name, what, i, e)
-            # per row: against the row's own scale, floored at a tenth of the global one (rows of tiny norm carry rounding only)
-            rs = u.abs().amax(dim=1).clamp_min(0.1 * scale)
-            er = ((v - u).abs().amax(dim=1) / rs).max().item()
-            _log_parity(f"full-size hid {what}{i} per row {name}", er, tol, 3.0)
-            assert er <= 3.0 * tol, (name, what, i, "row", er)
+
+    def row_err(v, u):  # against the row's own scale, floored at a tenth of the tensor's (rows of tiny norm carry rounding only)
+        rs = u.abs().amax(dim=1).clamp_min(0.1 * u.abs().max().clamp_min(1e-12))
+        return ((v - u).abs().amax(dim=1) / rs).max().item()
+    for what, ref, per_layer, got in (("y", ro, o0, o1), ("dx", rg, g0, g1)):
+        for i, (u, w, v) in enumerate(zip(ref, per_layer, got)):
+            e = ((v - u).abs().max() / u.abs().max().clamp_min(1e-12)).item()
+            e_old = ((w - u).abs().max() / u.abs().max().clamp_min(1e-12)).item()
+            # the north-star tolerance; for the task input gradients dX_t = Q1_t A1_t -- a rank-4 product whose M x 4 factor BOTH paths (and the
+            # reference under autocast) keep in 16 bits -- plus what the exact Q rounded once to 16 bits loses on that tensor (measured above:
+            # 0.24-0.31 %; the per-layer path reads 0.65-1.03 % on the same tensors, this one 0.70-1.12 %)
+            fl = floors[i - 1] if (what == "dx" and i >= 1) else 0.0
+            _log_parity(f"full-size hid {what}{i} {name} (per-layer path: {e_old:.3e}, 16-bit Q floor: {fl:.3e})", e, tol, 1.0)
+            assert e <= tol + fl, (name, what, i, e, e_old, fl)
+            er, er_old = row_err(v, u), row_err(w, u)
+            _log_parity(f"full-size hid {what}{i} per row {name} (per-layer path: {er_old:.3e})", er, tol, 3.0)
+            assert er <= max(3.0 * tol, 1.5 * er_old), (name, what, i, "row", er, er_old)
     for k in p1:
-        e = rel_err(p1[k], p0[k])
+        e = rel_err(p1[k], rp[k])
         _log_parity(f"full-size hid d{k} {name}", e, tol, 1.0)
         assert e <= tol, (name, k, e)
 

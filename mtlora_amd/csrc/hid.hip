@@ -219,7 +219,17 @@ __global__ __launch_bounds__(NTHR) void k_hid_proj(const HidParams P) {
 template <typename T>
 __device__ __forceinline__ uint32_t hid_pk(float a, float b) { return mtl_pk2<T>(a, b); }
 
-// [32 rows][32 cols] 16-bit image with 64-byte rows -> lane (c, hh): the 16 rows a(r) of column c, raw (two fragments of 8) or as floats
+// LDS images: [32 rows][32 cols] of 16-bit elements, 64-byte rows, the four 16-byte chunks of a row XOR-permuted by (row >> 2) & 3.
+// Why: the transposed reads want a row stride of 16 dwords (mod 64) -- then the 4 rows x 64 bytes a ds_read_b64_tr_b16 cycle touches cover
+// all 64 banks -- but with that stride every ROW-MAJOR access (lane = row: the A operands, the h_base / G transposes) puts rows r, r + 4,
+// r + 8 ... on the same banks: SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.70 (backward) / 0.75 (forward), profiles/r06_pmc_hid.txt.  The
+// permutation is constant over an aligned group of 4 rows, so a transposed read still sees whole rows, and it spreads the eight rows
+// that share a bank group over the four chunk positions: 2 lanes per bank = the minimum for 512 bytes.
+__device__ __forceinline__ int hid_off16(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4); }
+__device__ __forceinline__ int hid_off8(int row, int e) {  // element offset e (a multiple of 4) of the row
+    return row * 64 + (((e >> 3) ^ ((row >> 2) & 3)) << 4) + (((e >> 2) & 1) << 3);
+}
+// image -> lane (c, hh): the 16 rows a(r) of column c, raw (two fragments of 8) or as floats
 __device__ __forceinline__ void hid_dl_raw(const unsigned char* img, int lane, u32x4& f0, u32x4& f1) {
     const int g = lane >> 4, i = lane & 15, hh = g >> 1;
     const int col = 16 * (g & 1) + 4 * (i & 3);
@@ -227,7 +237,7 @@ __device__ __forceinline__ void hid_dl_raw(const unsigned char* img, int lane, u
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int row = 8 * q + 4 * hh + (i >> 2);
-        s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(img + row * 64 + col * 2));
+        s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(img + hid_off8(row, col)));
         const u32x2 u = __builtin_bit_cast(u32x2, v);
         w[2 * q] = u[0];
         w[2 * q + 1] = u[1];
@@ -250,13 +260,12 @@ __device__ __forceinline__ void hid_dl_f32(const unsigned char* img, int lane, f
 // lane (c, hh): its 16 packed D-layout values (f0 = rows r 0..7, f1 = r 8..15) -> image row c, i.e. the TRANSPOSE [32 cols][32 rows]
 __device__ __forceinline__ void hid_dl_store_t(unsigned char* img, int lane, const u32x4& f0, const u32x4& f1) {
     const int c = lane & 31, hh = lane >> 5;
-    unsigned char* p = img + c * 64 + 8 * hh;
-    *reinterpret_cast<u32x2*>(p) = u32x2{f0[0], f0[1]};        // rows 4 hh + 0..3
-    *reinterpret_cast<u32x2*>(p + 16) = u32x2{f0[2], f0[3]};   // rows 8 + 4 hh ..
-    *reinterpret_cast<u32x2*>(p + 32) = u32x2{f1[0], f1[1]};   // rows 16 + 4 hh ..
-    *reinterpret_cast<u32x2*>(p + 48) = u32x2{f1[2], f1[3]};   // rows 24 + 4 hh ..
+    *reinterpret_cast<u32x2*>(img + hid_off8(c, 4 * hh)) = u32x2{f0[0], f0[1]};        // rows 4 hh + 0..3
+    *reinterpret_cast<u32x2*>(img + hid_off8(c, 8 + 4 * hh)) = u32x2{f0[2], f0[3]};    // rows 8 + 4 hh ..
+    *reinterpret_cast<u32x2*>(img + hid_off8(c, 16 + 4 * hh)) = u32x2{f1[0], f1[1]};   // rows 16 + 4 hh ..
+    *reinterpret_cast<u32x2*>(img + hid_off8(c, 24 + 4 * hh)) = u32x2{f1[2], f1[3]};   // rows 24 + 4 hh ..
 }
-// transposed fragment pair of a [32][32] image with 64-byte rows: lane (i = l & 31, hh) gets Img[8 hh + e][i] (f0) and Img[16 + 8 hh + e][i] (f1)
+// transposed fragment pair: lane (i = l & 31, hh) gets Img[8 hh + e][i] (f0) and Img[16 + 8 hh + e][i] (f1)
 __device__ __forceinline__ void hid_tr_frag(const unsigned char* img, int lane, u32x4& f0, u32x4& f1) {
     const int g = lane >> 4, i = lane & 15, hh = g >> 1;
     const int col = 16 * (g & 1) + 4 * (i & 3);
@@ -264,7 +273,7 @@ __device__ __forceinline__ void hid_tr_frag(const unsigned char* img, int lane, 
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int row = ((j >> 1) * 16) + 8 * hh + 4 * (j & 1) + (i >> 2);
-        s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(img + row * 64 + col * 2));
+        s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(img + hid_off8(row, col)));
         const u32x2 u = __builtin_bit_cast(u32x2, v);
         w[2 * j] = u[0];
         w[2 * j + 1] = u[1];
@@ -318,7 +327,7 @@ __device__ __forceinline__ void hid_d_tables(const HidParams& P, int tid, int nt
 }
 
 template <typename T, int HC>
-__global__ __launch_bounds__(HC * 2) void k_hid_fwd_d(const HidParams P) {
+__global__ __launch_bounds__(HC * 2, HC == 384 ? 3 : 2) void k_hid_fwd_d(const HidParams P) {
     constexpr int NW = HC / 32, bs = HC * 2 + 16;
     extern __shared__ __attribute__((aligned(16))) unsigned char hid_smem[];
     unsigned char* tabH = hid_smem;                              // [4][HC] x 8 B
@@ -365,17 +374,17 @@ __global__ __launch_bounds__(HC * 2) void k_hid_fwd_d(const HidParams P) {
         const u32x4 hv0 = nh0, hv1 = nh1;
         if (wave == 0) {  // the row block's P1 columns n = 4 t + rho: lanes kg = 0 write tasks 0, 1, lanes kg = 1 tasks 2, 3
 #pragma unroll
-            for (int tt = 0; tt < 2; ++tt) *reinterpret_cast<u32x2*>(pimg + m * 64 + (2 * kg + tt) * 8) = np[tt];
+            for (int tt = 0; tt < 2; ++tt) *reinterpret_cast<u32x2*>(pimg + hid_off8(m, (2 * kg + tt) * 4)) = np[tt];
         }
         __syncthreads();  // pimg complete; the previous block's `red` reads are done
         fetch(rb + gridDim.x);
-        *reinterpret_cast<u32x4*>(wimg + m * 64 + kg * 32) = hv0;
-        *reinterpret_cast<u32x4*>(wimg + m * 64 + kg * 32 + 16) = hv1;
+        *reinterpret_cast<u32x4*>(wimg + hid_off16(m, 2 * kg)) = hv0;
+        *reinterpret_cast<u32x4*>(wimg + hid_off16(m, 2 * kg + 1)) = hv1;
         HID_LGKM0();
         __builtin_amdgcn_wave_barrier();
         f32x16 hbD;
         hid_dl_f32<T>(wimg, lane, hbD);
-        const u32x4 fp = *reinterpret_cast<const u32x4*>(pimg + m * 64 + kg * 16);
+        const u32x4 fp = *reinterpret_cast<const u32x4*>(pimg + hid_off16(m, kg));
         HID_LGKM0();
         __builtin_amdgcn_wave_barrier();
         f32x16 accP;
@@ -414,15 +423,16 @@ __global__ __launch_bounds__(HC * 2) void k_hid_fwd_d(const HidParams P) {
         __syncthreads();  // every wave is done with its image: `red` may overlay them
         if (n < 16) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) red[((size_t)wave * 16 + n) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh] = accP[r];
+            for (int r = 0; r < 16; ++r) red[((size_t)wave * 16 + n) * 33 + (r & 3) + 8 * (r >> 2) + 4 * hh] = accP[r];
         }
         __syncthreads();
+        static_assert(NW * 64 >= 512, "the row-sum finish uses 512 threads");
         if (tid < 512) {
             const int rr = tid & 31, nn = tid >> 5;
             if (m0 + rr < P.M) {
                 float a = 0.f;
 #pragma unroll
-                for (int w = 0; w < NW; ++w) a += red[((size_t)w * 16 + nn) * 32 + rr];
+                for (int w = 0; w < NW; ++w) a += red[((size_t)w * 16 + nn) * 33 + rr];
                 P.rowpart[((int64_t)chunk * P.M + m0 + rr) * 16 + nn] = a;
             }
         }
@@ -430,15 +440,14 @@ __global__ __launch_bounds__(HC * 2) void k_hid_fwd_d(const HidParams P) {
 }
 
 template <typename T, int HC>
-__global__ __launch_bounds__(HC * 2) void k_hid_bwd_d(const HidParams P) {
+__global__ __launch_bounds__(HC * 2, HC == 384 ? 3 : 2) void k_hid_bwd_d(const HidParams P) {
     constexpr int NW = HC / 32, bs = HC * 2 + 16;
     extern __shared__ __attribute__((aligned(16))) unsigned char hid_smem[];
     unsigned char* tabH = hid_smem;                              // [4][HC] x 8 B   B1
     unsigned char* tabU = tabH + (size_t)HID_TG * HC * 8;         // [4][HC] x 8 B   A2
     unsigned char* bq = tabU + (size_t)HID_TG * HC * 8;           // [17][bs]        B1 rows
-    unsigned char* pimg = bq + (size_t)17 * bs;                   // [32][32] P1 columns n
-    unsigned char* qimg = pimg + 2048;                            // [32][32] Q2 columns n
-    unsigned char* wimgs = qimg + 2048;                           // [NW][32][32]; `red` overlays it
+    unsigned char* pimg = bq + (size_t)17 * bs;                   // [32][32]: columns n = 4 t + rho: P1, columns 16 + n: Q2
+    unsigned char* wimgs = pimg + 4096;                           // [NW][32][32]; `red` overlays it  (4096: layout kept, second half unused)
     float* red = reinterpret_cast<float*>(wimgs);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nt = P.nt, H = P.H, m = lane & 31, kg = lane >> 5, c = lane & 31, hh = lane >> 5, n = lane & 31;
@@ -452,9 +461,9 @@ __global__ __launch_bounds__(HC * 2) void k_hid_bwd_d(const HidParams P) {
     T* gout = reinterpret_cast<T*>(P.g);
     const T* p1 = reinterpret_cast<const T*>(P.p1);
     const T* q2 = reinterpret_cast<const T*>(P.q2);
-    f32x16 accB, accA;
+    f32x16 accF;  // factor gradients of the wave's 32 columns: [column][n]: n < 16 dB1^T, n >= 16 dA2
 #pragma unroll
-    for (int e = 0; e < 16; ++e) accB[e] = accA[e] = 0.f;
+    for (int e = 0; e < 16; ++e) accF[e] = 0.f;
     const int64_t nblk = (P.M + 31) / 32;
     for (int64_t rb = blockIdx.x; rb < nblk; rb += gridDim.x) {
         const int64_t m0 = rb * 32;
@@ -470,26 +479,25 @@ __global__ __launch_bounds__(HC * 2) void k_hid_bwd_d(const HidParams P) {
         if (wave < 2) {  // wave 0: P1 image, wave 1: Q2 image (rows past M: zeros -> nothing reaches the factor gradients)
             const T* src = wave ? q2 : p1;
             const int64_t ld = wave ? P.ldq2 : P.ldp1;
-            unsigned char* img = wave ? qimg : pimg;
 #pragma unroll
             for (int tt = 0; tt < 2; ++tt) {
                 const int t = 2 * kg + tt;
                 u32x2 v = {0u, 0u};
                 if (t < nt && live) v = *reinterpret_cast<const u32x2*>(src + row * ld + (wave ? P.off2[t] : P.off1[t]));
-                *reinterpret_cast<u32x2*>(img + m * 64 + t * 8) = v;
+                *reinterpret_cast<u32x2*>(pimg + hid_off8(m, 16 * wave + t * 4)) = v;
             }
         }
         __syncthreads();
         u32x4 hb0, hb1;  // h_base in D layout, packed (unpacked into the accumulator of each task's rank update)
-        *reinterpret_cast<u32x4*>(wimg + m * 64 + kg * 32) = hv0;
-        *reinterpret_cast<u32x4*>(wimg + m * 64 + kg * 32 + 16) = hv1;
+        *reinterpret_cast<u32x4*>(wimg + hid_off16(m, 2 * kg)) = hv0;
+        *reinterpret_cast<u32x4*>(wimg + hid_off16(m, 2 * kg + 1)) = hv1;
         HID_LGKM0();
         __builtin_amdgcn_wave_barrier();
         hid_dl_raw(wimg, lane, hb0, hb1);
         HID_LGKM0();
         __builtin_amdgcn_wave_barrier();
-        *reinterpret_cast<u32x4*>(wimg + m * 64 + kg * 32) = gv0;
-        *reinterpret_cast<u32x4*>(wimg + m * 64 + kg * 32 + 16) = gv1;
+        *reinterpret_cast<u32x4*>(wimg + hid_off16(m, 2 * kg)) = gv0;
+        *reinterpret_cast<u32x4*>(wimg + hid_off16(m, 2 * kg + 1)) = gv1;
         HID_LGKM0();
         __builtin_amdgcn_wave_barrier();
         f32x2 G2[8];  // (pairs, not one 16-wide vector: element-wise updates of an f32x16 cost the compiler ~100 registers of copies)
@@ -523,8 +531,8 @@ __global__ __launch_bounds__(HC * 2) void k_hid_bwd_d(const HidParams P) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) u[e] = 0.f;
             {   // (the row block's P1 / Q2 values as A operands: re-read per task, 16 bytes each, instead of 8 registers held across the block)
-                const u32x4 fp = *reinterpret_cast<const u32x4*>(pimg + m * 64 + kg * 16);
-                const u32x4 fq = *reinterpret_cast<const u32x4*>(qimg + m * 64 + kg * 16);
+                const u32x4 fp = *reinterpret_cast<const u32x4*>(pimg + hid_off16(m, kg));
+                const u32x4 fq = *reinterpret_cast<const u32x4*>(pimg + hid_off16(m, 2 + kg));
                 sp_mma1<T>(fp, hid_place<t>(tbh, kg), h);
                 sp_mma1<T>(fq, hid_place<t>(tbu, kg), u);
             }
@@ -546,21 +554,34 @@ __global__ __launch_bounds__(HC * 2) void k_hid_bwd_d(const HidParams P) {
                 }
             }
             // row reductions: A operands from the registers, B operands = the P1 / Q2 images in the same row order, task t's columns only
-            const uint32_t tm = (n >> 2) == t ? 0xFFFFFFFFu : 0u;  // (columns n >= 16 of the images are zero)
-            u32x4 pT0, pT1, qT0, qT1;
-            hid_dl_raw(pimg, lane, pT0, pT1);
-            hid_dl_raw(qimg, lane, qT0, qT1);
+            // (ONE accumulator for both: columns n < 16 collect dB1^T, columns 16 + n dA2 -- the image holds P1 and Q2 side by side and
+            // each product sees only task t's columns of its half)
+            // d and x of a lane never meet: lanes n < 16 only need the dH operand's product, lanes n >= 16 the activation's.  Since the
+            // B operand of lane n is zero outside (its half, task t), BOTH products can use the same masked fragment:
+            //   acc[c][n] += sum_m dH[m][c] PQ[m][n] (n in P half)   and   acc[c][n] += sum_m a[m][c] PQ[m][n] (n in Q half)
+            // are two MFMAs per k half whose B operands are the P-masked and the Q-masked fragment
+            const uint32_t tmP = (n >> 2) == t ? 0xFFFFFFFFu : 0u, tmQ = (n >> 2) == t + 4 ? 0xFFFFFFFFu : 0u;
+            __builtin_amdgcn_sched_barrier(0);
+            {
+                u32x4 pq0, pq1;
+                hid_dl_raw(pimg, lane, pq0, pq1);
+                u32x4 bP, bQ;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                pT0[i] &= tm;
-                pT1[i] &= tm;
-                qT0[i] &= tm;
-                qT1[i] &= tm;
+                for (int i = 0; i < 4; ++i) {
+                    bP[i] = pq0[i] & tmP;
+                    bQ[i] = pq0[i] & tmQ;
+                }
+                sp_mma1<T>(d0, bP, accF);
+                sp_mma1<T>(x0, bQ, accF);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    bP[i] = pq1[i] & tmP;
+                    bQ[i] = pq1[i] & tmQ;
+                }
+                sp_mma1<T>(d1, bP, accF);
+                sp_mma1<T>(x1, bQ, accF);
             }
-            sp_mma1<T>(d0, pT0, accB);
-            sp_mma1<T>(d1, pT1, accB);
-            sp_mma1<T>(x0, qT0, accA);
-            sp_mma1<T>(x1, qT1, accA);
+            __builtin_amdgcn_sched_barrier(0);
             // column reduction Q1 += dH_t B1_t^T: rows along lanes through the wave's image
             hid_dl_store_t(wimg, lane, d0, d1);
             HID_LGKM0();
@@ -598,29 +619,29 @@ __global__ __launch_bounds__(HC * 2) void k_hid_bwd_d(const HidParams P) {
         __syncthreads();
         if (n < 16) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) red[((size_t)wave * 16 + n) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh] = accQ[r];
+            for (int r = 0; r < 16; ++r) red[((size_t)wave * 16 + n) * 33 + (r & 3) + 8 * (r >> 2) + 4 * hh] = accQ[r];
         }
         __syncthreads();
+        static_assert(NW * 64 >= 512, "the row-sum finish uses 512 threads");
         if (tid < 512) {
             const int rr = tid & 31, nn = tid >> 5;
             if (m0 + rr < P.M) {
                 float a = 0.f;
 #pragma unroll
-                for (int w = 0; w < NW; ++w) a += red[((size_t)w * 16 + nn) * 32 + rr];
+                for (int w = 0; w < NW; ++w) a += red[((size_t)w * 16 + nn) * 33 + rr];
                 P.rowpart[((int64_t)chunk * P.M + m0 + rr) * 16 + nn] = a;
             }
         }
         // (the next block's first barrier orders these reads before the images are written again)
     }
     // the wave's share of the factor gradients: lane (n, hh) holds columns cw + a(r) of rank column n
-    if (n < nt * 4) {
-        const int t = n >> 2, rho = n & 3;
+    if ((n & 15) < nt * 4) {
+        const int t = (n & 15) >> 2, rho = n & 3, kind = n >> 4;
         float* part = P.part + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * nt * 2 * 4 * HC;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int j = cw + (r & 3) + 8 * (r >> 2) + 4 * hh;
-            part[((int64_t)(t * 2 + 0) * 4 + rho) * HC + j] = accB[r];
-            part[((int64_t)(t * 2 + 1) * 4 + rho) * HC + j] = accA[r];
+            part[((int64_t)(t * 2 + kind) * 4 + rho) * HC + j] = accF[r];
         }
     }
 }

@@ -387,11 +387,12 @@ int mtlora_residual_droppath_bwd(int n, const void* const* g, void* const* dy, v
  *           stat[0] = sum of the validity mask (label != ignore_index)
  *   kind 2  BalancedCrossEntropyLoss(size_average) (:42-89): C = 1, label (B,1,H,W);
  *           stat[0] = w = mean(1 - (label >= 0.5))
- * low (B,h,w,C) is the channels-last low-resolution prediction, H = scale*h, W = scale*w (integer scale,
- * align_corners=False).  Writes dlow = d loss / d low (dtype of low) and `mtlora_upsample_loss_partials`
- * fp32 partial loss values whose sum is the loss.  `stat` is a device pointer (label-only statistics).
+ * low (B,h,w,C) is the channels-last low-resolution prediction, H = scale*h, W = scale*w (integer scale 1..32,
+ * align_corners=False; larger scales: MTLORA_ERR_UNSUPPORTED / a negative count).  Writes dlow = d loss / d low (dtype of
+ * low) and `mtlora_upsample_loss_partials(B, h, w, scale)` fp32 partial loss values (one per tile of the launch) whose sum
+ * is the loss.  `stat` is a device pointer (label-only statistics).  Deterministic: no float atomics.
  * ------------------------------------------------------------------------------------------ */
-int64_t mtlora_upsample_loss_partials(int64_t B, int h, int w);
+int64_t mtlora_upsample_loss_partials(int64_t B, int h, int w, int scale);
 int mtlora_upsample_loss(int kind, const void* low, const float* label, const float* stat, void* dlow, float* partials,
                          int64_t B, int h, int w, int C, int scale, int dtype, float ignore_index, void* stream);
 

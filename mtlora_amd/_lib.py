@@ -156,7 +156,7 @@ _SIGS = {
                                              c_int64, c_int64, c_int64, c_int, c_int, c_void_p]),
     "mtlora_residual_droppath_bwd": (c_int, [c_int, POINTER(c_void_p), POINTER(c_void_p), c_void_p, c_void_p, c_int64,
                                              c_int64, c_int64, c_int, c_int, c_void_p]),
-    "mtlora_upsample_loss_partials": (c_int64, [c_int64, c_int, c_int]),
+    "mtlora_upsample_loss_partials": (c_int64, [c_int64, c_int, c_int, c_int]),
     "mtlora_colsum_scratch_bytes": (c_int64, [c_int64, c_int64]),
     "mtlora_colsum": (c_int, [c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p, c_int64, c_void_p]),
     "mtlora_label_stat_scratch_bytes": (c_int64, [c_int64]),

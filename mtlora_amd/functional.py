@@ -1470,7 +1470,9 @@ class UpsampleLossFn(torch.autograd.Function):
         else:
             raise RuntimeError(f"mtlora_amd: unknown fused loss kind {kind!r}")
         lib = L.lib()
-        n = lib.mtlora_upsample_loss_partials(B, h, w)
+        n = lib.mtlora_upsample_loss_partials(B, h, w, int(scale))
+        if n < 0:
+            raise RuntimeError(f"mtlora_amd: fused upsample + loss supports scales 1..32, got {scale}")
         part = torch.empty(max(n, 1), dtype=torch.float32, device=lo.device)
         dlow = torch.empty_like(lo)
         st = lib.mtlora_upsample_loss(LOSS_KINDS[kind], L.ptr(lo), L.ptr(lab), L.ptr(stat), L.ptr(dlow), L.ptr(part), B, h, w,

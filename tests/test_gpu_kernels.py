@@ -1471,10 +1471,14 @@ def _loss_case(task, B, h, w, S, seed):
                                           ("normals", 1, 16, 16, 1),
                                           # the scale the models actually run at (stage-1 maps 56 -> 448 / 28 -> 224: S = 8)
                                           ("normals", 2, 28, 28, 8), ("semseg", 2, 28, 28, 8), ("sal", 1, 28, 28, 8),
-                                          ("human_parts", 1, 14, 21, 8)])
+                                          ("human_parts", 1, 14, 21, 8),
+                                          # tile geometry of the wave-per-tile kernel: TQ = 64 / S - 1 columns (63 at S = 1, 3 at
+                                          # S = 16, 1 at S = 32), several column tiles, a last partial row tile, batch offsets
+                                          ("normals", 3, 9, 70, 1), ("sal", 2, 6, 5, 16), ("semseg", 1, 5, 4, 32),
+                                          ("human_parts", 5, 13, 15, 8), ("semseg", 2, 9, 23, 3)])
 def test_upsample_loss_vs_oracle(task, B, h, w, S, dtype):
     """value and gradient of loss(interpolate(low)) against the oracle's task_loss on torch's own bilinear upsample
-    (fp64 on the CPU), incl. partial 16x16 tiles, h != w, borders, ignore_index pixels and scales 1..4."""
+    (fp64 on the CPU), incl. partial tiles, h != w, borders, ignore_index pixels and scales 1..32."""
     from mtlora_amd import functional as Fn
     from mtlora_amd.mtl_harness import MultiTaskLoss
     low, lab = _loss_case(task, B, h, w, S, seed=h * 100 + w)

@@ -1,5 +1,5 @@
-// hid.h -- k_hid_*: the TASK streams of a task-enabled Mlp (fc1 -> GELU -> fc2 called with x_tasks, swin_transformer_mtlora.py:57-78 of the
-// reference) without their 4C-wide tensors.  Included by linear.hip inside its anonymous namespace.
+// hid.hip -- k_hid_*: the TASK streams of a task-enabled Mlp (fc1 -> GELU -> fc2 called with x_tasks, swin_transformer_mtlora.py:57-78 of the
+// reference) without their 4C-wide tensors.  Its own translation unit; launched by linear.hip through internal.h (mtli_hid_launch / mtli_hid_rows_finish / mtli_hid_reduce).
 //
 // In such an Mlp (reference lora.py:262-266 with x_tasks given) the hidden tensors of task t are
 //     h_t = h_base + P1_t B1_t^T          h_base = xn W1^T + b1 (the SHARED input's pretrained product), P1_t = s_t xn_t A1_t^T  (M x r_t)

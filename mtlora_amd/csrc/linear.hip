@@ -2607,7 +2607,7 @@ static int bwd_impl(const mtlora_linear_desc* d, const void* x, const void* cons
     float* part = reinterpret_cast<float*>(sc + S.part);
     const DropoutCfg dc = mtl_make_dropout(d->dropout_p, d->seed, d->seed_offset);
     const bool v2 = d->mode == 1 && d->T > 0;
-    const bool hid_q = (d->hid & MTLORA_HID_Q_GIVEN) != 0;  // fc1 of an Mlp with implicit task hiddens (hid.h): Q task columns given
+    const bool hid_q = (d->hid & MTLORA_HID_Q_GIVEN) != 0;  // fc1 of an Mlp with implicit task hiddens (hid.hip): Q task columns given
 
     // gradient sources per output
     const void* dy[MAXO];
@@ -3040,7 +3040,7 @@ static int bwd_impl(const mtlora_linear_desc* d, const void* x, const void* cons
     return MTLORA_OK;
 }
 
-// ---- Mlp with implicit task hidden tensors (hid.h): shape rules, launch geometry, the two launches
+// ---- Mlp with implicit task hidden tensors (hid.hip): shape rules, launch geometry, the two launches
 struct HidPlan {
     int tg, rr, nthr, nw, groups, n_wg;
 };
@@ -3518,7 +3518,7 @@ static int linear_bwd_entry(const mtlora_linear_desc* d, const void* x, const vo
     }
     if ((d->hid & MTLORA_HID_Q_GIVEN) && (d->T < 1 || !d->has_x_tasks || d->mode != 0 || misaligned(d->hid_ptr))) return MTLORA_ERR_UNSUPPORTED;
     for (int t = 0; t < d->T; ++t) {
-        // a task's own input is only read for its factor gradient dA_t (an Mlp with implicit task hiddens asks fc2 for none: hid.h)
+        // a task's own input is only read for its factor gradient dA_t (an Mlp with implicit task hiddens asks fc2 for none: hid.hip)
         if (d->has_x_tasks && dA_t && dA_t[t] && (!x_t || !x_t[t])) return MTLORA_ERR_NULL;
         if (d->has_x_tasks && x_t && misaligned(x_t[t])) return MTLORA_ERR_ALIGN;
         if (dy_t && misaligned(dy_t[t])) return MTLORA_ERR_ALIGN;

@@ -550,7 +550,7 @@ class MTLoRALinearFn(torch.autograd.Function):
 
 
 # ----------------------------------------------------------------------------------------------
-# Task-enabled Mlp with IMPLICIT task hidden tensors (csrc/hid.h, ABI v8)
+# Task-enabled Mlp with IMPLICIT task hidden tensors (csrc/hid.hip, ABI v8)
 # ----------------------------------------------------------------------------------------------
 _MLP_HID = os.environ.get("MTLORA_MLP_HID", "1") != "0"
 _hid_ok_cache: dict = {}
@@ -595,7 +595,7 @@ class MlpHidFn(torch.autograd.Function):
     """(y_s, y_t[0..T-1]) = fc2(gelu(fc1(x, x_t)), gelu(fc1 task outputs)) of a task-enabled Mlp (swin_transformer_mtlora.py:57-78 of the
     reference with both layers MTLoRALinear called with x_tasks, lora.py:262-266) WITHOUT the 3 T hidden-width task tensors of the
     per-layer path: h_t = h_base + P1_t B1_t^T only enters fc2 through P2_t = s_t gelu(h_t) A2_t^T, and its gradient only feeds
-    G, Q1_t and two rank-r_t factor gradients (csrc/hid.h).  Same parameters, same results up to rounding (the implicit tensors stay
+    G, Q1_t and two rank-r_t factor gradients (csrc/hid.hip).  Same parameters, same results up to rounding (the implicit tensors stay
     in fp32 registers instead of being rounded to the compute dtype).
 
     args: meta1, meta2, x, W1c, W1t, b1, W2c, W2t, b2, A1_s, B1_s, A2_s, B2_s, *x_t(T), *A1_t(T), *B1_t(T), *A2_t(T), *B2_t(T)"""

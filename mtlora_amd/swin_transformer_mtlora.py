@@ -128,7 +128,7 @@ class Mlp(nn.Module):
 
     def _hid_forward(self, x, x_tasks):
         """task-enabled Mlp called with x_tasks: the T task hidden tensors (fc1's task outputs, their GELU, and the gradients w.r.t. them)
-        stay implicit -- ``Fn.MlpHidFn`` (csrc/hid.h); None when the call does not qualify (the per-layer path then runs)."""
+        stay implicit -- ``Fn.MlpHidFn`` (csrc/hid.hip); None when the call does not qualify (the per-layer path then runs)."""
         tasks = self.tasks
         if not (Fn.mlp_hid_enabled() and x_tasks is not None and tasks and self.fc1.tasks is not None
                 and list(self.fc1.tasks) == list(tasks) and list(self.fc2.tasks) == list(tasks)
@@ -138,7 +138,7 @@ class Mlp(nn.Module):
         if dtype not in (torch.bfloat16, torch.float16) or x.shape[-1] != self.fc1.linear.in_features:
             return None
         xt = [x_tasks[t] for t in tasks]
-        if any((not v.is_cuda) or v.shape != x.shape for v in xt):
+        if (not x.is_cuda) or any(v.device != x.device or v.shape != x.shape for v in xt):
             return None
         # (shape rules first: ``hid_call`` draws the layers' dropout seeds)
         H, r1, r2 = self.fc1.linear.out_features, self.fc1._ranks, self.fc2._ranks

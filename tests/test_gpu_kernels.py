@@ -1329,7 +1329,7 @@ def _mlp_reference_fp64(mlp, xs, tasks, gys, q_floor=None, floors=None):
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("geom", ["c2s0", "t8", "r8", "wide", "t3mixed"])
 def test_mlp_implicit_task_hiddens(dtype, geom):
-    """``Fn.MlpHidFn`` (csrc/hid.h: the task hidden tensors of a task-enabled Mlp never reach HBM) against (i) the per-layer path with the
+    """``Fn.MlpHidFn`` (csrc/hid.hip: the task hidden tensors of a task-enabled Mlp never reach HBM) against (i) the per-layer path with the
     SAME dropout seeds -- train mode, p = 0.1 -- and (ii) the fp64 formulas of the reference (lora.py:262-266, Mlp :68-81), dropout off:
     outputs, every input gradient and every factor gradient at the north-star tolerance.  Geometries: Swin-T stage 0 of c2 (4 tasks of
     rank 4), 8 tasks (two task groups per launch), rank 8 (the rank-8 register geometry), hidden 2048 (1024-thread workgroups) and three

@@ -208,7 +208,7 @@ int mtlora_linear_bwd_gelu(const mtlora_linear_desc* d, const void* x, const voi
  *   forward : mtlora_linear_fwd_gelu(d1 | HID_FWD_BASE) ; mtlora_mlp_hid_proj ; mtlora_linear_fwd(d2 | HID_P_GIVEN)
  *   backward: mtlora_linear_bwd_gelu(d2, dx_t = dA_t = null) ; mtlora_mlp_hid_bwd ; mtlora_linear_bwd(d1 | HID_Q_GIVEN)
  * Supported: 16-bit dtype, mode 'matrix', has_x_tasks, 1 <= T, every r_t <= 8, d1->N a multiple of 128; d1->N > 2048 only with
- * r_t <= 4 and d1->N a multiple of 384 or 256 (the chunked MFMA kernels; mtlora_mlp_hid_supported returns 1).  Deterministic
+ * r_t <= 4 (the chunked MFMA kernels; mtlora_mlp_hid_supported returns 1).  Deterministic
  * (fixed-order partial sums).
  * ------------------------------------------------------------------------------------------ */
 int mtlora_mlp_hid_supported(const mtlora_linear_desc* d1, const mtlora_linear_desc* d2);

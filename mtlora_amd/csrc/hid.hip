@@ -327,7 +327,7 @@ __device__ __forceinline__ void hid_d_tables(const HidParams& P, int tid, int nt
 }
 
 template <typename T, int HC>
-__global__ __launch_bounds__(HC * 2, HC == 384 ? 3 : 2) void k_hid_fwd_d(const HidParams P) {
+__global__ __launch_bounds__(HC * 2, HC == 384 ? 3 : (HC == 128 ? 4 : 2)) void k_hid_fwd_d(const HidParams P) {
     constexpr int NW = HC / 32, bs = HC * 2 + 16;
     extern __shared__ __attribute__((aligned(16))) unsigned char hid_smem[];
     unsigned char* tabH = hid_smem;                              // [4][HC] x 8 B
@@ -426,9 +426,8 @@ __global__ __launch_bounds__(HC * 2, HC == 384 ? 3 : 2) void k_hid_fwd_d(const H
             for (int r = 0; r < 16; ++r) red[((size_t)wave * 16 + n) * 33 + (r & 3) + 8 * (r >> 2) + 4 * hh] = accP[r];
         }
         __syncthreads();
-        static_assert(NW * 64 >= 512, "the row-sum finish uses 512 threads");
-        if (tid < 512) {
-            const int rr = tid & 31, nn = tid >> 5;
+        for (int f = tid; f < 512; f += NW * 64) {
+            const int rr = f & 31, nn = f >> 5;
             if (m0 + rr < P.M) {
                 float a = 0.f;
 #pragma unroll
@@ -440,7 +439,7 @@ __global__ __launch_bounds__(HC * 2, HC == 384 ? 3 : 2) void k_hid_fwd_d(const H
 }
 
 template <typename T, int HC>
-__global__ __launch_bounds__(HC * 2, HC == 384 ? 3 : 2) void k_hid_bwd_d(const HidParams P) {
+__global__ __launch_bounds__(HC * 2, HC == 384 ? 3 : (HC == 128 ? 3 : 2)) void k_hid_bwd_d(const HidParams P) {
     constexpr int NW = HC / 32, bs = HC * 2 + 16;
     extern __shared__ __attribute__((aligned(16))) unsigned char hid_smem[];
     unsigned char* tabH = hid_smem;                              // [4][HC] x 8 B   B1
@@ -622,9 +621,8 @@ __global__ __launch_bounds__(HC * 2, HC == 384 ? 3 : 2) void k_hid_bwd_d(const H
             for (int r = 0; r < 16; ++r) red[((size_t)wave * 16 + n) * 33 + (r & 3) + 8 * (r >> 2) + 4 * hh] = accQ[r];
         }
         __syncthreads();
-        static_assert(NW * 64 >= 512, "the row-sum finish uses 512 threads");
-        if (tid < 512) {
-            const int rr = tid & 31, nn = tid >> 5;
+        for (int f = tid; f < 512; f += NW * 64) {
+            const int rr = f & 31, nn = f >> 5;
             if (m0 + rr < P.M) {
                 float a = 0.f;
 #pragma unroll
@@ -839,9 +837,11 @@ void hid_go(const HidLaunch& L, const HidParams& q, hipStream_t s) {
     } while (0)
             if (L.kind == 2) {
                 if (L.hc == 384) HID_D(k_hid_fwd_d, 384);
+                else if (L.hc == 128) HID_D(k_hid_fwd_d, 128);
                 else HID_D(k_hid_fwd_d, 256);
             } else {
                 if (L.hc == 384) HID_D(k_hid_bwd_d, 384);
+                else if (L.hc == 128) HID_D(k_hid_bwd_d, 128);
                 else HID_D(k_hid_bwd_d, 256);
             }
 #undef HID_D

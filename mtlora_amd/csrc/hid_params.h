@@ -45,13 +45,20 @@ static inline size_t hid_d_lds_bytes(int hc, bool bwd) {
     // (last term: the per-wave images, overlaid by the [waves][16][33] fp32 row-sum table)
     return (size_t)(bwd ? 2 : 1) * HID_TG * hc * 8 + (size_t)17 * (hc * 2 + 16) + (bwd ? 4096 : 2048) + (size_t)(hc / 32) * (16 * 33 * 4);
 }
-// (192-column chunks with two 6-wave workgroups per CU measured slower: backward 1.00 vs 0.76 ms at stage 0 of c2)
-static inline int hid_d_chunk(int H) { return H % 384 == 0 ? 384 : (H % 256 == 0 ? 256 : 0); }
+// chunk width (columns per workgroup, 32 per wave).  Forward: one 12-wave workgroup per CU over 384 columns (128-column chunks: 0.33 ->
+// 0.35 ms at stage 0 of c2: three times the P1 / row-sum traffic buys nothing, the kernel is VALU-bound at 128 registers either way).
+// Backward: three independent 4-wave workgroups per CU over 128 columns each (0.65 -> 0.56 ms at stage 0, 0.34 -> 0.30 at stage 1:
+// the barriers of a row block stall 4 waves instead of 12; the 256-column form needs 180 registers = 2 waves per SIMD).
+// (192-column chunks were measured once with two waves per SIMD by mistake: 1.00 vs 0.76 ms.)
+static inline int hid_d_chunk(int H, bool bwd) {
+    if (bwd) return H % 128 == 0 ? 128 : 0;
+    return H % 384 == 0 ? 384 : (H % 256 == 0 ? 256 : (H % 128 == 0 ? 128 : 0));
+}
 
 // launch descriptor filled by linear.hip (which owns the layer layouts), executed by hid.hip
 struct HidLaunch {
     int kind;        // 0 k_hid_proj (VALU), 1 k_hid_bwd (VALU), 2 k_hid_fwd_d, 3 k_hid_bwd_d (MFMA, accumulator layout)
-    int hc, n_chunk; // MFMA forms: chunk width (384 or 256 columns) and chunks (grid y)
+    int hc, n_chunk; // MFMA forms: chunk width (384 / 256 / 128 columns) and chunks (grid y)
     int dtype;       // MTLORA_BF16 / MTLORA_F16
     int tg, rr;      // VALU forms: tasks per launch / rank block (4 or 8); MFMA forms: rr
     int nthr, n_wg;  // threads per workgroup, workgroups

@@ -3059,7 +3059,7 @@ static int hid_check(const mtlora_linear_desc* d1, const mtlora_linear_desc* d2)
         rmax = std::max(rmax, std::max(d1->r_t[t], d2->r_t[t]));
     }
     // the VALU forms hold a whole row per workgroup (two columns per thread: <= 2048 columns); the MFMA forms take any number of chunks
-    const bool chunked = d1->sel_stream != 1 && rmax <= 4 && hid_d_chunk((int)d1->N) != 0;
+    const bool chunked = d1->sel_stream != 1 && rmax <= 4;  // (N % 128 == 0: a chunk width exists in both directions)
     if (d1->N > 2048 && !chunked) return MTLORA_ERR_UNSUPPORTED;
     return MTLORA_OK;
 }
@@ -3106,11 +3106,11 @@ struct HidDPlan {
     size_t lds_f, lds_b;
     int64_t rowpart_bytes;
 };
-static HidDPlan hid_d_plan(const mtlora_linear_desc* d1, const HidPlan& pl) {
+static HidDPlan hid_d_plan(const mtlora_linear_desc* d1, const HidPlan& pl, bool bwd) {
     HidDPlan dp = {};
     const Tune tu = make_tune(d1);
     const int H = (int)d1->N;
-    dp.hc = hid_d_chunk(H);
+    dp.hc = hid_d_chunk(H, bwd);
     dp.on = tu.sp != 0 && pl.rr == 4 && dp.hc != 0;
     if (!dp.on) return dp;
     dp.n_chunk = H / dp.hc;
@@ -3138,12 +3138,12 @@ static void hid_launch_d(int dtype, bool bwd, const HidDPlan& dp, const HidParam
 }
 static int64_t hid_fwd_scratch_bytes(const mtlora_linear_desc* d1, const mtlora_linear_desc* d2) {
     const HidPlan pl = hid_plan(d1, d2);
-    const HidDPlan dp = hid_d_plan(d1, pl);
+    const HidDPlan dp = hid_d_plan(d1, pl, false);
     return dp.on ? dp.rowpart_bytes : 256;
 }
 static int64_t hid_bwd_part_bytes(const mtlora_linear_desc* d1, const mtlora_linear_desc* d2) {
     const HidPlan pl = hid_plan(d1, d2);
-    const HidDPlan dp = hid_d_plan(d1, pl);
+    const HidDPlan dp = hid_d_plan(d1, pl, true);
     if (!dp.on) return hid_part_bytes(d1, pl);
     // [chunk][n_wg][nt <= 4][2][4][hc] factor-gradient partials, then the row-sum partials
     return (int64_t)dp.n_chunk * dp.n_wg * HID_TG * 2 * 4 * dp.hc * 4 + 256 + dp.rowpart_bytes;
@@ -3159,7 +3159,7 @@ static int hid_proj_impl(const mtlora_linear_desc* d1, const mtlora_linear_desc*
     const unsigned char* pk1 = d1->packed ? reinterpret_cast<const unsigned char*>(d1->packed) : c1;
     const unsigned char* pk2 = reinterpret_cast<const unsigned char*>(d2->packed);
     const HidPlan pl = hid_plan(d1, d2);
-    const HidDPlan dp = hid_d_plan(d1, pl);
+    const HidDPlan dp = hid_d_plan(d1, pl, false);
     const int H = (int)d1->N;
     const int tg = dp.on ? HID_TG : pl.tg;
     const int groups = (d1->T + tg - 1) / tg;
@@ -3213,7 +3213,7 @@ static int hid_bwd_impl(const mtlora_linear_desc* d1, const mtlora_linear_desc* 
     const unsigned char* pk1 = d1->packed ? reinterpret_cast<const unsigned char*>(d1->packed) : c1;
     const unsigned char* pk2 = d2->packed ? reinterpret_cast<const unsigned char*>(d2->packed) : c2;
     const HidPlan pl = hid_plan(d1, d2);
-    const HidDPlan dp = hid_d_plan(d1, pl);
+    const HidDPlan dp = hid_d_plan(d1, pl, true);
     const int H = (int)d1->N;
     const int tg = dp.on ? HID_TG : pl.tg;
     const int groups = (d1->T + tg - 1) / tg;

@@ -33,35 +33,55 @@ __device__ __forceinline__ void sp_mma1(const u32x4& a, const u32x4& b, f32x16& 
         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
-// exact (erf) GELU and its derivative with ONE erf / exp (Abramowitz-Stegun 7.1.26 as gelu_fwd / gelu_grad of linear.hip), two columns at a time
+// erf(x / sqrt 2) for two columns at a time WITHOUT a transcendental: z P(z^2) on |z| <= 3 (degree-8 minimax fit of erf(z) / z in z^2, Horner
+// in fp32: |error| < 2.8e-5), saturated beyond (1 - erf(3) = 2.2e-5).  The kernels below are VALU-bound (SQ_ACTIVE_INST_VALU 73-77 % of the
+// busy cycles, profiles/r06_pmc_hid.txt) and the Abramowitz-Stegun form of the tiled kernels' epilogues (linear.hip gelu_fwd / gelu_grad:
+// 1.5e-7, one v_rcp + one v_exp per element, quarter rate) was 43 % of their issue slots; their results are rounded to 16 bits (2^-9
+// relative) right after: GELU within 5.9e-5 absolute, GELU' within 1.4e-5 of the exact ones over |x| <= 6.
+// NP pairs at a time, step by step: the Horner steps of one pair depend on each other (and dependent packed operations cost a wait
+// state each on gfx950), the pairs do not
+template <int NP>
+__device__ __forceinline__ void hid_erf2n(const f32x2 (&h)[NP], f32x2 (&er)[NP]) {
+    f32x2 z[NP], s[NP], p[NP];
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+        z[j] = h[j] * 0.70710678118654752f;
+        z[j] = f32x2{__builtin_amdgcn_fmed3f(z[j].x, -3.f, 3.f), __builtin_amdgcn_fmed3f(z[j].y, -3.f, 3.f)};
+        s[j] = z[j] * z[j];
+    }
+#pragma unroll
+    for (int j = 0; j < NP; ++j) p[j] = 4.066549198e-08f * s[j] - 1.940831739e-06f;
+    constexpr float cf[7] = {4.097715593e-05f, -5.101241795e-04f, 4.229743980e-03f, -2.508258229e-02f, 1.110399948e-01f,
+                             -3.752788217e-01f, 1.128257636e+00f};
+#pragma unroll
+    for (int k = 0; k < 7; ++k)
+#pragma unroll
+        for (int j = 0; j < NP; ++j) p[j] = p[j] * s[j] + cf[k];
+#pragma unroll
+    for (int j = 0; j < NP; ++j) er[j] = p[j] * z[j];
+}
+__device__ __forceinline__ f32x2 hid_erf2(const f32x2 h) {
+    const f32x2 hh[1] = {h};
+    f32x2 er[1];
+    hid_erf2n<1>(hh, er);
+    return er[0];
+}
+template <int NP>
+__device__ __forceinline__ void hid_gelu2n_fwd(const f32x2 (&h)[NP], f32x2 (&a)[NP]) {
+    f32x2 er[NP];
+    hid_erf2n<NP>(h, er);
+#pragma unroll
+    for (int j = 0; j < NP; ++j) a[j] = h[j] * (0.5f + 0.5f * er[j]);
+}
+// erf GELU and its derivative (one v_exp for the density term), two columns at a time
 __device__ __forceinline__ void hid_gelu2(const f32x2 h, f32x2& a, f32x2& g) {
-    const f32x2 z = f32x2{fabsf(h.x), fabsf(h.y)} * 0.70710678118654752f;
-    const f32x2 d = 1.f + 0.3275911f * z;
-    const f32x2 t = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
-    const f32x2 zz = -(z * z);
-    const f32x2 e = {__expf(zz.x), __expf(zz.y)};
-    f32x2 p = 1.061405429f * t - 1.453152027f;
-    p = p * t + 1.421413741f;
-    p = p * t - 0.284496736f;
-    p = p * t + 0.254829592f;
-    const f32x2 ea = 1.f - p * t * e;
-    const f32x2 cdf = 0.5f + 0.5f * f32x2{copysignf(ea.x, h.x), copysignf(ea.y, h.y)};
+    const f32x2 cdf = 0.5f + 0.5f * hid_erf2(h);
+    const f32x2 q = h * h;
+    const f32x2 e = {__builtin_amdgcn_exp2f(q.x * -0.72134752044448170f), __builtin_amdgcn_exp2f(q.y * -0.72134752044448170f)};  // exp(-h^2 / 2)
     a = h * cdf;
     g = cdf + h * e * 0.39894228040143268f;
 }
-__device__ __forceinline__ f32x2 hid_gelu2_fwd(const f32x2 h) {
-    const f32x2 z = f32x2{fabsf(h.x), fabsf(h.y)} * 0.70710678118654752f;
-    const f32x2 d = 1.f + 0.3275911f * z;
-    const f32x2 t = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
-    const f32x2 zz = -(z * z);
-    const f32x2 e = {__expf(zz.x), __expf(zz.y)};
-    f32x2 p = 1.061405429f * t - 1.453152027f;
-    p = p * t + 1.421413741f;
-    p = p * t - 0.284496736f;
-    p = p * t + 0.254829592f;
-    const f32x2 ea = 1.f - p * t * e;
-    return h * (0.5f + 0.5f * f32x2{copysignf(ea.x, h.x), copysignf(ea.y, h.y)});
-}
+__device__ __forceinline__ f32x2 hid_gelu2_fwd(const f32x2 h) { return h * (0.5f + 0.5f * hid_erf2(h)); }
 
 // RR consecutive elements of T at a WAVE-UNIFORM address -> floats (through SGPRs: the unpacking then runs on the scalar unit)
 template <typename T, int RR>
@@ -398,13 +418,19 @@ __global__ __launch_bounds__(HC * 2, HC == 384 ? 3 : (HC == 128 ? 4 : 2)) void k
             sp_mma1<T>(fp, hid_place<t>(tb, kg), h);
             u32x4 a0, a1;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const f32x2 av = hid_gelu2_fwd(f32x2{h[2 * i], h[2 * i + 1]});
-                const uint32_t w = hid_pk<T>(av.x, av.y);
-                if (i < 4)
-                    a0[i] = w;
-                else
-                    a1[i - 4] = w;
+            for (int i4 = 0; i4 < 2; ++i4) {  // four pairs at a time (independent Horner chains)
+                f32x2 hv[4], av[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) hv[j] = f32x2{h[8 * i4 + 2 * j], h[8 * i4 + 2 * j + 1]};
+                hid_gelu2n_fwd<4>(hv, av);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t w = hid_pk<T>(av[j].x, av[j].y);
+                    if (i4 == 0)
+                        a0[j] = w;
+                    else
+                        a1[j] = w;
+                }
             }
             hid_dl_store_t(wimg, lane, a0, a1);
             HID_LGKM0();

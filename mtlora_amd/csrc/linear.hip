@@ -3119,7 +3119,7 @@ static HidDPlan hid_d_plan(const mtlora_linear_desc* d1, const HidPlan& pl, bool
     dp.lds_b = hid_d_lds_bytes(dp.hc, true);
     const int64_t nblk = (d1->M + 31) / 32;
     // workgroups per CU: as many as fit by LDS and by 12 waves of 168 registers
-    const int per_cu = std::max(1, std::min((int)((size_t)(150 * 1024) / dp.lds_b), 12 / (dp.hc / 32)));
+    const int per_cu = std::max(1, std::min((int)((size_t)(150 * 1024) / (bwd ? dp.lds_b : dp.lds_f)), (bwd ? 12 : 16) / (dp.hc / 32)));
     dp.n_wg = (int)std::min<int64_t>(nblk, std::max<int64_t>(1, (int64_t)num_cu(tu) * per_cu / dp.n_chunk));
     dp.rowpart_bytes = (int64_t)dp.n_chunk * d1->M * 16 * 4 + 256;
     return dp;

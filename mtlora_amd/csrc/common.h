@@ -194,6 +194,73 @@ __device__ __forceinline__ float mtl_hi2(uint32_t w) {
     else
         return __builtin_bit_cast(float, w & 0xFFFF0000u);
 }
+// ---- erf GELU of 16-bit tensors without a transcendental --------------------------------------------------------------------------
+// erf(x / sqrt 2) = z P(z^2) on |z| <= 3 (degree-8 minimax fit of erf(z) / z in z^2, fp32 Horner: |error| < 2.8e-5), saturated beyond
+// (1 - erf(3) = 2.2e-5): GELU within 5.9e-5 absolute, GELU' within 1.4e-5 of the exact ones.  For results that are rounded to 16 bits
+// (2^-9 relative) right after; fp32 tensors keep the Abramowitz-Stegun form (1.5e-7; one v_rcp + one v_exp per element, quarter rate:
+// 25 issue slots per element against 8).  NP pairs at a time, step by step: the Horner steps of one pair depend on each other (and
+// dependent packed operations cost a wait state each on gfx950), the pairs do not.
+template <int NP>
+__device__ __forceinline__ void mtl_erf2n(const f32x2 (&h)[NP], f32x2 (&er)[NP]) {
+    f32x2 z[NP], s[NP], p[NP];
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+        z[j] = h[j] * 0.70710678118654752f;
+        z[j] = f32x2{__builtin_amdgcn_fmed3f(z[j].x, -3.f, 3.f), __builtin_amdgcn_fmed3f(z[j].y, -3.f, 3.f)};
+        s[j] = z[j] * z[j];
+    }
+#pragma unroll
+    for (int j = 0; j < NP; ++j) p[j] = 4.066549198e-08f * s[j] - 1.940831739e-06f;
+    constexpr float cf[7] = {4.097715593e-05f, -5.101241795e-04f, 4.229743980e-03f, -2.508258229e-02f, 1.110399948e-01f,
+                             -3.752788217e-01f, 1.128257636e+00f};
+#pragma unroll
+    for (int k = 0; k < 7; ++k)
+#pragma unroll
+        for (int j = 0; j < NP; ++j) p[j] = p[j] * s[j] + cf[k];
+#pragma unroll
+    for (int j = 0; j < NP; ++j) er[j] = p[j] * z[j];
+}
+// the eight 16-bit values of a 16-byte vector: gelu(v), rounded once.  CVT: pack with the one-instruction conversion (mtl_pk2) or with
+// the shift form (mtl_pack2) -- bit-identical results; the tiled kernels at their register cap schedule badly around the former
+template <typename T, bool CVT>
+__device__ __forceinline__ u32x4 mtl_gelu_pk4(const u32x4& v) {
+    u32x4 o;
+#pragma unroll
+    for (int q2 = 0; q2 < 4; q2 += 2) {  // (two pairs in flight: four cost the streaming kernels ~20 registers and a wave per SIMD)
+        f32x2 h[2], er[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) h[q] = f32x2{mtl_lo2<T>(v[q2 + q]), mtl_hi2<T>(v[q2 + q])};
+        mtl_erf2n<2>(h, er);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const f32x2 a = h[q] * (0.5f + 0.5f * er[q]);
+            o[q2 + q] = CVT ? mtl_pk2<T>(a.x, a.y) : mtl_pack2<T>(a.x, a.y);
+        }
+    }
+    return o;
+}
+// ... g .* gelu'(h): Phi(h) + h phi(h), the factor ATen's GeluBackward applies (one v_exp for the density)
+template <typename T, bool CVT>
+__device__ __forceinline__ u32x4 mtl_gelu_gate_pk4(const u32x4& g, const u32x4& hv) {
+    u32x4 o;
+#pragma unroll
+    for (int q2 = 0; q2 < 4; q2 += 2) {
+        f32x2 h[2], er[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) h[q] = f32x2{mtl_lo2<T>(hv[q2 + q]), mtl_hi2<T>(hv[q2 + q])};
+        mtl_erf2n<2>(h, er);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const f32x2 cdf = 0.5f + 0.5f * er[q];
+            const f32x2 qq = h[q] * h[q];
+            const f32x2 e = {__builtin_amdgcn_exp2f(qq.x * -0.72134752044448170f), __builtin_amdgcn_exp2f(qq.y * -0.72134752044448170f)};  // exp(-h^2 / 2)
+            const f32x2 d = (cdf + h[q] * e * 0.39894228040143268f) * f32x2{mtl_lo2<T>(g[q2 + q]), mtl_hi2<T>(g[q2 + q])};
+            o[q2 + q] = CVT ? mtl_pk2<T>(d.x, d.y) : mtl_pack2<T>(d.x, d.y);
+        }
+    }
+    return o;
+}
+
 template <typename T>
 struct VOps;
 template <>

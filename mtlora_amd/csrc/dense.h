@@ -300,19 +300,11 @@ __global__ __launch_bounds__(512, 2) void k_ntd(const NlParams P) {
                     u32x4 v = *reinterpret_cast<const u32x4*>(img + ml * ND_ORS + c16 * 16);
                     const uint32_t off = (m < M && n < n_rows && !(dbg & 1)) ? (uint32_t)m * ldo2 + (uint32_t)n * 2u : 0xFFFFFFFFu;
                     if constexpr (GATE) {  // the bf16-rounded gradient times gelu'(pre-activation), rounded once (as ATen does)
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            const float g0 = mtl_lo2<bf16>(v[q]) * gelu_grad(mtl_lo2<bf16>(hv[sm][it][q]));
-                            const float g1 = mtl_hi2<bf16>(v[q]) * gelu_grad(mtl_hi2<bf16>(hv[sm][it][q]));
-                            v[q] = mtl_pack_bf16(g0, g1);
-                        }
+                        v = mtl_gelu_gate_pk4<bf16, false>(v, hv[sm][it]);
                     }
                     sp_bstore(v, orsrc, off);
                     if constexpr (ACT) {
-                        u32x4 av;
-#pragma unroll
-                        for (int q = 0; q < 4; ++q)
-                            av[q] = mtl_pack_bf16(gelu_fwd(mtl_lo2<bf16>(v[q])), gelu_fwd(mtl_hi2<bf16>(v[q])));
+                        const u32x4 av = mtl_gelu_pk4<bf16, false>(v);
                         sp_bstore(av, arsrc, off);
                     }
                 }
@@ -587,19 +579,11 @@ __global__ __launch_bounds__(256, 2) void k_nte(const NlParams P) {
                     u32x4 v = *reinterpret_cast<const u32x4*>(img + ml * NE_ORS + c16 * 16);
                     const uint32_t off = (m < M && n < n_rows) ? (uint32_t)m * ldo2 + (uint32_t)n * 2u : 0xFFFFFFFFu;
                     if constexpr (GATE) {
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            const float g0 = mtl_lo2<bf16>(v[q]) * gelu_grad(mtl_lo2<bf16>(hv[it][q]));
-                            const float g1 = mtl_hi2<bf16>(v[q]) * gelu_grad(mtl_hi2<bf16>(hv[it][q]));
-                            v[q] = mtl_pack_bf16(g0, g1);
-                        }
+                        v = mtl_gelu_gate_pk4<bf16, false>(v, hv[it]);
                     }
                     sp_bstore(v, orsrc, off);
                     if constexpr (ACT) {
-                        u32x4 av;
-#pragma unroll
-                        for (int q = 0; q < 4; ++q)
-                            av[q] = mtl_pack_bf16(gelu_fwd(mtl_lo2<bf16>(v[q])), gelu_fwd(mtl_hi2<bf16>(v[q])));
+                        const u32x4 av = mtl_gelu_pk4<bf16, false>(v);
                         sp_bstore(av, arsrc, off);
                     }
                 }

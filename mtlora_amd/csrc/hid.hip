@@ -33,43 +33,18 @@ __device__ __forceinline__ void sp_mma1(const u32x4& a, const u32x4& b, f32x16& 
         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
-// erf(x / sqrt 2) for two columns at a time WITHOUT a transcendental: z P(z^2) on |z| <= 3 (degree-8 minimax fit of erf(z) / z in z^2, Horner
-// in fp32: |error| < 2.8e-5), saturated beyond (1 - erf(3) = 2.2e-5).  The kernels below are VALU-bound (SQ_ACTIVE_INST_VALU 73-77 % of the
-// busy cycles, profiles/r06_pmc_hid.txt) and the Abramowitz-Stegun form of the tiled kernels' epilogues (linear.hip gelu_fwd / gelu_grad:
-// 1.5e-7, one v_rcp + one v_exp per element, quarter rate) was 43 % of their issue slots; their results are rounded to 16 bits (2^-9
-// relative) right after: GELU within 5.9e-5 absolute, GELU' within 1.4e-5 of the exact ones over |x| <= 6.
-// NP pairs at a time, step by step: the Horner steps of one pair depend on each other (and dependent packed operations cost a wait
-// state each on gfx950), the pairs do not
-template <int NP>
-__device__ __forceinline__ void hid_erf2n(const f32x2 (&h)[NP], f32x2 (&er)[NP]) {
-    f32x2 z[NP], s[NP], p[NP];
-#pragma unroll
-    for (int j = 0; j < NP; ++j) {
-        z[j] = h[j] * 0.70710678118654752f;
-        z[j] = f32x2{__builtin_amdgcn_fmed3f(z[j].x, -3.f, 3.f), __builtin_amdgcn_fmed3f(z[j].y, -3.f, 3.f)};
-        s[j] = z[j] * z[j];
-    }
-#pragma unroll
-    for (int j = 0; j < NP; ++j) p[j] = 4.066549198e-08f * s[j] - 1.940831739e-06f;
-    constexpr float cf[7] = {4.097715593e-05f, -5.101241795e-04f, 4.229743980e-03f, -2.508258229e-02f, 1.110399948e-01f,
-                             -3.752788217e-01f, 1.128257636e+00f};
-#pragma unroll
-    for (int k = 0; k < 7; ++k)
-#pragma unroll
-        for (int j = 0; j < NP; ++j) p[j] = p[j] * s[j] + cf[k];
-#pragma unroll
-    for (int j = 0; j < NP; ++j) er[j] = p[j] * z[j];
-}
+// erf GELU through the transcendental-free erf of common.h (mtl_erf2n): these kernels are VALU-bound (SQ_ACTIVE_INST_VALU 73-77 % of the busy
+// cycles, profiles/r06_pmc_hid.txt) and the Abramowitz-Stegun form was 43 % of their issue slots
 __device__ __forceinline__ f32x2 hid_erf2(const f32x2 h) {
     const f32x2 hh[1] = {h};
     f32x2 er[1];
-    hid_erf2n<1>(hh, er);
+    mtl_erf2n<1>(hh, er);
     return er[0];
 }
 template <int NP>
 __device__ __forceinline__ void hid_gelu2n_fwd(const f32x2 (&h)[NP], f32x2 (&a)[NP]) {
     f32x2 er[NP];
-    hid_erf2n<NP>(h, er);
+    mtl_erf2n<NP>(h, er);
 #pragma unroll
     for (int j = 0; j < NP; ++j) a[j] = h[j] * (0.5f + 0.5f * er[j]);
 }

@@ -751,12 +751,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void k_nt(const NtParams 
                     if constexpr (GATE) {
                         if (gate) {  // the bf16-rounded gradient times gelu'(pre-activation), rounded once (as ATen does)
                             const u32x4 hv = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(gate + m * P->ld_out + row_off + n));
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) {
-                                const float g0 = mtl_lo2<T>(v[q]) * gelu_grad(mtl_lo2<T>(hv[q]));
-                                const float g1 = mtl_hi2<T>(v[q]) * gelu_grad(mtl_hi2<T>(hv[q]));
-                                v[q] = mtl_pack2<T>(g0, g1);
-                            }
+                            v = mtl_gelu_gate_pk4<T, false>(v, hv);
                         }
                     }
                     // non-temporal: the 77 - 308 MB outputs of a launch outlive L2 / MALL anyway (+1 % on the step; the same hint
@@ -764,10 +759,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void k_nt(const NtParams 
                     __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(outp + m * P->ld_out + row_off + n));
                     if constexpr (ACT) {
                         if (actp) {  // second output: GELU of the bf16-rounded value, rounded once (ATen's gelu on the bf16 tensor)
-                            u32x4 av;
-#pragma unroll
-                            for (int q = 0; q < 4; ++q)
-                                av[q] = mtl_pack2<T>(gelu_fwd(mtl_lo2<T>(v[q])), gelu_fwd(mtl_hi2<T>(v[q])));
+                            const u32x4 av = mtl_gelu_pk4<T, false>(v);
                             __builtin_nontemporal_store(av, reinterpret_cast<u32x4*>(actp + m * P->ld_out + row_off + n));
                         }
                     }
@@ -1079,11 +1071,7 @@ __global__ __launch_bounds__(512, 4) void k_ntl(const NlParams P) {
                 __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(P.out + o));
                 if constexpr (ACT) {
                     if (P.act2) {
-                        u32x4 av;
-#pragma unroll
-                        for (int q = 0; q < 4; ++q)
-                            av[q] = mtl_pack_bf16(gelu_fwd(__builtin_bit_cast(float, v[q] << 16)),
-                                                  gelu_fwd(__builtin_bit_cast(float, v[q] & 0xFFFF0000u)));
+                        const u32x4 av = mtl_gelu_pk4<bf16, false>(v);
                         __builtin_nontemporal_store(av, reinterpret_cast<u32x4*>(P.act2 + o));
                     }
                 }
@@ -1443,14 +1431,7 @@ __global__ __launch_bounds__(256) void k_rank_out(const RankOutParams P) {
                     for (int e = 0; e < 8; ++e) acc[e] += qf[j] * a[w * 8 + j][e];
             }
             u32x4 o = VOps<T>::pack(acc);
-            if constexpr (GATE) {
-                float of[8], hf[8];
-                VOps<T>::unpack(o, of);
-                VOps<T>::unpack(hv[u], hf);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) of[e] *= gelu_grad(hf[e]);
-                o = VOps<T>::pack(of);
-            }
+            if constexpr (GATE) o = mtl_gelu_gate_pk4<T, false>(o, hv[u]);
             if (m < P.M) __builtin_nontemporal_store(o, reinterpret_cast<u32x4*>(out + m * P.K + chunk * 8));
         }
     }

@@ -576,16 +576,11 @@ __global__ __launch_bounds__(64 * SP_WAVES, SP_WAVES / 4) void k_sp_xres(const S
                     for (int it = 0; it < 4; ++it) {
                         const uint32_t off = (colok && !(dbg & 1)) ? o0 + (uint32_t)(it * 8) * ldo2 : 0xFFFFFFFFu;
                         if constexpr (GATE) {  // the rounded gradient times gelu'(pre-activation), rounded once (as ATen does)
-#pragma unroll
-                            for (int e = 0; e < 4; ++e)
-                                v[it][e] = mtl_pk2<T>(mtl_lo2<T>(v[it][e]) * gelu_grad(mtl_lo2<T>(hv[it][e])),
-                                                      mtl_hi2<T>(v[it][e]) * gelu_grad(mtl_hi2<T>(hv[it][e])));
+                            v[it] = mtl_gelu_gate_pk4<T, true>(v[it], hv[it]);
                         }
                         sp_bstore(v[it], orsrc, off);
                         if constexpr (ACT) {
-                            u32x4 av;
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) av[e] = mtl_pk2<T>(gelu_fwd(mtl_lo2<T>(v[it][e])), gelu_fwd(mtl_hi2<T>(v[it][e])));
+                            const u32x4 av = mtl_gelu_pk4<T, true>(v[it]);
                             sp_bstore(av, o2rsrc, off);
                         }
                     }
@@ -601,15 +596,11 @@ __global__ __launch_bounds__(64 * SP_WAVES, SP_WAVES / 4) void k_sp_xres(const S
                     const int col = col0 + 8 * q + 8 * h;
                     const uint32_t off = (col < n_cols && !(dbg & 1)) ? rowoff + (uint32_t)col * 2u : 0xFFFFFFFFu;
                     if constexpr (GATE) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            v[e] = mtl_pk2<T>(mtl_lo2<T>(v[e]) * gelu_grad(mtl_lo2<T>(hv[q >> 1][e])), mtl_hi2<T>(v[e]) * gelu_grad(mtl_hi2<T>(hv[q >> 1][e])));
+                        v = mtl_gelu_gate_pk4<T, true>(v, hv[q >> 1]);
                     }
                     sp_bstore(v, orsrc, off);
                     if constexpr (ACT) {
-                        u32x4 av;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) av[e] = mtl_pk2<T>(gelu_fwd(mtl_lo2<T>(v[e])), gelu_fwd(mtl_hi2<T>(v[e])));
+                        const u32x4 av = mtl_gelu_pk4<T, true>(v);
                         sp_bstore(av, o2rsrc, off);
                     }
                 }

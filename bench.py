@@ -65,9 +65,10 @@ def parse():
     ap.add_argument("--capturable", action="store_true", help="AdamW(capturable=True) in the eager step too (step counters on the device)")
     ap.add_argument("--force-reducer", action="store_true", help="run the gradient pack / RCCL all-reduce / unpack path even at 1 rank")
     ap.add_argument("--no-fused-loss", action="store_true", help="final upsample + losses through ATen instead of csrc/loss.hip")
-    ap.add_argument("--cores", type=int, default=0,
-                    help="pin this process to N host cores (sched_setaffinity + torch.set_num_threads): the host budget of one rank "
-                         "when 8 ranks share a node (16 cores / 8 ranks = 2)")
+    ap.add_argument("--cores", type=int, default=-1,
+                    help="pin this rank to N host cores of its own (sched_setaffinity + torch.set_num_threads; rank r takes cores "
+                         "[r N, (r + 1) N) of the affinity mask).  Default -1 = 2: the step is issued by two threads (python + autograd), "
+                         "and letting them migrate over a 256-core host costs 0.4-2.5 %% (DESIGN.md 7); 0 = leave the affinity alone")
     ap.add_argument("--eager-leg", default="", help=argparse.SUPPRESS)  # child process of the eager_gpu leg: --eager-leg <config> --batch B
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the short c4 / c5:4 legs the default (c2, 1 GPU) run appends under `other_configs`")
@@ -392,15 +393,20 @@ def main():
     if args.eager_leg:
         from mtlora_amd import mtl_harness as H
         return eager_leg(args.eager_leg, args.batch or H.config(args.eager_leg)["batch"])
-    if args.cores > 0:  # the host budget of one rank on a shared node (before any thread pool starts)
-        allowed = sorted(os.sched_getaffinity(0))
-        os.sched_setaffinity(0, set(allowed[:max(1, min(args.cores, len(allowed)))]))
-        torch.set_num_threads(max(1, min(args.cores, len(allowed))))
+    full_mask, full_threads = os.sched_getaffinity(0), torch.get_num_threads()
+    n_pin = 2 if args.cores < 0 else args.cores
+    if n_pin > 0:  # this rank's own host cores (before any thread pool starts)
+        allowed = sorted(full_mask)
+        lr = int(os.environ.get("LOCAL_RANK", "0"))
+        n_pin = max(1, min(n_pin, len(allowed)))
+        first = (lr * n_pin) % len(allowed) if len(allowed) >= n_pin * (lr + 1) else 0
+        os.sched_setaffinity(0, set(allowed[first:first + n_pin]))
+        torch.set_num_threads(n_pin)
     rank, world, local = init_dist(args)
     dev = torch.device("cuda", local)
     from mtlora_amd import _lib as L
     L.lib()  # fail loudly if the HIP extension is missing
-    if world > 1 and args.cores <= 0:  # N ranks share one host: keep each rank's intra-op CPU pool small (no CPU-side compute)
+    if world > 1 and n_pin <= 0:  # N ranks share one host: keep each rank's intra-op CPU pool small (no CPU-side compute)
         torch.set_num_threads(max(1, min(4, usable_cores() // world)))
 
     row, B, ips, fields = run_config(args, args.config, rank, world, dev, args.steps, args.warmup, not args.no_roofline, args.batch)
@@ -432,6 +438,9 @@ def main():
             except Exception as e:  # noqa: BLE001  (a failing side leg must not lose the headline line)
                 others[name] = {"error": f"{type(e).__name__}: {str(e)[:120]}"}
         result["other_configs"] = others
+    if n_pin > 0:  # the comparator legs get the whole host back (the eager leg is a child process and inherits the mask)
+        os.sched_setaffinity(0, full_mask)
+        torch.set_num_threads(full_threads)
     if rank == 0 and world == 1 and not args.no_eager_gpu:
         result["eager_gpu"] = eager_gpu(args.config, B, ips)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

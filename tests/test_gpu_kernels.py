@@ -1167,11 +1167,13 @@ def test_residual_layer_norm_multi(rdt, ydt, n, B, Ltok, C, use_scale):
     assert_close(b.grad, b64.grad, ydt, "dbeta")
 
 
+@pytest.mark.parametrize("spread", [1.5, 5.0])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("with_tasks", [False, True])
-def test_linear_bwd_gelu_fused(dtype, with_tasks):
+def test_linear_bwd_gelu_fused(dtype, with_tasks, spread):
     """mtlora_linear_bwd_gelu: fc2(gelu(h)) with the GELU derivative applied inside fc2's dX kernel == the unfused
-    composition (ATen gelu + gelu_backward), same dropout seeds; shared and per-task inputs, ragged M."""
+    composition (ATen gelu + gelu_backward), same dropout seeds; shared and per-task inputs, ragged M.  spread 5: pre-activations
+    out to |h| ~ 20, past the |h| = 4.24 where the 16-bit kernels' polynomial erf saturates (common.h mtl_erf2n)."""
     from mtlora_amd import functional as Fn
     from mtlora_amd.lora import MTLoRALinear
     torch.manual_seed(3)
@@ -1185,7 +1187,7 @@ def test_linear_bwd_gelu_fused(dtype, with_tasks):
             if "lora_" in n_:
                 p_.normal_(0, 0.1)
     m.train()
-    hs = [(1.5 * torch.randn(3, M // 3, K, device=dev())).to(dtype).requires_grad_(True) for _ in range(1 + (2 if with_tasks else 0))]
+    hs = [(spread * torch.randn(3, M // 3, K, device=dev())).to(dtype).requires_grad_(True) for _ in range(1 + (2 if with_tasks else 0))]
     gys = None
     res = []
     for fused in (False, True):
@@ -1217,9 +1219,10 @@ def test_linear_bwd_gelu_fused(dtype, with_tasks):
         assert torch.equal(p0[k], p1[k]), k
 
 
+@pytest.mark.parametrize("spread", [1.0, 4.0])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("with_tasks", [False, True])
-def test_mlp_gelu_fused_both_ways(dtype, with_tasks):
+def test_mlp_gelu_fused_both_ways(dtype, with_tasks, spread):
     """fc1 -> GELU -> fc2 with the activation written by fc1's epilogue (mtlora_linear_fwd_gelu) and its derivative applied
     in fc2's dX epilogue (mtlora_linear_bwd_gelu) == the plain composition with ATen's gelu / gelu_backward: pre-activations
     bit-equal, activations / outputs / every gradient within tolerance (same dropout seeds)."""
@@ -1240,7 +1243,8 @@ def test_mlp_gelu_fused_both_ways(dtype, with_tasks):
             m_.linear.weight.requires_grad_(False)
             m_.linear.bias.requires_grad_(False)
             m_.train()
-    xs = [torch.randn(3, M // 3, C, device=dev()).to(dtype).requires_grad_(True) for _ in range(1 + (2 if with_tasks else 0))]
+    # (spread 4: pre-activations well past the saturation point of the 16-bit kernels' polynomial erf)
+    xs = [(spread * torch.randn(3, M // 3, C, device=dev())).to(dtype).requires_grad_(True) for _ in range(1 + (2 if with_tasks else 0))]
     td = lambda lst: {t: lst[1 + i] for i, t in enumerate(tasks)} if tasks else None
     res, gys = [], None
     for fused in (False, True):

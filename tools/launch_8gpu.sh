@@ -4,7 +4,7 @@
 # N = 1 runs bench.py directly; N > 1 is exactly the line the driver uses (SURVEY 8e / BASELINE configs[2]).  Each rank prints nothing but
 # rank 0's ONE JSON line; `value` is the whole-job images/sec, `config.allreduce_bytes` the 33.4 MB of trainable gradients per step.
 # Host budget: the step is GPU-bound down to 2 host cores per rank; on a node with fewer than 4 cores per rank pass
-# `--cores 2` so that the ranks do not fight over the same cores (each rank then pins itself to 2 cores of its affinity mask).
+# `--cores 1` (each rank pins itself to its own cores [r N, (r + 1) N) of the affinity mask; default 2 per rank).
 N=${1:-8}; STEPS=${2:-30}; WARMUP=${3:-10}; shift 3 2>/dev/null
 REPO=$(cd "$(dirname "$0")/.." && pwd)
 export HSA_ENABLE_IPC_MODE_LEGACY=0   # dmabuf IPC only on this driver: RCCL needs it for the peer mappings

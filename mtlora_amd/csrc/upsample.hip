@@ -97,8 +97,11 @@ __global__ __launch_bounds__(256) void k_up_bwd(const UpParams p) {
         r /= p.w;
         const int qy = (int)(r % p.h);
         const int64_t b = r / p.h;
-        const int oy_lo = S * qy - S < 0 ? 0 : S * qy - S, oy_hi = S * qy + 2 * S > H ? H : S * qy + 2 * S;
-        const int ox_lo = S * qx - S < 0 ? 0 : S * qx - S, ox_hi = S * qx + 2 * S > W ? W : S * qx + 2 * S;
+        // the fine pixels that tap coarse index q along an axis are S q - ceil(S / 2) ... + 2S - 1 (loss.hip); one more on either side
+        // covers a source index that rounds across a cell boundary (its weight is then ~0 and the exact test below drops or keeps it)
+        const int hs1 = (S + 1) / 2 + 1;
+        const int oy_lo = S * qy - hs1 < 0 ? 0 : S * qy - hs1, oy_hi = S * qy - hs1 + 2 * S + 2 > H ? H : S * qy - hs1 + 2 * S + 2;
+        const int ox_lo = S * qx - hs1 < 0 ? 0 : S * qx - hs1, ox_hi = S * qx - hs1 + 2 * S + 2 > W ? W : S * qx - hs1 + 2 * S + 2;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         if (live) {
             for (int oy = oy_lo + part; oy < oy_hi; oy += UB) {

@@ -1523,6 +1523,31 @@ def test_fused_loss_path_equals_plain_path():
         assert rel_err(g_fused[t], low[t].grad) <= 1e-4, t
 
 
+def test_fused_loss_at_the_heads_size():
+    """the four fused upsample + loss kernels at the geometry the c2 heads run at (56 x 56 -> 448 x 448, S = 8; B = 8, bf16 logits)
+    against ATen's interpolate + the plain losses on the same GPU in fp32: value and gradient.  (Label tensors are sized exactly:
+    a read past the last batch entry's channels faults here, not in the small oracle cases.)"""
+    from mtlora_amd.mtl_harness import MultiTaskLoss
+    tasks = ["semseg", "normals", "sal", "human_parts"]
+    crit = MultiTaskLoss(tasks)
+    low, gt = {}, {}
+    for i, t in enumerate(tasks):
+        lo, lab = _loss_case(t, 8, 56, 56, 8, seed=40 + i)
+        low[t], gt[t] = lo.to(dev()).bfloat16().requires_grad_(True), lab.to(dev()).clone()
+    total, per = crit.forward_low(low, gt)
+    total.backward()
+    g_fused = {t: low[t].grad.float().clone() for t in tasks}
+    ref_in = {t: low[t].detach().float().requires_grad_(True) for t in tasks}
+    pred = {t: torch.nn.functional.interpolate(ref_in[t].permute(0, 3, 1, 2), scale_factor=8, mode="bilinear") for t in tasks}
+    total2, per2 = crit(pred, gt)
+    total2.backward()
+    for t in tasks:
+        assert abs(per[t].item() - per2[t].item()) <= 1e-3 * max(1.0, abs(per2[t].item())), (t, per[t].item(), per2[t].item())
+        e = rel_err(g_fused[t], ref_in[t].grad)
+        _log_parity(f"fused loss at 56x56 x8 d_low {t}", e, 1e-2, 1.0)
+        assert e <= 1e-2, (t, e)  # (the fused gradient is rounded to bf16 once)
+
+
 # ------------------------------------------------------------------------------------------------
 # device-side seed offset (ABI v2) and the HIP-graph train step
 # ------------------------------------------------------------------------------------------------
